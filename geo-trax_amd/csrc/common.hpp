@@ -1,0 +1,72 @@
+// Shared host-side helpers for the gtx runtime (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace gtx {
+
+// Error transport: C++ exceptions never cross the C ABI; gtx_api.cpp catches
+// them, stores the text in a thread-local buffer and returns a negative code.
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+#define GTX_HIP(expr)                                                         \
+  do {                                                                        \
+    hipError_t e__ = (expr);                                                  \
+    if (e__ != hipSuccess)                                                    \
+      ::gtx::fail(-2, "HIP error %d (%s) at %s:%d: %s", (int)e__,             \
+                  hipGetErrorString(e__), __FILE__, __LINE__, #expr);         \
+  } while (0)
+
+#define GTX_CHECK(cond, ...)                                                  \
+  do {                                                                        \
+    if (!(cond)) ::gtx::fail(-3, __VA_ARGS__);                                \
+  } while (0)
+
+// Device allocation owned by a context. 256-B aligned by hipMalloc.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n) {
+    release();
+    if (n == 0) n = 256;
+    GTX_HIP(hipMalloc(&p, n));
+    bytes = n;
+  }
+  void release() {
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace gtx

@@ -1,0 +1,374 @@
+// Implicit-GEMM Conv(+bias+SiLU[+residual]) on MFMA with LDS-staged im2col patches.
+// gfx950 only. See conv_igemm.hpp for the data layout.
+//
+// Work decomposition
+//   workgroup (256 threads = 4 waves) -> 8x16 output pixels x BN output channels
+//   wave w                            -> output rows {2w, 2w+1} (32 pixels) x BN channels
+//   MFMA                              -> D[cout 32][pixel 32] += W[cout][k] * X[k][pixel]
+//                                        (weights are the A operand so that every lane ends up
+//                                        holding 4 *consecutive* channels of one pixel: 8/16-B
+//                                        NHWC stores instead of 2-B ones)
+// K loop: for each chunk of KC input channels the (TH*s+KS-1)x(TW*s+KS-1) input patch and the
+// KS*KS weight taps of that chunk are staged in LDS once; the KS*KS taps then read their A/B
+// fragments from LDS at shifted addresses (im2col never exists in memory). Global loads of
+// chunk i+1 are issued into registers before the MFMAs of chunk i (register prefetch).
+// LDS rows are 64 or 128 B; 16-B chunks are XOR-swizzled so that ds_read_b128 fragment reads of
+// 16 consecutive rows hit 16 distinct 16-B slots of the 256-B bank row.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "conv_igemm.hpp"
+
+namespace gtx {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<_Float16> {
+  using frag_t = half8;
+  static __device__ __forceinline__ void run(floatx16& acc, const frag_t& a, const frag_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  using frag_t = float4;
+  // 32x32x2 f32 MFMA: lane (i = l&31, kk = l>>5) supplies A[i][kk] / B[kk][i]. A 16-B chunk
+  // per lane therefore feeds four MFMAs; both operands use the same k permutation.
+  static __device__ __forceinline__ void run(floatx16& acc, const frag_t& a, const frag_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int KS, int STRIDE, int WN, int CPR>
+struct ConvTile {
+  static constexpr int TH = 8, TW = 16;
+  static constexpr int BN = 32 * WN;
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = (TH - 1) * STRIDE + KS;
+  static constexpr int PW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = PH * PW;
+  static constexpr int RB = CPR * 16;                // bytes per LDS row
+  static constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-B chunk
+  static constexpr int KC = CPR * EPC;               // input channels per K chunk
+  static constexpr int PATCH_CHUNKS = NPIX * CPR;
+  static constexpr int PATCH_SLOTS = (PATCH_CHUNKS + 255) / 256;
+  static constexpr int W_CHUNKS = KS * KS * BN * CPR;
+  static constexpr int W_SLOTS = (W_CHUNKS + 255) / 256;
+  static constexpr int PATCH_BYTES = NPIX * RB;
+  static constexpr int LDS_BYTES = PATCH_BYTES + KS * KS * BN * RB;
+  static constexpr int ROWS_PER_BANKROW = 256 / RB;  // 4 (RB=64) or 2 (RB=128)
+  static __host__ __device__ constexpr int swz(int row) {
+    return (row / ROWS_PER_BANKROW) & (CPR - 1);
+  }
+};
+
+__device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+
+template <typename T> __device__ __forceinline__ void store4(T* dst, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* dst, const float (&v)[4]) {
+  half4 h;
+  h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+  *reinterpret_cast<half4*>(dst) = h;
+}
+template <> __device__ __forceinline__ void store4<float>(float* dst, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <typename T> __device__ __forceinline__ void load4(const T* src, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<_Float16>(const _Float16* src, float (&v)[4]) {
+  half4 h = *reinterpret_cast<const half4*>(src);
+  v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+}
+template <> __device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
+  float4 f = *reinterpret_cast<const float4*>(src);
+  v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+
+template <typename T, int KS, int STRIDE, int WN, int CPR>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGroup g) {
+  using Tile = ConvTile<T, KS, STRIDE, WN, CPR>;
+  using frag_t = typename Mma<T>::frag_t;
+  constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB;
+  constexpr int EPC = Tile::EPC, KC = Tile::KC;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_patch = smem;
+  char* lds_w = smem + Tile::PATCH_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware logical block id: blocks b and b+8 share an XCD (speed only, never correctness);
+  // give each XCD a contiguous run of logical blocks so that the cout tiles of one pixel tile
+  // (same input patch) and neighbouring pixel tiles (shared halo) meet in one L2.
+  int L;
+  {
+    const int b = blockIdx.x, nb = g.total_blocks;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.count && L >= g.p[i].block_begin) pi = i;
+  const ConvProblem& P = g.p[pi];
+
+  const int lb = L - P.block_begin;
+  const int ct = lb % P.n_ct;
+  const int pt = lb / P.n_ct;
+  const int tx = pt % P.tiles_x;
+  const int t2 = pt / P.tiles_x;
+  const int ty = t2 % P.tiles_y;
+  const int n = t2 / P.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;
+
+  const T* __restrict__ in = static_cast<const T*>(P.in);
+  const int nchunks = P.Cin / KC;
+
+  // ---- per-thread staging slots (loop invariant over K chunks) ----
+  long goff[Tile::PATCH_SLOTS];   // element offset of this slot's 16-B chunk, -1 = zero fill
+  int loff[Tile::PATCH_SLOTS];    // LDS byte offset, -1 = slot unused
+#pragma unroll
+  for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {
+    const int qid = tid + 256 * s;
+    const int p = qid / CPR, c = qid % CPR;
+    const int py = p / PW, px = p - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool used = qid < Tile::PATCH_CHUNKS;
+    const bool inb = used && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    goff[s] = inb ? ((long)(n * P.H + iy) * P.W + ix) * P.in_cstride + P.in_coff + c * EPC : -1;
+    loff[s] = used ? p * RB + ((c ^ Tile::swz(p)) << 4) : -1;
+  }
+  const uint4* __restrict__ wsrc =
+      reinterpret_cast<const uint4*>(P.wpack) + (size_t)ct * nchunks * Tile::W_CHUNKS + tid;
+
+  uint4 pre_p[Tile::PATCH_SLOTS];
+  uint4 pre_w[Tile::W_SLOTS];
+  // Register prefetch of one K chunk (global -> VGPR) and its commit (VGPR -> LDS). Macros, not
+  // lambdas: captured arrays defeat SROA and end up in scratch.
+#define GTX_PREFETCH(CHUNK)                                                                  \
+  {                                                                                          \
+    const int c0__ = (CHUNK) * KC;                                                           \
+    _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
+      uint4 v__ = make_uint4(0, 0, 0, 0);                                                    \
+      if (goff[s] >= 0) v__ = *reinterpret_cast<const uint4*>(in + goff[s] + c0__);          \
+      pre_p[s] = v__;                                                                        \
+    }                                                                                        \
+    const uint4* w__ = wsrc + (size_t)(CHUNK) * Tile::W_CHUNKS;                              \
+    _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
+      uint4 v__ = make_uint4(0, 0, 0, 0);                                                    \
+      if (Tile::W_CHUNKS % 256 == 0 || tid + 256 * s < Tile::W_CHUNKS) v__ = w__[256 * s];  \
+      pre_w[s] = v__;                                                                        \
+    }                                                                                        \
+  }
+#define GTX_COMMIT()                                                                         \
+  {                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
+      if (loff[s] >= 0) *reinterpret_cast<uint4*>(lds_patch + loff[s]) = pre_p[s];           \
+    }                                                                                        \
+    _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
+      if (Tile::W_CHUNKS % 256 == 0 || tid + 256 * s < Tile::W_CHUNKS)                       \
+        *reinterpret_cast<uint4*>(lds_w + (tid + 256 * s) * 16) = pre_w[s];                  \
+    }                                                                                        \
+  }
+
+  // ---- fragment addressing ----
+  const int prow = lane & 31, h = lane >> 5;
+  const int trow = 2 * wave + (prow >> 4), tcol = prow & 15;
+  const int p0 = trow * STRIDE * PW + tcol * STRIDE;
+
+  floatx16 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  GTX_PREFETCH(0)
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();   // previous chunk's fragment reads are done
+    GTX_COMMIT()
+    __syncthreads();
+    if (chunk + 1 < nchunks) GTX_PREFETCH(chunk + 1)
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int p = p0 + ky * PW + kx;
+        const int tap = ky * KS + kx;
+        const char* prow_ptr = lds_patch + p * RB;
+        const int pswz = Tile::swz(p);
+#pragma unroll
+        for (int ks = 0; ks < CPR / 2; ++ks) {
+          const int c = 2 * ks + h;
+          const frag_t bfrag = *reinterpret_cast<const frag_t*>(prow_ptr + ((c ^ pswz) << 4));
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int nrow = 32 * j + prow;
+            const frag_t afrag = *reinterpret_cast<const frag_t*>(
+                lds_w + (tap * BN + nrow) * RB + ((c ^ Tile::swz(nrow)) << 4));
+            Mma<T>::run(acc[j], afrag, bfrag);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + SiLU (+ residual) -> NHWC store, 4 consecutive channels per lane ----
+  const int oy = oy0 + trow, ox = ox0 + tcol;
+  if (oy < P.Ho && ox < P.Wo) {
+    const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
+    T* __restrict__ out = static_cast<T*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
+    const T* __restrict__ res =
+        P.res ? static_cast<const T*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+    const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = 32 * j + 8 * g4 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[j][4 * g4 + i] + (bias ? bias[cl + i] : 0.f);
+          if (P.act) v[i] = silu(v[i]);
+        }
+        if (res) {
+          float rv[4];
+          load4<T>(res + cl, rv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += rv[i];
+        }
+        store4<T>(out + cl, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout) {
+  ConvConfig c{};
+  c.dtype = dtype;
+  c.ks = ks;
+  c.stride = stride;
+  const int epc = dtype == DT_F16 ? 8 : 4;
+  int cpr = 4;
+  if (ks == 1 && cin % (8 * epc) == 0) cpr = 8;
+  c.kc = cpr * epc;
+  c.bn = (cout % 64 == 0) ? 64 : 32;
+  GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
+  GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
+  GTX_CHECK((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1),
+            "conv: unsupported kernel %dx%d stride %d", ks, ks, stride);
+  return c;
+}
+
+namespace {
+inline uint16_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+}  // namespace
+
+std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg) {
+  const int es = (int)dtype_size(cfg.dtype);
+  const int epc = 16 / es;
+  const int cpr = cfg.kc / epc;
+  const int rb = cpr * 16;
+  const int rows_per_bankrow = 256 / rb;
+  const int taps = cfg.ks * cfg.ks;
+  const int n_ct = cout / cfg.bn, nchunks = cin / cfg.kc;
+  std::vector<uint8_t> out((size_t)cout * taps * cin * es);
+  for (int ct = 0; ct < n_ct; ++ct)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int n = 0; n < cfg.bn; ++n)
+          for (int c = 0; c < cpr; ++c) {
+            const int cs = c ^ ((n / rows_per_bankrow) & (cpr - 1));
+            const size_t dst16 = ((((size_t)ct * nchunks + ch) * taps + tap) * cfg.bn + n) * cpr + cs;
+            for (int e = 0; e < epc; ++e) {
+              const int ci = ch * cfg.kc + c * epc + e;
+              const float v = w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci];
+              if (cfg.dtype == DT_F16) {
+                const uint16_t hb = f32_to_f16_bits(v);
+                memcpy(&out[dst16 * 16 + e * 2], &hb, 2);
+              } else {
+                memcpy(&out[dst16 * 16 + e * 4], &v, 4);
+              }
+            }
+          }
+  return out;
+}
+
+void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
+  int total = 0;
+  for (int i = 0; i < g.count; ++i) {
+    ConvProblem& p = g.p[i];
+    p.tiles_x = cdiv(p.Wo, 16);
+    p.tiles_y = cdiv(p.Ho, 8);
+    p.n_ct = p.Cout / cfg.bn;
+    p.block_begin = total;
+    total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
+  }
+  g.total_blocks = total;
+}
+
+double conv_flops(const ConvProblem& p, int ks) {
+  return 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * p.Cin * ks * ks;
+}
+
+namespace {
+template <typename T, int KS, int STRIDE, int WN, int CPR>
+void launch_t(const ConvGroup& g, hipStream_t stream) {
+  using Tile = ConvTile<T, KS, STRIDE, WN, CPR>;
+  auto kern = conv_igemm_kernel<T, KS, STRIDE, WN, CPR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
+  GTX_HIP(hipGetLastError());
+}
+
+template <typename T>
+void launch_dt(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
+  const int cpr = c.kc * (int)sizeof(T) / 16;
+  const int wn = c.bn / 32;
+#define GTX_CASE(KS, ST, WN, CPR) \
+  if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR) return launch_t<T, KS, ST, WN, CPR>(g, s);
+  GTX_CASE(3, 1, 1, 4) GTX_CASE(3, 1, 2, 4)
+  GTX_CASE(3, 2, 1, 4) GTX_CASE(3, 2, 2, 4)
+  GTX_CASE(1, 1, 1, 4) GTX_CASE(1, 1, 2, 4)
+  GTX_CASE(1, 1, 1, 8) GTX_CASE(1, 1, 2, 8)
+#undef GTX_CASE
+  fail(-3, "conv: no kernel for ks=%d stride=%d bn=%d kc=%d", c.ks, c.stride, c.bn, c.kc);
+}
+}  // namespace
+
+void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) {
+  GTX_CHECK(g.count >= 1 && g.count <= kMaxGroup, "conv: bad group size %d", g.count);
+  if (g.total_blocks == 0) return;
+  if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
+  else launch_dt<float>(g, cfg, stream);
+}
+
+const char* conv_kernel_name(const ConvConfig& c) {
+  static thread_local char buf[96];
+  snprintf(buf, sizeof buf, "conv_igemm_kernel<%s, %d, %d, %d, %d>", c.dtype == DT_F16 ? "_Float16" : "float",
+           c.ks, c.stride, c.bn / 32, c.kc * (int)dtype_size(c.dtype) / 16);
+  return buf;
+}
+
+}  // namespace gtx

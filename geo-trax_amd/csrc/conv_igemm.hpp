@@ -1,0 +1,78 @@
+// Implicit-GEMM convolution for the YOLOv8 Conv block (conv + folded BN + SiLU),
+// MI355X / gfx950. Replaces what ultralytics' `Conv.forward_fuse` computes per layer
+// (reached from the reference at geotrax/extract.py:153).
+//
+// Data layout in HBM
+//   activations : NHWC, element type T (fp16 or fp32), addressed as
+//                 base + ((n*H + y)*W + x)*cstride + coff + c  -- cstride/coff let a conv
+//                 read a channel slice of, or write straight into, a concat buffer
+//                 (C2f / SPPF / FPN concats never materialise as copies).
+//   weights     : pre-packed by pack_conv_weights() into the exact LDS image the kernel
+//                 stages per (cout tile, cin chunk): [tap][n][swizzled 16-B chunk].
+//   bias        : fp32 [Cout].
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+
+namespace gtx {
+
+enum DType : int { DT_F16 = 0, DT_F32 = 1 };
+inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : 4; }
+
+// One convolution problem. Plain-old-data; copied into kernarg space.
+struct ConvProblem {
+  const void* in;       // NHWC input
+  void* out;            // NHWC output
+  const void* wpack;    // packed weights (see pack_conv_weights)
+  const float* bias;    // [Cout] fp32 (may be null -> 0)
+  const void* res;      // optional residual, same spatial dims as out (may be null)
+  int N, H, W;          // input batch / spatial
+  int Ho, Wo;           // output spatial
+  int Cin, Cout;
+  int in_cstride, in_coff;
+  int out_cstride, out_coff;
+  int res_cstride, res_coff;
+  int act;              // 1 = SiLU, 0 = identity
+  int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8)
+  int n_ct;             // cout tiles (Cout / BN)
+  int block_begin;      // first logical block of this problem inside a grouped launch
+};
+
+constexpr int kMaxGroup = 8;
+struct ConvGroup {
+  ConvProblem p[kMaxGroup];
+  int count;
+  int total_blocks;
+};
+
+// Kernel family selector; every member of a grouped launch shares one config.
+struct ConvConfig {
+  int dtype;   // DType
+  int ks;      // 1 or 3
+  int stride;  // 1 or 2
+  int bn;      // cout tile: 32, 64 or 128
+  int kc;      // cin elements staged per K chunk
+};
+
+// Picks the tile configuration used for a layer shape.
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout);
+
+// Host-side weight packing: w is [Cout][KS][KS][Cin] fp32 (OHWI). Returns the packed
+// byte image for `cfg` (element type per cfg.dtype).
+std::vector<uint8_t> pack_conv_weights(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg);
+
+// Fills tiles_x/tiles_y/n_ct/block_begin/total_blocks for a group.
+void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg);
+
+// Launch one grouped conv on `stream`.
+void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
+
+// Algorithmic FLOPs (2*MAC) of a problem.
+double conv_flops(const ConvProblem& p, int ks);
+
+// Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
+const char* conv_kernel_name(const ConvConfig& cfg);
+
+}  // namespace gtx

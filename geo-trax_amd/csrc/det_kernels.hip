@@ -1,0 +1,671 @@
+// Non-GEMM detector kernels for gfx950. Behaviour specifications are restated in
+// oracle/yolov8_ref.py (the checker); the third-party calls they stand in for are listed in
+// SURVEY.md §2b (K2 preprocess, K3 stem/SPPF/upsample, K4 decode + NMS).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+
+#include "det_kernels.hpp"
+
+namespace gtx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// ============================================================================ letterbox
+namespace {
+// Python's round(): ties to even.
+inline double py_round(double v) { return std::nearbyint(v); }
+}  // namespace
+
+Letterbox letterbox_geometry(int src_h, int src_w, int imgsz, bool rect, int stride) {
+  Letterbox lb{};
+  lb.src_h = src_h;
+  lb.src_w = src_w;
+  const double r = std::min((double)imgsz / src_h, (double)imgsz / src_w);
+  lb.new_w = (int)py_round(src_w * r);
+  lb.new_h = (int)py_round(src_h * r);
+  double dw = imgsz - lb.new_w, dh = imgsz - lb.new_h;
+  if (rect) {
+    dw = std::fmod(dw, (double)stride);
+    dh = std::fmod(dh, (double)stride);
+  }
+  dw /= 2;
+  dh /= 2;
+  const int top = (int)py_round(dh - 0.1), bottom = (int)py_round(dh + 0.1);
+  const int left = (int)py_round(dw - 0.1), right = (int)py_round(dw + 0.1);
+  lb.top = top;
+  lb.left = left;
+  lb.net_h = lb.new_h + top + bottom;
+  lb.net_w = lb.new_w + left + right;
+  lb.gain = std::min((double)lb.net_h / src_h, (double)lb.net_w / src_w);
+  return lb;
+}
+
+// ============================================================================ preprocess
+// cv2.cvtColor(BGR2GRAY) 8-bit fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+__device__ __forceinline__ int bgr2gray(int b, int g, int r) {
+  return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;
+}
+
+template <typename T> __device__ __forceinline__ void store_rgb0(T* dst, float r, float g, float b);
+template <> __device__ __forceinline__ void store_rgb0<_Float16>(_Float16* dst, float r, float g, float b) {
+  half4 v;
+  v[0] = (_Float16)r; v[1] = (_Float16)g; v[2] = (_Float16)b; v[3] = (_Float16)0.f;
+  *reinterpret_cast<half4*>(dst) = v;
+}
+template <> __device__ __forceinline__ void store_rgb0<float>(float* dst, float r, float g, float b) {
+  *reinterpret_cast<float4*>(dst) = make_float4(r, g, b, 0.f);
+}
+
+struct PreParams {
+  const uint8_t* frames;
+  void* img;
+  uint8_t* gray;
+  int src_h, src_w, net_h, net_w, new_h, new_w, top, left, gh, gw;
+  int exact2x;       // new == src/2: cv2.resize INTER_LINEAR degenerates to the rounded 2x2 mean
+  float scale_x, scale_y;  // src/new for the general bilinear path
+};
+
+// One thread per network-input pixel. Exact-2x path: out = (a+b+c+d+2)>>2 per channel, which is
+// what cv2.resize(INTER_LINEAR) yields for an exact 0.5 scale (OpenCV switches to its 2x2 area
+// kernel; the fixed-point bilinear gives the same integers). General path: OpenCV's 11-bit
+// fixed-point bilinear [restated from memory of resize.cpp -- unverified against cv2 here].
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  const int n = blockIdx.z;
+  if (ox >= p.net_w) return;
+  const uint8_t* __restrict__ src = p.frames + (size_t)n * p.src_h * p.src_w * 3;
+  T* __restrict__ dst = static_cast<T*>(p.img) + (((size_t)n * p.net_h + oy) * p.net_w + ox) * 4;
+  const int ry = oy - p.top, rx = ox - p.left;
+  if (ry < 0 || ry >= p.new_h || rx < 0 || rx >= p.new_w) {
+    const float pad = 114.f / 255.f;
+    store_rgb0<T>(dst, pad, pad, pad);
+    return;
+  }
+  int B, G, R;
+  if (p.exact2x) {
+    const uint8_t* r0 = src + ((size_t)(2 * ry) * p.src_w + 2 * rx) * 3;
+    const uint8_t* r1 = r0 + (size_t)p.src_w * 3;
+    B = (r0[0] + r0[3] + r1[0] + r1[3] + 2) >> 2;
+    G = (r0[1] + r0[4] + r1[1] + r1[4] + 2) >> 2;
+    R = (r0[2] + r0[5] + r1[2] + r1[5] + 2) >> 2;
+    if (p.gray) {
+      const int g00 = bgr2gray(r0[0], r0[1], r0[2]), g01 = bgr2gray(r0[3], r0[4], r0[5]);
+      const int g10 = bgr2gray(r1[0], r1[1], r1[2]), g11 = bgr2gray(r1[3], r1[4], r1[5]);
+      p.gray[((size_t)n * p.gh + ry) * p.gw + rx] = (uint8_t)((g00 + g01 + g10 + g11 + 2) >> 2);
+    }
+  } else {
+    float fx = (rx + 0.5f) * p.scale_x - 0.5f;
+    float fy = (ry + 0.5f) * p.scale_y - 0.5f;
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= sx;
+    fy -= sy;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= p.src_w - 1) { sx = p.src_w - 1; fx = 0.f; }
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    if (sy >= p.src_h - 1) { sy = p.src_h - 1; fy = 0.f; }
+    const int sx1 = min(sx + 1, p.src_w - 1), sy1 = min(sy + 1, p.src_h - 1);
+    const int a1 = __float2int_rn(fx * 2048.f), a0 = __float2int_rn((1.f - fx) * 2048.f);
+    const int b1 = __float2int_rn(fy * 2048.f), b0 = __float2int_rn((1.f - fy) * 2048.f);
+    const uint8_t* r0 = src + (size_t)sy * p.src_w * 3;
+    const uint8_t* r1 = src + (size_t)sy1 * p.src_w * 3;
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+      const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+      v[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    }
+    B = v[0]; G = v[1]; R = v[2];
+  }
+  store_rgb0<T>(dst, (float)R / 255.f, (float)G / 255.f, (float)B / 255.f);
+}
+
+// Gray-only pass for frames whose letterbox is not the exact-2x case but the stabilizer still
+// wants full-res gray -> 2x2 mean.
+__global__ __launch_bounds__(256) void gray_half_kernel(const uint8_t* __restrict__ frames, int n_img,
+                                                        int h, int w, uint8_t* __restrict__ gray,
+                                                        int gh, int gw) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+  if (x >= gw) return;
+  const uint8_t* r0 = frames + ((size_t)n * h * w + (size_t)(2 * y) * w + 2 * x) * 3;
+  const uint8_t* r1 = r0 + (size_t)w * 3;
+  const int g00 = bgr2gray(r0[0], r0[1], r0[2]), g01 = bgr2gray(r0[3], r0[4], r0[5]);
+  const int g10 = bgr2gray(r1[0], r1[1], r1[2]), g11 = bgr2gray(r1[3], r1[4], r1[5]);
+  gray[((size_t)n * gh + y) * gw + x] = (uint8_t)((g00 + g01 + g10 + g11 + 2) >> 2);
+}
+
+void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox& lb, void* img,
+                       uint8_t* gray, int gh, int gw, hipStream_t s) {
+  PreParams p{};
+  p.frames = frames;
+  p.img = img;
+  p.src_h = lb.src_h; p.src_w = lb.src_w;
+  p.net_h = lb.net_h; p.net_w = lb.net_w;
+  p.new_h = lb.new_h; p.new_w = lb.new_w;
+  p.top = lb.top; p.left = lb.left;
+  p.gh = gh; p.gw = gw;
+  p.exact2x = (lb.new_h * 2 == lb.src_h && lb.new_w * 2 == lb.src_w) ? 1 : 0;
+  p.scale_x = (float)((double)lb.src_w / lb.new_w);
+  p.scale_y = (float)((double)lb.src_h / lb.new_h);
+  const bool fuse_gray = gray && p.exact2x && gh == lb.new_h && gw == lb.new_w;
+  p.gray = fuse_gray ? gray : nullptr;
+  dim3 grid(cdiv(lb.net_w, 256), lb.net_h, n);
+  if (dtype == DT_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, s, p);
+  GTX_HIP(hipGetLastError());
+  if (gray && !fuse_gray) {
+    GTX_CHECK(gh * 2 == lb.src_h && gw * 2 == lb.src_w, "gray output must be half the frame size");
+    hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(gw, 256), gh, n), dim3(256), 0, s, frames, n,
+                       lb.src_h, lb.src_w, gray, gh, gw);
+    GTX_HIP(hipGetLastError());
+  }
+}
+
+// ============================================================================ stem conv
+__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+
+template <typename T> __device__ __forceinline__ void load_px4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load_px4<_Float16>(const _Float16* p, float (&v)[4]) {
+  half4 h = *reinterpret_cast<const half4*>(p);
+  v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+}
+template <> __device__ __forceinline__ void load_px4<float>(const float* p, float (&v)[4]) {
+  float4 f = *reinterpret_cast<const float4*>(p);
+  v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
+template <> __device__ __forceinline__ void store8<_Float16>(_Float16* dst, const float* v) {
+  half8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i];
+  *reinterpret_cast<half8*>(dst) = h;
+}
+template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
+  reinterpret_cast<float4*>(dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// One thread = one output pixel, all C0 output channels (direct 27-tap conv on the VALU; the
+// layer is bound by its 2*C0-byte-per-pixel store, not by arithmetic). Weights are read through
+// wave-uniform addresses, i.e. the scalar cache.
+template <typename T, int C0>
+__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ img, int h, int w,
+                                                   const float* __restrict__ w27,
+                                                   const float* __restrict__ bias, T* __restrict__ out,
+                                                   int ho, int wo) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  if (ox >= wo) return;
+  float acc[C0];
+#pragma unroll
+  for (int c = 0; c < C0; ++c) acc[c] = bias[c];
+  const T* base = img + (size_t)n * h * w * 4;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      float px[4] = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < h && ix >= 0 && ix < w) load_px4<T>(base + ((size_t)iy * w + ix) * 4, px);
+      const float* wt = w27 + (ky * 3 + kx) * 3 * C0;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int c = 0; c < C0; ++c) acc[c] = fmaf(px[ci], wt[ci * C0 + c], acc[c]);
+    }
+  }
+  T* o = out + (((size_t)n * ho + oy) * wo + ox) * C0;
+#pragma unroll
+  for (int c = 0; c < C0; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(acc[c + i]);
+    store8<T>(o + c, v);
+  }
+}
+
+void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
+                 int c0, void* out, int ho, int wo, hipStream_t s) {
+  dim3 grid(cdiv(wo, 256), ho, n), block(256);
+#define GTX_STEM(C)                                                                              \
+  if (c0 == C) {                                                                                 \
+    if (dtype == DT_F16)                                                                         \
+      hipLaunchKernelGGL((stem_kernel<_Float16, C>), grid, block, 0, s, (const _Float16*)img, h, \
+                         w, w27, bias, (_Float16*)out, ho, wo);                                  \
+    else                                                                                         \
+      hipLaunchKernelGGL((stem_kernel<float, C>), grid, block, 0, s, (const float*)img, h, w,    \
+                         w27, bias, (float*)out, ho, wo);                                        \
+    GTX_HIP(hipGetLastError());                                                                  \
+    return;                                                                                      \
+  }
+  GTX_STEM(16) GTX_STEM(32) GTX_STEM(48) GTX_STEM(64) GTX_STEM(80)
+#undef GTX_STEM
+  fail(-3, "stem: unsupported channel count %d", c0);
+}
+
+// ============================================================================ SPPF pools
+template <typename T> struct Vec16;  // 16-byte vector of T
+template <> struct Vec16<_Float16> { using type = half8; static constexpr int N = 8; };
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h, int w, int c) {
+  constexpr int VN = Vec16<T>::N;
+  const int vecs = c / VN;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)gridDim.y * h * w * vecs;  // gridDim.y = batch handled via blockIdx.y
+  (void)total;
+  const int n = blockIdx.y;
+  if (gid >= (long)h * w * vecs) return;
+  const int v = (int)(gid % vecs);
+  const int pix = (int)(gid / vecs);
+  const int py = pix / w, px = pix % w;
+  const int cs = 4 * c;
+  T* img = x + (size_t)n * h * w * cs;
+  float m5[VN], m9[VN], m13[VN];
+#pragma unroll
+  for (int i = 0; i < VN; ++i) m5[i] = m9[i] = m13[i] = -INFINITY;
+  for (int dy = -6; dy <= 6; ++dy) {
+    const int yy = py + dy;
+    if (yy < 0 || yy >= h) continue;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int xx = px + dx;
+      if (xx < 0 || xx >= w) continue;
+      const T* src = img + ((size_t)yy * w + xx) * cs + v * VN;
+      float f[VN];
+      if constexpr (VN == 8) {
+        half8 hv = *reinterpret_cast<const half8*>(src);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)hv[i];
+      } else {
+        float4 fv = *reinterpret_cast<const float4*>(src);
+        f[0] = fv.x; f[1] = fv.y; f[2] = fv.z; f[3] = fv.w;
+      }
+      const int ad = max(abs(dy), abs(dx));
+#pragma unroll
+      for (int i = 0; i < VN; ++i) {
+        m13[i] = fmaxf(m13[i], f[i]);
+        if (ad <= 4) m9[i] = fmaxf(m9[i], f[i]);
+        if (ad <= 2) m5[i] = fmaxf(m5[i], f[i]);
+      }
+    }
+  }
+  T* dst = img + ((size_t)py * w + px) * cs + v * VN;
+  if constexpr (VN == 8) {
+    store8<T>(dst + c, m5);
+    store8<T>(dst + 2 * c, m9);
+    store8<T>(dst + 3 * c, m13);
+  } else {
+    *reinterpret_cast<float4*>(dst + c) = make_float4(m5[0], m5[1], m5[2], m5[3]);
+    *reinterpret_cast<float4*>(dst + 2 * c) = make_float4(m9[0], m9[1], m9[2], m9[3]);
+    *reinterpret_cast<float4*>(dst + 3 * c) = make_float4(m13[0], m13[1], m13[2], m13[3]);
+  }
+}
+
+void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s) {
+  const int vn = dtype == DT_F16 ? 8 : 4;
+  GTX_CHECK(c % vn == 0, "sppf: channels %d not a multiple of %d", c, vn);
+  const long work = (long)h * w * (c / vn);
+  dim3 grid((unsigned)((work + 255) / 256), n), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, grid, block, 0, s, (_Float16*)x, h, w, c);
+  else hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, block, 0, s, (float*)x, h, w, c);
+  GTX_HIP(hipGetLastError());
+}
+
+// ============================================================================ upsample
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint4* __restrict__ x, int h, int w,
+                                                         int vecs, int in_vstride, int in_voff,
+                                                         uint4* __restrict__ y, int out_vstride,
+                                                         int out_voff) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  const int ho = 2 * h, wo = 2 * w;
+  if (gid >= (long)ho * wo * vecs) return;
+  const int v = (int)(gid % vecs);
+  const int pix = (int)(gid / vecs);
+  const int oy = pix / wo, ox = pix % wo;
+  const uint4 val = x[((size_t)(n * h + (oy >> 1)) * w + (ox >> 1)) * in_vstride + in_voff + v];
+  y[((size_t)(n * ho + oy) * wo + ox) * out_vstride + out_voff + v] = val;
+}
+
+void launch_upsample2x(int dtype, const void* x, int n, int h, int w, int c, int in_cstride,
+                       int in_coff, void* y, int out_cstride, int out_coff, hipStream_t s) {
+  const int vn = dtype == DT_F16 ? 8 : 4;
+  GTX_CHECK(c % vn == 0 && in_cstride % vn == 0 && in_coff % vn == 0 && out_cstride % vn == 0 &&
+                out_coff % vn == 0, "upsample: channel layout must be 16-byte aligned");
+  const long work = (long)4 * h * w * (c / vn);
+  dim3 grid((unsigned)((work + 255) / 256), n), block(256);
+  hipLaunchKernelGGL(upsample2x_kernel, grid, block, 0, s, (const uint4*)x, h, w, c / vn,
+                     in_cstride / vn, in_coff / vn, (uint4*)y, out_cstride / vn, out_coff / vn);
+  GTX_HIP(hipGetLastError());
+}
+
+// ============================================================================ head decode
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+
+__device__ __forceinline__ int find_level(const HeadParams& hp, int a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; ++i)
+    if (i < hp.n_levels && a >= hp.lv[i].anchor_begin) l = i;
+  return l;
+}
+
+// Class branch: final 1x1 conv (nc x cc) + sigmoid + max over classes, per anchor.
+template <typename T>
+__device__ __forceinline__ void anchor_cls(const HeadParams& hp, const HeadLevel& L, const T* f,
+                                           float& best, int& best_c) {
+  best = -1.f;
+  best_c = 0;
+  const T* fc = f + L.cb;
+  for (int c0 = 0; c0 < hp.nc; c0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (c0 + j < hp.nc) ? L.bc[c0 + j] : 0.f;
+    for (int k = 0; k < L.cc; ++k) {
+      const float v = ldf(fc + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < hp.nc) acc[j] = fmaf(v, L.wc[(c0 + j) * L.cc + k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (c0 + j < hp.nc) {
+        const float sc = 1.f / (1.f + expf(-acc[j]));
+        if (sc > best) { best = sc; best_c = c0 + j; }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams hp, const NmsBuffers nb) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (a >= hp.n_anchors) return;
+  const int l = find_level(hp, a);
+  const HeadLevel& L = hp.lv[l];
+  const int la = a - L.anchor_begin;
+  const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
+  float best;
+  int best_c;
+  anchor_cls<T>(hp, L, f, best, best_c);
+  if (best > hp.conf && ((hp.class_mask >> best_c) & 1ull)) {
+    const int idx = atomicAdd(&nb.count[n], 1);
+    if (idx < nb.cap) {
+      const size_t o = (size_t)n * nb.cap + idx;
+      nb.cand_score[o] = best;
+      nb.cand_anchor[o] = a;
+      nb.cand_cls[o] = best_c;
+    }
+  }
+}
+
+// Box branch for one anchor by one wave: 64 box logits (lane = side*16 + bin), DFL softmax
+// expectation per side, dist2bbox(xywh) * stride. Returns xywh in network pixels on every lane.
+template <typename T>
+__device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int la, int lane) {
+  float acc = L.bb[lane];
+  const float* wr = L.wb + (size_t)lane * L.cb;
+  for (int k = 0; k < L.cb; ++k) acc = fmaf(ldf(f + k), wr[k], acc);
+  // softmax over the 16 lanes of a side
+  float m = acc;
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float e = expf(acc - m);
+  float se = e, sw = e * (float)(lane & 15);
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) {
+    se += __shfl_xor(se, o, 64);
+    sw += __shfl_xor(sw, o, 64);
+  }
+  const float d = sw / se;
+  const float d0 = __shfl(d, 0, 64), d1 = __shfl(d, 16, 64), d2 = __shfl(d, 32, 64), d3 = __shfl(d, 48, 64);
+  const float ax = (float)(la % L.w) + 0.5f, ay = (float)(la / L.w) + 0.5f;
+  const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
+  return make_float4((x1 + x2) * 0.5f * L.stride, (y1 + y2) * 0.5f * L.stride, (x2 - x1) * L.stride,
+                     (y2 - y1) * L.stride);
+}
+
+// One wave per candidate.
+template <typename T>
+__global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, const NmsBuffers nb) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int cnt = min(nb.count[n], nb.cap);
+  for (int i = wave_g; i < cnt; i += nwaves) {
+    const size_t o = (size_t)n * nb.cap + i;
+    const int a = nb.cand_anchor[o];
+    const int l = find_level(hp, a);
+    const HeadLevel& L = hp.lv[l];
+    const int la = a - L.anchor_begin;
+    const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
+    const float4 b = anchor_box<T>(L, f, la, lane);
+    if (lane == 0) {
+      const float hw = b.z / 2.f, hh = b.w / 2.f;   // xywh2xyxy
+      reinterpret_cast<float4*>(nb.cand_box)[o] = make_float4(b.x - hw, b.y - hh, b.x + hw, b.y + hh);
+    }
+  }
+}
+
+// Debug / parity: full decode of every anchor -> [A][4+nc].
+template <typename T>
+__global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (a >= hp.n_anchors) return;
+  const int l = find_level(hp, a);
+  const HeadLevel& L = hp.lv[l];
+  const int la = a - L.anchor_begin;
+  const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
+  const float4 b = anchor_box<T>(L, f, la, lane);
+  float* o = out + ((size_t)n * hp.n_anchors + a) * (4 + hp.nc);
+  if (lane == 0) { o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; }
+  const T* fc = f + L.cb;
+  for (int c = lane; c < hp.nc; c += 64) {
+    float acc = L.bc[c];
+    for (int k = 0; k < L.cc; ++k) acc = fmaf(ldf(fc + k), L.wc[c * L.cc + k], acc);
+    o[4 + c] = 1.f / (1.f + expf(-acc));
+  }
+}
+
+void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
+  GTX_HIP(hipMemsetAsync(nb.count, 0, sizeof(int) * n, s));
+  dim3 grid(cdiv(hp.n_anchors, 256), n), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(head_candidates_kernel<_Float16>, grid, block, 0, s, hp, nb);
+  else hipLaunchKernelGGL(head_candidates_kernel<float>, grid, block, 0, s, hp, nb);
+  GTX_HIP(hipGetLastError());
+  dim3 grid2(64, n);
+  if (dtype == DT_F16) hipLaunchKernelGGL(head_boxes_kernel<_Float16>, grid2, block, 0, s, hp, nb);
+  else hipLaunchKernelGGL(head_boxes_kernel<float>, grid2, block, 0, s, hp, nb);
+  GTX_HIP(hipGetLastError());
+}
+
+void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, hipStream_t s) {
+  dim3 grid(cdiv(hp.n_anchors * 64, 256), n), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(head_raw_kernel<_Float16>, grid, block, 0, s, hp, out);
+  else hipLaunchKernelGGL(head_raw_kernel<float>, grid, block, 0, s, hp, out);
+  GTX_HIP(hipGetLastError());
+}
+
+// ============================================================================ NMS
+// (1) rank: position of each candidate in (score desc, anchor asc) order = stable descending
+//     sort of the anchor-ordered candidate list, which is what torchvision.ops.nms applies to
+//     the boolean-mask-filtered predictions. O(n^2) counting, keys tiled through LDS.
+__global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int limit, float cls_offset) {
+  __shared__ float s_sc[256];
+  __shared__ int s_an[256];
+  const int n = blockIdx.y;
+  const int cnt = min(nb.count[n], nb.cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x >= cnt) return;  // whole block idle
+  const size_t base = (size_t)n * nb.cap;
+  const bool act = i < cnt;
+  const float si = act ? nb.cand_score[base + i] : 0.f;
+  const int ai = act ? nb.cand_anchor[base + i] : 0;
+  int rank = 0;
+  for (int t0 = 0; t0 < cnt; t0 += 256) {
+    const int j = t0 + threadIdx.x;
+    s_sc[threadIdx.x] = j < cnt ? nb.cand_score[base + j] : -1.f;
+    s_an[threadIdx.x] = j < cnt ? nb.cand_anchor[base + j] : 0x7fffffff;
+    __syncthreads();
+    const int lim = min(256, cnt - t0);
+    for (int k = 0; k < lim; ++k) {
+      const float sj = s_sc[k];
+      rank += (sj > si || (sj == si && s_an[k] < ai)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) nb.sorted_n[n] = min(cnt, limit);
+  if (act && rank < limit) {
+    const size_t so = (size_t)n * nb.nms_cap + rank;
+    const float4 b = reinterpret_cast<const float4*>(nb.cand_box)[base + i];
+    const int c = nb.cand_cls[base + i];
+    reinterpret_cast<float4*>(nb.s_box)[so] = b;
+    nb.s_score[so] = si;
+    nb.s_cls[so] = c;
+    (void)cls_offset;
+  }
+}
+
+// (2) suppression bit matrix, upper triangle: bit j of mask[i][j/64] = IoU(i,j) > thr, j > i.
+//     Persistent grid over (row, word) work items.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const NmsBuffers nb, float thr, float cls_offset) {
+  const int n = blockIdx.y;
+  const int cnt = nb.sorted_n[n];
+  const int nwords = (cnt + 63) >> 6;
+  const int rs = nb.nms_cap >> 6;
+  const float4* boxes = reinterpret_cast<const float4*>(nb.s_box) + (size_t)n * nb.nms_cap;
+  const int* cls = nb.s_cls + (size_t)n * nb.nms_cap;
+  unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * rs;
+  const long total = (long)cnt * nwords;
+  for (long wi = (long)blockIdx.x * blockDim.x + threadIdx.x; wi < total; wi += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(wi / nwords), w = (int)(wi % nwords);
+    unsigned long long bits = 0ull;
+    if (w * 64 + 63 > i) {
+      float4 bi = boxes[i];
+      const float oi = cls_offset * (float)cls[i];
+      bi.x += oi; bi.y += oi; bi.z += oi; bi.w += oi;
+      const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+      const int j0 = w * 64;
+      const int jend = min(64, cnt - j0);
+      for (int k = 0; k < jend; ++k) {
+        const int j = j0 + k;
+        if (j <= i) continue;
+        float4 bj = boxes[j];
+        const float oj = cls_offset * (float)cls[j];
+        bj.x += oj; bj.y += oj; bj.z += oj; bj.w += oj;
+        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+        const float iw = fmaxf(0.f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
+        const float ih = fmaxf(0.f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
+        const float inter = iw * ih;
+        const float ovr = inter / (ai + aj - inter);
+        if (ovr > thr) bits |= 1ull << k;
+      }
+    }
+    mask[(size_t)i * rs + w] = bits;
+  }
+}
+
+// (3) greedy sweep, one wave per image; the removed-bitmap lives in registers (word w on lane
+//     w&63, slot w>>6). Mask rows are prefetched LA rows ahead so the serial chain never waits
+//     on L2. (4) kept rows are mapped back to frame pixels (ultralytics scale_boxes + clip).
+template <int SLOTS>
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const NmsBuffers nb, float gain, float padx,
+                                                       float pady, float fw, float fh) {
+  constexpr int LA = 4;
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int cnt = nb.sorted_n[n];
+  const int nwords = (cnt + 63) >> 6;
+  const int rs = nb.nms_cap >> 6;
+  const unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * rs;
+  unsigned long long rem[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) rem[s] = 0ull;
+  unsigned long long cur[LA][SLOTS], nxt[LA][SLOTS];
+  auto load_rows = [&](unsigned long long (&dst)[LA][SLOTS], int base) {
+#pragma unroll
+    for (int k = 0; k < LA; ++k)
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int w = 64 * s + lane;
+        dst[k][s] = (base + k < cnt && w < nwords) ? mask[(size_t)(base + k) * rs + w] : 0ull;
+      }
+  };
+  int nkeep = 0;
+  const float4* boxes = reinterpret_cast<const float4*>(nb.s_box) + (size_t)n * nb.nms_cap;
+  float* rows = nb.out_rows + (size_t)n * nb.max_det * 6;
+  load_rows(cur, 0);
+  for (int base = 0; base < cnt && nkeep < nb.max_det; base += LA) {
+    load_rows(nxt, base + LA);
+#pragma unroll
+    for (int k = 0; k < LA; ++k) {
+      const int i = base + k;
+      if (i < cnt && nkeep < nb.max_det) {
+        const int w = i >> 6;
+        unsigned long long word = 0ull;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          if ((w >> 6) == s) word = __shfl(rem[s], w & 63, 64);
+        if (!((word >> (i & 63)) & 1ull)) {
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) rem[s] |= cur[k][s];
+          if (lane == 0) {
+            float4 b = boxes[i];
+            b.x = (b.x - padx) / gain; b.y = (b.y - pady) / gain;
+            b.z = (b.z - padx) / gain; b.w = (b.w - pady) / gain;
+            b.x = fminf(fmaxf(b.x, 0.f), fw); b.z = fminf(fmaxf(b.z, 0.f), fw);
+            b.y = fminf(fmaxf(b.y, 0.f), fh); b.w = fminf(fmaxf(b.w, 0.f), fh);
+            float* r = rows + (size_t)nkeep * 6;
+            r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
+            r[4] = nb.s_score[(size_t)n * nb.nms_cap + i];
+            r[5] = (float)nb.s_cls[(size_t)n * nb.nms_cap + i];
+          }
+          ++nkeep;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LA; ++k)
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) cur[k][s] = nxt[k][s];
+  }
+  if (lane == 0) nb.out_n[n] = nkeep;
+}
+
+void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
+                const Letterbox& lb, hipStream_t s) {
+  const int limit = std::min(max_nms, nb.nms_cap);
+  const float cls_offset = agnostic ? 0.f : 7680.f;  // ultralytics max_wh
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(nb.cap, 256), n), dim3(256), 0, s, nb, limit, cls_offset);
+  GTX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(128, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
+  GTX_HIP(hipGetLastError());
+  // ultralytics scale_boxes: gain = min ratio, pad = round((net - src*gain)/2 - 0.1)
+  const double gain = lb.gain;
+  const float padx = (float)std::nearbyint((lb.net_w - lb.src_w * gain) / 2 - 0.1);
+  const float pady = (float)std::nearbyint((lb.net_h - lb.src_h * gain) / 2 - 0.1);
+  const int slots = cdiv(nb.nms_cap, 64 * 64);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, s, nb, (float)gain, padx, pady, (float)lb.src_w,
+                       (float)lb.src_h);
+  };
+  if (slots <= 1) go(nms_sweep_kernel<1>);
+  else if (slots <= 2) go(nms_sweep_kernel<2>);
+  else if (slots <= 4) go(nms_sweep_kernel<4>);
+  else if (slots <= 8) go(nms_sweep_kernel<8>);
+  else fail(-3, "nms: capacity %d too large", nb.nms_cap);
+  GTX_HIP(hipGetLastError());
+}
+
+}  // namespace gtx

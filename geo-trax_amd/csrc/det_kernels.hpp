@@ -1,0 +1,85 @@
+// Non-GEMM kernels of the detector: letterbox/normalise (+gray), the 3-channel stem conv,
+// SPPF pooling, nearest upsample, head decode (final 1x1 convs + DFL + sigmoid + threshold +
+// compaction) and NMS. gfx950 only. Host launch wrappers; kernels live in det_kernels.hip.
+#pragma once
+#include "common.hpp"
+#include "conv_igemm.hpp"
+
+namespace gtx {
+
+// ---- letterbox geometry (ultralytics LetterBox.__call__, reached from extract.py:153) ----
+struct Letterbox {
+  int src_h, src_w;    // frame
+  int net_h, net_w;    // network input
+  int new_h, new_w;    // resized (unpadded) content
+  int top, left;       // padding
+  double gain;         // min(net_h/src_h, net_w/src_w) of the *square* request
+};
+Letterbox letterbox_geometry(int src_h, int src_w, int imgsz, bool rect, int stride);
+
+// frame: BGR u8 [N][h][w][3] device; img: [N][net_h][net_w][4] T (RGB0, /255, pad 114/255);
+// gray: u8 [N][gh][gw] or null (full-res BGR2GRAY then 2x2 mean; requires gh=h/2, gw=w/2).
+void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox& lb, void* img,
+                       uint8_t* gray, int gh, int gw, hipStream_t s);
+
+// Stem: Conv(3, c0, k=3, s=2) + bias + SiLU on the RGB0 image. w: [27][c0] fp32 (tap-major:
+// (ky*3+kx)*3 + c), bias [c0]. c0 must be a multiple of 16 and <= 64.
+void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
+                 int c0, void* out, int ho, int wo, hipStream_t s);
+
+// SPPF pools: channels [0,c) -> 5x5 / 9x9 / 13x13 clipped-window maxima at [c,2c) [2c,3c) [3c,4c).
+void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s);
+
+void launch_upsample2x(int dtype, const void* x, int n, int h, int w, int c, int in_cstride,
+                       int in_coff, void* y, int out_cstride, int out_coff, hipStream_t s);
+
+// ---- head decode + NMS ----
+constexpr int kMaxLevels = 3;
+struct HeadLevel {
+  const void* feat;     // [N][h][w][cstride] T: channels [0,cb) box branch, [cb, cb+cc) cls branch
+  int h, w, cstride;
+  int cb, cc;           // box / cls feature channels (64 / 128 for YOLOv8s)
+  const float* wb;      // [64][cb] fp32  final box 1x1 conv (4*reg_max outputs)
+  const float* bb;      // [64]
+  const float* wc;      // [nc][cc] fp32  final cls 1x1 conv
+  const float* bc;      // [nc]
+  float stride;         // 8 / 16 / 32
+  int anchor_begin;     // index of this level's first anchor
+};
+struct HeadParams {
+  HeadLevel lv[kMaxLevels];
+  int n_levels;
+  int n_anchors;        // per image
+  int nc;
+  float conf;           // score threshold (strict >)
+  unsigned long long class_mask;  // bit c set = class c kept (ultralytics `classes`)
+};
+
+struct NmsBuffers {
+  // per image slot b: candidates are stored at [b*cap ...]
+  int cap;              // candidate capacity per image
+  int* count;           // [N] number of candidates (atomic)
+  float* cand_score;    // [N][cap]
+  int* cand_anchor;     // [N][cap]
+  int* cand_cls;        // [N][cap]
+  float* cand_box;      // [N][cap][4] xyxy network pixels
+  // sorted (score desc, anchor asc), truncated to nms_cap
+  int nms_cap;
+  int* sorted_n;        // [N]
+  float* s_box;         // [N][nms_cap][4]
+  float* s_score;       // [N][nms_cap]
+  int* s_cls;           // [N][nms_cap]
+  unsigned long long* mask;  // [N][nms_cap][nms_cap/64]
+  // final
+  int max_det;
+  int* out_n;           // [N]
+  float* out_rows;      // [N][max_det][6] x1 y1 x2 y2 conf cls (frame pixels)
+};
+
+void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
+// Decode every anchor (debug / parity): out [N][A][4+nc] fp32 = xywh (network px) + scores.
+void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, hipStream_t s);
+void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
+                const Letterbox& lb, hipStream_t s);
+
+}  // namespace gtx

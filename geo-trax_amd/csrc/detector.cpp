@@ -1,0 +1,545 @@
+// YOLOv8 (detect) graph builder + executor. Layer topology follows ultralytics'
+// cfg/models/v8/yolov8.yaml (backbone 0-9, head 10-22); channel widths and bottleneck counts
+// are read off the tensor shapes, so every v8 scale (n/s/m/l/x) loads unchanged.
+#include "detector.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace gtx {
+
+Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cfg) {
+  GTX_CHECK(cfg.imgsz > 0 && cfg.imgsz % 32 == 0, "imgsz must be a positive multiple of 32 (got %d)", cfg.imgsz);
+  GTX_CHECK(cfg.max_det > 0 && cfg.nc > 0 && cfg.nc <= 64, "bad max_det / nc");
+  GTX_CHECK(cfg.frame_h > 0 && cfg.frame_w > 0, "frame size must be given");
+  if (cfg_.max_batch < 1) cfg_.max_batch = 1;
+  dtype_ = cfg.half ? DT_F16 : DT_F32;
+  es_ = dtype_size(dtype_);
+  lb_ = letterbox_geometry(cfg.frame_h, cfg.frame_w, cfg.imgsz, cfg.rect != 0, 32);
+  GTX_CHECK(lb_.net_h % 32 == 0 && lb_.net_w % 32 == 0, "network input %dx%d is not stride aligned", lb_.net_h, lb_.net_w);
+  GTX_HIP(hipSetDevice(ctx->device));
+  for (auto& e : ev_) GTX_HIP(hipEventCreate(&e));
+  for (auto& e : ev_up_) GTX_HIP(hipEventCreate(&e));
+}
+
+Detector::~Detector() {
+  if (h_out_n_) (void)hipHostFree(h_out_n_);
+  if (h_out_rows_) (void)hipHostFree(h_out_rows_);
+  for (auto& e : ev_)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_up_)
+    if (e) (void)hipEventDestroy(e);
+}
+
+void Detector::set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape) {
+  GTX_CHECK(!finalized_, "set_tensor after finalize");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  t.data.assign(data, data + n);
+  tensors_[name] = std::move(t);
+}
+
+const HostTensor& Detector::tensor(const std::string& name) const {
+  auto it = tensors_.find(name);
+  if (it == tensors_.end()) fail(-1, "missing tensor '%s'", name.c_str());
+  return it->second;
+}
+
+void* Detector::alloc(size_t bytes) {
+  bufs_.emplace_back(bytes);
+  GTX_HIP(hipMemset(bufs_.back().p, 0, bufs_.back().bytes));
+  return bufs_.back().p;
+}
+
+View Detector::new_view(int h, int w, int c) {
+  View v;
+  v.n = cfg_.max_batch;
+  v.h = h;
+  v.w = w;
+  v.cstride = c;
+  v.coff = 0;
+  v.c = c;
+  v.ptr = alloc((size_t)v.n * h * w * c * es_);
+  return v;
+}
+
+namespace {
+// OIHW -> OHWI
+std::vector<float> to_ohwi(const HostTensor& t) {
+  const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
+  std::vector<float> r((size_t)O * I * KH * KW);
+  for (int o = 0; o < O; ++o)
+    for (int i = 0; i < I; ++i)
+      for (int y = 0; y < KH; ++y)
+        for (int x = 0; x < KW; ++x)
+          r[(((size_t)o * KH + y) * KW + x) * I + i] = t.data[(((size_t)o * I + i) * KH + y) * KW + x];
+  return r;
+}
+}  // namespace
+
+// Emits one Conv op: weights "<name>.weight" (OIHW) / "<name>.bias" (optional).
+View Detector::conv(const std::string& name, const View& x, int stride, bool act, const View* out_slice,
+                    const View* residual) {
+  const HostTensor& w = tensor(name + ".weight");
+  GTX_CHECK(w.shape.size() == 4 && w.shape[2] == w.shape[3], "%s: expected OIHW square kernel", name.c_str());
+  const int cout = (int)w.shape[0], cin = (int)w.shape[1], ks = (int)w.shape[2];
+  GTX_CHECK(cin == x.c, "%s: weight expects %d input channels, input view has %d", name.c_str(), cin, x.c);
+  const int pad = ks / 2;
+  const int ho = (x.h + 2 * pad - ks) / stride + 1, wo = (x.w + 2 * pad - ks) / stride + 1;
+  View out = out_slice ? *out_slice : new_view(ho, wo, cout);
+  GTX_CHECK(out.h == ho && out.w == wo && out.c == cout, "%s: output view mismatch", name.c_str());
+
+  Op op;
+  op.kind = Op::CONV;
+  op.name = name;
+  op.cfg = conv_pick_config(dtype_, ks, stride, cin, cout);
+  const std::vector<float> ohwi = to_ohwi(w);
+  const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg);
+  void* dw = alloc(packed.size());
+  GTX_HIP(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  float* db = nullptr;
+  if (has(name + ".bias")) {
+    const HostTensor& b = tensor(name + ".bias");
+    GTX_CHECK((int)b.data.size() == cout, "%s: bias size", name.c_str());
+    db = (float*)alloc(cout * sizeof(float));
+    GTX_HIP(hipMemcpy(db, b.data.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  ConvProblem& p = op.grp.p[0];
+  p.in = x.ptr; p.out = out.ptr; p.wpack = dw; p.bias = db;
+  p.res = residual ? residual->ptr : nullptr;
+  p.N = x.n; p.H = x.h; p.W = x.w; p.Ho = ho; p.Wo = wo; p.Cin = cin; p.Cout = cout;
+  p.in_cstride = x.cstride; p.in_coff = x.coff;
+  p.out_cstride = out.cstride; p.out_coff = out.coff;
+  p.res_cstride = residual ? residual->cstride : 0;
+  p.res_coff = residual ? residual->coff : 0;
+  p.act = act ? 1 : 0;
+  op.grp.count = 1;
+  op.family = conv_kernel_name(op.cfg);
+  ops_.push_back(op);
+  layer_views_[name] = out;
+  return out;
+}
+
+View Detector::c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice) {
+  const HostTensor& w1 = tensor(pfx + ".cv1.conv.weight");
+  const int c = (int)w1.shape[0] / 2;
+  int n = 0;
+  while (has(pfx + ".m." + std::to_string(n) + ".cv1.conv.weight")) ++n;
+  View cat = new_view(x.h, x.w, (2 + n) * c);
+  View first = cat.slice(0, 2 * c);
+  conv(pfx + ".cv1.conv", x, 1, true, &first, nullptr);
+  View tmp = new_view(x.h, x.w, c);
+  for (int k = 0; k < n; ++k) {
+    const std::string m = pfx + ".m." + std::to_string(k);
+    View src = cat.slice((1 + k) * c, c);
+    View dst = cat.slice((2 + k) * c, c);
+    conv(m + ".cv1.conv", src, 1, true, &tmp, nullptr);
+    conv(m + ".cv2.conv", tmp, 1, true, &dst, shortcut ? &src : nullptr);
+  }
+  View out = conv(pfx + ".cv2.conv", cat, 1, true, out_slice, nullptr);
+  layer_views_[pfx] = out;
+  return out;
+}
+
+void Detector::build_graph() {
+  const int H = lb_.net_h, W = lb_.net_w;
+  img_ = new_view(H, W, 4);
+
+  // ---- layer 0: stem (dedicated 3-channel kernel) ----
+  const HostTensor& w0 = tensor("model.0.conv.weight");
+  GTX_CHECK(w0.shape.size() == 4 && w0.shape[1] == 3 && w0.shape[2] == 3, "model.0 must be a 3x3 conv on 3 channels");
+  const int c0 = (int)w0.shape[0];
+  View a0 = new_view(H / 2, W / 2, c0);
+  {
+    std::vector<float> w27((size_t)27 * c0);
+    for (int o = 0; o < c0; ++o)
+      for (int i = 0; i < 3; ++i)
+        for (int y = 0; y < 3; ++y)
+          for (int x = 0; x < 3; ++x)
+            w27[(size_t)((y * 3 + x) * 3 + i) * c0 + o] = w0.data[(((size_t)o * 3 + i) * 3 + y) * 3 + x];
+    float* dw = (float*)alloc(w27.size() * sizeof(float));
+    GTX_HIP(hipMemcpy(dw, w27.data(), w27.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> b(c0, 0.f);
+    if (has("model.0.conv.bias")) b = tensor("model.0.conv.bias").data;
+    float* db = (float*)alloc(c0 * sizeof(float));
+    GTX_HIP(hipMemcpy(db, b.data(), c0 * sizeof(float), hipMemcpyHostToDevice));
+    Op op;
+    op.kind = Op::STEM;
+    op.name = "model.0.conv";
+    op.family = "stem_kernel";
+    op.in = img_;
+    op.out = a0;
+    op.w27 = dw;
+    op.bias = db;
+    ops_.push_back(op);
+    layer_views_["model.0.conv"] = a0;
+  }
+
+  auto cout_of = [&](const std::string& n) { return (int)tensor(n + ".weight").shape[0]; };
+
+  // ---- backbone ----
+  View a1 = conv("model.1.conv", a0, 2, true, nullptr, nullptr);
+  View a2 = c2f("model.2", a1, true, nullptr);
+  View a3 = conv("model.3.conv", a2, 2, true, nullptr, nullptr);
+  // model.4 output feeds conv5 and Concat(14) = [up13, model.4]
+  const int c4 = cout_of("model.4.cv2.conv"), c6 = cout_of("model.6.cv2.conv");
+  const int c9 = cout_of("model.9.cv2.conv"), c12 = cout_of("model.12.cv2.conv");
+  const int c16 = cout_of("model.16.conv"), c19 = cout_of("model.19.conv");
+  View cat14 = new_view(H / 8, W / 8, c12 + c4);
+  View s4 = cat14.slice(c12, c4);
+  View a4 = c2f("model.4", a3, true, &s4);
+  View a5 = conv("model.5.conv", a4, 2, true, nullptr, nullptr);
+  View cat11 = new_view(H / 16, W / 16, c9 + c6);
+  View s6 = cat11.slice(c9, c6);
+  View a6 = c2f("model.6", a5, true, &s6);
+  View a7 = conv("model.7.conv", a6, 2, true, nullptr, nullptr);
+  View a8 = c2f("model.8", a7, true, nullptr);
+  // ---- SPPF (model.9): cv1 -> 3 cascaded pools -> cv2; output lives in Concat(20) = [conv19, model.9]
+  View cat20 = new_view(H / 32, W / 32, c19 + c9);
+  View s9 = cat20.slice(c19, c9);
+  {
+    const int cm = cout_of("model.9.cv1.conv");
+    View sp = new_view(a8.h, a8.w, 4 * cm);
+    View sp0 = sp.slice(0, cm);
+    conv("model.9.cv1.conv", a8, 1, true, &sp0, nullptr);
+    Op op;
+    op.kind = Op::POOL;
+    op.name = "model.9.m";
+    op.family = "sppf_pool_kernel";
+    op.in = sp0;
+    op.out = sp;
+    ops_.push_back(op);
+    conv("model.9.cv2.conv", sp, 1, true, &s9, nullptr);
+    layer_views_["model.9"] = s9;
+  }
+  // ---- head ----
+  auto upsample = [&](const std::string& name, const View& src, const View& dst) {
+    Op op;
+    op.kind = Op::UPSAMPLE;
+    op.name = name;
+    op.family = "upsample2x_kernel";
+    op.in = src;
+    op.out = dst;
+    ops_.push_back(op);
+  };
+  upsample("model.10", s9, cat11.slice(0, c9));
+  View cat17 = new_view(H / 16, W / 16, c16 + c12);
+  View s12 = cat17.slice(c16, c12);
+  c2f("model.12", cat11, false, &s12);
+  upsample("model.13", s12, cat14.slice(0, c12));
+  View a15 = c2f("model.15", cat14, false, nullptr);
+  View s16 = cat17.slice(0, c16);
+  conv("model.16.conv", a15, 2, true, &s16, nullptr);
+  View a18 = c2f("model.18", cat17, false, nullptr);
+  View s19 = cat20.slice(0, c19);
+  conv("model.19.conv", a18, 2, true, &s19, nullptr);
+  View a21 = c2f("model.21", cat20, false, nullptr);
+
+  // ---- Detect (model.22) ----
+  // Stage 1 fuses the sibling convs cv2[l][0] and cv3[l][0] (same input) into one conv by
+  // stacking their output channels; stage 2 runs cv2[l][1] and cv3[l][1] on channel slices.
+  // The three levels go out as one grouped launch per stage. The final 1x1 convs are folded
+  // into the decode kernels (the box one only runs for anchors that pass the score gate).
+  const View lvl_in[3] = {a15, a18, a21};
+  const float strides[3] = {8.f, 16.f, 32.f};
+  Op st1, st2;
+  st1.kind = st2.kind = Op::CONV;
+  st1.name = "model.22.stage1";
+  st2.name = "model.22.stage2";
+  head_ = HeadParams{};
+  head_.n_levels = 3;
+  head_.nc = cfg_.nc;
+  head_.conf = cfg_.conf;
+  head_.class_mask = 0ull;
+  if (cfg_.n_classes == 0) head_.class_mask = ~0ull;
+  for (int i = 0; i < cfg_.n_classes; ++i)
+    if (cfg_.classes[i] >= 0 && cfg_.classes[i] < 64) head_.class_mask |= 1ull << cfg_.classes[i];
+  int anchor = 0;
+  for (int l = 0; l < 3; ++l) {
+    const std::string b2 = "model.22.cv2." + std::to_string(l), b3 = "model.22.cv3." + std::to_string(l);
+    const HostTensor &w20 = tensor(b2 + ".0.conv.weight"), &w30 = tensor(b3 + ".0.conv.weight");
+    const int cb = (int)w20.shape[0], cc = (int)w30.shape[0], cin = (int)w20.shape[1];
+    GTX_CHECK(cin == lvl_in[l].c && (int)w30.shape[1] == cin, "Detect level %d input channels", l);
+    // stacked stage-1 weights / bias
+    HostTensor ws;
+    ws.shape = {cb + cc, cin, 3, 3};
+    ws.data = w20.data;
+    ws.data.insert(ws.data.end(), w30.data.begin(), w30.data.end());
+    tensors_["__head" + std::to_string(l) + ".s1.weight"] = ws;
+    HostTensor bs;
+    bs.shape = {cb + cc};
+    bs.data = tensor(b2 + ".0.conv.bias").data;
+    const auto& b30 = tensor(b3 + ".0.conv.bias").data;
+    bs.data.insert(bs.data.end(), b30.begin(), b30.end());
+    tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
+    const size_t mark = ops_.size();
+    View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
+    View h2 = new_view(h1.h, h1.w, cb + cc);
+    View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
+    conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
+    conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
+    // move the three freshly built single-problem ops into the two grouped stage ops
+    GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
+    Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
+    ops_.resize(mark);
+    if (l == 0) { st1.cfg = o1.cfg; st2.cfg = o2.cfg; }
+    auto same = [](const ConvConfig& a, const ConvConfig& b) {
+      return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc;
+    };
+    GTX_CHECK(same(st1.cfg, o1.cfg) && same(st2.cfg, o2.cfg) && same(st2.cfg, o3.cfg),
+              "Detect level %d does not share a kernel configuration with level 0", l);
+    st1.grp.p[st1.grp.count++] = o1.grp.p[0];
+    st2.grp.p[st2.grp.count++] = o2.grp.p[0];
+    st2.grp.p[st2.grp.count++] = o3.grp.p[0];
+
+    HeadLevel& L = head_.lv[l];
+    L.feat = h2.ptr; L.h = h2.h; L.w = h2.w; L.cstride = h2.cstride; L.cb = cb; L.cc = cc;
+    L.stride = strides[l];
+    L.anchor_begin = anchor;
+    anchor += h2.h * h2.w;
+    auto upload = [&](const std::vector<float>& v) {
+      float* d = (float*)alloc(v.size() * sizeof(float));
+      GTX_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+      return d;
+    };
+    const HostTensor &wb = tensor(b2 + ".2.weight"), &wc = tensor(b3 + ".2.weight");
+    GTX_CHECK(wb.shape[0] == 64 && (int)wb.shape[1] == cb, "Detect box head must have 4*16 outputs");
+    GTX_CHECK((int)wc.shape[0] == cfg_.nc && (int)wc.shape[1] == cc, "Detect cls head has %d outputs, nc=%d", (int)wc.shape[0], cfg_.nc);
+    L.wb = upload(wb.data); L.bb = upload(tensor(b2 + ".2.bias").data);
+    L.wc = upload(wc.data); L.bc = upload(tensor(b3 + ".2.bias").data);
+    layer_views_["model.22.feat" + std::to_string(l)] = h2;
+  }
+  head_.n_anchors = anchor;
+  st1.family = conv_kernel_name(st1.cfg);
+  st2.family = conv_kernel_name(st2.cfg);
+  ops_.push_back(st1);
+  ops_.push_back(st2);
+}
+
+void Detector::set_batch(int nb) {
+  if (nb == cur_nb_) return;
+  for (Op& op : ops_) {
+    if (op.kind != Op::CONV) continue;
+    for (int i = 0; i < op.grp.count; ++i) op.grp.p[i].N = nb;
+    conv_group_finalize(op.grp, op.cfg);
+    op.flops = 0;
+    op.bytes = 0;
+    for (int i = 0; i < op.grp.count; ++i) {
+      const ConvProblem& p = op.grp.p[i];
+      op.flops += conv_flops(p, op.cfg.ks);
+      op.bytes += ((double)p.N * p.H * p.W * p.Cin + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
+                  (double)p.Cout * p.Cin * op.cfg.ks * op.cfg.ks * es_;
+    }
+  }
+  for (Op& op : ops_) {
+    if (op.kind == Op::STEM) {
+      op.flops = 2.0 * nb * op.out.h * op.out.w * op.out.c * 27;
+      op.bytes = (double)nb * (op.in.h * op.in.w * 4 + (double)op.out.h * op.out.w * op.out.c) * es_;
+    } else if (op.kind == Op::POOL) {
+      op.flops = 0;
+      op.bytes = (double)nb * op.in.h * op.in.w * op.in.c * 4 * es_;
+    } else if (op.kind == Op::UPSAMPLE) {
+      op.flops = 0;
+      op.bytes = (double)nb * op.in.h * op.in.w * op.in.c * 5 * es_;
+    }
+  }
+  cur_nb_ = nb;
+}
+
+void Detector::finalize() {
+  GTX_CHECK(!finalized_, "finalize called twice");
+  GTX_HIP(hipSetDevice(ctx_->device));
+  build_graph();
+  const int N = cfg_.max_batch;
+  gray_h_ = cfg_.frame_h / 2;
+  gray_w_ = cfg_.frame_w / 2;
+  gray_.alloc((size_t)N * gray_h_ * gray_w_);
+  // NMS workspace. Candidate capacity = every anchor; sort/NMS capacity = ultralytics max_nms.
+  nms_ = NmsBuffers{};
+  nms_.cap = head_.n_anchors;
+  nms_.nms_cap = 30016;  // >= max_nms (30000), multiple of 64
+  nms_.max_det = cfg_.max_det;
+  nms_.count = (int*)alloc(sizeof(int) * N);
+  nms_.cand_score = (float*)alloc(sizeof(float) * N * nms_.cap);
+  nms_.cand_anchor = (int*)alloc(sizeof(int) * N * nms_.cap);
+  nms_.cand_cls = (int*)alloc(sizeof(int) * N * nms_.cap);
+  nms_.cand_box = (float*)alloc(sizeof(float) * 4 * N * nms_.cap);
+  nms_.sorted_n = (int*)alloc(sizeof(int) * N);
+  nms_.s_box = (float*)alloc(sizeof(float) * 4 * N * nms_.nms_cap);
+  nms_.s_score = (float*)alloc(sizeof(float) * N * nms_.nms_cap);
+  nms_.s_cls = (int*)alloc(sizeof(int) * N * nms_.nms_cap);
+  nms_.mask = (unsigned long long*)alloc(sizeof(unsigned long long) * N * (size_t)nms_.nms_cap * (nms_.nms_cap / 64));
+  nms_.out_n = (int*)alloc(sizeof(int) * N);
+  nms_.out_rows = (float*)alloc(sizeof(float) * 6 * N * cfg_.max_det);
+  GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
+  GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
+  tensors_.clear();  // host copies are no longer needed
+  set_batch(1);
+  GTX_HIP(hipStreamSynchronize(ctx_->stream));
+  finalized_ = true;
+}
+
+void Detector::run_op(const Op& op, int nb, hipStream_t s) {
+  switch (op.kind) {
+    case Op::CONV: conv_launch(op.grp, op.cfg, s); break;
+    case Op::STEM:
+      launch_stem(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.out.c, op.out.ptr, op.out.h, op.out.w, s);
+      break;
+    case Op::POOL: launch_sppf_pool(dtype_, op.out.ptr, nb, op.in.h, op.in.w, op.in.c, s); break;
+    case Op::UPSAMPLE:
+      launch_upsample2x(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.in.c, op.in.cstride, op.in.coff, op.out.ptr,
+                        op.out.cstride, op.out.coff, s);
+      break;
+  }
+}
+
+void Detector::run_forward(int nb, hipStream_t s) {
+  for (const Op& op : ops_) run_op(op, nb, s);
+}
+
+void Detector::run_post(int nb, hipStream_t s) {
+  launch_head_candidates(dtype_, head_, nb, nms_, s);
+  launch_nms(nms_, nb, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
+  GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
+}
+
+void Detector::detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
+                          int* cls, float speed_ms[3]) {
+  GTX_CHECK(finalized_, "detector not finalized");
+  GTX_CHECK(nb >= 1 && nb <= cfg_.max_batch, "batch %d outside [1,%d]", nb, cfg_.max_batch);
+  GTX_CHECK(h == cfg_.frame_h && w == cfg_.frame_w, "frame is %dx%d, detector was created for %dx%d", w, h, cfg_.frame_w, cfg_.frame_h);
+  GTX_HIP(hipSetDevice(ctx_->device));
+  hipStream_t s = ctx_->stream;
+  set_batch(nb);
+  cur_frames_ = frames;
+  GTX_HIP(hipEventRecord(ev_[0], s));
+  launch_preprocess(dtype_, (const uint8_t*)frames, nb, lb_, img_.ptr, gray_.as<uint8_t>(), gray_h_, gray_w_, s);
+  GTX_HIP(hipEventRecord(ev_[1], s));
+  run_forward(nb, s);
+  GTX_HIP(hipEventRecord(ev_[2], s));
+  run_post(nb, s);
+  GTX_HIP(hipEventRecord(ev_[3], s));
+  GTX_HIP(hipStreamSynchronize(s));
+  for (int b = 0; b < nb; ++b) {
+    const int n = h_out_n_[b];
+    n_out[b] = n;
+    const float* rows = h_out_rows_ + (size_t)b * cfg_.max_det * 6;
+    for (int i = 0; i < n; ++i) {
+      float* bx = xyxy + ((size_t)b * cfg_.max_det + i) * 4;
+      bx[0] = rows[i * 6 + 0]; bx[1] = rows[i * 6 + 1]; bx[2] = rows[i * 6 + 2]; bx[3] = rows[i * 6 + 3];
+      conf[(size_t)b * cfg_.max_det + i] = rows[i * 6 + 4];
+      cls[(size_t)b * cfg_.max_det + i] = (int)rows[i * 6 + 5];
+    }
+  }
+  if (speed_ms) {
+    for (int i = 0; i < 3; ++i) GTX_HIP(hipEventElapsedTime(&speed_ms[i], ev_[i], ev_[i + 1]));
+  }
+}
+
+void Detector::detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf, int* cls,
+                           float speed_ms[3]) {
+  GTX_CHECK(finalized_, "detector not finalized");
+  GTX_HIP(hipSetDevice(ctx_->device));
+  const size_t bytes = (size_t)h * w * 3;
+  if (frame_stage_.bytes < bytes) frame_stage_.alloc(bytes);
+  GTX_HIP(hipEventRecord(ev_up_[0], ctx_->stream));
+  GTX_HIP(hipMemcpyAsync(frame_stage_.p, frame, bytes, hipMemcpyHostToDevice, ctx_->stream));
+  GTX_HIP(hipEventRecord(ev_up_[1], ctx_->stream));
+  detect_dev(frame_stage_.p, 1, h, w, n_out, xyxy, conf, cls, speed_ms);
+  if (speed_ms) {
+    float up_ms = 0.f;
+    GTX_HIP(hipEventElapsedTime(&up_ms, ev_up_[0], ev_up_[1]));
+    speed_ms[0] += up_ms;  // the host->device copy is part of "preprocess"
+  }
+}
+
+const void* Detector::gray(int b, int* gh, int* gw) const {
+  if (gh) *gh = gray_h_;
+  if (gw) *gw = gray_w_;
+  if (b < 0 || b >= cfg_.max_batch) return nullptr;
+  return gray_.as<uint8_t>() + (size_t)b * gray_h_ * gray_w_;
+}
+
+void Detector::raw_output(int b, float* out, int* n_anchors) {
+  GTX_CHECK(finalized_ && cur_nb_ > 0 && b >= 0 && b < cur_nb_, "raw_output: no forward pass for slot %d", b);
+  const size_t per = (size_t)head_.n_anchors * (4 + head_.nc);
+  if (raw_.bytes < per * cur_nb_ * sizeof(float)) raw_.alloc(per * cur_nb_ * sizeof(float));
+  launch_head_raw(dtype_, head_, cur_nb_, raw_.as<float>(), ctx_->stream);
+  GTX_HIP(hipMemcpyAsync(out, raw_.as<float>() + per * b, per * sizeof(float), hipMemcpyDeviceToHost, ctx_->stream));
+  GTX_HIP(hipStreamSynchronize(ctx_->stream));
+  if (n_anchors) *n_anchors = head_.n_anchors;
+}
+
+void Detector::layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c) {
+  auto it = layer_views_.find(layer);
+  if (it == layer_views_.end()) fail(-1, "unknown layer '%s'", layer.c_str());
+  const View& v = it->second;
+  if (h) *h = v.h;
+  if (w) *w = v.w;
+  if (c) *c = v.c;
+  if (!out) return;
+  GTX_CHECK(b >= 0 && b < cfg_.max_batch, "bad batch slot");
+  const size_t px = (size_t)v.h * v.w;
+  std::vector<uint8_t> host(px * v.cstride * es_);
+  GTX_HIP(hipMemcpy(host.data(), (const uint8_t*)v.ptr + (size_t)b * px * v.cstride * es_, host.size(), hipMemcpyDeviceToHost));
+  for (size_t p = 0; p < px; ++p)
+    for (int k = 0; k < v.c; ++k) {
+      const size_t src = p * v.cstride + v.coff + k;
+      float f;
+      if (dtype_ == DT_F16) {
+        _Float16 hv;
+        memcpy(&hv, host.data() + src * 2, 2);
+        f = (float)hv;
+      } else {
+        memcpy(&f, host.data() + src * 4, 4);
+      }
+      out[p * v.c + k] = f;
+    }
+}
+
+void Detector::profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
+                       std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes) {
+  GTX_CHECK(finalized_, "detector not finalized");
+  GTX_CHECK(nb >= 1 && nb <= cfg_.max_batch && iters >= 1, "bad profile arguments");
+  hipStream_t s = ctx_->stream;
+  set_batch(nb);
+  std::vector<hipEvent_t> ev(ops_.size() + 1);
+  for (auto& e : ev) GTX_HIP(hipEventCreate(&e));
+  std::map<std::string, size_t> idx;
+  auto slot = [&](const std::string& fam) {
+    auto it = idx.find(fam);
+    if (it != idx.end()) return it->second;
+    idx[fam] = names.size();
+    names.push_back(fam);
+    launches.push_back(0);
+    ms.push_back(0.f);
+    flops.push_back(0.0);
+    bytes.push_back(0.0);
+    return names.size() - 1;
+  };
+  for (int it = 0; it < iters; ++it) {
+    for (size_t i = 0; i < ops_.size(); ++i) {
+      GTX_HIP(hipEventRecord(ev[i], s));
+      run_op(ops_[i], nb, s);
+    }
+    GTX_HIP(hipEventRecord(ev[ops_.size()], s));
+    GTX_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < ops_.size(); ++i) {
+      float t = 0.f;
+      GTX_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      const size_t k = slot(ops_[i].family);
+      launches[k] += 1;
+      ms[k] += t;
+      flops[k] += ops_[i].flops;
+      bytes[k] += ops_[i].bytes;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+}
+
+}  // namespace gtx

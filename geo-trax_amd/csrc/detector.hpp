@@ -1,0 +1,125 @@
+// YOLOv8 detector runtime: builds the layer graph from ultralytics-named fused tensors, plans
+// the NHWC buffers (concats are channel slices, never copies), and runs
+// preprocess -> forward -> decode -> NMS on a HIP stream. Stands in for what
+// ultralytics' predictor does underneath model.track() (geotrax/extract.py:153).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gtx.h"
+#include "common.hpp"
+#include "conv_igemm.hpp"
+#include "det_kernels.hpp"
+
+struct gtx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  ~gtx_ctx() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace gtx {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+// A channel slice of an NHWC device buffer.
+struct View {
+  void* ptr = nullptr;
+  int n = 0, h = 0, w = 0;
+  int cstride = 0, coff = 0, c = 0;
+  View slice(int off, int cnt) const {
+    View v = *this;
+    v.coff = coff + off;
+    v.c = cnt;
+    return v;
+  }
+};
+
+struct Op {
+  enum Kind { CONV, STEM, POOL, UPSAMPLE } kind = CONV;
+  std::string name;      // ultralytics module path ("model.2.m.0.cv1") or group label
+  std::string family;    // kernel symbol, as rocprof prints it
+  ConvGroup grp{};       // CONV
+  ConvConfig cfg{};
+  // STEM / POOL / UPSAMPLE parameters
+  View in, out;
+  const float* w27 = nullptr;
+  const float* bias = nullptr;
+  double flops = 0;      // algorithmic 2*MAC
+  double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
+};
+
+class Detector {
+ public:
+  Detector(gtx_ctx* ctx, const gtx_det_config& cfg);
+  ~Detector();
+  void set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape);
+  void finalize();
+  void input_size(int* h, int* w) const { *h = lb_.net_h; *w = lb_.net_w; }
+
+  // frames: device pointer, nb frames [h][w][3] u8 back to back. Outputs sized [nb][max_det].
+  void detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
+                  int* cls, float speed_ms[3]);
+  void detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf,
+                   int* cls, float speed_ms[3]);
+  const void* gray(int b, int* gh, int* gw) const;
+  void raw_output(int b, float* out, int* n_anchors);
+  void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c);
+  void profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
+               std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes);
+  int max_det() const { return cfg_.max_det; }
+
+ private:
+  void* alloc(size_t bytes);
+  View new_view(int h, int w, int c);
+  const HostTensor& tensor(const std::string& name) const;
+  bool has(const std::string& name) const { return tensors_.count(name) != 0; }
+  // graph building
+  View conv(const std::string& name, const View& x, int stride, bool act, const View* out_slice,
+            const View* residual);
+  View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice);
+  void build_graph();
+  void run_op(const Op& op, int nb, hipStream_t s);
+  void run_forward(int nb, hipStream_t s);
+  void run_post(int nb, hipStream_t s);
+  void set_batch(int nb);
+
+  gtx_ctx* ctx_;
+  gtx_det_config cfg_;
+  int dtype_;
+  size_t es_;
+  Letterbox lb_{};
+  std::map<std::string, HostTensor> tensors_;
+  std::vector<DevBuf> bufs_;
+  std::vector<Op> ops_;
+  std::map<std::string, View> layer_views_;
+  bool finalized_ = false;
+  int cur_nb_ = 0;
+
+  View img_;                 // [N][net_h][net_w][4]
+  DevBuf frame_stage_;       // device copy of host frames for detect_host
+  DevBuf gray_;              // [N][gh][gw] u8
+  int gray_h_ = 0, gray_w_ = 0;
+  const void* cur_frames_ = nullptr;
+
+  HeadParams head_{};
+  NmsBuffers nms_{};
+  DevBuf raw_;               // debug raw output
+  int* h_out_n_ = nullptr;   // pinned
+  float* h_out_rows_ = nullptr;
+  hipEvent_t ev_[4]{};
+  hipEvent_t ev_up_[2]{};
+};
+
+}  // namespace gtx
+
+struct gtx_detector {
+  std::unique_ptr<gtx::Detector> impl;
+};

@@ -1,0 +1,24 @@
+// Small projective-geometry helpers of the path (host, f64).
+#pragma once
+#include <cstdint>
+
+struct gtx_ctx;
+
+namespace gtx {
+
+// stabilo Stabilizer.transform_cur_boxes() as pinned on the reference's golden output
+// (SURVEY.md K10): the four corners of each xywh box go through H, the axis-aligned bounding
+// rectangle of the four images comes back as xywh.
+void warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_out);
+
+// cv2.perspectiveTransform on f64 points (geotrax/georeference.py:599-605).
+void perspective_points(const double H[9], const double* x, const double* y, int n, double* ox, double* oy);
+
+// cv2.warpPerspective(frame, H, (w, h)): dst(x,y) = bilinear src(H^-1 (x,y)), constant 0 border
+// (geotrax/visualize.py:289). Device kernel in warp.hip.
+void warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr);
+
+// 3x3 inverse (adjugate / det). Returns false if singular.
+bool invert3x3(const double m[9], double inv[9]);
+
+}  // namespace gtx

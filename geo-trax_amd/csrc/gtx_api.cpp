@@ -1,0 +1,430 @@
+// C ABI of libgtx.so (see include/gtx.h). Everything here is a thin try/catch shim that turns
+// gtx::Error into a status code + thread-local message.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/gtx.h"
+#include "common.hpp"
+#include "conv_igemm.hpp"
+#include "det_kernels.hpp"
+#include "detector.hpp"
+#include "geometry.hpp"
+#include "stabilizer.hpp"
+#include "tracker.hpp"
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    g_last_error.clear();
+    return GTX_OK;
+  } catch (const gtx::Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return GTX_ERR_INTERNAL;
+  } catch (...) {
+    g_last_error = "unknown exception";
+    return GTX_ERR_INTERNAL;
+  }
+}
+
+void need(const void* p, const char* what) {
+  if (!p) gtx::fail(GTX_ERR_INVALID, "%s is NULL", what);
+}
+}  // namespace
+
+extern "C" {
+
+int gtx_abi_version(void) { return GTX_ABI_VERSION; }
+const char* gtx_last_error(void) { return g_last_error.c_str(); }
+
+int gtx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int gtx_ctx_create(int device, gtx_ctx** out) {
+  return guarded([&] {
+    need(out, "out");
+    int n = 0;
+    GTX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) gtx::fail(GTX_ERR_INVALID, "device %d not in [0,%d)", device, n);
+    GTX_HIP(hipSetDevice(device));
+    std::unique_ptr<gtx_ctx> c(new gtx_ctx);
+    c->device = device;
+    GTX_HIP(hipGetDeviceProperties(&c->prop, device));
+    if (std::string(c->prop.gcnArchName).find("gfx950") == std::string::npos)
+      gtx::fail(GTX_ERR_UNSUPPORTED, "libgtx is built for gfx950 only; device %d is %s", device, c->prop.gcnArchName);
+    GTX_HIP(hipStreamCreate(&c->stream));
+    *out = c.release();
+  });
+}
+
+void gtx_ctx_destroy(gtx_ctx* ctx) { delete ctx; }
+
+int gtx_ctx_synchronize(gtx_ctx* ctx) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    GTX_HIP(hipSetDevice(ctx->device));
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int gtx_dev_alloc(gtx_ctx* ctx, size_t bytes, void** dptr) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(dptr, "dptr");
+    GTX_HIP(hipSetDevice(ctx->device));
+    GTX_HIP(hipMalloc(dptr, bytes ? bytes : 256));
+  });
+}
+int gtx_dev_free(gtx_ctx* ctx, void* dptr) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    GTX_HIP(hipSetDevice(ctx->device));
+    if (dptr) GTX_HIP(hipFree(dptr));
+  });
+}
+int gtx_dev_upload(gtx_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(dptr, "dptr"); need(host, "host");
+    GTX_HIP(hipSetDevice(ctx->device));
+    GTX_HIP(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+int gtx_dev_download(gtx_ctx* ctx, void* host, const void* dptr, size_t bytes) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(dptr, "dptr"); need(host, "host");
+    GTX_HIP(hipSetDevice(ctx->device));
+    GTX_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+/* ------------------------------------------------------------------ operator level */
+
+namespace {
+struct ConvOpState {
+  gtx::DevBuf x, w, b, r, y;
+  gtx::ConvGroup g{};
+  gtx::ConvConfig cfg{};
+  int ho = 0, wo = 0;
+};
+
+void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float* w, const float* bias,
+                const void* residual, const void* y_init, ConvOpState& st) {
+  using namespace gtx;
+  need(ctx, "ctx"); need(d, "desc");
+  GTX_HIP(hipSetDevice(ctx->device));
+  if (d->dtype != GTX_F16 && d->dtype != GTX_F32) fail(GTX_ERR_INVALID, "bad dtype %d", d->dtype);
+  const size_t es = dtype_size(d->dtype);
+  const int pad = d->ksize / 2;
+  st.ho = (d->h + 2 * pad - d->ksize) / d->stride + 1;
+  st.wo = (d->w + 2 * pad - d->ksize) / d->stride + 1;
+  st.cfg = conv_pick_config(d->dtype, d->ksize, d->stride, d->cin, d->cout);
+  const int vn = 16 / (int)es;
+  GTX_CHECK(d->in_cstride % vn == 0 && d->in_coff % vn == 0 && d->out_cstride % 4 == 0 && d->out_coff % 4 == 0,
+            "conv: channel strides/offsets must keep 16-byte (input) / 4-element (output) alignment");
+  GTX_CHECK(d->in_coff + d->cin <= d->in_cstride && d->out_coff + d->cout <= d->out_cstride, "conv: slice outside buffer");
+  const size_t xin = (size_t)d->n * d->h * d->w * d->in_cstride * es;
+  const size_t yout = (size_t)d->n * st.ho * st.wo * d->out_cstride * es;
+  st.x.alloc(xin);
+  st.y.alloc(yout);
+  if (x) GTX_HIP(hipMemcpy(st.x.p, x, xin, hipMemcpyHostToDevice));
+  else GTX_HIP(hipMemset(st.x.p, 0, xin));
+  if (y_init) GTX_HIP(hipMemcpy(st.y.p, y_init, yout, hipMemcpyHostToDevice));
+  std::vector<uint8_t> packed;
+  if (w) {
+    packed = pack_conv_weights(w, d->cout, d->cin, st.cfg);
+  } else {
+    packed.assign((size_t)d->cout * d->cin * d->ksize * d->ksize * es, 0);
+  }
+  st.w.alloc(packed.size());
+  GTX_HIP(hipMemcpy(st.w.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  if (bias) {
+    st.b.alloc(d->cout * sizeof(float));
+    GTX_HIP(hipMemcpy(st.b.p, bias, d->cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (d->has_residual) {
+    const size_t rb = (size_t)d->n * st.ho * st.wo * d->cout * es;
+    st.r.alloc(rb);
+    if (residual) GTX_HIP(hipMemcpy(st.r.p, residual, rb, hipMemcpyHostToDevice));
+    else GTX_HIP(hipMemset(st.r.p, 0, rb));
+  }
+  ConvProblem& p = st.g.p[0];
+  p.in = st.x.p; p.out = st.y.p; p.wpack = st.w.p;
+  p.bias = bias ? st.b.as<float>() : nullptr;
+  p.res = d->has_residual ? st.r.p : nullptr;
+  p.N = d->n; p.H = d->h; p.W = d->w; p.Ho = st.ho; p.Wo = st.wo; p.Cin = d->cin; p.Cout = d->cout;
+  p.in_cstride = d->in_cstride; p.in_coff = d->in_coff;
+  p.out_cstride = d->out_cstride; p.out_coff = d->out_coff;
+  p.res_cstride = d->cout; p.res_coff = 0;
+  p.act = d->act;
+  st.g.count = 1;
+  conv_group_finalize(st.g, st.cfg);
+}
+}  // namespace
+
+int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float* w_ohwi, const float* bias,
+                  const void* residual, void* y) {
+  return guarded([&] {
+    need(x, "x"); need(w_ohwi, "w"); need(y, "y");
+    if (d && d->has_residual) need(residual, "residual");
+    ConvOpState st;
+    conv_setup(ctx, d, x, w_ohwi, bias, residual, y, st);
+    gtx::conv_launch(st.g, st.cfg, ctx->stream);
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+    GTX_HIP(hipMemcpy(y, st.y.p, st.y.bytes >= 256 ? (size_t)d->n * st.ho * st.wo * d->out_cstride * gtx::dtype_size(d->dtype) : 0,
+                      hipMemcpyDeviceToHost));
+  });
+}
+
+int gtx_op_conv2d_time(gtx_ctx* ctx, const gtx_conv_desc* d, int iters, float* ms_per_launch, double* flops) {
+  return guarded([&] {
+    need(ms_per_launch, "ms_per_launch");
+    if (iters < 1) gtx::fail(GTX_ERR_INVALID, "iters must be >= 1");
+    ConvOpState st;
+    conv_setup(ctx, d, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    hipEvent_t e0, e1;
+    GTX_HIP(hipEventCreate(&e0));
+    GTX_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) gtx::conv_launch(st.g, st.cfg, ctx->stream);
+    GTX_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; ++i) gtx::conv_launch(st.g, st.cfg, ctx->stream);
+    GTX_HIP(hipEventRecord(e1, ctx->stream));
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    GTX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
+    if (flops) *flops = gtx::conv_flops(st.g.p[0], d->ksize);
+  });
+}
+
+int gtx_op_sppf_pool(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, void* x_inout) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(x_inout, "x");
+    GTX_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * h * w * 4 * c * gtx::dtype_size(dtype);
+    gtx::DevBuf d(bytes);
+    GTX_HIP(hipMemcpy(d.p, x_inout, bytes, hipMemcpyHostToDevice));
+    gtx::launch_sppf_pool(dtype, d.p, n, h, w, c, ctx->stream);
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+    GTX_HIP(hipMemcpy(x_inout, d.p, bytes, hipMemcpyDeviceToHost));
+  });
+}
+
+int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const void* x, int in_cstride,
+                      int in_coff, void* y, int out_cstride, int out_coff) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(x, "x"); need(y, "y");
+    GTX_HIP(hipSetDevice(ctx->device));
+    const size_t es = gtx::dtype_size(dtype);
+    const size_t xb = (size_t)n * h * w * in_cstride * es, yb = (size_t)n * 4 * h * w * out_cstride * es;
+    gtx::DevBuf dx(xb), dy(yb);
+    GTX_HIP(hipMemcpy(dx.p, x, xb, hipMemcpyHostToDevice));
+    GTX_HIP(hipMemcpy(dy.p, y, yb, hipMemcpyHostToDevice));
+    gtx::launch_upsample2x(dtype, dx.p, n, h, w, c, in_cstride, in_coff, dy.p, out_cstride, out_coff, ctx->stream);
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+    GTX_HIP(hipMemcpy(y, dy.p, yb, hipMemcpyDeviceToHost));
+  });
+}
+
+int gtx_op_preprocess(gtx_ctx* ctx, int dtype, const uint8_t* frame, int h, int w, int net_h, int net_w,
+                      void* out_img, uint8_t* out_gray, int gray_h, int gray_w) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(frame, "frame"); need(out_img, "out_img");
+    GTX_HIP(hipSetDevice(ctx->device));
+    // Letterbox of the frame into exactly net_h x net_w (ultralytics geometry for that target).
+    gtx::Letterbox lb{};
+    lb.src_h = h; lb.src_w = w; lb.net_h = net_h; lb.net_w = net_w;
+    const double r = std::min((double)net_h / h, (double)net_w / w);
+    lb.new_w = (int)std::nearbyint(w * r);
+    lb.new_h = (int)std::nearbyint(h * r);
+    lb.top = (int)std::nearbyint((net_h - lb.new_h) / 2.0 - 0.1);
+    lb.left = (int)std::nearbyint((net_w - lb.new_w) / 2.0 - 0.1);
+    lb.gain = r;
+    const size_t fb = (size_t)h * w * 3, ib = (size_t)net_h * net_w * 4 * gtx::dtype_size(dtype);
+    gtx::DevBuf df(fb), di(ib), dg;
+    if (out_gray) dg.alloc((size_t)gray_h * gray_w);
+    GTX_HIP(hipMemcpy(df.p, frame, fb, hipMemcpyHostToDevice));
+    gtx::launch_preprocess(dtype, df.as<uint8_t>(), 1, lb, di.p, out_gray ? dg.as<uint8_t>() : nullptr, gray_h, gray_w, ctx->stream);
+    GTX_HIP(hipStreamSynchronize(ctx->stream));
+    GTX_HIP(hipMemcpy(out_img, di.p, ib, hipMemcpyDeviceToHost));
+    if (out_gray) GTX_HIP(hipMemcpy(out_gray, dg.p, (size_t)gray_h * gray_w, hipMemcpyDeviceToHost));
+  });
+}
+
+/* ------------------------------------------------------------------ detector */
+
+int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(cfg, "cfg"); need(out, "out");
+    std::unique_ptr<gtx_detector> d(new gtx_detector);
+    d->impl.reset(new gtx::Detector(ctx, *cfg));
+    *out = d.release();
+  });
+}
+void gtx_detector_destroy(gtx_detector* det) { delete det; }
+
+int gtx_detector_set_tensor(gtx_detector* det, const char* name, const float* data, int ndim, const int64_t* shape) {
+  return guarded([&] {
+    need(det, "det"); need(name, "name"); need(data, "data"); need(shape, "shape");
+    det->impl->set_tensor(name, data, ndim, shape);
+  });
+}
+int gtx_detector_finalize(gtx_detector* det) {
+  return guarded([&] { need(det, "det"); det->impl->finalize(); });
+}
+int gtx_detector_input_size(gtx_detector* det, int* net_h, int* net_w) {
+  return guarded([&] { need(det, "det"); need(net_h, "net_h"); need(net_w, "net_w"); det->impl->input_size(net_h, net_w); });
+}
+int gtx_detector_detect(gtx_detector* det, const uint8_t* frame_bgr, int h, int w, int* n_out, float* xyxy,
+                        float* conf, int* cls, float speed_ms[3]) {
+  return guarded([&] {
+    need(det, "det"); need(frame_bgr, "frame"); need(n_out, "n_out"); need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls");
+    det->impl->detect_host(frame_bgr, h, w, n_out, xyxy, conf, cls, speed_ms);
+  });
+}
+int gtx_detector_detect_dev(gtx_detector* det, const void* frame_dptr, int h, int w, int* n_out, float* xyxy,
+                            float* conf, int* cls, float speed_ms[3]) {
+  return guarded([&] {
+    need(det, "det"); need(frame_dptr, "frame"); need(n_out, "n_out"); need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls");
+    det->impl->detect_dev(frame_dptr, 1, h, w, n_out, xyxy, conf, cls, speed_ms);
+  });
+}
+int gtx_detector_detect_batch_dev(gtx_detector* det, const void* frames_dptr, int nb, int h, int w, int* n_out,
+                                  float* xyxy, float* conf, int* cls, float speed_ms[3]) {
+  return guarded([&] {
+    need(det, "det"); need(frames_dptr, "frames"); need(n_out, "n_out"); need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls");
+    det->impl->detect_dev(frames_dptr, nb, h, w, n_out, xyxy, conf, cls, speed_ms);
+  });
+}
+const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w) {
+  if (!det) return nullptr;
+  return det->impl->gray(b, gray_h, gray_w);
+}
+int gtx_detector_raw_output(gtx_detector* det, int b, float* out, int* n_anchors) {
+  return guarded([&] { need(det, "det"); need(out, "out"); det->impl->raw_output(b, out, n_anchors); });
+}
+int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out, int* h, int* w, int* c) {
+  return guarded([&] { need(det, "det"); need(layer, "layer"); det->impl->layer_output(b, layer, out, h, w, c); });
+}
+int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* names, int* launches, float* total_ms,
+                         double* flops, double* bytes, int* n_families) {
+  return guarded([&] {
+    need(det, "det"); need(names, "names"); need(launches, "launches"); need(total_ms, "total_ms");
+    need(flops, "flops"); need(bytes, "bytes"); need(n_families, "n_families");
+    std::vector<std::string> nm;
+    std::vector<int> la;
+    std::vector<float> ms;
+    std::vector<double> fl, by;
+    det->impl->profile(nb, iters, nm, la, ms, fl, by);
+    const int n = std::min<int>(cap, (int)nm.size());
+    for (int i = 0; i < n; ++i) {
+      std::strncpy(names + (size_t)i * 96, nm[i].c_str(), 95);
+      names[(size_t)i * 96 + 95] = 0;
+      launches[i] = la[i]; total_ms[i] = ms[i]; flops[i] = fl[i]; bytes[i] = by[i];
+    }
+    *n_families = n;
+  });
+}
+
+/* ------------------------------------------------------------------ tracker */
+
+int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out) {
+  return guarded([&] {
+    need(cfg, "cfg"); need(out, "out");
+    std::unique_ptr<gtx_tracker> t(new gtx_tracker);
+    t->impl.reset(new gtx::ByteTracker(*cfg));
+    *out = t.release();
+  });
+}
+void gtx_tracker_destroy(gtx_tracker* trk) { delete trk; }
+int gtx_tracker_reset(gtx_tracker* trk) {
+  return guarded([&] { need(trk, "trk"); trk->impl->reset(); });
+}
+int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* conf, const int* cls,
+                       const double* gmc_affine, int cap, int* n_out, float* out_xyxy, int* out_id, float* out_score,
+                       int* out_cls, int* out_det_idx) {
+  return guarded([&] {
+    need(trk, "trk"); need(n_out, "n_out");
+    if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
+    trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+  });
+}
+
+/* ------------------------------------------------------------------ stabilizer */
+
+int gtx_stabilizer_create(gtx_ctx* ctx, const gtx_stab_config* cfg, gtx_stabilizer** out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(cfg, "cfg"); need(out, "out");
+    std::unique_ptr<gtx_stabilizer> s(new gtx_stabilizer);
+    s->impl.reset(new gtx::Stabilizer(ctx, *cfg));
+    *out = s.release();
+  });
+}
+void gtx_stabilizer_destroy(gtx_stabilizer* st) { delete st; }
+int gtx_stabilizer_set_ref_frame(gtx_stabilizer* st, const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n) {
+  return guarded([&] { need(st, "st"); need(frame_bgr, "frame"); st->impl->set_ref_frame(frame_bgr, h, w, boxes_xywh, n); });
+}
+int gtx_stabilizer_set_ref_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw, const float* boxes_xywh, int n) {
+  return guarded([&] { need(st, "st"); need(gray_dptr, "gray"); st->impl->set_ref_gray_dev(gray_dptr, gh, gw, boxes_xywh, n); });
+}
+int gtx_stabilizer_stabilize(gtx_stabilizer* st, const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n,
+                             double H[9], int* valid, int stats[4]) {
+  return guarded([&] {
+    need(st, "st"); need(frame_bgr, "frame"); need(H, "H"); need(valid, "valid");
+    st->impl->stabilize(frame_bgr, h, w, boxes_xywh, n, H, valid, stats);
+  });
+}
+int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw, const float* boxes_xywh,
+                                      int n, double H[9], int* valid, int stats[4]) {
+  return guarded([&] {
+    need(st, "st"); need(gray_dptr, "gray"); need(H, "H"); need(valid, "valid");
+    st->impl->stabilize_gray_dev(gray_dptr, gh, gw, boxes_xywh, n, H, valid, stats);
+  });
+}
+int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc) {
+  return guarded([&] { need(st, "st"); need(n, "n"); st->impl->keypoints(which, cap, n, xy, level, angle_bin, desc); });
+}
+int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, int* ref_idx, int* dist) {
+  return guarded([&] { need(st, "st"); need(n, "n"); st->impl->matches(cap, n, cur_idx, ref_idx, dist); });
+}
+
+/* ------------------------------------------------------------------ geometry */
+
+int gtx_warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_out) {
+  return guarded([&] {
+    need(H, "H");
+    if (n > 0) { need(xywh_in, "xywh_in"); need(xywh_out, "xywh_out"); }
+    gtx::warp_boxes(H, xywh_in, n, xywh_out);
+  });
+}
+int gtx_perspective_points(const double H[9], const double* x, const double* y, int n, double* ox, double* oy) {
+  return guarded([&] {
+    need(H, "H");
+    if (n > 0) { need(x, "x"); need(y, "y"); need(ox, "ox"); need(oy, "oy"); }
+    gtx::perspective_points(H, x, y, n, ox, oy);
+  });
+}
+int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(src_bgr, "src"); need(H, "H"); need(dst_bgr, "dst");
+    gtx::warp_frame(ctx, src_bgr, h, w, H, dst_bgr);
+  });
+}
+
+}  // extern "C"

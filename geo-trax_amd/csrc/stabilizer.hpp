@@ -1,0 +1,30 @@
+// GPU homography stabilizer (ORB-style keypoints + Hamming matching + RANSAC homography).
+#pragma once
+#include <memory>
+
+#include "../../include/gtx.h"
+#include "common.hpp"
+
+struct gtx_ctx;
+
+namespace gtx {
+class Stabilizer {
+ public:
+  Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg);
+  ~Stabilizer();
+  void set_ref_frame(const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n);
+  void set_ref_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n);
+  void stabilize(const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]);
+  void stabilize_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]);
+  void keypoints(int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc);
+  void matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+}  // namespace gtx
+
+struct gtx_stabilizer {
+  std::unique_ptr<gtx::Stabilizer> impl;
+};

@@ -1,0 +1,185 @@
+"""ctypes binding of libgtx.so (C ABI declared in include/gtx.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, a
+GtxError is raised. Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("GTX_LIB", _HERE / "libgtx.so"))
+
+
+class GtxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libgtx error {code}: {msg}")
+        self.code = code
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "n", "h", "w", "cin", "cout", "ksize", "stride", "act",
+        "in_cstride", "in_coff", "out_cstride", "out_coff", "has_residual")]
+
+
+class DetConfig(C.Structure):
+    _fields_ = [
+        ("imgsz", C.c_int), ("conf", C.c_float), ("iou", C.c_float), ("max_det", C.c_int),
+        ("agnostic_nms", C.c_int), ("half", C.c_int), ("rect", C.c_int), ("nc", C.c_int),
+        ("n_classes", C.c_int), ("classes", C.c_int * 80), ("max_batch", C.c_int),
+        ("frame_h", C.c_int), ("frame_w", C.c_int),
+    ]
+
+
+class TrackerConfig(C.Structure):
+    _fields_ = [
+        ("type", C.c_int), ("track_high_thresh", C.c_float), ("track_low_thresh", C.c_float),
+        ("new_track_thresh", C.c_float), ("track_buffer", C.c_int), ("match_thresh", C.c_float),
+        ("fuse_score", C.c_int), ("frame_rate", C.c_int),
+    ]
+
+
+class StabConfig(C.Structure):
+    _fields_ = [
+        ("downsample_ratio", C.c_float), ("max_features", C.c_int), ("ref_multiplier", C.c_float),
+        ("filter_ratio", C.c_float), ("ransac_threshold", C.c_float), ("ransac_max_iter", C.c_int),
+        ("ransac_confidence", C.c_float), ("mask_use", C.c_int), ("mask_margin_ratio", C.c_float),
+        ("fast_threshold", C.c_int), ("n_levels", C.c_int), ("scale_factor", C.c_float),
+        ("seed", C.c_uint32), ("frame_h", C.c_int), ("frame_w", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check the export list against
+# include/gtx.h.
+_P = C.c_void_p
+_SIGNATURES = {
+    "gtx_abi_version": (C.c_int, []),
+    "gtx_last_error": (C.c_char_p, []),
+    "gtx_device_count": (C.c_int, []),
+    "gtx_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gtx_ctx_destroy": (None, [_P]),
+    "gtx_ctx_synchronize": (C.c_int, [_P]),
+    "gtx_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gtx_dev_free": (C.c_int, [_P, _P]),
+    "gtx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "gtx_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "gtx_op_conv2d": (C.c_int, [_P, C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "gtx_op_conv2d_time": (C.c_int, [_P, C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "gtx_op_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gtx_op_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "gtx_op_preprocess": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
+    "gtx_detector_create": (C.c_int, [_P, C.POINTER(DetConfig), C.POINTER(_P)]),
+    "gtx_detector_destroy": (None, [_P]),
+    "gtx_detector_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
+    "gtx_detector_finalize": (C.c_int, [_P]),
+    "gtx_detector_input_size": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gtx_detector_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "gtx_detector_detect_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "gtx_detector_detect_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "gtx_detector_gray": (_P, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gtx_detector_raw_output": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "gtx_detector_layer_output": (C.c_int, [_P, C.c_int, C.c_char_p, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gtx_detector_profile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
+    "gtx_tracker_create": (C.c_int, [C.POINTER(TrackerConfig), C.POINTER(_P)]),
+    "gtx_tracker_destroy": (None, [_P]),
+    "gtx_tracker_reset": (C.c_int, [_P]),
+    "gtx_tracker_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
+    "gtx_stabilizer_create": (C.c_int, [_P, C.POINTER(StabConfig), C.POINTER(_P)]),
+    "gtx_stabilizer_destroy": (None, [_P]),
+    "gtx_stabilizer_set_ref_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "gtx_stabilizer_set_ref_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "gtx_stabilizer_stabilize": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
+    "gtx_stabilizer_stabilize_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
+    "gtx_stabilizer_keypoints": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P]),
+    "gtx_stabilizer_matches": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
+    "gtx_warp_boxes": (C.c_int, [_P, _P, C.c_int, _P]),
+    "gtx_perspective_points": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libgtx.so; raises if it has not been built (`make -C geo-trax_amd`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise GtxError(-100, f"{LIB_PATH} not found; build it with `make -C geo-trax_amd` "
+                             "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise GtxError(status, load().gtx_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a: np.ndarray | None):
+    """Pointer to a C-contiguous numpy array (or NULL)."""
+    if a is None:
+        return None
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array passed to libgtx must be C-contiguous")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One context per GPU (include/gtx.h: gtx_ctx_create)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.gtx_ctx_create(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def synchronize(self):
+        check(self.lib.gtx_ctx_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gtx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # raw device memory (inputs kept resident in HBM by bench.py)
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(self.lib.gtx_dev_alloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, dptr: int):
+        check(self.lib.gtx_dev_free(self.handle, C.c_void_p(dptr)))
+
+    def dev_upload(self, dptr: int, a: np.ndarray):
+        check(self.lib.gtx_dev_upload(self.handle, C.c_void_p(dptr), ptr(a), a.nbytes))
+
+    def dev_download(self, a: np.ndarray, dptr: int):
+        check(self.lib.gtx_dev_download(self.handle, ptr(a), C.c_void_p(dptr), a.nbytes))
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,144 @@
+"""Detector object over the C ABI (gtx_detector_*): the predict half of ``model.track()``.
+
+Reference behaviour replaced: ultralytics' predictor pipeline reached from
+geotrax/extract.py:153 -- LetterBox + normalise, YOLOv8 forward, confidence filter,
+class-agnostic NMS, scaling back to frame pixels -- with the config keys the reference passes
+(geotrax/cfg/default.yaml:229-262: imgsz, conf, iou, max_det, classes, agnostic_nms, half, rect).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import DetConfig, check, ptr
+
+
+@dataclass
+class Detections:
+    xyxy: np.ndarray   # [n,4] float32, frame pixels
+    conf: np.ndarray   # [n] float32
+    cls: np.ndarray    # [n] int32
+    speed: dict        # {'preprocess','inference','postprocess'} ms, like results[0].speed
+
+    def __len__(self):
+        return len(self.conf)
+
+    @property
+    def xywh(self) -> np.ndarray:
+        b = self.xyxy
+        return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) \
+            if len(b) else np.zeros((0, 4), np.float32)
+
+
+class Detector:
+    def __init__(self, tensors: dict[str, np.ndarray], frame_hw: tuple[int, int], *, imgsz: int = 1920,
+                 conf: float = 0.25, iou: float = 0.7, max_det: int = 1000, classes=None,
+                 agnostic_nms: bool = True, half: bool = False, rect: bool = False, max_batch: int = 1,
+                 ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        lib = self.ctx.lib
+        nc = int(tensors["model.22.cv3.0.2.weight"].shape[0])
+        cfg = DetConfig(imgsz=imgsz, conf=conf, iou=iou, max_det=max_det, agnostic_nms=int(agnostic_nms),
+                        half=int(half), rect=int(rect), nc=nc, n_classes=0, max_batch=max_batch,
+                        frame_h=frame_hw[0], frame_w=frame_hw[1])
+        if classes is not None:
+            classes = list(classes)
+            cfg.n_classes = len(classes)
+            for i, c in enumerate(classes):
+                cfg.classes[i] = int(c)
+        self.max_det, self.max_batch, self.nc, self.frame_hw = max_det, max_batch, nc, tuple(frame_hw)
+        h = C.c_void_p()
+        check(lib.gtx_detector_create(self.ctx.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+        for name, arr in tensors.items():
+            if name.endswith("dfl.conv.weight") or ".bn." in name:
+                continue
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(lib.gtx_detector_set_tensor(h, name.encode(), ptr(a), a.ndim, shape))
+        check(lib.gtx_detector_finalize(h))
+        nh, nw = C.c_int(), C.c_int()
+        check(lib.gtx_detector_input_size(h, C.byref(nh), C.byref(nw)))
+        self.net_hw = (nh.value, nw.value)
+        self._n = np.zeros(max_batch, np.int32)
+        self._xyxy = np.zeros((max_batch, max_det, 4), np.float32)
+        self._conf = np.zeros((max_batch, max_det), np.float32)
+        self._cls = np.zeros((max_batch, max_det), np.int32)
+        self._speed = np.zeros(3, np.float32)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.gtx_detector_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _collect(self, nb: int) -> list[Detections]:
+        sp = dict(preprocess=float(self._speed[0]), inference=float(self._speed[1]), postprocess=float(self._speed[2]))
+        out = []
+        for b in range(nb):
+            n = int(self._n[b])
+            out.append(Detections(self._xyxy[b, :n].copy(), self._conf[b, :n].copy(), self._cls[b, :n].copy(), sp))
+        return out
+
+    def detect(self, frame_bgr: np.ndarray) -> Detections:
+        """One host frame (HxWx3 BGR uint8)."""
+        f = np.ascontiguousarray(frame_bgr, dtype=np.uint8)
+        h, w, _ = f.shape
+        check(self.ctx.lib.gtx_detector_detect(self.handle, ptr(f), h, w, ptr(self._n), ptr(self._xyxy),
+                                               ptr(self._conf), ptr(self._cls), ptr(self._speed)))
+        return self._collect(1)[0]
+
+    def detect_dev(self, frames_dptr: int, nb: int = 1) -> list[Detections]:
+        """nb frames already resident in HBM, back to back."""
+        h, w = self.frame_hw
+        check(self.ctx.lib.gtx_detector_detect_batch_dev(self.handle, C.c_void_p(frames_dptr), nb, h, w, ptr(self._n),
+                                                         ptr(self._xyxy), ptr(self._conf), ptr(self._cls), ptr(self._speed)))
+        return self._collect(nb)
+
+    def gray_dptr(self, b: int = 0) -> tuple[int, int, int]:
+        gh, gw = C.c_int(), C.c_int()
+        p = self.ctx.lib.gtx_detector_gray(self.handle, b, C.byref(gh), C.byref(gw))
+        return p, gh.value, gw.value
+
+    def raw_output(self, b: int = 0) -> np.ndarray:
+        """[anchors, 4+nc] fp32 of the last forward (xywh network pixels + class scores)."""
+        na = C.c_int()
+        h, w = self.net_hw
+        anchors = (h // 8) * (w // 8) + (h // 16) * (w // 16) + (h // 32) * (w // 32)
+        out = np.zeros((anchors, 4 + self.nc), np.float32)
+        check(self.ctx.lib.gtx_detector_raw_output(self.handle, b, ptr(out), C.byref(na)))
+        assert na.value == anchors
+        return out
+
+    def layer_output(self, layer: str, b: int = 0) -> np.ndarray:
+        h, w, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.ctx.lib.gtx_detector_layer_output(self.handle, b, layer.encode(), None, C.byref(h), C.byref(w), C.byref(c)))
+        out = np.zeros((h.value, w.value, c.value), np.float32)
+        check(self.ctx.lib.gtx_detector_layer_output(self.handle, b, layer.encode(), ptr(out), C.byref(h), C.byref(w), C.byref(c)))
+        return out
+
+    def profile(self, nb: int = 1, iters: int = 5) -> list[dict]:
+        """Per-kernel-family totals of `iters` forward passes (HIP events around every launch)."""
+        cap = 64
+        names = C.create_string_buffer(cap * 96)
+        launches = np.zeros(cap, np.int32)
+        ms = np.zeros(cap, np.float32)
+        flops = np.zeros(cap, np.float64)
+        nbytes = np.zeros(cap, np.float64)
+        n = C.c_int()
+        check(self.ctx.lib.gtx_detector_profile(self.handle, nb, iters, cap, names, ptr(launches), ptr(ms), ptr(flops),
+                                                ptr(nbytes), C.byref(n)))
+        out = []
+        for i in range(n.value):
+            nm = names.raw[i * 96:(i + 1) * 96].split(b"\0")[0].decode()
+            out.append(dict(kernel=nm, launches=int(launches[i]), total_ms=float(ms[i]), flops=float(flops[i]),
+                            bytes=float(nbytes[i])))
+        return out

@@ -1,0 +1,134 @@
+"""Detector weights: flat tensor files and seeded synthetic weights.
+
+The reference loads an ultralytics ``.pt`` (geotrax/extract.py:222, cfg extraction.model,
+geotrax/cfg/default.yaml:81) -- a pickle of ultralytics classes that cannot be read without that
+package. This build reads a flat ``.safetensors`` file with the model's ``state_dict`` names
+instead (``tools/convert_weights.py`` writes one where ultralytics is installed). Conv+BN pairs
+may be stored fused (``model.0.conv.weight/.bias``) or unfused (``.conv.weight`` +
+``.bn.{weight,bias,running_mean,running_var}``); unfused pairs are folded here exactly like
+ultralytics' ``fuse_conv_and_bn``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+BN_EPS = 1e-3  # ultralytics sets BatchNorm2d.eps = 1e-3 at model build time
+
+# yolov8.yaml scales: depth, width, max_channels
+SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768),
+          "l": (1.00, 1.00, 512), "x": (1.00, 1.25, 512)}
+
+
+def fold_bn(tensors: dict[str, np.ndarray], eps: float = BN_EPS) -> dict[str, np.ndarray]:
+    """Folds every ``X.bn.*`` into ``X.conv.{weight,bias}`` (fp64 arithmetic, fp32 result)."""
+    out = {}
+    for k, v in tensors.items():
+        if ".bn." in k or k.endswith("num_batches_tracked"):
+            continue
+        out[k] = np.asarray(v, dtype=np.float32)
+    for k in list(tensors):
+        if not k.endswith(".bn.weight"):
+            continue
+        pfx = k[: -len(".bn.weight")]
+        g = tensors[pfx + ".bn.weight"].astype(np.float64)
+        b = tensors[pfx + ".bn.bias"].astype(np.float64)
+        m = tensors[pfx + ".bn.running_mean"].astype(np.float64)
+        var = tensors[pfx + ".bn.running_var"].astype(np.float64)
+        w = tensors[pfx + ".conv.weight"].astype(np.float64)
+        s = g / np.sqrt(var + eps)
+        out[pfx + ".conv.weight"] = (w * s[:, None, None, None]).astype(np.float32)
+        cb = tensors.get(pfx + ".conv.bias")
+        cb = np.zeros_like(m) if cb is None else cb.astype(np.float64)
+        out[pfx + ".conv.bias"] = ((cb - m) * s + b).astype(np.float32)
+    return out
+
+
+def load_weights(path: str | Path) -> dict[str, np.ndarray]:
+    from safetensors.numpy import load_file
+
+    t = load_file(str(path))
+    t = {k: np.asarray(v, dtype=np.float32) for k, v in t.items()}
+    return fold_bn(t)
+
+
+def save_weights(tensors: dict[str, np.ndarray], path: str | Path) -> None:
+    from safetensors.numpy import save_file
+
+    save_file({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in tensors.items()}, str(path))
+
+
+def _make_divisible(x: float, d: int = 8) -> int:
+    return int(np.ceil(x / d) * d)
+
+
+def yolov8_layer_specs(scale: str = "s", nc: int = 4) -> list[tuple[str, tuple[int, ...], bool]]:
+    """(tensor name, OIHW shape, has_act) for every conv of a fused YOLOv8 detect model."""
+    depth, width, maxc = SCALES[scale]
+    ch = lambda c: _make_divisible(min(c, maxc) * width)
+    rep = lambda n: max(round(n * depth), 1)
+    specs: list[tuple[str, tuple[int, ...], bool]] = []
+
+    def conv(name, cin, cout, k):
+        specs.append((name, (cout, cin, k, k), True))
+
+    def c2f(pfx, cin, cout, n):
+        c = cout // 2
+        conv(f"{pfx}.cv1.conv", cin, 2 * c, 1)
+        for k in range(n):
+            conv(f"{pfx}.m.{k}.cv1.conv", c, c, 3)
+            conv(f"{pfx}.m.{k}.cv2.conv", c, c, 3)
+        conv(f"{pfx}.cv2.conv", (2 + n) * c, cout, 1)
+
+    c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+    conv("model.0.conv", 3, c1, 3)
+    conv("model.1.conv", c1, c2, 3)
+    c2f("model.2", c2, c2, rep(3))
+    conv("model.3.conv", c2, c3, 3)
+    c2f("model.4", c3, c3, rep(6))
+    conv("model.5.conv", c3, c4, 3)
+    c2f("model.6", c4, c4, rep(6))
+    conv("model.7.conv", c4, c5, 3)
+    c2f("model.8", c5, c5, rep(3))
+    conv("model.9.cv1.conv", c5, c5 // 2, 1)
+    conv("model.9.cv2.conv", c5 * 2, c5, 1)
+    c2f("model.12", c5 + c4, c4, rep(3))
+    c2f("model.15", c4 + c3, c3, rep(3))
+    conv("model.16.conv", c3, c3, 3)
+    c2f("model.18", c3 + c4, c4, rep(3))
+    conv("model.19.conv", c4, c4, 3)
+    c2f("model.21", c4 + c5, c5, rep(3))
+    cb = max(16, c3 // 4, 64)
+    cc = max(c3, min(nc, 100))
+    for l, cin in enumerate((c3, c4, c5)):
+        conv(f"model.22.cv2.{l}.0.conv", cin, cb, 3)
+        conv(f"model.22.cv2.{l}.1.conv", cb, cb, 3)
+        specs.append((f"model.22.cv2.{l}.2", (64, cb, 1, 1), False))
+        conv(f"model.22.cv3.{l}.0.conv", cin, cc, 3)
+        conv(f"model.22.cv3.{l}.1.conv", cc, cc, 3)
+        specs.append((f"model.22.cv3.{l}.2", (nc, cc, 1, 1), False))
+    return specs
+
+
+def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: float = -4.0,
+                     gain: float = 1.7) -> dict[str, np.ndarray]:
+    """Seeded random fused weights of the YOLOv8 architecture (no checkpoint is reachable here).
+
+    Conv weights ~ N(0, gain^2 / fan_in) so activations keep O(1) scale through the SiLU stack;
+    biases ~ N(0, 0.05^2). ``cls_bias`` shifts the class logits so that only a few percent of the
+    anchors clear the confidence threshold, which is the load the decode/NMS stage sees on real
+    footage."""
+    rng = np.random.default_rng(seed)
+    t: dict[str, np.ndarray] = {}
+    for name, shape, has_act in yolov8_layer_specs(scale, nc):
+        fan_in = shape[1] * shape[2] * shape[3]
+        g = gain if has_act else 1.0
+        t[name + ".weight"] = (rng.standard_normal(shape) * (g / np.sqrt(fan_in))).astype(np.float32)
+        b = rng.standard_normal(shape[0]) * 0.05
+        if name.endswith("cv3.0.2") or name.endswith("cv3.1.2") or name.endswith("cv3.2.2"):
+            b = b + cls_bias
+        if ".cv2." in name and name.endswith(".2"):
+            b = b + 1.0  # ultralytics initialises the box-branch bias to 1.0
+        t[name + ".bias"] = b.astype(np.float32)
+    return t

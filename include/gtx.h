@@ -1,0 +1,269 @@
+/*
+ * gtx.h -- C ABI of libgtx.so, the MI355X (gfx950) implementation of the geo-trax
+ * per-frame extraction hot path.
+ *
+ * The reference (rfonod/geo-trax) has no FFI of its own: its hot path is two duck-typed
+ * Python objects called from one loop, geotrax/extract.py:134-214 --
+ *   model.track(frame, **cfg, persist=True)                      extract.py:153
+ *   Stabilizer(**cfg).set_ref_frame / .stabilize /
+ *     .transform_cur_boxes / .get_cur_trans_matrix               extract.py:139,177-184
+ * plus cv2.perspectiveTransform in geotrax/georeference.py:599-605 and
+ * cv2.warpPerspective in geotrax/visualize.py:289.
+ * Each entry point below names the reference call it stands in for. The Python classes in
+ * geo-trax_amd/geotrax_amd/ (YOLO, Stabilizer) bind these symbols with ctypes and keep the
+ * reference's method names, argument meaning and error behaviour.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative gtx_status; the text of the last
+ *     error on the calling thread is available from gtx_last_error();
+ *   - no C++ exception crosses this boundary;
+ *   - the library owns all device memory; the caller owns every host pointer it passes and
+ *     may reuse it as soon as the call returns (calls are synchronous unless named *_submit);
+ *   - a context (and everything created from it) is bound to one GPU and is not thread-safe:
+ *     one context = one host thread, exactly like the reference's single-threaded loop;
+ *   - plain C types only: pointers, sizes, ints, floats, doubles.
+ */
+#ifndef GTX_H_
+#define GTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTX_ABI_VERSION 1
+
+typedef enum gtx_status {
+  GTX_OK = 0,
+  GTX_ERR_INVALID = -1,     /* bad argument */
+  GTX_ERR_HIP = -2,         /* HIP runtime error */
+  GTX_ERR_UNSUPPORTED = -3, /* shape / option outside what the kernels implement */
+  GTX_ERR_STATE = -4,       /* call order (e.g. stabilize before set_ref_frame) */
+  GTX_ERR_INTERNAL = -5
+} gtx_status;
+
+typedef enum gtx_dtype { GTX_F16 = 0, GTX_F32 = 1 } gtx_dtype;
+
+typedef struct gtx_ctx gtx_ctx;
+typedef struct gtx_detector gtx_detector;
+typedef struct gtx_stabilizer gtx_stabilizer;
+typedef struct gtx_tracker gtx_tracker;
+
+/* ------------------------------------------------------------------ library / context */
+
+int gtx_abi_version(void);
+/* Last error message of the calling thread ("" if none). Never NULL. */
+const char* gtx_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int gtx_device_count(void);
+
+/* One context per GPU. Replaces the implicit torch device selection the reference leaves to
+ * ultralytics (cfg ultralytics.device, geotrax/cfg/default.yaml:236). */
+int gtx_ctx_create(int device, gtx_ctx** out);
+void gtx_ctx_destroy(gtx_ctx* ctx);
+int gtx_ctx_synchronize(gtx_ctx* ctx);
+/* Raw device memory for callers that keep inputs resident in HBM (bench.py). */
+int gtx_dev_alloc(gtx_ctx* ctx, size_t bytes, void** dptr);
+int gtx_dev_free(gtx_ctx* ctx, void* dptr);
+int gtx_dev_upload(gtx_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int gtx_dev_download(gtx_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ------------------------------------------------------------------ operator level
+ * Single operators of the detector, exposed so the parity tests can check every kernel
+ * against oracle/ on the exact layer shapes. Host buffers in, host buffers out. */
+
+typedef struct gtx_conv_desc {
+  int dtype;               /* gtx_dtype of activations (weights/bias always given as fp32) */
+  int n, h, w;             /* input batch / height / width */
+  int cin, cout;
+  int ksize;               /* 1 or 3 (padding = ksize/2) */
+  int stride;              /* 1 or 2 */
+  int act;                 /* 1 = SiLU, 0 = identity */
+  int in_cstride, in_coff; /* input buffer has in_cstride channels per pixel; conv reads
+                              channels [in_coff, in_coff+cin) */
+  int out_cstride, out_coff;
+  int has_residual;        /* y += residual (residual laid out like the output slice) */
+} gtx_conv_desc;
+
+/* ultralytics Conv.forward_fuse: act(conv2d(x, w) + b) on NHWC data.
+ * x: [n,h,w,in_cstride] dtype; w_ohwi: [cout,k,k,cin] fp32; bias: [cout] fp32 or NULL;
+ * residual: [n,ho,wo,cout] dtype or NULL; y: [n,ho,wo,out_cstride] dtype (only the slice is
+ * written; the rest of y is copied through from the caller's buffer). */
+int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float* w_ohwi,
+                  const float* bias, const void* residual, void* y);
+/* Repeats the same launch `iters` times and returns the mean kernel time (ms) measured with
+ * HIP events on the launch stream, plus the algorithmic FLOPs of one launch. */
+int gtx_op_conv2d_time(gtx_ctx* ctx, const gtx_conv_desc* d, int iters, float* ms_per_launch,
+                       double* flops);
+
+/* SPPF max-pool cascade (three 5x5/s1/p2 pools of ultralytics SPPF.forward): reads channels
+ * [0,c) of x and writes the 5x5, 9x9 and 13x13 window maxima to channels [c,2c), [2c,3c),
+ * [3c,4c) of the same NHWC buffer (cstride = 4c). */
+int gtx_op_sppf_pool(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, void* x_inout);
+/* nn.Upsample(scale_factor=2, mode="nearest") writing into a channel slice. */
+int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const void* x,
+                      int in_cstride, int in_coff, void* y, int out_cstride, int out_coff);
+
+/* LetterBox + BGR->RGB + /255 (ultralytics predictor preprocess, reached from
+ * extract.py:153) fused with the stabilizer's gray + resize (stabilo, extract.py:177,181).
+ * frame: BGR u8 [h,w,3]. out_img: [net_h,net_w,4] dtype (RGB0). out_gray: u8
+ * [gray_h,gray_w] (may be NULL). */
+int gtx_op_preprocess(gtx_ctx* ctx, int dtype, const uint8_t* frame, int h, int w, int net_h,
+                      int net_w, void* out_img, uint8_t* out_gray, int gray_h, int gray_w);
+
+/* ------------------------------------------------------------------ detector
+ * Stands in for ultralytics YOLO(model).predict half of model.track() -- preprocess,
+ * YOLOv8 forward, decode, NMS, scale back to frame coordinates (extract.py:153,222). */
+
+typedef struct gtx_det_config {
+  int imgsz;        /* cfg ultralytics.imgsz (default.yaml:235) */
+  float conf;       /* ultralytics.conf  */
+  float iou;        /* ultralytics.iou   */
+  int max_det;      /* ultralytics.max_det */
+  int agnostic_nms; /* ultralytics.agnostic_nms */
+  int half;         /* ultralytics.half: 0 = fp32 activations/MFMA, 1 = fp16 */
+  int rect;         /* ultralytics.rect: 0 = pad to imgsz x imgsz, 1 = minimal stride-32 rectangle */
+  int nc;           /* number of classes of the model */
+  int n_classes;    /* length of classes[]; 0 = keep all (ultralytics.classes) */
+  int classes[80];
+  int max_batch;    /* frames per forward pass the buffers are sized for (>=1) */
+  int frame_h, frame_w; /* source frame size the buffers are sized for */
+} gtx_det_config;
+
+int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out);
+void gtx_detector_destroy(gtx_detector* det);
+/* Weight hand-over, one tensor at a time, using ultralytics state_dict names of the *fused*
+ * model (e.g. "model.0.conv.weight" OIHW fp32, "model.0.conv.bias"). The Python host reads the
+ * safetensors file. Replaces YOLO(model=...) (extract.py:222). */
+int gtx_detector_set_tensor(gtx_detector* det, const char* name, const float* data, int ndim,
+                            const int64_t* shape);
+/* Packs weights for the kernels, plans buffers, captures the hipGraph. */
+int gtx_detector_finalize(gtx_detector* det);
+/* Network input size actually used (after imgsz / rect / stride rounding). */
+int gtx_detector_input_size(gtx_detector* det, int* net_h, int* net_w);
+
+/* One frame, host BGR u8 [h,w,3] -> boxes in frame pixels, sorted by confidence (the order
+ * ultralytics' NMS returns). Output arrays must hold max_det entries.
+ * speed_ms[3] = preprocess, inference, postprocess -- the `results[0].speed` dict that
+ * extract.py:155-156 sums. */
+int gtx_detector_detect(gtx_detector* det, const uint8_t* frame_bgr, int h, int w, int* n_out,
+                        float* xyxy, float* conf, int* cls, float speed_ms[3]);
+/* Same, frame already resident in HBM (dptr from gtx_dev_alloc). */
+int gtx_detector_detect_dev(gtx_detector* det, const void* frame_dptr, int h, int w, int* n_out,
+                            float* xyxy, float* conf, int* cls, float speed_ms[3]);
+/* Batched variant: nb frames resident in HBM back to back; outputs are [nb][max_det]. */
+int gtx_detector_detect_batch_dev(gtx_detector* det, const void* frames_dptr, int nb, int h, int w,
+                                  int* n_out, float* xyxy, float* conf, int* cls,
+                                  float speed_ms[3]);
+/* Device pointer of the half-resolution gray image the preprocess pass of the last detect
+ * call wrote (batch slot b), or NULL if disabled. The stabilizer consumes it so the frame is
+ * read from HBM once. */
+const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w);
+/* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
+ * pixels + sigmoid class scores), like the tensor ultralytics' Detect returns. */
+int gtx_detector_raw_output(gtx_detector* det, int b, float* out, int* n_anchors);
+/* Activation of a named layer of the last forward ("model.4" ...), NHWC fp32, for parity. */
+int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out,
+                              int* h, int* w, int* c);
+/* Per-kernel-family profile of one forward pass: launches, total ms (HIP events around every
+ * launch on the launch stream, graph disabled) and algorithmic FLOPs / bytes. `names` receives
+ * up to cap entries of 96 chars. Feeds bench.py's roofline object. */
+int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* names,
+                         int* launches, float* total_ms, double* flops, double* bytes,
+                         int* n_families);
+
+/* ------------------------------------------------------------------ tracker (host, C++)
+ * Stands in for the tracker callback ultralytics runs inside model.track()
+ * (BYTETracker / BOTSORT.update; cfg tracker.* default.yaml:361-389). */
+
+typedef struct gtx_tracker_config {
+  int type;                /* 0 = bytetrack, 1 = botsort */
+  float track_high_thresh;
+  float track_low_thresh;
+  float new_track_thresh;
+  int track_buffer;
+  float match_thresh;
+  int fuse_score;
+  int frame_rate;          /* ultralytics passes 30 */
+} gtx_tracker_config;
+
+int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);
+void gtx_tracker_destroy(gtx_tracker* trk);
+int gtx_tracker_reset(gtx_tracker* trk);
+/* One frame of detections (xyxy, conf, cls; n entries) -> active tracks. Outputs hold up to
+ * cap rows: xyxy (Kalman posterior box), track id, score, class, index of the matched
+ * detection. gmc_affine: optional 2x3 row-major camera-motion matrix (BoT-SORT GMC), NULL =
+ * identity. Mirrors BYTETracker.update + the result rewrite in
+ * ultralytics/trackers/track.py:on_predict_postprocess_end. */
+int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* conf,
+                       const int* cls, const double* gmc_affine, int cap, int* n_out,
+                       float* out_xyxy, int* out_id, float* out_score, int* out_cls,
+                       int* out_det_idx);
+
+/* ------------------------------------------------------------------ stabilizer
+ * Stands in for stabilo.Stabilizer as used at extract.py:139,177-187 and
+ * geotrax/utils/registration.py:59-85. */
+
+typedef struct gtx_stab_config {
+  float downsample_ratio;      /* stabilo downsample_ratio (default.yaml:106) */
+  int max_features;            /* per frame; the reference frame gets ref_multiplier x */
+  float ref_multiplier;
+  float filter_ratio;          /* Lowe ratio */
+  float ransac_threshold;      /* px, full-resolution units */
+  int ransac_max_iter;
+  float ransac_confidence;
+  int mask_use;
+  float mask_margin_ratio;
+  int fast_threshold;          /* ORB fastThreshold (OpenCV default 20) */
+  int n_levels;                /* ORB pyramid levels (8) */
+  float scale_factor;          /* ORB pyramid scale (1.2) */
+  uint32_t seed;               /* RANSAC sampling seed */
+  int frame_h, frame_w;
+} gtx_stab_config;
+
+int gtx_stabilizer_create(gtx_ctx* ctx, const gtx_stab_config* cfg, gtx_stabilizer** out);
+void gtx_stabilizer_destroy(gtx_stabilizer* st);
+/* Stabilizer.set_ref_frame(frame, boxes): boxes xywh [n,4] in frame pixels or NULL. */
+int gtx_stabilizer_set_ref_frame(gtx_stabilizer* st, const uint8_t* frame_bgr, int h, int w,
+                                 const float* boxes_xywh, int n);
+/* Same, from a half-resolution gray image already in HBM (gtx_detector_gray). */
+int gtx_stabilizer_set_ref_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
+                                    const float* boxes_xywh, int n);
+/* Stabilizer.stabilize(frame, boxes) + get_cur_trans_matrix(): H maps current-frame pixels
+ * to reference-frame pixels (row-major 3x3 f64). valid = 0 when no transform could be
+ * estimated (the reference then gets None and skips the row, extract.py:185). stats[4] =
+ * keypoints ref, keypoints cur, good matches, inliers (registration.py:83-85). */
+int gtx_stabilizer_stabilize(gtx_stabilizer* st, const uint8_t* frame_bgr, int h, int w,
+                             const float* boxes_xywh, int n, double H[9], int* valid,
+                             int stats[4]);
+int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
+                                      const float* boxes_xywh, int n, double H[9], int* valid,
+                                      int stats[4]);
+/* Keypoints / descriptors of the last processed image (for parity tests): xy in full-res
+ * pixels, level, angle bin, 32-byte descriptors. */
+int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which /*0 ref, 1 cur*/, int cap, int* n,
+                             float* xy, int* level, int* angle_bin, uint8_t* desc);
+/* Good matches of the last stabilize call: pairs (cur index, ref index) and Hamming distance. */
+int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, int* ref_idx,
+                           int* dist);
+
+/* Stabilizer.transform_cur_boxes(): maps the 4 corners of each xywh box through H and
+ * returns the axis-aligned bounding rectangle as xywh (rule pinned on the reference's golden
+ * output). Pure host arithmetic, f64 inside, f32 out. */
+int gtx_warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_out);
+
+/* cv2.perspectiveTransform on N points (georeference.py:599-605), f64. */
+int gtx_perspective_points(const double H[9], const double* x, const double* y, int n,
+                           double* ox, double* oy);
+
+/* cv2.warpPerspective(frame, H, (w,h)) with bilinear sampling and constant-0 border
+ * (visualize.py:289). BGR u8 in/out, host buffers. */
+int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9],
+                   uint8_t* dst_bgr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTX_H_ */

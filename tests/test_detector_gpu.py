@@ -1,0 +1,104 @@
+"""End-to-end parity of the HIP detector against oracle/yolov8_ref.py through the C ABI:
+per-layer activations, raw head output, and post-NMS boxes, fp32 and fp16, square and rect."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FRAME_HW = (432, 768)
+
+
+def _frame(seed=0, hw=FRAME_HW):
+    rng = np.random.default_rng(seed)
+    h, w = hw
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 110 + 50 * np.sin(xx / 37.0) * np.cos(yy / 23.0)
+    f = np.stack([base + 20 * rng.standard_normal((h, w)) for _ in range(3)], -1)
+    for _ in range(25):
+        x, y = rng.integers(0, w - 40), rng.integers(0, h - 20)
+        f[y:y + rng.integers(8, 20), x:x + rng.integers(15, 40)] = rng.integers(150, 255, 3)
+    return np.clip(f, 0, 255).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def weights():
+    from geotrax_amd.weights import synthetic_yolov8
+
+    return synthetic_yolov8(seed=1, nc=4, scale="s", cls_bias=-3.0)
+
+
+LAYERS = ["model.0.conv", "model.1.conv", "model.2", "model.3.conv", "model.4", "model.6", "model.8", "model.9",
+          "model.12", "model.15", "model.18", "model.21", "model.22.feat0", "model.22.feat1", "model.22.feat2"]
+
+
+@pytest.mark.parametrize("half,rect,imgsz", [(False, False, 384), (True, False, 384), (False, True, 384), (True, True, 384)])
+def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz):
+    from geotrax_amd.detector import Detector
+    from oracle.yolov8_ref import YoloV8Ref, detect, letterbox
+
+    frame = _frame(0)
+    kw = dict(conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True)
+    det = Detector(weights, FRAME_HW, imgsz=imgsz, half=half, rect=rect, ctx=gtx_ctx, **kw)
+    got = det.detect(frame)
+
+    ref_model = YoloV8Ref(weights, emulate_half=half)
+    x, g = letterbox(frame, imgsz, rect, half=half)
+    assert det.net_hw == (g["net_h"], g["net_w"])
+    ref_raw = ref_model.forward(x)[0].numpy()
+
+    # fp32: fmaf-chain MFMA vs torch's blocked conv, only summation order differs.
+    # fp16: both sides round every stored activation to fp16; a different fp32 summation order
+    # flips an fp16 rounding now and then and the flips compound over ~25 layers.
+    rel = 2e-4 if not half else 3e-2
+    for name in LAYERS:
+        a = det.layer_output(name)
+        r = ref_model.acts[name][0].permute(1, 2, 0).numpy()
+        assert a.shape == r.shape, name
+        err = np.abs(a - r).max() / (np.abs(r).max() + 1e-6)
+        assert err < rel, f"{name}: rel-to-max error {err:.3e}"
+
+    raw = det.raw_output()
+    assert raw.shape == ref_raw.shape
+    np.testing.assert_allclose(raw[:, 4:], ref_raw[:, 4:], atol=1e-4 if not half else 2e-2)
+    np.testing.assert_allclose(raw[:, :4], ref_raw[:, :4], atol=2e-3 if not half else 0.5)
+
+    xyxy, conf, cls = detect(ref_model, frame, imgsz, rect, kw["conf"], kw["iou"], kw["classes"], True, kw["max_det"])
+    if not half:
+        # identical detections in identical (score) order, boxes within 0.01 px
+        assert len(got) == len(conf)
+        np.testing.assert_array_equal(got.cls, cls)
+        np.testing.assert_allclose(got.conf, conf, atol=1e-5)
+        np.testing.assert_allclose(got.xyxy, xyxy, atol=1e-2)
+    else:
+        # fp16: same detections up to threshold-borderline ones; match by IoU
+        assert abs(len(got) - len(conf)) <= max(2, len(conf) // 50)
+        matched = 0
+        for b, c in zip(xyxy, conf):
+            if len(got) == 0:
+                break
+            ix1, iy1 = np.maximum(got.xyxy[:, 0], b[0]), np.maximum(got.xyxy[:, 1], b[1])
+            ix2, iy2 = np.minimum(got.xyxy[:, 2], b[2]), np.minimum(got.xyxy[:, 3], b[3])
+            inter = np.clip(ix2 - ix1, 0, None) * np.clip(iy2 - iy1, 0, None)
+            a = (got.xyxy[:, 2] - got.xyxy[:, 0]) * (got.xyxy[:, 3] - got.xyxy[:, 1])
+            iou = inter / (a + (b[2] - b[0]) * (b[3] - b[1]) - inter + 1e-9)
+            matched += iou.max() > 0.9
+        assert matched >= 0.95 * len(conf)
+    assert len(got) > 0, "test weights/frame should produce detections"
+
+
+def test_detector_batch_equals_single(gtx_ctx, weights):
+    from geotrax_amd.detector import Detector
+
+    frames = np.stack([_frame(s) for s in range(3)])
+    det = Detector(weights, FRAME_HW, imgsz=384, half=True, max_batch=3, ctx=gtx_ctx, conf=0.25, max_det=300)
+    singles = [det.detect(f) for f in frames]
+    dptr = gtx_ctx.dev_alloc(frames.nbytes)
+    try:
+        gtx_ctx.dev_upload(dptr, frames)
+        batch = det.detect_dev(dptr, 3)
+    finally:
+        gtx_ctx.dev_free(dptr)
+    for s, b in zip(singles, batch):
+        np.testing.assert_array_equal(s.xyxy, b.xyxy)
+        np.testing.assert_array_equal(s.conf, b.conf)
+        np.testing.assert_array_equal(s.cls, b.cls)

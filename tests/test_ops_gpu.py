@@ -1,0 +1,132 @@
+"""Parity of every detector HIP kernel against oracle/ through the C ABI (gtx_op_*), on the
+layer shapes YOLOv8s actually runs at sizes the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, shape, dtype):
+    return rng.standard_normal(shape).astype(np.float32).astype(dtype)
+
+
+def _tol(dtype):
+    # fp32: MFMA f32 is an exact fmaf chain, only the summation order differs from the oracle.
+    # fp16: inputs are identical fp16 values, products accumulate in fp32, the stored output is
+    # rounded to fp16 once (rel 2^-11) -- BASELINE.md §5 allows 2e-2 rel for this path.
+    return (2e-4, 2e-4) if dtype == np.float32 else (4e-3, 4e-3)
+
+
+# (cin, cout, k, stride, h, w): stem-adjacent, C2f inner, stride-2 downsamples, SPPF / concat 1x1s
+CONV_CASES = [
+    (32, 64, 3, 2, 40, 56),     # model.1
+    (32, 32, 3, 1, 24, 40),     # model.2.m.0.cv1 (BN=32 path)
+    (64, 64, 1, 1, 24, 40),     # model.2.cv1 (KC=64 path)
+    (96, 64, 1, 1, 17, 33),     # model.2.cv2 (Cin=96 -> KC=32 1x1 path), ragged tile edges
+    (64, 128, 3, 2, 33, 47),    # model.3, odd input size
+    (128, 128, 3, 1, 16, 16),   # head cls conv, exactly one tile
+    (256, 512, 3, 2, 14, 14),   # model.7, deep K
+    (512, 256, 1, 1, 9, 20),    # model.9.cv1
+    (768, 256, 1, 1, 8, 16),    # model.12.cv1
+    (128, 192, 3, 1, 20, 36),   # fused Detect stage 1 at P3 (3 cout tiles)
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_oracle(gtx_ctx, dtype, case):
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import conv2d_nhwc
+
+    cin, cout, k, stride, h, w = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = _rand(rng, (2, h, w, cin), dtype)
+    wt = (rng.standard_normal((cout, k, k, cin)) / np.sqrt(cin * k * k)).astype(np.float32)
+    if dtype == np.float16:
+        wt = wt.astype(np.float16).astype(np.float32)  # the kernel stores weights in fp16
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    got = ops.conv2d(x, wt, b, stride=stride, act=True, ctx=gtx_ctx)
+    ref = conv2d_nhwc(x, wt, b, stride=stride, act=True)
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(got.astype(np.float32), ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_conv2d_slices_residual_identity(gtx_ctx, dtype):
+    """Channel-slice input, channel-slice output (concat buffer untouched elsewhere), residual
+    add after SiLU (Bottleneck shortcut) and the identity-activation variant."""
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import conv2d_nhwc
+
+    rng = np.random.default_rng(7)
+    n, h, w = 1, 19, 27
+    buf = _rand(rng, (n, h, w, 96), dtype)          # C2f concat buffer: 3 chunks of 32
+    wt = (rng.standard_normal((32, 3, 3, 32)) / 17).astype(np.float32)
+    if dtype == np.float16:
+        wt = wt.astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32) * 0.1
+    res = np.ascontiguousarray(buf[..., 32:64])
+    out = buf.copy()
+    got = ops.conv2d(buf, wt, b, in_coff=32, cin=32, out=out, out_coff=64, residual=res, ctx=gtx_ctx)
+    ref = conv2d_nhwc(buf[..., 32:64], wt, b, residual=res.astype(np.float32))
+    rtol, atol = _tol(dtype)
+    np.testing.assert_allclose(got[..., 64:96].astype(np.float32), ref, rtol=rtol, atol=atol)
+    np.testing.assert_array_equal(got[..., :64], buf[..., :64])  # rest of the buffer untouched
+    got2 = ops.conv2d(np.ascontiguousarray(buf[..., :32]), wt, None, act=False, ctx=gtx_ctx)
+    ref2 = conv2d_nhwc(buf[..., :32], wt, None, act=False)
+    np.testing.assert_allclose(got2.astype(np.float32), ref2, rtol=rtol, atol=atol)
+
+
+def test_conv2d_exact_integer_data(gtx_ctx):
+    """Small-integer inputs make every partial sum exact in fp32: any layout / fragment-mapping
+    slip shows up as a hard mismatch rather than a tolerance question (asymmetric weights)."""
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import conv2d_nhwc
+
+    rng = np.random.default_rng(3)
+    for dtype in (np.float16, np.float32):
+        for (cin, cout, k, s) in [(32, 64, 3, 1), (64, 32, 3, 2), (128, 64, 1, 1)]:
+            x = rng.integers(-3, 4, (1, 21, 35, cin)).astype(dtype)
+            wt = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
+            b = rng.integers(-4, 5, cout).astype(np.float32)
+            got = ops.conv2d(x, wt, b, stride=s, act=False, ctx=gtx_ctx)
+            ref = conv2d_nhwc(x, wt, b, stride=s, act=False)
+            assert np.abs(ref).max() < 2048  # exactly representable in fp16 too
+            np.testing.assert_array_equal(got.astype(np.float32), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_sppf_pool_and_upsample(gtx_ctx, dtype):
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import sppf_pools_nhwc, upsample2x_nhwc
+
+    rng = np.random.default_rng(11)
+    c = 64
+    x = np.zeros((2, 13, 22, 4 * c), dtype=dtype)
+    x[..., :c] = _rand(rng, (2, 13, 22, c), dtype)
+    got = ops.sppf_pool(x, c, ctx=gtx_ctx)
+    np.testing.assert_array_equal(got.astype(np.float32), sppf_pools_nhwc(x[..., :c]))
+
+    src = _rand(rng, (2, 7, 9, 48), dtype)
+    dst = _rand(rng, (2, 14, 18, 80), dtype)
+    got = ops.upsample2x(src, 32, 16, dst, 40, ctx=gtx_ctx)
+    np.testing.assert_array_equal(got[..., 40:72], upsample2x_nhwc(src[..., 16:48]))
+    np.testing.assert_array_equal(got[..., :40], dst[..., :40])
+    np.testing.assert_array_equal(got[..., 72:], dst[..., 72:])
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("shape,imgsz,rect", [((216, 384), 192, False), ((216, 384), 192, True), ((200, 300), 256, False)])
+def test_preprocess_matches_oracle(gtx_ctx, dtype, shape, imgsz, rect):
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import bgr2gray_half, letterbox
+
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (*shape, 3), dtype=np.uint8)
+    ref, g = letterbox(frame, imgsz, rect, half=(dtype == np.float16))
+    img, gray = ops.preprocess(frame, g["net_h"], g["net_w"], dtype=dtype, ctx=gtx_ctx)
+    ref_nhwc = ref[0].permute(1, 2, 0).numpy()
+    # integer pixel pipeline is exact; the /255 is one correctly rounded fp32 (or fp16) division
+    np.testing.assert_array_equal(img[..., :3].astype(np.float32), ref_nhwc.astype(dtype).astype(np.float32))
+    assert not img[..., 3].any()
+    np.testing.assert_array_equal(gray, bgr2gray_half(frame))
