@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int 
   const int n = blockIdx.y;
   const int cnt = min(nb.count[n], nb.cap);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) nb.sorted_n[n] = min(cnt, limit);  // also when cnt == 0
   if (blockIdx.x * blockDim.x >= cnt) return;  // whole block idle
   const size_t base = (size_t)n * nb.cap;
   const bool act = i < cnt;
@@ -525,7 +526,6 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int 
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) nb.sorted_n[n] = min(cnt, limit);
   if (act && rank < limit) {
     const size_t so = (size_t)n * nb.nms_cap + rank;
     const float4 b = reinterpret_cast<const float4*>(nb.cand_box)[base + i];

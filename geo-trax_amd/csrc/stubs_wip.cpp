@@ -1,13 +1,7 @@
 // Temporary: entry points whose implementation lands later in this round.
 #include "geometry.hpp"
 #include "stabilizer.hpp"
-#include "tracker.hpp"
 namespace gtx {
-struct ByteTracker::Impl {};
-ByteTracker::ByteTracker(const gtx_tracker_config&) { fail(GTX_ERR_UNSUPPORTED, "tracker not built yet"); }
-ByteTracker::~ByteTracker() = default;
-void ByteTracker::reset() {}
-void ByteTracker::update(int, const float*, const float*, const int*, const double*, int, int*, float*, int*, float*, int*, int*) {}
 struct Stabilizer::Impl {};
 Stabilizer::Stabilizer(gtx_ctx*, const gtx_stab_config&) { fail(GTX_ERR_UNSUPPORTED, "stabilizer not built yet"); }
 Stabilizer::~Stabilizer() = default;

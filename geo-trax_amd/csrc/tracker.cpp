@@ -1,0 +1,557 @@
+// ByteTrack / BoT-SORT association on the host (C++), the sequential part of the hot path.
+//
+// Stands in for ultralytics.trackers.{byte_tracker.BYTETracker, bot_sort.BOTSORT}.update and
+// the lapx solver it calls (reference call site geotrax/extract.py:153 with persist=True;
+// parameters geotrax/cfg/default.yaml:361-389). The algorithm is restated step for step in
+// oracle/bytetrack_ref.py; both follow the published ByteTrack procedure as ultralytics ships
+// it: Kalman predict -> (GMC) -> IoU(+score fusion) cost -> LAP with cost limit -> second
+// association on low-score detections -> unconfirmed tracks -> new tracks -> lost/removed
+// bookkeeping -> duplicate removal.
+//
+// The LAP: lap.lapjv(cost, extend_cost=True, cost_limit=t) minimises the assignment cost where
+// leaving a row or a column unmatched costs t/2 each, i.e. a pair is only worth matching when
+// cost < t. Pairs at or above the limit can therefore be dropped up front, the bipartite graph
+// falls apart into small connected components (vehicles rarely overlap), and every component is
+// solved exactly with a dense Hungarian on its own extended matrix. Same optimum, ~100x less
+// work than one (n+m)^2 problem per frame.
+#include "tracker.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_set>
+#include <vector>
+
+namespace gtx {
+
+namespace {
+
+enum State { kNew = 0, kTracked = 1, kLost = 2, kRemoved = 3 };
+
+struct Kalman {
+  bool xywh;  // false: XYAH (ByteTrack), true: XYWH (BoT-SORT)
+  static constexpr double swp = 1.0 / 20, swv = 1.0 / 160;
+
+  void stds(const double* m, double k_pos, double k_vel, double a_pos, double a_vel, double* s) const {
+    if (xywh) {
+      const double w = m[2], h = m[3];
+      s[0] = k_pos * swp * w; s[1] = k_pos * swp * h; s[2] = k_pos * swp * w; s[3] = k_pos * swp * h;
+      s[4] = k_vel * swv * w; s[5] = k_vel * swv * h; s[6] = k_vel * swv * w; s[7] = k_vel * swv * h;
+    } else {
+      const double h = m[3];
+      s[0] = k_pos * swp * h; s[1] = k_pos * swp * h; s[2] = a_pos; s[3] = k_pos * swp * h;
+      s[4] = k_vel * swv * h; s[5] = k_vel * swv * h; s[6] = a_vel; s[7] = k_vel * swv * h;
+    }
+  }
+
+  void initiate(const double z[4], double* mean, double* cov) const {
+    for (int i = 0; i < 4; ++i) { mean[i] = z[i]; mean[4 + i] = 0; }
+    double s[8];
+    stds(mean, 2, 10, 1e-2, 1e-5, s);
+    std::fill(cov, cov + 64, 0.0);
+    for (int i = 0; i < 8; ++i) cov[i * 9] = s[i] * s[i];
+  }
+
+  // mean <- F mean, cov <- F cov F^T + Q, F = I + shift(4)
+  void predict(double* mean, double* cov) const {
+    double s[8];
+    stds(mean, 1, 1, 1e-2, 1e-5, s);
+    for (int i = 0; i < 4; ++i) mean[i] += mean[4 + i];
+    double t[64];
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j) t[i * 8 + j] = cov[i * 8 + j] + (i < 4 ? cov[(i + 4) * 8 + j] : 0.0);  // F cov
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j) cov[i * 8 + j] = t[i * 8 + j] + (j < 4 ? t[i * 8 + j + 4] : 0.0);      // (.) F^T
+    for (int i = 0; i < 8; ++i) cov[i * 9] += s[i] * s[i];
+  }
+
+  void update(double* mean, double* cov, const double z[4]) const {
+    double s[8];
+    stds(mean, 1, 1, 1e-1, 0, s);
+    // S = H cov H^T + R (4x4), H = [I 0]
+    double S[16];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) S[i * 4 + j] = cov[i * 8 + j] + (i == j ? s[i] * s[i] : 0.0);
+    // Cholesky S = L L^T
+    double L[16] = {0};
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double v = S[i * 4 + j];
+        for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
+        L[i * 4 + j] = (i == j) ? std::sqrt(v) : v / L[j * 4 + j];
+      }
+    // K = cov H^T S^-1  (8x4): solve S K^T = (cov H^T)^T column by column
+    double K[32];
+    for (int r = 0; r < 8; ++r) {
+      double y[4], x[4];
+      for (int i = 0; i < 4; ++i) {
+        double v = cov[r * 8 + i];
+        for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * y[k];
+        y[i] = v / L[i * 4 + i];
+      }
+      for (int i = 3; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 4; ++k) v -= L[k * 4 + i] * x[k];
+        x[i] = v / L[i * 4 + i];
+      }
+      for (int i = 0; i < 4; ++i) K[r * 4 + i] = x[i];
+    }
+    double innov[4];
+    for (int i = 0; i < 4; ++i) innov[i] = z[i] - mean[i];
+    for (int r = 0; r < 8; ++r)
+      for (int i = 0; i < 4; ++i) mean[r] += innov[i] * K[r * 4 + i];
+    // cov -= K S K^T
+    double KS[32];
+    for (int r = 0; r < 8; ++r)
+      for (int j = 0; j < 4; ++j) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += K[r * 4 + k] * S[k * 4 + j];
+        KS[r * 4 + j] = v;
+      }
+    for (int r = 0; r < 8; ++r)
+      for (int c = 0; c < 8; ++c) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += KS[r * 4 + k] * K[c * 4 + k];
+        cov[r * 8 + c] -= v;
+      }
+  }
+};
+
+struct Track {
+  float tlwh0[4];       // detection box (top-left, w, h), float32 like STrack._tlwh
+  double mean[8];
+  double cov[64];
+  bool has_mean = false;
+  bool activated = false;
+  int state = kNew;
+  float score = 0;
+  int cls = 0;
+  int idx = 0;          // index of the detection inside the frame's detection list
+  int id = 0;
+  int frame_id = 0, start_frame = 0, tracklet_len = 0;
+};
+
+// ---- exact small LAP: Hungarian (Kuhn-Munkres with potentials) on a square matrix ----
+// Returns col assigned to each row.
+void hungarian(const std::vector<double>& a, int n, std::vector<int>& row_to_col) {
+  const double INF = std::numeric_limits<double>::infinity();
+  std::vector<double> u(n + 1, 0), v(n + 1, 0), minv(n + 1);
+  std::vector<int> p(n + 1, 0), way(n + 1, 0);
+  std::vector<char> used(n + 1);
+  for (int i = 1; i <= n; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    std::fill(minv.begin(), minv.end(), INF);
+    std::fill(used.begin(), used.end(), 0);
+    do {
+      used[j0] = 1;
+      const int i0 = p[j0];
+      double delta = INF;
+      int j1 = 0;
+      for (int j = 1; j <= n; ++j) {
+        if (used[j]) continue;
+        const double cur = a[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
+        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+      }
+      for (int j = 0; j <= n; ++j) {
+        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+        else minv[j] -= delta;
+      }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0);
+  }
+  row_to_col.assign(n, -1);
+  for (int j = 1; j <= n; ++j)
+    if (p[j]) row_to_col[p[j] - 1] = j - 1;
+}
+
+// lap.lapjv(cost, extend_cost=True, cost_limit=limit) semantics. cost: rows x cols, row-major
+// float32 (as numpy hands it over). x[r] = matched col or -1, y[c] = matched row or -1.
+void linear_assignment(const std::vector<float>& cost, int rows, int cols, double limit, std::vector<int>& x,
+                       std::vector<int>& y) {
+  x.assign(rows, -1);
+  y.assign(cols, -1);
+  if (rows == 0 || cols == 0) return;
+  // union-find over rows [0,rows) and cols [rows, rows+cols) along feasible edges
+  std::vector<int> parent(rows + cols);
+  std::iota(parent.begin(), parent.end(), 0);
+  auto find = [&](int a) {
+    while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; }
+    return a;
+  };
+  std::vector<char> row_has(rows, 0);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c)
+      if ((double)cost[(size_t)r * cols + c] < limit) {
+        row_has[r] = 1;
+        const int a = find(r), b = find(rows + c);
+        if (a != b) parent[a] = b;
+      }
+  // group members per root
+  std::vector<int> root_of(rows + cols);
+  for (int i = 0; i < rows + cols; ++i) root_of[i] = find(i);
+  std::vector<int> order(rows + cols);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return root_of[a] < root_of[b]; });
+  std::vector<int> rr, cc, r2c;
+  std::vector<double> ext;
+  size_t i = 0;
+  while (i < order.size()) {
+    size_t j = i;
+    rr.clear();
+    cc.clear();
+    while (j < order.size() && root_of[order[j]] == root_of[order[i]]) {
+      const int m = order[j];
+      if (m < rows) rr.push_back(m); else cc.push_back(m - rows);
+      ++j;
+    }
+    i = j;
+    if (rr.empty() || cc.empty()) continue;
+    const int nr = (int)rr.size(), nc = (int)cc.size();
+    if (nr == 1 && nc == 1) {
+      x[rr[0]] = cc[0];
+      y[cc[0]] = rr[0];
+      continue;
+    }
+    // extended (nr+nc)^2 matrix exactly as lapjv builds it
+    const int n = nr + nc;
+    ext.assign((size_t)n * n, limit / 2.0);
+    for (int a = nr; a < n; ++a)
+      for (int b = nc; b < n; ++b) ext[(size_t)a * n + b] = 0.0;
+    for (int a = 0; a < nr; ++a)
+      for (int b = 0; b < nc; ++b) ext[(size_t)a * n + b] = (double)cost[(size_t)rr[a] * cols + cc[b]];
+    hungarian(ext, n, r2c);
+    for (int a = 0; a < nr; ++a)
+      if (r2c[a] >= 0 && r2c[a] < nc) {
+        x[rr[a]] = cc[r2c[a]];
+        y[cc[r2c[a]]] = rr[a];
+      }
+  }
+}
+
+inline void xyxy_of(const Track& t, bool xywh_state, float out[4]) {
+  double tl[4];
+  if (!t.has_mean) {
+    for (int i = 0; i < 4; ++i) tl[i] = t.tlwh0[i];
+  } else if (xywh_state) {
+    tl[2] = t.mean[2]; tl[3] = t.mean[3];
+    tl[0] = t.mean[0] - tl[2] / 2; tl[1] = t.mean[1] - tl[3] / 2;
+  } else {
+    tl[3] = t.mean[3]; tl[2] = t.mean[2] * t.mean[3];
+    tl[0] = t.mean[0] - tl[2] / 2; tl[1] = t.mean[1] - tl[3] / 2;
+  }
+  if (!t.has_mean) {
+    // float32 arithmetic on the float32 _tlwh, like numpy does
+    out[0] = t.tlwh0[0]; out[1] = t.tlwh0[1];
+    out[2] = t.tlwh0[2] + t.tlwh0[0]; out[3] = t.tlwh0[3] + t.tlwh0[1];
+  } else {
+    out[0] = (float)tl[0]; out[1] = (float)tl[1]; out[2] = (float)(tl[2] + tl[0]); out[3] = (float)(tl[3] + tl[1]);
+  }
+}
+
+}  // namespace
+
+struct ByteTracker::Impl {
+  gtx_tracker_config cfg;
+  Kalman kf;
+  std::vector<Track> tracked, lost, removed;
+  int frame_id = 0;
+  int next_id = 0;
+  int max_time_lost = 30;
+
+  int new_id() { return ++next_id; }
+
+  void measurement(const float tlwh[4], double z[4]) const {
+    // tlwh_to_xyah / tlwh_to_xywh on float32 input (numpy float32 arithmetic)
+    float r[4] = {tlwh[0], tlwh[1], tlwh[2], tlwh[3]};
+    r[0] += r[2] / 2;
+    r[1] += r[3] / 2;
+    if (!kf.xywh) r[2] /= r[3];
+    for (int i = 0; i < 4; ++i) z[i] = r[i];
+  }
+  void tlwh_of(const Track& t, float out[4]) const {
+    if (!t.has_mean) { std::memcpy(out, t.tlwh0, sizeof(float) * 4); return; }
+    double w, h;
+    if (kf.xywh) { w = t.mean[2]; h = t.mean[3]; } else { h = t.mean[3]; w = t.mean[2] * t.mean[3]; }
+    out[0] = (float)(t.mean[0] - w / 2); out[1] = (float)(t.mean[1] - h / 2); out[2] = (float)w; out[3] = (float)h;
+  }
+
+  // 1 - IoU (float32 like matching.iou_distance), optionally fused with detection scores
+  std::vector<float> dists(const std::vector<Track*>& a, const std::vector<Track*>& b, bool fuse) const {
+    std::vector<float> d(a.size() * b.size());
+    std::vector<float> ab(a.size() * 4), bb(b.size() * 4);
+    for (size_t i = 0; i < a.size(); ++i) xyxy_of(*a[i], kf.xywh, &ab[i * 4]);
+    for (size_t j = 0; j < b.size(); ++j) xyxy_of(*b[j], kf.xywh, &bb[j * 4]);
+    for (size_t i = 0; i < a.size(); ++i) {
+      const float* p = &ab[i * 4];
+      const float a1 = (p[2] - p[0]) * (p[3] - p[1]);
+      for (size_t j = 0; j < b.size(); ++j) {
+        const float* q = &bb[j * 4];
+        const float iw = std::max(0.f, std::min(p[2], q[2]) - std::max(p[0], q[0]));
+        const float ih = std::max(0.f, std::min(p[3], q[3]) - std::max(p[1], q[1]));
+        const float inter = iw * ih;
+        float area = (q[2] - q[0]) * (q[3] - q[1]);
+        area = area + a1 - inter;
+        const float iou = inter / (area + 1e-7f);
+        float cost = 1.f - iou;
+        if (fuse) {
+          const float sim = (1.f - cost) * b[j]->score;
+          cost = 1.f - sim;
+        }
+        d[i * b.size() + j] = cost;
+      }
+    }
+    return d;
+  }
+
+  void activate(Track& t) {
+    t.id = new_id();
+    double z[4];
+    measurement(t.tlwh0, z);
+    kf.initiate(z, t.mean, t.cov);
+    t.has_mean = true;
+    t.tracklet_len = 0;
+    t.state = kTracked;
+    if (frame_id == 1) t.activated = true;
+    t.frame_id = frame_id;
+    t.start_frame = frame_id;
+  }
+  void absorb(Track& t, const Track& det, bool re_activate) {
+    float tl[4];
+    tlwh_of(det, tl);
+    double z[4];
+    measurement(tl, z);
+    kf.update(t.mean, t.cov, z);
+    if (re_activate) t.tracklet_len = 0; else t.tracklet_len += 1;
+    t.state = kTracked;
+    t.activated = true;
+    t.frame_id = frame_id;
+    t.score = det.score;
+    t.cls = det.cls;
+    t.idx = det.idx;
+  }
+};
+
+ByteTracker::ByteTracker(const gtx_tracker_config& cfg) : impl_(new Impl) {
+  GTX_CHECK(cfg.type == 0 || cfg.type == 1, "tracker type %d: only bytetrack (0) and botsort (1) are implemented", cfg.type);
+  impl_->cfg = cfg;
+  impl_->kf.xywh = cfg.type == 1;
+  const int fr = cfg.frame_rate > 0 ? cfg.frame_rate : 30;
+  impl_->max_time_lost = (int)(fr / 30.0 * cfg.track_buffer);
+}
+ByteTracker::~ByteTracker() = default;
+
+void ByteTracker::reset() {
+  impl_->tracked.clear();
+  impl_->lost.clear();
+  impl_->removed.clear();
+  impl_->frame_id = 0;
+  impl_->next_id = 0;
+}
+
+void ByteTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap,
+                         int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
+  Impl& S = *impl_;
+  const gtx_tracker_config& A = S.cfg;
+  S.frame_id += 1;
+
+  // detections -> candidate tracks (xyxy2xywh then xywh2ltwh in float32)
+  std::vector<Track> det_hi, det_lo;
+  for (int i = 0; i < n; ++i) {
+    const float* b = xyxy + 4 * i;
+    const float cx = (b[0] + b[2]) / 2, cy = (b[1] + b[3]) / 2, w = b[2] - b[0], h = b[3] - b[1];
+    Track t;
+    t.tlwh0[0] = cx - w / 2; t.tlwh0[1] = cy - h / 2; t.tlwh0[2] = w; t.tlwh0[3] = h;
+    t.score = conf[i];
+    t.cls = cls[i];
+    t.idx = i;
+    if (conf[i] >= A.track_high_thresh) det_hi.push_back(t);
+    else if (conf[i] > A.track_low_thresh) det_lo.push_back(t);
+  }
+
+  std::vector<Track*> unconfirmed, confirmed;
+  for (Track& t : S.tracked) (t.activated ? confirmed : unconfirmed).push_back(&t);
+  // pool = joint(confirmed, lost)
+  std::vector<Track*> pool = confirmed;
+  {
+    std::unordered_set<int> ids;
+    for (Track* t : confirmed) ids.insert(t->id);
+    for (Track& t : S.lost)
+      if (!ids.count(t.id)) { ids.insert(t.id); pool.push_back(&t); }
+  }
+  // Kalman predict (velocity of the size/aspect state is zeroed for non-tracked tracks)
+  for (Track* t : pool) {
+    if (t->state != kTracked) {
+      if (S.kf.xywh) { t->mean[6] = 0; t->mean[7] = 0; } else { t->mean[7] = 0; }
+    }
+    S.kf.predict(t->mean, t->cov);
+  }
+  if (A.type == 1 && gmc) {
+    // STrack.multi_gmc: mean <- kron(I4, R) mean (+t on xy), cov <- R8 cov R8^T
+    const double R[4] = {gmc[0], gmc[1], gmc[3], gmc[4]}, tx = gmc[2], ty = gmc[5];
+    auto apply = [&](Track* t) {
+      double m[8];
+      for (int b = 0; b < 4; ++b) {
+        m[2 * b] = R[0] * t->mean[2 * b] + R[1] * t->mean[2 * b + 1];
+        m[2 * b + 1] = R[2] * t->mean[2 * b] + R[3] * t->mean[2 * b + 1];
+      }
+      m[0] += tx; m[1] += ty;
+      std::memcpy(t->mean, m, sizeof m);
+      double tmp[64], out[64];
+      for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+          const int bi = i / 2, ri = i % 2;
+          tmp[i * 8 + j] = R[ri * 2] * t->cov[(2 * bi) * 8 + j] + R[ri * 2 + 1] * t->cov[(2 * bi + 1) * 8 + j];
+        }
+      for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+          const int bj = j / 2, rj = j % 2;
+          out[i * 8 + j] = tmp[i * 8 + 2 * bj] * R[rj * 2] + tmp[i * 8 + 2 * bj + 1] * R[rj * 2 + 1];
+        }
+      std::memcpy(t->cov, out, sizeof out);
+    };
+    for (Track* t : pool) apply(t);
+    for (Track* t : unconfirmed) apply(t);
+  }
+
+  std::vector<Track> activated_new;             // tracks created this frame
+  std::vector<Track*> activated, refind, lost_now, removed_now;
+  std::vector<int> x, y;
+
+  // ---- first association: pool vs high-score detections ----
+  std::vector<Track*> dh;
+  for (Track& d : det_hi) dh.push_back(&d);
+  std::vector<float> c1 = S.dists(pool, dh, A.fuse_score != 0);
+  linear_assignment(c1, (int)pool.size(), (int)dh.size(), A.match_thresh, x, y);
+  std::vector<int> u_track, u_det;
+  for (size_t i = 0; i < pool.size(); ++i) {
+    if (x[i] >= 0) {
+      Track* t = pool[i];
+      if (t->state == kTracked) { S.absorb(*t, *dh[x[i]], false); activated.push_back(t); }
+      else { S.absorb(*t, *dh[x[i]], true); refind.push_back(t); }
+    } else u_track.push_back((int)i);
+  }
+  for (size_t j = 0; j < dh.size(); ++j)
+    if (y[j] < 0) u_det.push_back((int)j);
+
+  // ---- second association: remaining tracked tracks vs low-score detections (plain IoU, 0.5) ----
+  std::vector<Track*> r_tracked, dl;
+  for (int i : u_track)
+    if (pool[i]->state == kTracked) r_tracked.push_back(pool[i]);
+  for (Track& d : det_lo) dl.push_back(&d);
+  std::vector<float> c2 = S.dists(r_tracked, dl, false);
+  linear_assignment(c2, (int)r_tracked.size(), (int)dl.size(), 0.5, x, y);
+  for (size_t i = 0; i < r_tracked.size(); ++i) {
+    Track* t = r_tracked[i];
+    if (x[i] >= 0) {
+      if (t->state == kTracked) { S.absorb(*t, *dl[x[i]], false); activated.push_back(t); }
+      else { S.absorb(*t, *dl[x[i]], true); refind.push_back(t); }
+    } else if (t->state != kLost) {
+      t->state = kLost;
+      lost_now.push_back(t);
+    }
+  }
+
+  // ---- unconfirmed tracks vs leftover high-score detections (0.7) ----
+  std::vector<Track*> dleft;
+  for (int j : u_det) dleft.push_back(dh[j]);
+  std::vector<float> c3 = S.dists(unconfirmed, dleft, A.fuse_score != 0);
+  linear_assignment(c3, (int)unconfirmed.size(), (int)dleft.size(), 0.7, x, y);
+  for (size_t i = 0; i < unconfirmed.size(); ++i) {
+    if (x[i] >= 0) { S.absorb(*unconfirmed[i], *dleft[x[i]], false); activated.push_back(unconfirmed[i]); }
+    else { unconfirmed[i]->state = kRemoved; removed_now.push_back(unconfirmed[i]); }
+  }
+  // ---- new tracks ----
+  for (size_t j = 0; j < dleft.size(); ++j) {
+    if (y[j] >= 0) continue;
+    Track t = *dleft[j];
+    if (t.score < A.new_track_thresh) continue;
+    S.activate(t);
+    activated_new.push_back(t);
+  }
+  // ---- lost tracks that timed out ----
+  for (Track& t : S.lost)
+    if (S.frame_id - t.frame_id > S.max_time_lost) { t.state = kRemoved; removed_now.push_back(&t); }
+
+  // ---- state update (order of the lists is part of the output contract) ----
+  auto has_ptr = [](const std::vector<Track*>& v, const Track* p) { return std::find(v.begin(), v.end(), p) != v.end(); };
+  std::vector<Track> new_tracked, new_lost;
+  std::unordered_set<int> ids;
+  for (Track& t : S.tracked)
+    if (t.state == kTracked) { new_tracked.push_back(t); ids.insert(t.id); }
+  // joint(tracked, activated): `activated` holds existing tracks (already in tracked if they were
+  // tracked before) and the new ones, in the order they were appended upstream
+  // -> first-association matches, second-association matches, unconfirmed matches, new tracks.
+  for (Track* t : activated)
+    if (!ids.count(t->id)) { ids.insert(t->id); new_tracked.push_back(*t); }
+  for (Track& t : activated_new)
+    if (!ids.count(t.id)) { ids.insert(t.id); new_tracked.push_back(t); }
+  for (Track* t : refind)
+    if (!ids.count(t->id)) { ids.insert(t->id); new_tracked.push_back(*t); }
+  // lost = sub(lost, tracked) + lost_now, then minus removed
+  std::vector<Track> removed_all = S.removed;
+  for (Track* t : removed_now) removed_all.push_back(*t);
+  std::unordered_set<int> removed_ids;
+  // ultralytics subtracts self.removed_stracks *before* extending it with this frame's removals
+  for (const Track& t : S.removed) removed_ids.insert(t.id);
+  for (Track& t : S.lost)
+    if (!ids.count(t.id) && !has_ptr(lost_now, &t)) new_lost.push_back(t);
+  for (Track* t : lost_now) new_lost.push_back(*t);
+  {
+    std::vector<Track> keep;
+    for (Track& t : new_lost)
+      if (!removed_ids.count(t.id)) keep.push_back(t);
+    new_lost.swap(keep);
+  }
+  // duplicates between tracked and lost (IoU distance < 0.15): keep the older track
+  {
+    std::vector<Track*> pa, pb;
+    for (Track& t : new_tracked) pa.push_back(&t);
+    for (Track& t : new_lost) pb.push_back(&t);
+    std::vector<float> pd = S.dists(pa, pb, false);
+    std::vector<char> dupa(pa.size(), 0), dupb(pb.size(), 0);
+    for (size_t p = 0; p < pa.size(); ++p)
+      for (size_t q = 0; q < pb.size(); ++q)
+        if (pd[p * pb.size() + q] < 0.15f) {
+          const int tp = pa[p]->frame_id - pa[p]->start_frame, tq = pb[q]->frame_id - pb[q]->start_frame;
+          if (tp > tq) dupb[q] = 1; else dupa[p] = 1;
+        }
+    std::vector<Track> ta, tb;
+    for (size_t p = 0; p < pa.size(); ++p) if (!dupa[p]) ta.push_back(*pa[p]);
+    for (size_t q = 0; q < pb.size(); ++q) if (!dupb[q]) tb.push_back(*pb[q]);
+    new_tracked.swap(ta);
+    new_lost.swap(tb);
+  }
+  // lost tracks that were marked removed this frame stay in `lost` until the next frame's
+  // subtraction (upstream behaviour); keep their state so they never match again.
+  S.tracked.swap(new_tracked);
+  S.lost.swap(new_lost);
+  S.removed.swap(removed_all);
+  if (S.removed.size() > 1000) S.removed.erase(S.removed.begin(), S.removed.end() - 999);
+
+  int k = 0;
+  for (const Track& t : S.tracked) {
+    if (!t.activated) continue;
+    if (k < cap) {
+      float b[4];
+      xyxy_of(t, S.kf.xywh, b);
+      if (out_xyxy) std::memcpy(out_xyxy + 4 * k, b, sizeof b);
+      if (out_id) out_id[k] = t.id;
+      if (out_score) out_score[k] = t.score;
+      if (out_cls) out_cls[k] = t.cls;
+      if (out_det_idx) out_det_idx[k] = t.idx;
+    }
+    ++k;
+  }
+  *n_out = std::min(k, cap);
+}
+
+}  // namespace gtx
