@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams h
 template <typename T>
 __device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int la, int lane) {
   float acc = L.bb[lane];
-  const float* wr = L.wb + (size_t)lane * L.cb;
-  for (int k = 0; k < L.cb; ++k) acc = fmaf(ldf(f + k), wr[k], acc);
+  const float* wr = L.wb + lane;   // wb is stored transposed, [cb][64]: lanes read one 256-B line
+  for (int k = 0; k < L.cb; ++k) acc = fmaf(ldf(f + k), wr[(size_t)k * 64], acc);
   // softmax over the 16 lanes of a side
   float m = acc;
 #pragma unroll
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, co
 
 // Debug / parity: full decode of every anchor -> [A][4+nc].
 template <typename T>
-__global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, float* __restrict__ out, int logits) {
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, floa
   for (int c = lane; c < hp.nc; c += 64) {
     float acc = L.bc[c];
     for (int k = 0; k < L.cc; ++k) acc = fmaf(ldf(fc + k), L.wc[c * L.cc + k], acc);
-    o[4 + c] = 1.f / (1.f + expf(-acc));
+    o[4 + c] = logits ? acc : 1.f / (1.f + expf(-acc));
   }
 }
 
@@ -490,10 +490,10 @@ void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuf
   GTX_HIP(hipGetLastError());
 }
 
-void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, hipStream_t s) {
+void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, bool logits, hipStream_t s) {
   dim3 grid(cdiv(hp.n_anchors * 64, 256), n), block(256);
-  if (dtype == DT_F16) hipLaunchKernelGGL(head_raw_kernel<_Float16>, grid, block, 0, s, hp, out);
-  else hipLaunchKernelGGL(head_raw_kernel<float>, grid, block, 0, s, hp, out);
+  if (dtype == DT_F16) hipLaunchKernelGGL(head_raw_kernel<_Float16>, grid, block, 0, s, hp, out, logits ? 1 : 0);
+  else hipLaunchKernelGGL(head_raw_kernel<float>, grid, block, 0, s, hp, out, logits ? 1 : 0);
   GTX_HIP(hipGetLastError());
 }
 
@@ -537,134 +537,160 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int 
   }
 }
 
-// (2) suppression bit matrix, upper triangle: bit j of mask[i][j/64] = IoU(i,j) > thr, j > i.
-//     Persistent grid over (row, word) work items.
+// (2) suppression bit matrix, full and symmetric, stored word-major: bit (j&63) of
+//     mask[j/64][i] = IoU(i,j) > thr, j != i.
+//     One wave per 64x64 tile; the 64 column boxes sit in LDS, each lane owns one row.
+//     IoU arithmetic is torchvision's fp32 sequence: inter / (area_i + area_j - inter).
 __global__ __launch_bounds__(256) void nms_mask_kernel(const NmsBuffers nb, float thr, float cls_offset) {
+  __shared__ float4 s_box[4][64];
   const int n = blockIdx.y;
   const int cnt = nb.sorted_n[n];
-  const int nwords = (cnt + 63) >> 6;
+  const int nblk = (cnt + 63) >> 6;
   const int rs = nb.nms_cap >> 6;
   const float4* boxes = reinterpret_cast<const float4*>(nb.s_box) + (size_t)n * nb.nms_cap;
   const int* cls = nb.s_cls + (size_t)n * nb.nms_cap;
   unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * rs;
-  const long total = (long)cnt * nwords;
-  for (long wi = (long)blockIdx.x * blockDim.x + threadIdx.x; wi < total; wi += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(wi / nwords), w = (int)(wi % nwords);
-    unsigned long long bits = 0ull;
-    if (w * 64 + 63 > i) {
-      float4 bi = boxes[i];
-      const float oi = cls_offset * (float)cls[i];
-      bi.x += oi; bi.y += oi; bi.z += oi; bi.w += oi;
-      const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-      const int j0 = w * 64;
-      const int jend = min(64, cnt - j0);
-      for (int k = 0; k < jend; ++k) {
-        const int j = j0 + k;
-        if (j <= i) continue;
-        float4 bj = boxes[j];
-        const float oj = cls_offset * (float)cls[j];
-        bj.x += oj; bj.y += oj; bj.z += oj; bj.w += oj;
-        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-        const float iw = fmaxf(0.f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
-        const float ih = fmaxf(0.f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
-        const float inter = iw * ih;
-        const float ovr = inter / (ai + aj - inter);
-        if (ovr > thr) bits |= 1ull << k;
-      }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long ntiles = (long)nblk * nblk;
+  for (long t = (long)blockIdx.x * 4 + wv; t < ntiles; t += (long)gridDim.x * 4) {
+    const int bi = (int)(t / nblk), bj = (int)(t % nblk);
+    const int i = bi * 64 + lane, jc = bj * 64 + lane;
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jc < cnt) {
+      bc = boxes[jc];
+      const float o = cls_offset * (float)cls[jc];
+      bc.x += o; bc.y += o; bc.z += o; bc.w += o;
     }
-    mask[(size_t)i * rs + w] = bits;
+    s_box[wv][lane] = bc;   // wave-private row of LDS: no workgroup barrier needed
+    float4 br = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < cnt) {
+      br = boxes[i];
+      const float o = cls_offset * (float)cls[i];
+      br.x += o; br.y += o; br.z += o; br.w += o;
+    }
+    const float ai = (br.z - br.x) * (br.w - br.y);
+    unsigned long long bits = 0ull;
+    const int jend = min(64, cnt - bj * 64);
+    for (int k = 0; k < jend; ++k) {
+      const float4 q = s_box[wv][k];
+      const float aj = (q.z - q.x) * (q.w - q.y);
+      const float iw = fmaxf(0.f, fminf(br.z, q.z) - fmaxf(br.x, q.x));
+      const float ih = fmaxf(0.f, fminf(br.w, q.w) - fmaxf(br.y, q.y));
+      const float inter = iw * ih;
+      const float ovr = inter / (ai + aj - inter);
+      if (ovr > thr && (bj * 64 + k) != i) bits |= 1ull << k;
+    }
+    if (i < cnt) mask[(size_t)bj * nb.nms_cap + i] = bits;   // [word][box]: coalesced here and in the resolve
   }
 }
 
-// (3) greedy sweep, one wave per image; the removed-bitmap lives in registers (word w on lane
-//     w&63, slot w>>6). Mask rows are prefetched LA rows ahead so the serial chain never waits
-//     on L2. (4) kept rows are mapped back to frame pixels (ultralytics scale_boxes + clip).
-template <int SLOTS>
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const NmsBuffers nb, float gain, float padx,
-                                                       float pady, float fw, float fh) {
-  constexpr int LA = 4;
+// (3) greedy NMS (torchvision.ops.nms order) as a wave pipeline, one workgroup per image.
+//     Boxes are ranked; block b = ranks [64b, 64b+64). A box is removed iff a kept higher-ranked
+//     box overlaps it. Wave k owns blocks k, k+16, ...: each lane streams its box's mask words
+//     over the already decided blocks (AND with their keep words, waiting on an in-order
+//     "blocks done" counter only when it catches up with the block in front), then the 64 boxes
+//     of the block are settled among themselves by a monotone fixpoint on wave ballots (removed
+//     as soon as a kept higher-ranked overlap exists, kept as soon as all higher-ranked overlaps
+//     are removed; rounds = longest suppression chain inside the block). The serial chain per
+//     block is a few hundred cycles, independent of how many candidates overlap.
+// (4) kept boxes are compacted in rank order, capped at max_det, and mapped back to frame
+//     pixels (ultralytics scale_boxes + clip_boxes).
+constexpr int kNmsWords = 512;  // >= nms_cap / 64
+__global__ __launch_bounds__(1024) void nms_resolve_kernel(const NmsBuffers nb, float gain, float padx,
+                                                           float pady, float fw, float fh) {
+  __shared__ unsigned long long s_keep[kNmsWords];
+  __shared__ int s_prefix[kNmsWords];
+  __shared__ int s_done;
   const int n = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
   const int cnt = nb.sorted_n[n];
-  const int nwords = (cnt + 63) >> 6;
-  const int rs = nb.nms_cap >> 6;
-  const unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * rs;
-  unsigned long long rem[SLOTS];
+  const int nblk = (cnt + 63) >> 6;
+  const unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * (nb.nms_cap >> 6);
+  if (tid == 0) s_done = 0;
+  __syncthreads();
+  volatile int* done = &s_done;
+  volatile unsigned long long* keep = s_keep;
+  for (int b = wave; b < nblk; b += nwaves) {
+    const int i = b * 64 + lane;
+    const bool valid = i < cnt;
+    bool rem = false;
+    int ready = *done;
+    for (int w0 = 0; w0 < b; w0 += 8) {
+      unsigned long long m[8];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) rem[s] = 0ull;
-  unsigned long long cur[LA][SLOTS], nxt[LA][SLOTS];
-  auto load_rows = [&](unsigned long long (&dst)[LA][SLOTS], int base) {
+      for (int k = 0; k < 8; ++k) m[k] = (valid && w0 + k < b) ? mask[(size_t)(w0 + k) * nb.nms_cap + i] : 0ull;
+      const int need = min(w0 + 8, b);
+      while (ready < need) { __builtin_amdgcn_s_sleep(1); ready = *done; }
 #pragma unroll
-    for (int k = 0; k < LA; ++k)
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        const int w = 64 * s + lane;
-        dst[k][s] = (base + k < cnt && w < nwords) ? mask[(size_t)(base + k) * rs + w] : 0ull;
+      for (int k = 0; k < 8; ++k)
+        if (w0 + k < b && (m[k] & keep[w0 + k])) rem = true;
+    }
+    const unsigned long long low = (1ull << lane) - 1ull;
+    const unsigned long long d = valid ? (mask[(size_t)b * nb.nms_cap + i] & low) : 0ull;
+    unsigned long long removed = __ballot(rem || !valid), kept = 0ull;
+    const unsigned long long me = 1ull << lane;
+    for (int round = 0; round < 64; ++round) {
+      const unsigned long long und = ~(kept | removed);
+      if (und == 0ull) break;
+      bool nk = false, nr = false;
+      if (und & me) {
+        if (d & kept) nr = true;
+        else if ((d & ~removed) == 0ull) nk = true;
       }
-  };
-  int nkeep = 0;
+      kept |= __ballot(nk);
+      removed |= __ballot(nr);
+    }
+    if (lane == 0) {
+      keep[b] = kept;
+      __threadfence_block();
+      *done = b + 1;
+    }
+  }
+  __syncthreads();
+  // compaction in rank order
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < nblk; ++w) { s_prefix[w] = acc; acc += __popcll(s_keep[w]); }
+    nb.out_n[n] = min(acc, nb.max_det);
+  }
+  __syncthreads();
   const float4* boxes = reinterpret_cast<const float4*>(nb.s_box) + (size_t)n * nb.nms_cap;
   float* rows = nb.out_rows + (size_t)n * nb.max_det * 6;
-  load_rows(cur, 0);
-  for (int base = 0; base < cnt && nkeep < nb.max_det; base += LA) {
-    load_rows(nxt, base + LA);
-#pragma unroll
-    for (int k = 0; k < LA; ++k) {
-      const int i = base + k;
-      if (i < cnt && nkeep < nb.max_det) {
-        const int w = i >> 6;
-        unsigned long long word = 0ull;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-          if ((w >> 6) == s) word = __shfl(rem[s], w & 63, 64);
-        if (!((word >> (i & 63)) & 1ull)) {
-#pragma unroll
-          for (int s = 0; s < SLOTS; ++s) rem[s] |= cur[k][s];
-          if (lane == 0) {
-            float4 b = boxes[i];
-            b.x = (b.x - padx) / gain; b.y = (b.y - pady) / gain;
-            b.z = (b.z - padx) / gain; b.w = (b.w - pady) / gain;
-            b.x = fminf(fmaxf(b.x, 0.f), fw); b.z = fminf(fmaxf(b.z, 0.f), fw);
-            b.y = fminf(fmaxf(b.y, 0.f), fh); b.w = fminf(fmaxf(b.w, 0.f), fh);
-            float* r = rows + (size_t)nkeep * 6;
-            r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
-            r[4] = nb.s_score[(size_t)n * nb.nms_cap + i];
-            r[5] = (float)nb.s_cls[(size_t)n * nb.nms_cap + i];
-          }
-          ++nkeep;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < LA; ++k)
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) cur[k][s] = nxt[k][s];
+  for (int i = tid; i < cnt; i += blockDim.x) {
+    const int wl = i >> 6;
+    const unsigned long long bit = 1ull << (i & 63);
+    if (!(s_keep[wl] & bit)) continue;
+    const int slot = s_prefix[wl] + __popcll(s_keep[wl] & (bit - 1ull));
+    if (slot >= nb.max_det) continue;
+    float4 b = boxes[i];
+    b.x = (b.x - padx) / gain; b.y = (b.y - pady) / gain;
+    b.z = (b.z - padx) / gain; b.w = (b.w - pady) / gain;
+    b.x = fminf(fmaxf(b.x, 0.f), fw); b.z = fminf(fmaxf(b.z, 0.f), fw);
+    b.y = fminf(fmaxf(b.y, 0.f), fh); b.w = fminf(fmaxf(b.w, 0.f), fh);
+    float* r = rows + (size_t)slot * 6;
+    r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
+    r[4] = nb.s_score[(size_t)n * nb.nms_cap + i];
+    r[5] = (float)nb.s_cls[(size_t)n * nb.nms_cap + i];
   }
-  if (lane == 0) nb.out_n[n] = nkeep;
 }
 
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
                 const Letterbox& lb, hipStream_t s) {
+  GTX_CHECK(nb.nms_cap <= kNmsWords * 64, "nms: capacity %d too large", nb.nms_cap);
   const int limit = std::min(max_nms, nb.nms_cap);
   const float cls_offset = agnostic ? 0.f : 7680.f;  // ultralytics max_wh
   hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(nb.cap, 256), n), dim3(256), 0, s, nb, limit, cls_offset);
   GTX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(128, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(256, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
   GTX_HIP(hipGetLastError());
   // ultralytics scale_boxes: gain = min ratio, pad = round((net - src*gain)/2 - 0.1)
   const double gain = lb.gain;
   const float padx = (float)std::nearbyint((lb.net_w - lb.src_w * gain) / 2 - 0.1);
   const float pady = (float)std::nearbyint((lb.net_h - lb.src_h * gain) / 2 - 0.1);
-  const int slots = cdiv(nb.nms_cap, 64 * 64);
-  auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, s, nb, (float)gain, padx, pady, (float)lb.src_w,
-                       (float)lb.src_h);
-  };
-  if (slots <= 1) go(nms_sweep_kernel<1>);
-  else if (slots <= 2) go(nms_sweep_kernel<2>);
-  else if (slots <= 4) go(nms_sweep_kernel<4>);
-  else if (slots <= 8) go(nms_sweep_kernel<8>);
-  else fail(-3, "nms: capacity %d too large", nb.nms_cap);
+  hipLaunchKernelGGL(nms_resolve_kernel, dim3(n), dim3(1024), 0, s, nb, (float)gain, padx, pady,
+                     (float)lb.src_w, (float)lb.src_h);
   GTX_HIP(hipGetLastError());
 }
 

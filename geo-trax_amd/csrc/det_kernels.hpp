@@ -39,7 +39,7 @@ struct HeadLevel {
   const void* feat;     // [N][h][w][cstride] T: channels [0,cb) box branch, [cb, cb+cc) cls branch
   int h, w, cstride;
   int cb, cc;           // box / cls feature channels (64 / 128 for YOLOv8s)
-  const float* wb;      // [64][cb] fp32  final box 1x1 conv (4*reg_max outputs)
+  const float* wb;      // [cb][64] fp32  final box 1x1 conv (4*reg_max outputs), transposed
   const float* bb;      // [64]
   const float* wc;      // [nc][cc] fp32  final cls 1x1 conv
   const float* bc;      // [nc]
@@ -77,8 +77,9 @@ struct NmsBuffers {
 };
 
 void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
-// Decode every anchor (debug / parity): out [N][A][4+nc] fp32 = xywh (network px) + scores.
-void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, hipStream_t s);
+// Decode every anchor (debug / parity): out [N][A][4+nc] fp32 = xywh (network px) + class scores
+// (or class logits).
+void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, bool logits, hipStream_t s);
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
                 const Letterbox& lb, hipStream_t s);
 

@@ -309,7 +309,13 @@ void Detector::build_graph() {
     const HostTensor &wb = tensor(b2 + ".2.weight"), &wc = tensor(b3 + ".2.weight");
     GTX_CHECK(wb.shape[0] == 64 && (int)wb.shape[1] == cb, "Detect box head must have 4*16 outputs");
     GTX_CHECK((int)wc.shape[0] == cfg_.nc && (int)wc.shape[1] == cc, "Detect cls head has %d outputs, nc=%d", (int)wc.shape[0], cfg_.nc);
-    L.wb = upload(wb.data); L.bb = upload(tensor(b2 + ".2.bias").data);
+    {
+      std::vector<float> wbt((size_t)cb * 64);  // [cb][64]: the decode wave reads one output per lane
+      for (int o = 0; o < 64; ++o)
+        for (int k = 0; k < cb; ++k) wbt[(size_t)k * 64 + o] = wb.data[(size_t)o * cb + k];
+      L.wb = upload(wbt);
+    }
+    L.bb = upload(tensor(b2 + ".2.bias").data);
     L.wc = upload(wc.data); L.bc = upload(tensor(b3 + ".2.bias").data);
     layer_views_["model.22.feat" + std::to_string(l)] = h2;
   }
@@ -465,11 +471,11 @@ const void* Detector::gray(int b, int* gh, int* gw) const {
   return gray_.as<uint8_t>() + (size_t)b * gray_h_ * gray_w_;
 }
 
-void Detector::raw_output(int b, float* out, int* n_anchors) {
+void Detector::raw_output(int b, float* out, int* n_anchors, bool logits) {
   GTX_CHECK(finalized_ && cur_nb_ > 0 && b >= 0 && b < cur_nb_, "raw_output: no forward pass for slot %d", b);
   const size_t per = (size_t)head_.n_anchors * (4 + head_.nc);
   if (raw_.bytes < per * cur_nb_ * sizeof(float)) raw_.alloc(per * cur_nb_ * sizeof(float));
-  launch_head_raw(dtype_, head_, cur_nb_, raw_.as<float>(), ctx_->stream);
+  launch_head_raw(dtype_, head_, cur_nb_, raw_.as<float>(), logits, ctx_->stream);
   GTX_HIP(hipMemcpyAsync(out, raw_.as<float>() + per * b, per * sizeof(float), hipMemcpyDeviceToHost, ctx_->stream));
   GTX_HIP(hipStreamSynchronize(ctx_->stream));
   if (n_anchors) *n_anchors = head_.n_anchors;

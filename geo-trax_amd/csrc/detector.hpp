@@ -70,7 +70,7 @@ class Detector {
   void detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf,
                    int* cls, float speed_ms[3]);
   const void* gray(int b, int* gh, int* gw) const;
-  void raw_output(int b, float* out, int* n_anchors);
+  void raw_output(int b, float* out, int* n_anchors, bool logits = false);
   void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c);
   void profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
                std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes);

@@ -319,6 +319,9 @@ const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w
 int gtx_detector_raw_output(gtx_detector* det, int b, float* out, int* n_anchors) {
   return guarded([&] { need(det, "det"); need(out, "out"); det->impl->raw_output(b, out, n_anchors); });
 }
+int gtx_detector_raw_logits(gtx_detector* det, int b, float* out, int* n_anchors) {
+  return guarded([&] { need(det, "det"); need(out, "out"); det->impl->raw_output(b, out, n_anchors, true); });
+}
 int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out, int* h, int* w, int* c) {
   return guarded([&] { need(det, "det"); need(layer, "layer"); det->impl->layer_output(b, layer, out, h, w, c); });
 }

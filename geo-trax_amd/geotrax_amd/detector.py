@@ -108,13 +108,15 @@ class Detector:
         p = self.ctx.lib.gtx_detector_gray(self.handle, b, C.byref(gh), C.byref(gw))
         return p, gh.value, gw.value
 
-    def raw_output(self, b: int = 0) -> np.ndarray:
-        """[anchors, 4+nc] fp32 of the last forward (xywh network pixels + class scores)."""
+    def raw_output(self, b: int = 0, logits: bool = False) -> np.ndarray:
+        """[anchors, 4+nc] fp32 of the last forward (xywh network pixels + class scores, or the
+        pre-sigmoid class logits)."""
         na = C.c_int()
         h, w = self.net_hw
         anchors = (h // 8) * (w // 8) + (h // 16) * (w // 16) + (h // 32) * (w // 32)
         out = np.zeros((anchors, 4 + self.nc), np.float32)
-        check(self.ctx.lib.gtx_detector_raw_output(self.handle, b, ptr(out), C.byref(na)))
+        fn = self.ctx.lib.gtx_detector_raw_logits if logits else self.ctx.lib.gtx_detector_raw_output
+        check(fn(self.handle, b, ptr(out), C.byref(na)))
         assert na.value == anchors
         return out
 

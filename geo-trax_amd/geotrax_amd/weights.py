@@ -132,3 +132,17 @@ def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: flo
             b = b + 1.0  # ultralytics initialises the box-branch bias to 1.0
         t[name + ".bias"] = b.astype(np.float32)
     return t
+
+
+def calibrate_cls_bias(tensors: dict[str, np.ndarray], raw_logits: np.ndarray, conf: float, target: int) -> dict[str, np.ndarray]:
+    """Returns a copy of `tensors` whose class-logit biases are shifted by one constant so that
+    about `target` anchors of the probed frame clear `conf`. raw_logits: [anchors, nc] class
+    logits of one forward pass with the unshifted weights (Detector.raw_output(logits=True)[:, 4:])."""
+    logit = np.sort(raw_logits.max(1).astype(np.float64))[::-1]
+    k = min(max(int(target), 1), len(logit) - 1)
+    delta = np.log(conf / (1 - conf)) - 0.5 * (logit[k - 1] + logit[k])
+    out = dict(tensors)
+    for name in tensors:
+        if ".cv3." in name and name.endswith(".2.bias"):
+            out[name] = (tensors[name] + np.float32(delta)).astype(np.float32)
+    return out

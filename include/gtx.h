@@ -164,6 +164,8 @@ const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w
 /* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
  * pixels + sigmoid class scores), like the tensor ultralytics' Detect returns. */
 int gtx_detector_raw_output(gtx_detector* det, int b, float* out, int* n_anchors);
+/* Same layout, class columns hold the pre-sigmoid logits (used to calibrate synthetic weights). */
+int gtx_detector_raw_logits(gtx_detector* det, int b, float* out, int* n_anchors);
 /* Activation of a named layer of the last forward ("model.4" ...), NHWC fp32, for parity. */
 int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out,
                               int* h, int* w, int* c);
