@@ -1,0 +1,66 @@
+"""Tracker object over the C ABI (gtx_tracker_*): the tracking half of ``model.track()``.
+
+Reference behaviour replaced: the tracker callback ultralytics registers for
+``model.track(..., persist=True)`` (geotrax/extract.py:153) with the active block of
+cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TrackerConfig, check, ptr
+
+TRACKER_TYPES = {"bytetrack": 0, "botsort": 1}
+
+
+class Tracker:
+    def __init__(self, tracker_type: str = "bytetrack", track_high_thresh: float = 0.25, track_low_thresh: float = 0.1,
+                 new_track_thresh: float = 0.25, track_buffer: int = 30, match_thresh: float = 0.8,
+                 fuse_score: bool = True, frame_rate: int = 30, max_tracks: int = 4096, **_ignored):
+        if tracker_type not in TRACKER_TYPES:
+            raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
+        self.lib = _lib.load()
+        cfg = TrackerConfig(type=TRACKER_TYPES[tracker_type], track_high_thresh=track_high_thresh,
+                            track_low_thresh=track_low_thresh, new_track_thresh=new_track_thresh,
+                            track_buffer=track_buffer, match_thresh=match_thresh, fuse_score=int(fuse_score),
+                            frame_rate=frame_rate)
+        h = C.c_void_p()
+        check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.cap = max_tracks
+        self._xyxy = np.zeros((max_tracks, 4), np.float32)
+        self._id = np.zeros(max_tracks, np.int32)
+        self._score = np.zeros(max_tracks, np.float32)
+        self._cls = np.zeros(max_tracks, np.int32)
+        self._idx = np.zeros(max_tracks, np.int32)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gtx_tracker_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(self.lib.gtx_tracker_reset(self.handle))
+
+    def update(self, xyxy: np.ndarray, conf: np.ndarray, cls: np.ndarray, gmc: np.ndarray | None = None):
+        """-> (xyxy [k,4] f32, id [k] i32, score [k] f32, cls [k] i32, det_idx [k] i32)."""
+        xyxy = np.ascontiguousarray(xyxy, dtype=np.float32).reshape(-1, 4)
+        conf = np.ascontiguousarray(conf, dtype=np.float32)
+        cls = np.ascontiguousarray(cls, dtype=np.int32)
+        g = None if gmc is None else np.ascontiguousarray(gmc, dtype=np.float64).reshape(6)
+        n = C.c_int()
+        check(self.lib.gtx_tracker_update(self.handle, len(conf), ptr(xyxy), ptr(conf), ptr(cls), ptr(g), self.cap,
+                                          C.byref(n), ptr(self._xyxy), ptr(self._id), ptr(self._score), ptr(self._cls),
+                                          ptr(self._idx)))
+        k = n.value
+        return (self._xyxy[:k].copy(), self._id[:k].copy(), self._score[:k].copy(), self._cls[:k].copy(),
+                self._idx[:k].copy())

@@ -1,0 +1,104 @@
+"""Host tracker (C++ ByteTrack / BoT-SORT association behind gtx_tracker_*) against
+oracle/bytetrack_ref.py on seeded detection streams with births, deaths, occlusions, low-score
+detections, crossings and empty frames. Runs on CPU: the tracker never touches the GPU."""
+import numpy as np
+import pytest
+
+
+def _stream(seed, n_obj=40, n_frames=60, w=3840, h=2160, p_miss=0.08, p_low=0.1, jitter=1.0):
+    rng = np.random.default_rng(seed)
+    pos = np.stack([rng.uniform(100, w - 100, n_obj), rng.uniform(100, h - 100, n_obj)], 1)
+    vel = rng.uniform(-6, 6, (n_obj, 2))
+    size = np.stack([rng.uniform(40, 160, n_obj), rng.uniform(25, 70, n_obj)], 1)
+    birth = rng.integers(0, n_frames // 3, n_obj) * (rng.random(n_obj) < 0.4)
+    death = n_frames - rng.integers(0, n_frames // 3, n_obj) * (rng.random(n_obj) < 0.4)
+    base_conf = rng.uniform(0.35, 0.95, n_obj)
+    for t in range(n_frames):
+        if t in (17, 18):  # two empty frames
+            yield np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32)
+            continue
+        rows, cf, cl = [], [], []
+        for k in range(n_obj):
+            if not (birth[k] <= t < death[k]) or rng.random() < p_miss:
+                continue
+            c = pos[k] + vel[k] * t + rng.normal(0, jitter, 2)
+            s = size[k] * (1 + rng.normal(0, 0.02, 2))
+            rows.append([c[0] - s[0] / 2, c[1] - s[1] / 2, c[0] + s[0] / 2, c[1] + s[1] / 2])
+            conf = base_conf[k] + rng.normal(0, 0.03)
+            if rng.random() < p_low:
+                conf = rng.uniform(0.11, 0.24)
+            cf.append(np.clip(conf, 0.05, 0.99))
+            cl.append(k % 4)
+        for _ in range(rng.integers(0, 3)):  # false positives
+            c = rng.uniform([50, 50], [w - 50, h - 50])
+            rows.append([c[0] - 30, c[1] - 20, c[0] + 30, c[1] + 20])
+            cf.append(rng.uniform(0.26, 0.5))
+            cl.append(int(rng.integers(0, 4)))
+        order = np.argsort(-np.asarray(cf), kind="stable")  # NMS output order: by confidence
+        yield (np.asarray(rows, np.float32).reshape(-1, 4)[order], np.asarray(cf, np.float32)[order],
+               np.asarray(cl, np.int32)[order])
+
+
+@pytest.mark.parametrize("kind", ["bytetrack", "botsort"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_tracker_matches_oracle(kind, seed):
+    from geotrax_amd.tracker import Tracker
+    from oracle.bytetrack_ref import ByteTrackRef
+
+    trk = Tracker(kind)
+    ref = ByteTrackRef(botsort=(kind == "botsort"))
+    n_rows = 0
+    rng = np.random.default_rng(seed + 100)
+    for t, (xyxy, conf, cls) in enumerate(_stream(seed)):
+        gmc = None
+        if kind == "botsort":
+            gmc = np.array([[1 + 1e-4 * rng.normal(), 1e-4 * rng.normal(), 0.3 * rng.normal()],
+                            [1e-4 * rng.normal(), 1 + 1e-4 * rng.normal(), 0.3 * rng.normal()]])
+        b, i, s, c, d = trk.update(xyxy, conf, cls, gmc)
+        r = ref.update(xyxy, conf, cls, gmc)
+        assert len(i) == len(r), f"frame {t}: {len(i)} tracks vs {len(r)}"
+        np.testing.assert_array_equal(i, r[:, 4].astype(np.int32), err_msg=f"frame {t} ids")
+        np.testing.assert_array_equal(d, r[:, 7].astype(np.int32), err_msg=f"frame {t} detection index")
+        np.testing.assert_array_equal(c, r[:, 6].astype(np.int32))
+        np.testing.assert_allclose(s, r[:, 5], rtol=0, atol=1e-7)
+        # Kalman posterior boxes: f64 state, two independent op orders -> agree far below 0.01 px
+        np.testing.assert_allclose(b, r[:, :4], rtol=0, atol=2e-3)
+        n_rows += len(i)
+    assert n_rows > 1000
+
+
+def test_tracker_first_frame_ids_follow_detection_order():
+    """Golden track file property (data/results-pixel/U_video_cut.txt): on the first frame ids are
+    1..N in detection order (descending confidence) and boxes equal the detections."""
+    from geotrax_amd.tracker import Tracker
+
+    xyxy, conf, cls = next(iter(_stream(5)))
+    b, i, s, c, d = Tracker("bytetrack").update(xyxy, conf, cls)
+    hi = conf >= 0.25
+    np.testing.assert_array_equal(i, np.arange(1, hi.sum() + 1))
+    np.testing.assert_array_equal(d, np.nonzero(hi)[0])
+    np.testing.assert_allclose(b, xyxy[hi], atol=1e-3)
+
+
+def test_tracker_reset_and_empty_input():
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("bytetrack")
+    out = trk.update(np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int32))
+    assert all(len(o) == 0 for o in out)
+    frames = list(_stream(3, n_frames=5))
+    a = [Tracker("bytetrack").update(*frames[0])[1]]
+    fresh = Tracker("bytetrack")
+    a = [fresh.update(*f)[1] for f in frames]
+    trk.reset()
+    b = [trk.update(*f)[1] for f in frames]
+    # after reset the id counter and the frame counter start again: identical to a fresh tracker
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_tracker_rejects_unknown_type():
+    from geotrax_amd.tracker import Tracker
+
+    with pytest.raises(NotImplementedError):
+        Tracker("ocsort")
