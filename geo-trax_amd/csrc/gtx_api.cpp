@@ -407,6 +407,10 @@ int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, in
   return guarded([&] { need(st, "st"); need(n, "n"); st->impl->matches(cap, n, cur_idx, ref_idx, dist); });
 }
 
+int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out) {
+  return guarded([&] { need(st, "st"); need(out, "out"); st->impl->pattern(out); });
+}
+
 /* ------------------------------------------------------------------ geometry */
 
 int gtx_warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_out) {

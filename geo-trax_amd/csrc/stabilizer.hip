@@ -1,0 +1,1061 @@
+// GPU homography stabilizer for gfx950: ORB-style keypoints (integer-exact pyramid, FAST-9/16,
+// Harris ranking, intensity-centroid orientation, steered BRIEF), brute-force Hamming 2-NN with
+// Lowe's ratio test, and a massively parallel RANSAC homography with an f64 refit on the host.
+//
+// Stands in for stabilo.Stabilizer as the reference drives it (geotrax/extract.py:139,177-187;
+// parameters geotrax/cfg/default.yaml:100-145): detector 'orb', matcher 'bf', filter 'ratio',
+// transformation 'projective', downsample_ratio 0.5, foreground mask from the frame's boxes.
+// stabilo delegates to OpenCV (ORB_create / BFMatcher.knnMatch / findHomography USAC_MAGSAC);
+// none of that source is in the reference tree, so the stages are specified here and restated
+// in oracle/stabilo_ref.py. Every stage up to and including matching is integer arithmetic and
+// is bit-exact against the oracle; the homography is f64 and compared by reprojection distance.
+//
+// All image work is HBM/L2-bound byte traffic (~7 MB of pyramid per frame): coalesced row
+// accesses, wave ballots / shuffles for reductions, LDS only for the per-keypoint patch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "detector.hpp"   // gtx_ctx
+#include "geometry.hpp"
+#include "stabilizer.hpp"
+
+namespace gtx {
+
+namespace {
+
+constexpr int kPyrLevels = 8;
+constexpr int kBorder = 31;        // ORB edgeThreshold
+constexpr int kPatchR = 20;        // patch radius staged per keypoint: 17 (rotated pattern) + 3 (blur)
+constexpr int kPatchW = 2 * kPatchR + 1;
+constexpr int kAngleBins = 256;
+
+struct Level {
+  int w, h;
+  int off;          // byte offset of this level in the pyramid / score buffers
+  int cand_off;     // first candidate slot of this level
+  int cand_cap;
+  int n_want;       // keypoints to keep
+  int kp_off;       // first output keypoint slot
+  float scale;      // level pixel -> level-0 pixel
+};
+
+struct Levels {
+  Level l[kPyrLevels];
+  int n;
+};
+
+// ------------------------------------------------------------------ gray / pyramid
+__device__ __forceinline__ int bgr2gray_u8(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
+
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ bgr, int h, int w, int half,
+                                                   uint8_t* __restrict__ out, int oh, int ow) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= ow) return;
+  if (half) {
+    const uint8_t* r0 = bgr + ((size_t)(2 * y) * w + 2 * x) * 3;
+    const uint8_t* r1 = r0 + (size_t)w * 3;
+    const int s = bgr2gray_u8(r0[0], r0[1], r0[2]) + bgr2gray_u8(r0[3], r0[4], r0[5]) +
+                  bgr2gray_u8(r1[0], r1[1], r1[2]) + bgr2gray_u8(r1[3], r1[4], r1[5]);
+    out[(size_t)y * ow + x] = (uint8_t)((s + 2) >> 2);
+  } else {
+    const uint8_t* p = bgr + ((size_t)y * w + x) * 3;
+    out[(size_t)y * ow + x] = (uint8_t)bgr2gray_u8(p[0], p[1], p[2]);
+  }
+}
+
+// Integer bilinear resize (11-bit weights, 16.16 source coordinates): bit-exact on any machine.
+__global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restrict__ src, int sw, int sh,
+                                                         uint8_t* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= dw) return;
+  long fxp = ((long)(2 * x + 1) * sw * 32768) / dw - 32768;
+  long fyp = ((long)(2 * y + 1) * sh * 32768) / dh - 32768;
+  if (fxp < 0) fxp = 0;
+  if (fyp < 0) fyp = 0;
+  const int x0 = (int)(fxp >> 16), y0 = (int)(fyp >> 16);
+  const int fx = (int)((fxp >> 5) & 2047), fy = (int)((fyp >> 5) & 2047);
+  const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+  const uint8_t* r0 = src + (size_t)min(y0, sh - 1) * sw;
+  const uint8_t* r1 = src + (size_t)y1 * sw;
+  const int xa = min(x0, sw - 1);
+  const int top = r0[xa] * (2048 - fx) + r0[x1] * fx;
+  const int bot = r1[xa] * (2048 - fx) + r1[x1] * fx;
+  dst[(size_t)y * dw + x] = (uint8_t)(((long)top * (2048 - fy) + (long)bot * fy + (1 << 21)) >> 22);
+}
+
+// Foreground mask at level-0 resolution: 255 = usable, 0 = inside a (grown) vehicle box.
+__global__ __launch_bounds__(256) void mask_fill_kernel(uint8_t* mask, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mask[i] = 255;
+}
+__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* mask, int w, int h, const int4* __restrict__ rects, int n) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int4 r = rects[b];
+  const int rw = r.z - r.x + 1, rh = r.w - r.y + 1;
+  for (int i = threadIdx.x; i < rw * rh; i += blockDim.x) {
+    const int x = r.x + i % rw, y = r.y + i / rw;
+    mask[(size_t)y * w + x] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ FAST-9/16 score
+__constant__ int c_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, {3, 1}, {2, 2}, {1, 3},
+                                    {0, 3}, {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+
+// score = max over the 16 arcs of 9 contiguous circle pixels of min(I_i - p) (bright) or
+// min(p - I_i) (dark); the pixel is a corner at threshold t iff score > t.
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
+                                                         const Levels L, int thr) {
+  const Level lv = L.l[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= lv.w || y >= lv.h) return;
+  uint8_t out = 0;
+  if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) {
+    const uint8_t* img = pyr + lv.off;
+    const int p = img[(size_t)y * lv.w + x];
+    // quick reject: at least one of each opposite pair must differ by more than thr
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = (int)img[(size_t)(y + c_circle[i][1]) * lv.w + x + c_circle[i][0]] - p;
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int mb = d[k], md = -d[k];
+#pragma unroll
+      for (int j = 1; j < 9; ++j) {
+        const int v = d[(k + j) & 15];
+        mb = min(mb, v);
+        md = min(md, -v);
+      }
+      best = max(best, max(mb, md));
+    }
+    if (best > thr) out = (uint8_t)min(best, 255);
+  }
+  score[lv.off + (size_t)y * lv.w + x] = out;
+}
+
+struct Cand {
+  long key;   // Harris response 25(ab - c^2) - (a+b)^2, exact integer
+  int pix;    // y * w + x at its level
+  int pad;
+};
+
+// 3x3 non-maximum suppression on the score image (strictly greater than all 8 neighbours), mask
+// test, Harris response -> per-level candidate list (atomic append; order is irrelevant, the
+// selection below is by (key, pix)).
+__global__ __launch_bounds__(256) void fast_nms_harris_kernel(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ score,
+                                                              const uint8_t* __restrict__ mask, int w0, int h0,
+                                                              const Levels L, Cand* __restrict__ cand, int* __restrict__ cand_n) {
+  const int li = blockIdx.z;
+  const Level lv = L.l[li];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < kBorder || x >= lv.w - kBorder || y < kBorder || y >= lv.h - kBorder) return;
+  const uint8_t* sc = score + lv.off;
+  const int s = sc[(size_t)y * lv.w + x];
+  if (s == 0) return;
+  const uint8_t* r0 = sc + (size_t)(y - 1) * lv.w + x;
+  const uint8_t* r1 = r0 + lv.w;
+  const uint8_t* r2 = r1 + lv.w;
+  if (!(s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1])) return;
+  if (mask) {
+    const int x0 = (int)(((long)x * w0 + lv.w / 2) / lv.w), y0 = (int)(((long)y * h0 + lv.h / 2) / lv.h);
+    if (mask[(size_t)min(y0, h0 - 1) * w0 + min(x0, w0 - 1)] == 0) return;
+  }
+  const uint8_t* img = pyr + lv.off;
+  long a = 0, b = 0, c = 0;
+  for (int dy = -3; dy <= 3; ++dy) {
+    const uint8_t* p0 = img + (size_t)(y + dy - 1) * lv.w + x;
+    const uint8_t* p1 = p0 + lv.w;
+    const uint8_t* p2 = p1 + lv.w;
+    for (int dx = -3; dx <= 3; ++dx) {
+      const int ix = (p0[dx + 1] + 2 * p1[dx + 1] + p2[dx + 1]) - (p0[dx - 1] + 2 * p1[dx - 1] + p2[dx - 1]);
+      const int iy = (p2[dx - 1] + 2 * p2[dx] + p2[dx + 1]) - (p0[dx - 1] + 2 * p0[dx] + p0[dx + 1]);
+      a += ix * ix;
+      b += iy * iy;
+      c += ix * iy;
+    }
+  }
+  const long key = 25 * (a * b - c * c) - (a + b) * (a + b);
+  const int slot = atomicAdd(&cand_n[li], 1);
+  if (slot < lv.cand_cap) {
+    Cand cd;
+    cd.key = key;
+    cd.pix = y * lv.w + x;
+    cd.pad = 0;
+    cand[lv.cand_off + slot] = cd;
+  }
+}
+
+// ------------------------------------------------------------------ top-N per level
+// One workgroup per level: 8-pass MSB radix select on the (sign-flipped) 64-bit key finds the
+// key of the n-th best candidate; candidates above it are kept, ties on the boundary key are
+// broken by the smaller pixel index; the kept set is then ordered by (key desc, pix asc) with a
+// counting rank so the output order is deterministic.
+struct KeyPoint {
+  int x, y;      // level pixel
+  int level;
+  int bin;       // orientation bin (filled by the describe kernel)
+};
+
+__device__ __forceinline__ unsigned long long flip_key(long k) { return (unsigned long long)k ^ 0x8000000000000000ull; }
+
+__global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
+                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n,
+                                                           unsigned long long* __restrict__ sel_key, int* __restrict__ sel_pix) {
+  __shared__ int hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_need, s_nsel, s_ntie_take;
+  const int li = blockIdx.x;
+  const Level lv = L.l[li];
+  const int tid = threadIdx.x;
+  const int n = min(cand_n[li], lv.cand_cap);
+  const Cand* c = cand + lv.cand_off;
+  const int want = min(lv.n_want, n);
+  if (want == 0) {
+    if (tid == 0) kp_n[li] = 0;
+    return;
+  }
+  // ---- radix select: find the key of rank `want` (1-based, descending)
+  if (tid == 0) { s_prefix = 0ull; s_need = want; }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    const unsigned long long pmask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    for (int i = tid; i < n; i += blockDim.x) {
+      const unsigned long long k = flip_key(c[i].key);
+      if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int need = s_need, b = 255;
+      for (; b > 0; --b) {
+        if (hist[b] >= need) break;
+        need -= hist[b];
+      }
+      s_need = need;
+      s_prefix = prefix | ((unsigned long long)b << shift);
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = s_prefix;   // key of the want-th best
+  const int tie_take = s_need;               // how many candidates with key == kth to keep
+  // ---- gather: all keys > kth, plus the `tie_take` smallest-pix candidates with key == kth
+  unsigned long long* okey = sel_key + lv.kp_off;
+  int* opix = sel_pix + lv.kp_off;
+  if (tid == 0) { s_nsel = 0; s_ntie_take = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    const unsigned long long k = flip_key(c[i].key);
+    bool take = k > kth;
+    if (k == kth) {
+      // rank among ties by pix (ties are rare: count smaller pix with the same key)
+      int r = 0;
+      for (int j = 0; j < n; ++j)
+        if (flip_key(c[j].key) == kth && c[j].pix < c[i].pix) ++r;
+      take = r < tie_take;
+    }
+    if (take) {
+      const int s = atomicAdd(&s_nsel, 1);
+      okey[s] = k;
+      opix[s] = c[i].pix;
+    }
+  }
+  __syncthreads();
+  const int m = s_nsel;   // == want
+  // ---- deterministic order: rank by (key desc, pix asc)
+  for (int i = tid; i < m; i += blockDim.x) {
+    const unsigned long long k = okey[i];
+    const int p = opix[i];
+    int r = 0;
+    for (int j = 0; j < m; ++j) {
+      const unsigned long long kj = okey[j];
+      r += (kj > k || (kj == k && opix[j] < p)) ? 1 : 0;
+    }
+    KeyPoint kp;
+    kp.x = p % lv.w;
+    kp.y = p / lv.w;
+    kp.level = li;
+    kp.bin = 0;
+    kps[lv.kp_off + r] = kp;
+  }
+  if (tid == 0) kp_n[li] = m;
+}
+
+// ------------------------------------------------------------------ orientation + descriptor
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ int c_gauss[7] = {18, 34, 49, 54, 49, 34, 18};
+// tan((j + 0.5) * 2*pi/256) * 2^24, j = 0..31: boundaries between orientation bins in the first octant
+__constant__ long c_tan[32];
+
+__device__ __forceinline__ int angle_bin(int m10, int m01) {
+  const long ax = m10 < 0 ? -(long)m10 : m10, ay = m01 < 0 ? -(long)m01 : m01;
+  const bool swap = ay > ax;
+  const long hi = swap ? ay : ax, lo = swap ? ax : ay;
+  int o = 0;
+  if (hi > 0) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) o += ((lo << 24) >= hi * c_tan[j]) ? 1 : 0;
+  }
+  if (swap) o = 64 - o;
+  if (m10 < 0) o = 128 - o;
+  if (m01 < 0) o = -o;
+  return o & (kAngleBins - 1);
+}
+
+// One wave per keypoint. The 41x41 patch is staged in wave-private LDS, the intensity centroid
+// gives the orientation bin, the 35x35 interior is blurred (separable integer 7-tap Gaussian) in
+// LDS, and the 256 steered-BRIEF tests are evaluated 64 at a time: a ballot per group of 64 tests
+// is one 64-bit word of the descriptor.
+__global__ __launch_bounds__(256) void describe_kernel(const uint8_t* __restrict__ pyr, const Levels L,
+                                                       KeyPoint* __restrict__ kps, const int* __restrict__ kp_n,
+                                                       const int8_t* __restrict__ pattern /*[bins][256][4]*/,
+                                                       unsigned long long* __restrict__ desc /*[slot][4]*/,
+                                                       float2* __restrict__ xy_full, float inv_ratio, int total_slots) {
+  __shared__ uint8_t s_patch[4][kPatchW * kPatchW];
+  __shared__ unsigned short s_h[4][kPatchW * (kPatchW - 6)];   // horizontal pass, columns 3..37
+  __shared__ uint8_t s_blur[4][(kPatchW - 6) * (kPatchW - 6)];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wv;
+  if (slot >= total_slots) return;
+  // which level does this slot belong to?
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < kPyrLevels; ++i)
+    if (i < L.n && slot >= L.l[i].kp_off) li = i;
+  const Level lv = L.l[li];
+  if (slot - lv.kp_off >= kp_n[li]) return;
+  KeyPoint kp = kps[slot];
+  const uint8_t* img = pyr + lv.off;
+  uint8_t* P = s_patch[wv];
+  for (int i = lane; i < kPatchW * kPatchW; i += 64) {
+    const int u = i % kPatchW - kPatchR, v = i / kPatchW - kPatchR;
+    P[i] = img[(size_t)(kp.y + v) * lv.w + kp.x + u];
+  }
+  // wave-private LDS: no workgroup barrier is needed, LDS instructions of one wave execute in
+  // order; the fence only keeps the compiler from moving reads above the writes.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int m10 = 0, m01 = 0;
+  for (int i = lane; i < 31 * 31; i += 64) {
+    const int u = i % 31 - 15, v = i / 31 - 15;
+    if (abs(u) <= c_umax[abs(v)]) {
+      const int val = P[(v + kPatchR) * kPatchW + u + kPatchR];
+      m10 += u * val;
+      m01 += v * val;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    m10 += __shfl_xor(m10, o, 64);
+    m01 += __shfl_xor(m01, o, 64);
+  }
+  const int bin = angle_bin(m10, m01);
+  // blur: horizontal pass over all 41 rows, columns -17..17
+  constexpr int BW = kPatchW - 6;   // 35
+  unsigned short* Hh = s_h[wv];
+  for (int i = lane; i < kPatchW * BW; i += 64) {
+    const int r = i / BW, cidx = i % BW;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc += c_gauss[k] * P[r * kPatchW + cidx + k];
+    Hh[i] = (unsigned short)acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint8_t* Bl = s_blur[wv];
+  for (int i = lane; i < BW * BW; i += 64) {
+    const int r = i / BW, cidx = i % BW;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc += c_gauss[k] * Hh[(r + k) * BW + cidx];
+    Bl[i] = (uint8_t)((acc + 32768) >> 16);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int8_t* pat = pattern + (size_t)bin * 256 * 4;
+  unsigned long long* d = desc + (size_t)slot * 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int t = g * 64 + lane;
+    const char4 q = reinterpret_cast<const char4*>(pat)[t];
+    const int va = Bl[(q.y + 17) * BW + q.x + 17], vb = Bl[(q.w + 17) * BW + q.z + 17];
+    const unsigned long long word = __ballot(va < vb);
+    if (lane == 0) d[g] = word;
+  }
+  if (lane == 0) {
+    kp.bin = bin;
+    kps[slot] = kp;
+    xy_full[slot] = make_float2((float)kp.x * lv.scale * inv_ratio, (float)kp.y * lv.scale * inv_ratio);
+  }
+}
+
+// Packs the per-level keypoint slots (gaps where a level found fewer than it wanted) into a dense
+// list, level by level, keeping the rank order inside a level.
+__global__ __launch_bounds__(256) void compact_kernel(const Levels L, const int* __restrict__ kp_n, const KeyPoint* __restrict__ kps,
+                                                      const unsigned long long* __restrict__ desc, const float2* __restrict__ xy,
+                                                      KeyPoint* __restrict__ okp, unsigned long long* __restrict__ odesc,
+                                                      float2* __restrict__ oxy, int* __restrict__ total) {
+  int base = 0;
+  for (int li = 0; li < L.n; ++li) {
+    const int n = kp_n[li];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int s = L.l[li].kp_off + i;
+      okp[base + i] = kps[s];
+      oxy[base + i] = xy[s];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) odesc[(size_t)(base + i) * 4 + k] = desc[(size_t)s * 4 + k];
+    }
+    base += n;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = base;
+}
+
+// ------------------------------------------------------------------ matching
+// Brute-force Hamming 2-NN: one thread per query descriptor, train descriptors tiled through LDS.
+__global__ __launch_bounds__(256) void match_kernel(const unsigned long long* __restrict__ q, const int* __restrict__ nq_p,
+                                                    const unsigned long long* __restrict__ t, const int* __restrict__ nt_p,
+                                                    int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d) {
+  __shared__ unsigned long long s_t[256 * 4];
+  const int nq = *nq_p, nt = *nt_p;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x >= nq) return;
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (i < nq) { a0 = q[(size_t)i * 4]; a1 = q[(size_t)i * 4 + 1]; a2 = q[(size_t)i * 4 + 2]; a3 = q[(size_t)i * 4 + 3]; }
+  int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    const int j = t0 + threadIdx.x;
+    if (j < nt) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_t[threadIdx.x * 4 + k] = t[(size_t)j * 4 + k];
+    }
+    __syncthreads();
+    const int lim = min(256, nt - t0);
+    for (int k = 0; k < lim; ++k) {
+      const int d = __popcll(a0 ^ s_t[k * 4]) + __popcll(a1 ^ s_t[k * 4 + 1]) + __popcll(a2 ^ s_t[k * 4 + 2]) +
+                    __popcll(a3 ^ s_t[k * 4 + 3]);
+      if (d < b1) { b2 = b1; b1 = d; bi = t0 + k; }
+      else if (d < b2) b2 = d;
+    }
+    __syncthreads();
+  }
+  if (i < nq) { best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2; }
+}
+
+// Lowe ratio test + ordered compaction (single workgroup, queries in index order).
+__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ nq_p, const int* __restrict__ nt_p,
+                                                             const int* __restrict__ best_idx, const int* __restrict__ best_d,
+                                                             const int* __restrict__ second_d, float ratio,
+                                                             const float2* __restrict__ q_xy, const float2* __restrict__ t_xy,
+                                                             int* __restrict__ m_q, int* __restrict__ m_t, int* __restrict__ m_d,
+                                                             float4* __restrict__ m_pts, int* __restrict__ n_match) {
+  __shared__ int s_cnt[1024];
+  const int nq = *nq_p, nt = *nt_p;
+  const int tid = threadIdx.x;
+  const int per = (nq + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, nq);
+  int c = 0;
+  for (int i = lo; i < hi; ++i)
+    if (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i]) ++c;
+  s_cnt[tid] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < 1024; ++i) { const int v = s_cnt[i]; s_cnt[i] = acc; acc += v; }
+    *n_match = acc;
+  }
+  __syncthreads();
+  int o = s_cnt[tid];
+  for (int i = lo; i < hi; ++i)
+    if (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i]) {
+      m_q[o] = i; m_t[o] = best_idx[i]; m_d[o] = best_d[i];
+      const float2 a = q_xy[i], b = t_xy[best_idx[i]];
+      m_pts[o] = make_float4(a.x, a.y, b.x, b.y);
+      ++o;
+    }
+}
+
+// ------------------------------------------------------------------ RANSAC
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+// Homography from 4 correspondences (x,y)->(u,v), coordinates pre-normalised to O(1):
+// 8x8 linear system with h33 = 1, Gaussian elimination with partial pivoting, f64.
+__device__ bool homography4(const double* px, const double* py, const double* qx, const double* qy, double* H) {
+  double A[8][9];
+  for (int i = 0; i < 4; ++i) {
+    const double x = px[i], y = py[i], u = qx[i], v = qy[i];
+    double* r0 = A[2 * i];
+    double* r1 = A[2 * i + 1];
+    r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * x; r0[7] = -u * y; r0[8] = u;
+    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
+  }
+  for (int c = 0; c < 8; ++c) {
+    int piv = c;
+    double best = fabs(A[c][c]);
+    for (int r = c + 1; r < 8; ++r)
+      if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
+    if (best < 1e-12) return false;
+    if (piv != c)
+      for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+    const double inv = 1.0 / A[c][c];
+    for (int r = c + 1; r < 8; ++r) {
+      const double f = A[r][c] * inv;
+      for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
+    }
+  }
+  for (int r = 7; r >= 0; --r) {
+    double s = A[r][8];
+    for (int k = r + 1; k < 8; ++k) s -= A[r][k] * H[k];
+    H[r] = s / A[r][r];
+  }
+  H[8] = 1.0;
+  return true;
+}
+
+// One wave per hypothesis: lane 0 draws 4 distinct matches (counter-based hash of seed,
+// hypothesis and draw) and solves for H; all lanes then score the matches with the truncated
+// squared reprojection error (MSAC), quantised to 1/1024 px^2 so that the sum is an exact
+// integer regardless of the reduction order.
+__global__ __launch_bounds__(256) void ransac_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, unsigned seed,
+                                                     int n_hyp, double cx, double cy, double sc, float thr2,
+                                                     double* __restrict__ Hout, long* __restrict__ cost) {
+  const int n = *n_p;
+  const int lane = threadIdx.x & 63;
+  const int hyp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (hyp >= n_hyp) return;
+  if (n < 4) {
+    if (lane == 0) cost[hyp] = 0x7fffffffffffffffl;
+    return;
+  }
+  double H[9];
+  int ok = 0;
+  if (lane == 0) {
+    int idx[4];
+    unsigned ctr = 0;
+    for (int k = 0; k < 4; ++k) {
+      for (;;) {
+        const int cand = (int)(hash_u32(seed ^ hash_u32((unsigned)hyp * 977u + ctr)) % (unsigned)n);
+        ++ctr;
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup |= idx[j] == cand;
+        if (!dup) { idx[k] = cand; break; }
+      }
+    }
+    double px[4], py[4], qx[4], qy[4];
+    for (int k = 0; k < 4; ++k) {
+      const float4 p = pts[idx[k]];
+      px[k] = ((double)p.x - cx) * sc; py[k] = ((double)p.y - cy) * sc;
+      qx[k] = ((double)p.z - cx) * sc; qy[k] = ((double)p.w - cy) * sc;
+    }
+    double Hn[9];
+    ok = homography4(px, py, qx, qy, Hn) ? 1 : 0;
+    if (ok) {
+      // de-normalise: H = T^-1 Hn T with T = [[sc,0,-sc*cx],[0,sc,-sc*cy],[0,0,1]]
+      const double is = 1.0 / sc;
+      double M[9];
+      for (int r = 0; r < 3; ++r) {   // M = Hn T
+        M[r * 3 + 0] = Hn[r * 3 + 0] * sc;
+        M[r * 3 + 1] = Hn[r * 3 + 1] * sc;
+        M[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
+      }
+      for (int k = 0; k < 3; ++k) {   // H = T^-1 M, T^-1 = [[is,0,cx],[0,is,cy],[0,0,1]]
+        H[0 + k] = is * M[0 + k] + cx * M[6 + k];
+        H[3 + k] = is * M[3 + k] + cy * M[6 + k];
+        H[6 + k] = M[6 + k];
+      }
+      if (!(fabs(H[8]) > 1e-12)) ok = 0;
+    }
+  }
+  ok = __shfl(ok, 0, 64);
+  if (!ok) {
+    if (lane == 0) cost[hyp] = 0x7fffffffffffffffl;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) H[k] = __shfl(H[k], 0, 64);
+  long acc = 0;
+  for (int i = lane; i < n; i += 64) {
+    const float4 p = pts[i];
+    const double x = p.x, y = p.y;
+    const double w = H[6] * x + H[7] * y + H[8];
+    double e = (double)thr2;
+    if (fabs(w) > 1e-12) {
+      const double iw = 1.0 / w;
+      const double dx = (H[0] * x + H[1] * y + H[2]) * iw - p.z;
+      const double dy = (H[3] * x + H[4] * y + H[5]) * iw - p.w;
+      e = fmin(dx * dx + dy * dy, (double)thr2);
+    }
+    acc += (long)(e * 1024.0 + 0.5);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    cost[hyp] = acc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hout[(size_t)hyp * 9 + k] = H[k];
+  }
+}
+
+__global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ cost, int n, int* __restrict__ best) {
+  __shared__ long s_c[1024];
+  __shared__ int s_i[1024];
+  long bc = 0x7fffffffffffffffl;
+  int bi = -1;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (cost[i] < bc) { bc = cost[i]; bi = i; }
+  s_c[threadIdx.x] = bc;
+  s_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 512; s >= 1; s >>= 1) {
+    if (threadIdx.x < s) {
+      const long oc = s_c[threadIdx.x + s];
+      const int oi = s_i[threadIdx.x + s];
+      if (oc < s_c[threadIdx.x] || (oc == s_c[threadIdx.x] && oi >= 0 && (s_i[threadIdx.x] < 0 || oi < s_i[threadIdx.x]))) {
+        s_c[threadIdx.x] = oc;
+        s_i[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *best = s_i[0];
+}
+
+}  // namespace
+
+// =========================================================================== host side
+
+namespace {
+
+// Steered-BRIEF sampling pattern: 256 point pairs drawn once from an isotropic Gaussian
+// (sigma = patch/5, BRIEF "G II"), clipped to |x|,|y| <= 12, fixed seed. OpenCV's learned ORB
+// table is not available in the reference tree; descriptor bits are internal to the stabilizer.
+void base_pattern(int8_t out[256][4]) {
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {   // splitmix64
+    s += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto gauss = [&]() {   // Irwin-Hall(12) - 6: integer-friendly approximate normal, exactly reproducible
+    long acc = 0;
+    for (int i = 0; i < 12; ++i) acc += (long)(next() >> 40);            // 24-bit uniforms
+    return ((double)acc / 16777216.0 - 6.0);
+  };
+  for (int i = 0; i < 256; ++i)
+    for (int k = 0; k < 4; ++k) {
+      for (;;) {
+        const double v = gauss() * 6.2;
+        const long r = std::lround(v);
+        if (r >= -12 && r <= 12) { out[i][k] = (int8_t)r; break; }
+      }
+    }
+  for (int i = 0; i < 256; ++i)   // a pair must not compare a pixel with itself
+    if (out[i][0] == out[i][2] && out[i][1] == out[i][3]) out[i][2] = (int8_t)(out[i][2] >= 12 ? out[i][2] - 1 : out[i][2] + 1);
+}
+
+}  // namespace
+
+struct Stabilizer::Impl {
+  gtx_ctx* ctx;
+  gtx_stab_config cfg;
+  int fh, fw;            // frame
+  int gh, gw;            // level-0 gray (frame * downsample_ratio)
+  int half;              // 1 when downsample_ratio == 0.5
+  Levels lev_ref{}, lev_cur{};
+  int pyr_bytes = 0, cand_total = 0, slots_ref = 0, slots_cur = 0;
+  int n_hyp = 0;
+  std::vector<int8_t> pattern;   // [bins][256][4]
+
+  DevBuf d_frame, d_pyr, d_score, d_mask, d_rects, d_cand, d_cand_n, d_kp_n, d_kps, d_desc, d_xy, d_selkey, d_selpix, d_pattern;
+  struct Feat {
+    DevBuf kps, desc, xy, n;
+    int host_n = 0;
+  } ref, cur;
+  DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_mpts, d_nmatch, d_H, d_cost, d_best;
+  bool have_ref = false;
+  // last results
+  double H[9];
+  bool valid = false;
+  int stats[4] = {0, 0, 0, 0};
+
+  void plan(Levels& L, int max_features, int& slots);
+  void build_rects(const float* boxes, int n, std::vector<int4>& rects) const;
+  void extract(const uint8_t* gray_dev, const float* boxes, int n, const Levels& L, int slots, Feat& out);
+  void gray_from_frame(const uint8_t* frame, int h, int w);
+  void run_stabilize(double Hout[9], int* valid_out, int st[4]);
+};
+
+void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
+  L.n = cfg.n_levels;
+  const double factor = 1.0 / cfg.scale_factor;
+  double want = max_features * (1.0 - factor) / (1.0 - std::pow(factor, L.n));
+  int sum = 0, off = 0, coff = 0, koff = 0;
+  for (int i = 0; i < L.n; ++i) {
+    Level& lv = L.l[i];
+    const double sc = std::pow((double)cfg.scale_factor, i);
+    lv.w = (int)std::lround(gw / sc);
+    lv.h = (int)std::lround(gh / sc);
+    lv.scale = (float)sc;
+    lv.off = off;
+    off += lv.w * lv.h;
+    lv.cand_off = coff;
+    lv.cand_cap = std::max(4096, lv.w * lv.h / 16);
+    coff += lv.cand_cap;
+    if (i < L.n - 1) {
+      lv.n_want = (int)std::lround(want);
+      sum += lv.n_want;
+      want *= factor;
+    } else {
+      lv.n_want = std::max(max_features - sum, 0);
+    }
+    lv.kp_off = koff;
+    koff += lv.n_want;
+  }
+  pyr_bytes = off;
+  cand_total = coff;
+  slots = koff;
+}
+
+Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Impl) {
+  Impl& S = *impl_;
+  S.ctx = ctx;
+  S.cfg = cfg;
+  GTX_CHECK(cfg.frame_h > 0 && cfg.frame_w > 0, "stabilizer: frame size must be given");
+  GTX_CHECK(cfg.downsample_ratio == 0.5f || cfg.downsample_ratio == 1.0f, "stabilizer: downsample_ratio must be 0.5 or 1.0 (got %g)", cfg.downsample_ratio);
+  GTX_CHECK(cfg.n_levels >= 1 && cfg.n_levels <= kPyrLevels, "stabilizer: n_levels must be in [1,%d]", kPyrLevels);
+  GTX_CHECK(cfg.scale_factor > 1.0f, "stabilizer: scale_factor must be > 1");
+  GTX_CHECK(cfg.max_features >= 8, "stabilizer: max_features too small");
+  S.fh = cfg.frame_h;
+  S.fw = cfg.frame_w;
+  S.half = cfg.downsample_ratio == 0.5f ? 1 : 0;
+  S.gh = S.half ? S.fh / 2 : S.fh;
+  S.gw = S.half ? S.fw / 2 : S.fw;
+  GTX_HIP(hipSetDevice(ctx->device));
+  const int ref_features = (int)std::lround(cfg.max_features * (double)cfg.ref_multiplier);
+  S.plan(S.lev_cur, cfg.max_features, S.slots_cur);
+  S.plan(S.lev_ref, ref_features, S.slots_ref);
+  const Level& last = S.lev_ref.l[S.lev_ref.n - 1];
+  GTX_CHECK(last.w > 2 * kBorder + 8 && last.h > 2 * kBorder + 8, "stabilizer: image too small for %d pyramid levels", cfg.n_levels);
+  const int slots = std::max(S.slots_ref, S.slots_cur);
+  S.d_pyr.alloc(S.pyr_bytes);
+  S.d_score.alloc(S.pyr_bytes);
+  S.d_mask.alloc((size_t)S.gw * S.gh);
+  S.d_rects.alloc(sizeof(int4) * 4096);
+  S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
+  S.d_cand_n.alloc(sizeof(int) * kPyrLevels);
+  S.d_kp_n.alloc(sizeof(int) * kPyrLevels);
+  S.d_kps.alloc(sizeof(KeyPoint) * slots);
+  S.d_desc.alloc(32 * (size_t)slots);
+  S.d_xy.alloc(sizeof(float2) * slots);
+  S.d_selkey.alloc(8 * (size_t)slots);
+  S.d_selpix.alloc(4 * (size_t)slots);
+  for (Impl::Feat* f : {&S.ref, &S.cur}) {
+    f->kps.alloc(sizeof(KeyPoint) * slots);
+    f->desc.alloc(32 * (size_t)slots);
+    f->xy.alloc(sizeof(float2) * slots);
+    f->n.alloc(sizeof(int));
+    GTX_HIP(hipMemset(f->n.p, 0, sizeof(int)));
+  }
+  S.d_bidx.alloc(4 * slots); S.d_bd.alloc(4 * slots); S.d_sd.alloc(4 * slots);
+  S.d_mq.alloc(4 * slots); S.d_mt.alloc(4 * slots); S.d_md.alloc(4 * slots);
+  S.d_mpts.alloc(sizeof(float4) * slots);
+  S.d_nmatch.alloc(sizeof(int));
+  S.n_hyp = std::max(64, std::min(cfg.ransac_max_iter, 2048));
+  S.d_H.alloc(sizeof(double) * 9 * S.n_hyp);
+  S.d_cost.alloc(sizeof(long) * S.n_hyp);
+  S.d_best.alloc(sizeof(int));
+  // rotated sampling patterns
+  int8_t base[256][4];
+  base_pattern(base);
+  S.pattern.resize((size_t)kAngleBins * 256 * 4);
+  for (int b = 0; b < kAngleBins; ++b) {
+    const double th = b * (2.0 * M_PI / kAngleBins), cs = std::cos(th), sn = std::sin(th);
+    for (int i = 0; i < 256; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const double x = base[i][2 * k], y = base[i][2 * k + 1];
+        S.pattern[((size_t)b * 256 + i) * 4 + 2 * k] = (int8_t)std::lround(x * cs - y * sn);
+        S.pattern[((size_t)b * 256 + i) * 4 + 2 * k + 1] = (int8_t)std::lround(x * sn + y * cs);
+      }
+  }
+  S.d_pattern.alloc(S.pattern.size());
+  GTX_HIP(hipMemcpy(S.d_pattern.p, S.pattern.data(), S.pattern.size(), hipMemcpyHostToDevice));
+  long tans[32];
+  for (int j = 0; j < 32; ++j) tans[j] = std::lround(std::tan((j + 0.5) * 2.0 * M_PI / kAngleBins) * 16777216.0);
+  GTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tan), tans, sizeof tans));
+}
+
+Stabilizer::~Stabilizer() = default;
+
+void Stabilizer::Impl::build_rects(const float* boxes, int n, std::vector<int4>& rects) const {
+  // stabilo masks each box grown by mask_margin_ratio of its size, drawn on the downsampled frame
+  const float r = cfg.downsample_ratio, m = cfg.mask_margin_ratio;
+  for (int i = 0; i < n && (int)rects.size() < 4096; ++i) {
+    const float cx = boxes[4 * i], cy = boxes[4 * i + 1], w = boxes[4 * i + 2] * (1.f + m), h = boxes[4 * i + 3] * (1.f + m);
+    int x1 = (int)std::floor((cx - w / 2) * r), y1 = (int)std::floor((cy - h / 2) * r);
+    int x2 = (int)std::ceil((cx + w / 2) * r), y2 = (int)std::ceil((cy + h / 2) * r);
+    x1 = std::max(x1, 0); y1 = std::max(y1, 0); x2 = std::min(x2, gw - 1); y2 = std::min(y2, gh - 1);
+    if (x2 >= x1 && y2 >= y1) rects.push_back(make_int4(x1, y1, x2, y2));
+  }
+}
+
+void Stabilizer::Impl::gray_from_frame(const uint8_t* frame, int h, int w) {
+  GTX_CHECK(h == fh && w == fw, "stabilizer: frame is %dx%d, created for %dx%d", w, h, fw, fh);
+  const size_t bytes = (size_t)h * w * 3;
+  if (d_frame.bytes < bytes) d_frame.alloc(bytes);
+  GTX_HIP(hipMemcpyAsync(d_frame.p, frame, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(gray_kernel, dim3(cdiv(gw, 256), gh), dim3(256), 0, ctx->stream, d_frame.as<uint8_t>(), h, w, half,
+                     d_pyr.as<uint8_t>(), gh, gw);
+  GTX_HIP(hipGetLastError());
+}
+
+// gray_dev == nullptr: level 0 is already in d_pyr.
+void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int n, const Levels& L, int slots, Feat& out) {
+  hipStream_t s = ctx->stream;
+  uint8_t* pyr = d_pyr.as<uint8_t>();
+  if (gray_dev) GTX_HIP(hipMemcpyAsync(pyr, gray_dev, (size_t)gw * gh, hipMemcpyDeviceToDevice, s));
+  for (int i = 1; i < L.n; ++i) {
+    hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 256), L.l[i].h), dim3(256), 0, s, pyr + L.l[i - 1].off,
+                       L.l[i - 1].w, L.l[i - 1].h, pyr + L.l[i].off, L.l[i].w, L.l[i].h);
+  }
+  const uint8_t* mask = nullptr;
+  if (cfg.mask_use && boxes && n > 0) {
+    std::vector<int4> rects;
+    build_rects(boxes, n, rects);
+    hipLaunchKernelGGL(mask_fill_kernel, dim3(cdiv(gw * gh, 256)), dim3(256), 0, s, d_mask.as<uint8_t>(), gw * gh);
+    if (!rects.empty()) {
+      GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size()), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, gh,
+                         d_rects.as<int4>(), (int)rects.size());
+    }
+    mask = d_mask.as<uint8_t>();
+  }
+  const dim3 grid(cdiv(L.l[0].w, 256), L.l[0].h, L.n);
+  hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, s, pyr, d_score.as<uint8_t>(), L, cfg.fast_threshold);
+  GTX_HIP(hipMemsetAsync(d_cand_n.p, 0, sizeof(int) * kPyrLevels, s));
+  hipLaunchKernelGGL(fast_nms_harris_kernel, grid, dim3(256), 0, s, pyr, d_score.as<uint8_t>(), mask, gw, gh, L,
+                     d_cand.as<Cand>(), d_cand_n.as<int>());
+  hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_cand.as<Cand>(), d_cand_n.as<int>(), L,
+                     d_kps.as<KeyPoint>(), d_kp_n.as<int>(), d_selkey.as<unsigned long long>(), d_selpix.as<int>());
+  hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, pyr, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
+                     d_pattern.as<int8_t>(), d_desc.as<unsigned long long>(), d_xy.as<float2>(), 1.0f / cfg.downsample_ratio, slots);
+  hipLaunchKernelGGL(compact_kernel, dim3(8), dim3(256), 0, s, L, d_kp_n.as<int>(), d_kps.as<KeyPoint>(),
+                     d_desc.as<unsigned long long>(), d_xy.as<float2>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(),
+                     out.xy.as<float2>(), out.n.as<int>());
+  GTX_HIP(hipGetLastError());
+  GTX_HIP(hipMemcpyAsync(&out.host_n, out.n.p, sizeof(int), hipMemcpyDeviceToHost, s));
+}
+
+namespace {
+
+// Least-squares homography on correspondences (x,y)->(u,v): normalised DLT with h33 free,
+// solved through the 9x9 normal matrix by Jacobi eigen-decomposition (smallest eigenvector).
+bool dlt_fit(const std::vector<float4>& pts, const std::vector<int>& idx, double cx, double cy, double sc, double H[9]) {
+  if (idx.size() < 4) return false;
+  double M[81] = {0};
+  for (int i : idx) {
+    const double x = (pts[i].x - cx) * sc, y = (pts[i].y - cy) * sc, u = (pts[i].z - cx) * sc, v = (pts[i].w - cy) * sc;
+    const double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, -u};
+    const double r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, -v};
+    for (int a = 0; a < 9; ++a)
+      for (int b = 0; b < 9; ++b) M[a * 9 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+  }
+  // Jacobi eigenvalue iteration on the symmetric 9x9
+  double V[81] = {0};
+  for (int i = 0; i < 9; ++i) V[i * 9 + i] = 1;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 9; ++p)
+      for (int q = p + 1; q < 9; ++q) off += M[p * 9 + q] * M[p * 9 + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 9; ++p)
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = M[p * 9 + q];
+        if (std::fabs(apq) < 1e-320) continue;
+        const double theta = (M[q * 9 + q] - M[p * 9 + p]) / (2 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+        const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 9; ++k) {
+          const double mkp = M[k * 9 + p], mkq = M[k * 9 + q];
+          M[k * 9 + p] = c * mkp - s * mkq;
+          M[k * 9 + q] = s * mkp + c * mkq;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double mpk = M[p * 9 + k], mqk = M[q * 9 + k];
+          M[p * 9 + k] = c * mpk - s * mqk;
+          M[q * 9 + k] = s * mpk + c * mqk;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
+          V[k * 9 + p] = c * vkp - s * vkq;
+          V[k * 9 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 9; ++i)
+    if (M[i * 9 + i] < M[best * 9 + best]) best = i;
+  double Hn[9];
+  for (int i = 0; i < 9; ++i) Hn[i] = V[i * 9 + best];
+  const double is = 1.0 / sc;
+  double T[9];
+  for (int r = 0; r < 3; ++r) {
+    T[r * 3 + 0] = Hn[r * 3 + 0] * sc;
+    T[r * 3 + 1] = Hn[r * 3 + 1] * sc;
+    T[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
+  }
+  for (int k = 0; k < 3; ++k) {
+    H[0 + k] = is * T[0 + k] + cx * T[6 + k];
+    H[3 + k] = is * T[3 + k] + cy * T[6 + k];
+    H[6 + k] = T[6 + k];
+  }
+  if (std::fabs(H[8]) < 1e-300) return false;
+  const double inv = 1.0 / H[8];
+  for (int i = 0; i < 9; ++i) H[i] *= inv;
+  return true;
+}
+
+void find_inliers(const std::vector<float4>& pts, const double H[9], double thr2, std::vector<int>& idx) {
+  idx.clear();
+  for (size_t i = 0; i < pts.size(); ++i) {
+    const double x = pts[i].x, y = pts[i].y;
+    const double w = H[6] * x + H[7] * y + H[8];
+    if (std::fabs(w) < 1e-12) continue;
+    const double dx = (H[0] * x + H[1] * y + H[2]) / w - pts[i].z, dy = (H[3] * x + H[4] * y + H[5]) / w - pts[i].w;
+    if (dx * dx + dy * dy <= thr2) idx.push_back((int)i);
+  }
+}
+
+}  // namespace
+
+void Stabilizer::Impl::run_stabilize(double Hout[9], int* valid_out, int st[4]) {
+  hipStream_t s = ctx->stream;
+  const int slots = std::max(slots_ref, slots_cur);
+  hipLaunchKernelGGL(match_kernel, dim3(cdiv(slots_cur, 256)), dim3(256), 0, s, cur.desc.as<unsigned long long>(), cur.n.as<int>(),
+                     ref.desc.as<unsigned long long>(), ref.n.as<int>(), d_bidx.as<int>(), d_bd.as<int>(), d_sd.as<int>());
+  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, cur.n.as<int>(), ref.n.as<int>(), d_bidx.as<int>(),
+                     d_bd.as<int>(), d_sd.as<int>(), cfg.filter_ratio, cur.xy.as<float2>(), ref.xy.as<float2>(), d_mq.as<int>(),
+                     d_mt.as<int>(), d_md.as<int>(), d_mpts.as<float4>(), d_nmatch.as<int>());
+  const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
+  const float thr2 = cfg.ransac_threshold * cfg.ransac_threshold;
+  hipLaunchKernelGGL(ransac_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), cfg.seed,
+                     n_hyp, cx, cy, sc, thr2, d_H.as<double>(), d_cost.as<long>());
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_best.as<int>());
+  GTX_HIP(hipGetLastError());
+  int n_match = 0, best = -1;
+  GTX_HIP(hipMemcpyAsync(&n_match, d_nmatch.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipMemcpyAsync(&best, d_best.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipStreamSynchronize(s));
+  (void)slots;
+  stats[0] = ref.host_n; stats[1] = cur.host_n; stats[2] = n_match; stats[3] = 0;
+  valid = false;
+  if (n_match >= 4 && best >= 0) {
+    std::vector<float4> pts(n_match);
+    double Hb[9];
+    GTX_HIP(hipMemcpy(pts.data(), d_mpts.p, sizeof(float4) * n_match, hipMemcpyDeviceToHost));
+    GTX_HIP(hipMemcpy(Hb, d_H.as<double>() + (size_t)best * 9, sizeof Hb, hipMemcpyDeviceToHost));
+    // local optimisation: inliers of the best hypothesis -> least-squares refit, twice
+    std::vector<int> inl;
+    double Hc[9];
+    std::memcpy(Hc, Hb, sizeof Hc);
+    const double inv = 1.0 / Hc[8];
+    for (double& v : Hc) v *= inv;
+    for (int it = 0; it < 3; ++it) {
+      find_inliers(pts, Hc, thr2, inl);
+      if (inl.size() < 4) break;
+      double Hn[9];
+      if (!dlt_fit(pts, inl, cx, cy, sc, Hn)) break;
+      std::memcpy(Hc, Hn, sizeof Hc);
+    }
+    find_inliers(pts, Hc, thr2, inl);
+    if (inl.size() >= 4) {
+      std::memcpy(H, Hc, sizeof H);
+      valid = true;
+      stats[3] = (int)inl.size();
+    }
+  }
+  if (Hout) std::memcpy(Hout, H, sizeof H);
+  if (valid_out) *valid_out = valid ? 1 : 0;
+  if (st) std::memcpy(st, stats, sizeof stats);
+}
+
+void Stabilizer::set_ref_frame(const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n) {
+  Impl& S = *impl_;
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  S.gray_from_frame(frame_bgr, h, w);
+  S.extract(nullptr, boxes_xywh, n, S.lev_ref, S.slots_ref, S.ref);
+  GTX_HIP(hipStreamSynchronize(S.ctx->stream));
+  S.have_ref = true;
+}
+
+void Stabilizer::set_ref_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n) {
+  Impl& S = *impl_;
+  GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_ref, S.slots_ref, S.ref);
+  GTX_HIP(hipStreamSynchronize(S.ctx->stream));
+  S.have_ref = true;
+}
+
+void Stabilizer::stabilize(const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]) {
+  Impl& S = *impl_;
+  if (!S.have_ref) fail(GTX_ERR_STATE, "stabilize called before set_ref_frame");
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  S.gray_from_frame(frame_bgr, h, w);
+  S.extract(nullptr, boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
+  S.run_stabilize(H, valid, stats);
+}
+
+void Stabilizer::stabilize_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]) {
+  Impl& S = *impl_;
+  if (!S.have_ref) fail(GTX_ERR_STATE, "stabilize called before set_ref_frame");
+  GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
+  S.run_stabilize(H, valid, stats);
+}
+
+void Stabilizer::keypoints(int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc) {
+  Impl& S = *impl_;
+  Impl::Feat& f = which == 0 ? S.ref : S.cur;
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  GTX_HIP(hipStreamSynchronize(S.ctx->stream));
+  const int k = std::min(cap, f.host_n);
+  *n = k;
+  if (k == 0) return;
+  std::vector<KeyPoint> kp(k);
+  GTX_HIP(hipMemcpy(kp.data(), f.kps.p, sizeof(KeyPoint) * k, hipMemcpyDeviceToHost));
+  if (xy) GTX_HIP(hipMemcpy(xy, f.xy.p, sizeof(float2) * k, hipMemcpyDeviceToHost));
+  if (desc) GTX_HIP(hipMemcpy(desc, f.desc.p, 32 * (size_t)k, hipMemcpyDeviceToHost));
+  for (int i = 0; i < k; ++i) {
+    if (level) level[i] = kp[i].level;
+    if (angle_bin) angle_bin[i] = kp[i].bin;
+  }
+}
+
+void Stabilizer::matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist) {
+  Impl& S = *impl_;
+  GTX_HIP(hipSetDevice(S.ctx->device));
+  GTX_HIP(hipStreamSynchronize(S.ctx->stream));
+  const int k = std::min(cap, S.stats[2]);
+  *n = k;
+  if (k == 0) return;
+  if (cur_idx) GTX_HIP(hipMemcpy(cur_idx, S.d_mq.p, 4 * (size_t)k, hipMemcpyDeviceToHost));
+  if (ref_idx) GTX_HIP(hipMemcpy(ref_idx, S.d_mt.p, 4 * (size_t)k, hipMemcpyDeviceToHost));
+  if (dist) GTX_HIP(hipMemcpy(dist, S.d_md.p, 4 * (size_t)k, hipMemcpyDeviceToHost));
+}
+
+void Stabilizer::pattern(int8_t* out) const { std::memcpy(out, impl_->pattern.data(), impl_->pattern.size()); }
+
+}  // namespace gtx

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "gtx_stabilizer_stabilize_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
     "gtx_stabilizer_keypoints": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "gtx_stabilizer_matches": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
+    "gtx_stabilizer_pattern": (C.c_int, [_P, _P]),
     "gtx_warp_boxes": (C.c_int, [_P, _P, C.c_int, _P]),
     "gtx_perspective_points": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),

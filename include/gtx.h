@@ -251,6 +251,10 @@ int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which /*0 ref, 1 cur*/, int
 int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, int* ref_idx,
                            int* dist);
 
+/* The steered-BRIEF sampling table the descriptor kernel uses: [256 orientation bins][256
+ * tests][ax, ay, bx, by] int8 = 262144 bytes. Data hand-over for the parity tests. */
+int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out);
+
 /* Stabilizer.transform_cur_boxes(): maps the 4 corners of each xywh box through H and
  * returns the axis-aligned bounding rectangle as xywh (rule pinned on the reference's golden
  * output). Pure host arithmetic, f64 inside, f32 out. */
