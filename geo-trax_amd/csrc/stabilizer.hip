@@ -859,82 +859,138 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
 
 namespace {
 
-// Least-squares homography on correspondences (x,y)->(u,v): normalised DLT with h33 free,
-// solved through the 9x9 normal matrix by Jacobi eigen-decomposition (smallest eigenvector).
-bool dlt_fit(const std::vector<float4>& pts, const std::vector<int>& idx, double cx, double cy, double sc, double H[9]) {
-  if (idx.size() < 4) return false;
-  double M[81] = {0};
-  for (int i : idx) {
-    const double x = (pts[i].x - cx) * sc, y = (pts[i].y - cy) * sc, u = (pts[i].z - cx) * sc, v = (pts[i].w - cy) * sc;
-    const double r0[9] = {x, y, 1, 0, 0, 0, -u * x, -u * y, -u};
-    const double r1[9] = {0, 0, 0, x, y, 1, -v * x, -v * y, -v};
-    for (int a = 0; a < 9; ++a)
-      for (int b = 0; b < 9; ++b) M[a * 9 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+// Robust refinement of the RANSAC winner. Keypoints sit on integer pixels of their pyramid level,
+// so matches carry 1-2 px of localisation noise in full-resolution pixels -- comparable to the
+// RANSAC threshold. A hard inlier cut at the threshold throws away (and biases) much of the
+// evidence. Instead: keep every match within 3x the threshold of the winner and minimise the
+// geometric transfer error with iteratively re-weighted Gauss-Newton (Tukey biweight, scale from
+// the median residual), h33 = 1, in normalised coordinates.
+bool refine_homography(const std::vector<float4>& pts, double cx, double cy, double sc,
+                       double thr, double H[9], int* n_inliers) {
+  const size_t n = pts.size();
+  // to normalised coordinates: Hn = T H T^-1
+  auto to_norm = [&](const double* Hp, double* Hn) {
+    const double is = 1.0 / sc;
+    double M[9];  // M = H T^-1, T^-1 = [[is,0,cx],[0,is,cy],[0,0,1]]
+    for (int r = 0; r < 3; ++r) {
+      M[r * 3 + 0] = Hp[r * 3 + 0] * is;
+      M[r * 3 + 1] = Hp[r * 3 + 1] * is;
+      M[r * 3 + 2] = Hp[r * 3 + 0] * cx + Hp[r * 3 + 1] * cy + Hp[r * 3 + 2];
+    }
+    for (int k = 0; k < 3; ++k) {  // Hn = T M, T = [[sc,0,-sc cx],[0,sc,-sc cy],[0,0,1]]
+      Hn[0 + k] = sc * M[0 + k] - sc * cx * M[6 + k];
+      Hn[3 + k] = sc * M[3 + k] - sc * cy * M[6 + k];
+      Hn[6 + k] = M[6 + k];
+    }
+    const double inv = 1.0 / Hn[8];
+    for (int i = 0; i < 9; ++i) Hn[i] *= inv;
+  };
+  auto from_norm = [&](const double* Hn, double* Hp) {
+    const double is = 1.0 / sc;
+    double M[9];  // M = Hn T
+    for (int r = 0; r < 3; ++r) {
+      M[r * 3 + 0] = Hn[r * 3 + 0] * sc;
+      M[r * 3 + 1] = Hn[r * 3 + 1] * sc;
+      M[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
+    }
+    for (int k = 0; k < 3; ++k) {
+      Hp[0 + k] = is * M[0 + k] + cx * M[6 + k];
+      Hp[3 + k] = is * M[3 + k] + cy * M[6 + k];
+      Hp[6 + k] = M[6 + k];
+    }
+    const double inv = 1.0 / Hp[8];
+    for (int i = 0; i < 9; ++i) Hp[i] *= inv;
+  };
+  std::vector<double> x(n), y(n), u(n), v(n);
+  for (size_t i = 0; i < n; ++i) {
+    x[i] = (pts[i].x - cx) * sc; y[i] = (pts[i].y - cy) * sc;
+    u[i] = (pts[i].z - cx) * sc; v[i] = (pts[i].w - cy) * sc;
   }
-  // Jacobi eigenvalue iteration on the symmetric 9x9
-  double V[81] = {0};
-  for (int i = 0; i < 9; ++i) V[i * 9 + i] = 1;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < 9; ++p)
-      for (int q = p + 1; q < 9; ++q) off += M[p * 9 + q] * M[p * 9 + q];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 9; ++p)
-      for (int q = p + 1; q < 9; ++q) {
-        const double apq = M[p * 9 + q];
-        if (std::fabs(apq) < 1e-320) continue;
-        const double theta = (M[q * 9 + q] - M[p * 9 + p]) / (2 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-        const double c = 1 / std::sqrt(t * t + 1), s = t * c;
-        for (int k = 0; k < 9; ++k) {
-          const double mkp = M[k * 9 + p], mkq = M[k * 9 + q];
-          M[k * 9 + p] = c * mkp - s * mkq;
-          M[k * 9 + q] = s * mkp + c * mkq;
-        }
-        for (int k = 0; k < 9; ++k) {
-          const double mpk = M[p * 9 + k], mqk = M[q * 9 + k];
-          M[p * 9 + k] = c * mpk - s * mqk;
-          M[q * 9 + k] = s * mpk + c * mqk;
-        }
-        for (int k = 0; k < 9; ++k) {
-          const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
-          V[k * 9 + p] = c * vkp - s * vkq;
-          V[k * 9 + q] = s * vkp + c * vkq;
+  double h[9];
+  to_norm(H, h);
+  auto residual = [&](size_t i, double& rx, double& ry, double& w) {
+    w = h[6] * x[i] + h[7] * y[i] + 1.0;
+    rx = (h[0] * x[i] + h[1] * y[i] + h[2]) / w - u[i];
+    ry = (h[3] * x[i] + h[4] * y[i] + h[5]) / w - v[i];
+  };
+  // support set: within 3 thresholds of the winner (fixed over the iterations)
+  std::vector<int> sup;
+  const double lim = 3.0 * thr * sc;
+  for (size_t i = 0; i < n; ++i) {
+    double rx, ry, w;
+    residual(i, rx, ry, w);
+    if (std::fabs(w) > 1e-9 && rx * rx + ry * ry <= lim * lim) sup.push_back((int)i);
+  }
+  if (sup.size() < 4) return false;
+  std::vector<double> un(sup.size());
+  for (int iter = 0; iter < 8; ++iter) {
+    for (size_t k = 0; k < sup.size(); ++k) {
+      double rx, ry, w;
+      residual(sup[k], rx, ry, w);
+      un[k] = std::sqrt(rx * rx + ry * ry) / sc;   // pixels
+    }
+    std::vector<double> tmp = un;
+    std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+    const double sigma = std::max(1.4826 * tmp[tmp.size() / 2], 0.05);
+    const double c = 4.685 * sigma;
+    double A[64] = {0}, g[8] = {0};
+    for (size_t k = 0; k < sup.size(); ++k) {
+      const int i = sup[k];
+      if (un[k] >= c) continue;
+      const double t = 1.0 - (un[k] / c) * (un[k] / c);
+      const double wt = t * t;
+      double rx, ry, w;
+      residual(i, rx, ry, w);
+      const double iw = 1.0 / w, px = rx + u[i], py = ry + v[i];
+      const double Jx[8] = {x[i] * iw, y[i] * iw, iw, 0, 0, 0, -px * x[i] * iw, -px * y[i] * iw};
+      const double Jy[8] = {0, 0, 0, x[i] * iw, y[i] * iw, iw, -py * x[i] * iw, -py * y[i] * iw};
+      for (int a = 0; a < 8; ++a) {
+        g[a] += wt * (Jx[a] * rx + Jy[a] * ry);
+        for (int b = a; b < 8; ++b) A[a * 8 + b] += wt * (Jx[a] * Jx[b] + Jy[a] * Jy[b]);
+      }
+    }
+    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < a; ++b) A[a * 8 + b] = A[b * 8 + a];
+    // Cholesky solve A d = g
+    double Lc[64] = {0};
+    bool ok = true;
+    for (int i = 0; i < 8 && ok; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = A[i * 8 + j];
+        for (int k = 0; k < j; ++k) s -= Lc[i * 8 + k] * Lc[j * 8 + k];
+        if (i == j) {
+          if (!(s > 0)) { ok = false; break; }
+          Lc[i * 8 + i] = std::sqrt(s);
+        } else {
+          Lc[i * 8 + j] = s / Lc[j * 8 + j];
         }
       }
+    if (!ok) break;
+    double yv[8], d[8];
+    for (int i = 0; i < 8; ++i) {
+      double s = g[i];
+      for (int k = 0; k < i; ++k) s -= Lc[i * 8 + k] * yv[k];
+      yv[i] = s / Lc[i * 8 + i];
+    }
+    for (int i = 7; i >= 0; --i) {
+      double s = yv[i];
+      for (int k = i + 1; k < 8; ++k) s -= Lc[k * 8 + i] * d[k];
+      d[i] = s / Lc[i * 8 + i];
+    }
+    double step = 0;
+    for (int a = 0; a < 8; ++a) { h[a] -= d[a]; step = std::max(step, std::fabs(d[a])); }
+    if (step < 1e-14) break;
   }
-  int best = 0;
-  for (int i = 1; i < 9; ++i)
-    if (M[i * 9 + i] < M[best * 9 + best]) best = i;
-  double Hn[9];
-  for (int i = 0; i < 9; ++i) Hn[i] = V[i * 9 + best];
-  const double is = 1.0 / sc;
-  double T[9];
-  for (int r = 0; r < 3; ++r) {
-    T[r * 3 + 0] = Hn[r * 3 + 0] * sc;
-    T[r * 3 + 1] = Hn[r * 3 + 1] * sc;
-    T[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
+  from_norm(h, H);
+  int cnt = 0;
+  const double t2 = thr * sc * thr * sc;
+  for (size_t i = 0; i < n; ++i) {
+    double rx, ry, w;
+    residual(i, rx, ry, w);
+    if (rx * rx + ry * ry <= t2) ++cnt;
   }
-  for (int k = 0; k < 3; ++k) {
-    H[0 + k] = is * T[0 + k] + cx * T[6 + k];
-    H[3 + k] = is * T[3 + k] + cy * T[6 + k];
-    H[6 + k] = T[6 + k];
-  }
-  if (std::fabs(H[8]) < 1e-300) return false;
-  const double inv = 1.0 / H[8];
-  for (int i = 0; i < 9; ++i) H[i] *= inv;
-  return true;
-}
-
-void find_inliers(const std::vector<float4>& pts, const double H[9], double thr2, std::vector<int>& idx) {
-  idx.clear();
-  for (size_t i = 0; i < pts.size(); ++i) {
-    const double x = pts[i].x, y = pts[i].y;
-    const double w = H[6] * x + H[7] * y + H[8];
-    if (std::fabs(w) < 1e-12) continue;
-    const double dx = (H[0] * x + H[1] * y + H[2]) / w - pts[i].z, dy = (H[3] * x + H[4] * y + H[5]) / w - pts[i].w;
-    if (dx * dx + dy * dy <= thr2) idx.push_back((int)i);
-  }
+  if (n_inliers) *n_inliers = cnt;
+  return cnt >= 4;
 }
 
 }  // namespace
@@ -965,24 +1021,15 @@ void Stabilizer::Impl::run_stabilize(double Hout[9], int* valid_out, int st[4]) 
     double Hb[9];
     GTX_HIP(hipMemcpy(pts.data(), d_mpts.p, sizeof(float4) * n_match, hipMemcpyDeviceToHost));
     GTX_HIP(hipMemcpy(Hb, d_H.as<double>() + (size_t)best * 9, sizeof Hb, hipMemcpyDeviceToHost));
-    // local optimisation: inliers of the best hypothesis -> least-squares refit, twice
-    std::vector<int> inl;
     double Hc[9];
     std::memcpy(Hc, Hb, sizeof Hc);
     const double inv = 1.0 / Hc[8];
     for (double& v : Hc) v *= inv;
-    for (int it = 0; it < 3; ++it) {
-      find_inliers(pts, Hc, thr2, inl);
-      if (inl.size() < 4) break;
-      double Hn[9];
-      if (!dlt_fit(pts, inl, cx, cy, sc, Hn)) break;
-      std::memcpy(Hc, Hn, sizeof Hc);
-    }
-    find_inliers(pts, Hc, thr2, inl);
-    if (inl.size() >= 4) {
+    int n_inl = 0;
+    if (refine_homography(pts, cx, cy, sc, (double)cfg.ransac_threshold, Hc, &n_inl)) {
       std::memcpy(H, Hc, sizeof H);
       valid = true;
-      stats[3] = (int)inl.size();
+      stats[3] = n_inl;
     }
   }
   if (Hout) std::memcpy(Hout, H, sizeof H);

@@ -12,7 +12,7 @@ installed here, and OpenCV's ORB sampling table and MAGSAC++ internals cannot be
 memory bit for bit. This file therefore restates the *published algorithms* (Rublee et al. ORB:
 scale pyramid, FAST-9/16 with 3x3 non-maximum suppression, Harris ranking, intensity-centroid
 orientation, steered BRIEF on a Gaussian-smoothed patch; Lowe's ratio test; RANSAC with an
-MSAC score and least-squares local refits) in the integer-exact form the HIP kernels implement
+MSAC score and a robust iteratively re-weighted Gauss-Newton refit) in the integer-exact form the HIP kernels implement
 (geo-trax_amd/csrc/stabilizer.hip), so that every stage can be compared bit for bit. The BRIEF
 sampling table is data handed over by the library (gtx_stabilizer_pattern).
 
@@ -244,13 +244,49 @@ def _denorm(Hn, cx, cy, sc):
     return np.linalg.inv(T) @ Hn @ T
 
 
-def _dlt(p, q, cx, cy, sc):
+def refine_homography(H0, p, q, cx, cy, sc, thr):
+    """Iteratively re-weighted Gauss-Newton on the transfer error (Tukey biweight, scale from the
+    median residual, support = matches within 3 thresholds of H0), h33 = 1, normalised
+    coordinates. Mirrors refine_homography() in csrc/stabilizer.hip."""
+    T = np.array([[sc, 0, -sc * cx], [0, sc, -sc * cy], [0, 0, 1.0]])
+    h = T @ H0 @ np.linalg.inv(T)
+    h = (h / h[2, 2]).reshape(9).copy()
     x, y, u, v = (p[:, 0] - cx) * sc, (p[:, 1] - cy) * sc, (q[:, 0] - cx) * sc, (q[:, 1] - cy) * sc
-    z, o = np.zeros_like(x), np.ones_like(x)
-    A = np.concatenate([np.stack([x, y, o, z, z, z, -u * x, -u * y, -u], 1), np.stack([z, z, z, x, y, o, -v * x, -v * y, -v], 1)])
-    w, V = np.linalg.eigh(A.T @ A)
-    H = _denorm(V[:, 0].reshape(3, 3), cx, cy, sc)
-    return H / H[2, 2]
+
+    def res(hv):
+        w = hv[6] * x + hv[7] * y + 1.0
+        return (hv[0] * x + hv[1] * y + hv[2]) / w - u, (hv[3] * x + hv[4] * y + hv[5]) / w - v, w
+
+    rx, ry, w = res(h)
+    sup = np.nonzero((np.abs(w) > 1e-9) & (rx * rx + ry * ry <= (3.0 * thr * sc) ** 2))[0]
+    if len(sup) < 4:
+        return None, 0
+    for _ in range(8):
+        rx, ry, w = res(h)
+        un = np.sqrt(rx[sup] ** 2 + ry[sup] ** 2) / sc
+        sigma = max(1.4826 * np.sort(un)[len(un) // 2], 0.05)
+        c = 4.685 * sigma
+        use = un < c
+        i = sup[use]
+        wt = (1.0 - (un[use] / c) ** 2) ** 2
+        iw = 1.0 / w[i]
+        px, py = rx[i] + u[i], ry[i] + v[i]
+        z = np.zeros_like(iw)
+        Jx = np.stack([x[i] * iw, y[i] * iw, iw, z, z, z, -px * x[i] * iw, -px * y[i] * iw], 1)
+        Jy = np.stack([z, z, z, x[i] * iw, y[i] * iw, iw, -py * x[i] * iw, -py * y[i] * iw], 1)
+        A = (Jx * wt[:, None]).T @ Jx + (Jy * wt[:, None]).T @ Jy
+        g = (Jx * (wt * rx[i])[:, None]).sum(0) + (Jy * (wt * ry[i])[:, None]).sum(0)
+        try:
+            d = np.linalg.solve(A, g)
+        except np.linalg.LinAlgError:
+            break
+        h[:8] -= d
+        if np.abs(d).max() < 1e-14:
+            break
+    rx, ry, w = res(h)
+    n_inl = int((rx * rx + ry * ry <= (thr * sc) ** 2).sum())
+    H = np.linalg.inv(T) @ h.reshape(3, 3) @ T
+    return (H / H[2, 2], n_inl) if n_inl >= 4 else (None, 0)
 
 
 def _errors(H, p, q):
@@ -297,16 +333,7 @@ def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float
             best_cost, best_H = cost, H
     if best_H is None:
         return None, 0
-    H = best_H / best_H[2, 2]
-    for _ in range(3):
-        inl = _errors(H, p, q) <= thr2
-        if inl.sum() < 4:
-            break
-        H = _dlt(p[inl], q[inl], cx, cy, sc)
-    inl = _errors(H, p, q) <= thr2
-    if inl.sum() < 4:
-        return None, 0
-    return H, int(inl.sum())
+    return refine_homography(best_H / best_H[2, 2], p, q, cx, cy, sc, float(np.float32(thr)))
 
 
 class StabilizerRef:
