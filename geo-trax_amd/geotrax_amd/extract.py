@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""extract -- the per-frame extraction stage on MI355X.
+
+Host-side restatement of the reference stage driver geotrax/extract.py (same function names,
+argument meaning, log lines, error behaviour and output files):
+
+    detect_track_stabilize   extract.py:114-131
+    track_with_model         extract.py:134-214   the hot loop
+    load_detector            extract.py:217-236
+    initialize_streams       extract.py:239-257
+    save_results             extract.py:487-523
+    add_processing_args / parse_cli_args / main   extract.py:571-612
+
+The loop body is the reference's; what sits underneath is this build's: ``YOLO.track`` runs the
+HIP detector and the C++ tracker, ``Stabilizer`` runs the HIP keypoint/matching/RANSAC kernels on
+the half-resolution gray image the detector's preprocess pass already produced on the GPU (so a
+frame crosses PCIe once and is read from HBM once).
+
+Usage:  python -m geotrax_amd.extract <source> [options]      (same flags as `geotrax extract`)
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import logging
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import yaml
+
+from . import __version__
+from .config_utils import backfill_args_from_config, load_config_all
+from .frames import get_video_dimensions, open_source, source_exists
+from .model import YOLO
+from .postprocess import aggregate_results, postprocess_tracks
+from .stabilizer import Stabilizer
+
+_INFERENCE_KEYS = {'conf', 'iou', 'imgsz', 'max_det', 'classes', 'augment', 'agnostic_nms', 'half', 'device',
+                   'vid_stride', 'mode', 'task', 'stream_buffer', 'rect'}
+
+
+def detect_track_stabilize(args: argparse.Namespace, logger: logging.Logger) -> None:
+    """Process one video (extract.py:114-131)."""
+    model = load_detector(args, logger)
+    config = load_config_all(args, logger, model_names=model.names if model else None)
+    proc = config['main']['processing']
+    out_cfg_raw = config['main'].get('output', {})
+    backfill_args_from_config(args, {
+        'cut_frame_left': proc['cut_frame_left'],
+        'cut_frame_right': proc['cut_frame_right'],
+        'interpolate': config['main']['extraction']['interpolate'],
+        'output_folder': out_cfg_raw.get('folder', 'results'),
+    })
+    out_cfg = {**out_cfg_raw, 'folder': args.output_folder}
+    tracks, transforms = track_with_model(model, config, logger)
+    w_h = get_video_dimensions(config['main']['args'].source)
+    tracks = postprocess_tracks(tracks, config, logger, w_h)
+    save_results(tracks, transforms, config, logger, out_cfg)
+
+
+class _Collector:
+    """Per-frame result lists in the layout aggregate_results() expects (extract.py:142,160-187)."""
+
+    def __init__(self):
+        self.frame, self.ids, self.raw, self.stab, self.cls, self.conf, self.transforms = [], [], [], [], [], [], []
+
+    def add_boxes(self, frame_num: int, boxes) -> np.ndarray | None:
+        n = len(boxes)
+        if n == 0:
+            return None
+        # the narrowings are part of the output contract: uint16 ids, uint8 classes, float32 boxes
+        ids = np.full((n, 1), -1) if boxes.id is None else boxes.id.detach().numpy(force=True).astype(np.uint16).reshape(-1, 1)
+        xywh = boxes.xywh.detach().numpy(force=True).astype(np.float32)
+        self.frame.append(np.full((n, 1), frame_num, dtype=np.uint32))
+        self.ids.append(ids)
+        self.raw.append(xywh)
+        self.cls.append(boxes.cls.detach().numpy(force=True).astype(np.uint8).reshape(-1, 1))
+        self.conf.append(boxes.conf.detach().numpy(force=True).astype(np.float32).reshape(-1, 1))
+        return xywh
+
+    def add_transform(self, frame_num: int, H: np.ndarray | None) -> None:
+        if H is not None:
+            self.transforms.append(np.hstack((np.array([[frame_num]]), H.flatten().reshape(1, -1))))
+
+
+def _stabilize_step(stabilizer: Stabilizer, model: YOLO, frame: np.ndarray, xywh, is_ref: bool, use_dev_gray: bool):
+    """Registers `frame` against the reference frame (or makes it the reference). The gray image the
+    detector's preprocess pass left in HBM is used when the stabilizer works at half resolution.
+    Returns (stabilized boxes or None, 3x3 matrix or None)."""
+    gray = model.detector.gray_dptr(0) if (use_dev_gray and model.detector is not None) else None
+    on_dev = gray is not None and bool(gray[0])
+    if on_dev and stabilizer.handle is None:
+        stabilizer._create(frame.shape[:2])
+    if is_ref:
+        if on_dev:
+            stabilizer.set_ref_gray_dev(gray[0], gray[1], gray[2], xywh)
+        else:
+            stabilizer.set_ref_frame(frame, xywh)
+        return xywh, None                                   # frame 0 is copied through (extract.py:178-179)
+    if on_dev:
+        stabilizer.stabilize_gray_dev(gray[0], gray[1], gray[2], xywh)
+    else:
+        stabilizer.stabilize(frame, xywh)
+    return (stabilizer.transform_cur_boxes() if xywh is not None else None), stabilizer.get_cur_trans_matrix()
+
+
+def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray]:
+    """The hot loop (extract.py:134-214): read -> detect+track -> stabilize, one frame at a time.
+    Any exception voids the whole video (empty tables), exactly like the reference (:198-200)."""
+    args = config['main']['args']
+    reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
+    stabilizer = Stabilizer(**{k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')})
+    use_dev_gray = float(config['stabilo'].get('downsample_ratio', 0.5)) == 0.5
+    do_stab = config['main']['extraction']['stabilize']
+    track_kw = {k: v for k, v in config['ultralytics'].items() if k != 'model'}
+    first, last = args.cut_frame_left, args.cut_frame_right
+    out, yolo_ms, stab_ms = _Collector(), [], []
+    t_wall = time.time()
+    try:
+        frame_num = 0
+        while reader.isOpened():
+            ok, frame = reader.read()
+            if frame_num < first:                           # skipped prefix still advances the counter
+                frame_num += 1
+                continue
+            if not ok:
+                break
+            res = model.track(frame, **track_kw, persist=True)[0]
+            yolo_ms.append(sum(res.speed.values()))
+            xywh = out.add_boxes(frame_num, res.boxes)
+            if do_stab:
+                t0 = time.time()
+                stab_boxes, H = _stabilize_step(stabilizer, model, frame, xywh, frame_num == first, use_dev_gray)
+                if stab_boxes is not None:
+                    out.stab.append(stab_boxes)
+                out.add_transform(frame_num, H)
+                stab_ms.append(1000 * (time.time() - t0))
+            if last is not None and frame_num >= last:
+                break
+            frame_num += 1
+    except Exception as e:
+        logger.error(f"Error processing: '{args.source}' due to: {e}")
+        return np.empty((0, 12), dtype=np.float32), np.empty((0, 10))
+    else:
+        if yolo_ms:
+            # the three lines (and what they count) are the reference's, extract.py:205-207
+            logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(yolo_ms) / len(yolo_ms):5.1f}ms.")
+            if stab_ms:
+                logger.info(f"Average stabilization time: {sum(stab_ms) / len(stab_ms):5.1f}ms")
+            logger.info(f"Average pipeline time: {1000 * len(yolo_ms) / (sum(yolo_ms) + sum(stab_ms)):4.1f}fps.")
+            logger.info(f"Wall clock incl. frame source, tracker and host loop: {len(yolo_ms) / (time.time() - t_wall):4.1f}fps.")
+    finally:
+        reader.release()
+    return aggregate_results(out.frame, out.ids, out.raw, out.stab, out.cls, out.conf, out.transforms, logger)
+
+
+def load_detector(args: argparse.Namespace, logger: logging.Logger) -> YOLO:
+    """extract.py:217-236. The model reference comes from --model or cfg -> extraction -> model."""
+    from .config_utils import load_config
+
+    raw = getattr(args, 'model', None)
+    if isinstance(raw, list):
+        raw = ' '.join(raw)
+    cfg = load_config(getattr(args, 'cfg', None), logger)
+    ref = raw or cfg.get('extraction', {}).get('model') or cfg.get('ultralytics', {}).get('model')
+    if not ref:
+        logger.critical("No detection model configured: set cfg -> extraction -> model or pass --model <file.safetensors>.")
+        sys.exit(1)
+    try:
+        if str(ref).startswith('synthetic:'):
+            from .weights import synthetic_yolov8
+
+            seed = int(str(ref).split(':', 1)[1] or 0)
+            model = YOLO(synthetic_yolov8(seed=seed, nc=4), task=cfg.get('ultralytics', {}).get('task', 'detect'))
+        else:
+            model = YOLO(model=ref, task=cfg.get('ultralytics', {}).get('task', 'detect'))
+    except Exception as e:
+        logger.error(f"Error loading the YOLOv8 model: {e}")
+        sys.exit(1)
+    logger.info(f"Detection model '{ref}' loaded successfully.")
+    return model
+
+
+def initialize_streams(config: dict, imgsz: int, logger: logging.Logger):
+    """Open the frame source (extract.py:239-257; no progress bar here)."""
+    source = config['args'].source
+    if not source_exists(source):
+        logger.critical(f"Video file '{source}' not found.")
+        sys.exit(1)
+    reader = open_source(source)
+    if not reader.isOpened():
+        logger.error(f"Failed to open: '{source}'.")
+        sys.exit(1)
+    return reader
+
+
+def get_output_dir(source: Path, out_cfg: dict) -> Path:
+    """file_utils.get_output_dir (file_utils.py:31-40): absolute folder as-is, else next to the video."""
+    folder = Path(out_cfg.get('folder', 'results'))
+    return folder if folder.is_absolute() else Path(source).parent / folder
+
+
+def _serializable(o):
+    if isinstance(o, dict):
+        return {(_serializable(k) if not isinstance(k, (str, int, float, bool)) else k): _serializable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_serializable(v) for v in o]
+    if isinstance(o, Path):
+        return str(o)
+    if isinstance(o, np.generic):
+        return o.item()
+    if isinstance(o, argparse.Namespace):
+        return _serializable(vars(o))
+    return o
+
+
+def save_results(tracks: np.ndarray, transforms: np.ndarray, config: dict, logger: logging.Logger, out_cfg: dict) -> None:
+    """<stem>.txt (%g), <stem>_vid_transf.txt (%.16g) and the run-metadata YAML (extract.py:487-523)."""
+    source = Path(str(config['main']['args'].source))
+    if str(source).startswith('synthetic:'):
+        source = Path('synthetic.mp4')
+    save_dir = get_output_dir(source, out_cfg)
+    save_dir.mkdir(parents=True, exist_ok=True)
+    tracks_txt_file = save_dir / f"{source.stem}{out_cfg.get('tracks_postfix', '')}.txt"
+    transf_txt_file = save_dir / f"{source.stem}{out_cfg.get('stab_transform_postfix', '_vid_transf')}.txt"
+    info_yaml_file = source.with_suffix('.yaml')
+
+    try:
+        if tracks.size != 0:
+            np.savetxt(tracks_txt_file, tracks, fmt='%g', delimiter=',')
+            logger.info(f"Tracking results saved to: '{tracks_txt_file.resolve()}'")
+    except Exception as e:
+        logger.error(f"Failed to save the tracking results to: '{tracks_txt_file.resolve()}' due to: {e}")
+
+    try:
+        if transforms.size != 0 and config['main']['extraction']['save_stab']:
+            frame_nums = transforms[:, 0].astype(int)
+            matrices = transforms[:, 1:].reshape((-1, 3, 3))
+            if not np.all(np.diff(frame_nums) == 1):
+                logger.warning(f"Missing frame ids found in: '{transf_txt_file}'.")
+            if not np.all(np.linalg.det(matrices) > 0):
+                logger.warning(f"Invalid transforms found in: '{transf_txt_file}'.")
+            np.savetxt(transf_txt_file, transforms, fmt='%.16g', delimiter=',')
+    except Exception as e:
+        logger.error(f"Failed to save the video stabilization results to: '{transf_txt_file.resolve()}' due to: {e}")
+    else:
+        logger.info(f"Video stabilization results saved to: '{transf_txt_file.resolve()}'")
+
+    metadata = _serializable(_build_run_metadata(config, save_dir))
+    with open(info_yaml_file, 'w') as f:
+        yaml.dump(metadata, f, default_flow_style=False, sort_keys=False)
+    logger.info(f"Video info and configs saved to: '{info_yaml_file.resolve()}'")
+
+
+def _build_run_metadata(config: dict, save_dir: Path) -> dict:
+    """Same sections as the reference's metadata file (extract.py:526-568)."""
+    main, ul, args = config['main'], config['ultralytics'], config['main']['args']
+    active_classes = ul.get('classes') or []
+    class_mapping = main.get('class_names', {})
+    return {
+        'run': {'geotrax_version': f'geotrax_amd-{__version__}', 'timestamp': datetime.datetime.now().isoformat(timespec='seconds'),
+                'source': str(args.source), 'config': str(getattr(args, 'cfg', None)), 'output_folder': str(save_dir)},
+        'model': {'configured': main.get('model_configured'), 'resolved': ul.get('model')},
+        'class_names': {'source': main.get('class_names_source', 'unknown'),
+                        'mapping': {k: class_mapping[k] for k in sorted(active_classes) if k in class_mapping}},
+        'extraction': {k: v for k, v in main.get('extraction', {}).items() if k != 'model'},
+        'processing': main.get('processing', {}),
+        'output': main.get('output', {}),
+        'detection': {k: v for k, v in ul.items() if k in _INFERENCE_KEYS},
+        'tracker': {'active': main.get('tracker_active'), 'params': main.get('tracker_params', {})},
+        'stabilo': config['stabilo'],
+        'georef': config['georef'],
+    }
+
+
+def add_common_args(group) -> None:
+    """The shared flags of every geotrax stage (cli_utils.add_common_args :16-32)."""
+    group.add_argument('--cfg', '-c', type=Path, default=None, help='Path to a custom pipeline config file.')
+    group.add_argument('--output-folder', '-of', type=str, default=None, help='Root folder for outputs.')
+    group.add_argument('--log-path', '-lp', type=str, default=None, help='Where to write logs.')
+    group.add_argument('--verbose', '-v', action='store_true', help='Set print verbosity level to INFO.')
+
+
+def add_processing_args(group) -> None:
+    """Same flags, spelling and defaults as the reference (extract.py:571-584)."""
+    group.add_argument('--model', '-m', nargs='+', default=None, metavar='MODEL')
+    group.add_argument('--class-names', '-cn', nargs='+', default=None, metavar='ID=NAME|FILE')
+    group.add_argument('--conf', '-co', type=float, default=None)
+    group.add_argument('--classes', '-cls', nargs='+', type=int, default=None)
+    group.add_argument('--cut-frame-left', '-cfl', type=int, default=None)
+    group.add_argument('--cut-frame-right', '-cfr', type=int, default=None)
+    group.add_argument('--interpolate', action=argparse.BooleanOptionalAction, default=None)
+
+
+def parse_cli_args(argv=None) -> argparse.Namespace:
+    parser = argparse.ArgumentParser(prog='geotrax extract', description='Vehicle Detection, Tracking, and Stabilization Pipeline')
+    parser.add_argument('source', type=str, help='Path to the input video / frame source.')
+    add_common_args(parser.add_argument_group('Optional arguments'))
+    add_processing_args(parser.add_argument_group('Processing arguments'))
+    return parser.parse_args(argv)
+
+
+def main(argv=None) -> None:
+    args = parse_cli_args(argv)
+    logging.basicConfig(level=logging.INFO if args.verbose else logging.WARNING, format='%(levelname)s: %(message)s')
+    detect_track_stabilize(args, logging.getLogger('geotrax_amd.extract'))
+
+
+if __name__ == '__main__':
+    main()

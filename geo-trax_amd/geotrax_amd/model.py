@@ -1,0 +1,193 @@
+"""``YOLO``: the detector+tracker object the extract loop calls, with ultralytics' call contract.
+
+Reference usage replaced (geotrax/extract.py:153-168, 222):
+
+    model = YOLO(model=path, task='detect')
+    results = model.track(frame, **config['ultralytics'], persist=True)
+    boxes = results[0].boxes          # .id (or None) / .xywh / .cls / .conf, len(boxes)
+    speed = results[0].speed          # {'preprocess','inference','postprocess'} in ms
+
+``track`` runs the HIP detector (geotrax_amd.detector.Detector) and the host C++ tracker
+(geotrax_amd.tracker.Tracker) and rewrites the boxes with the tracker output exactly like
+ultralytics' ``on_predict_postprocess_end`` callback: rows become the Kalman-posterior boxes of the
+active tracks, ``id`` is set, detections the tracker has not confirmed disappear; when the tracker
+returns nothing the raw detections are kept with ``id = None`` (the reference then writes -1 and
+drops the rows, extract.py:161-165, 287).
+
+Arrays come back as numpy; they also answer ``.detach()``, ``.cpu()`` and ``.numpy(force=True)`` so
+the unmodified reference loop can consume them.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import numpy as np
+import yaml
+
+from . import _lib
+from .detector import Detector
+from .tracker import TRACKER_TYPES, Tracker
+from .weights import load_weights
+
+logger = logging.getLogger(__name__)
+
+
+class _Arr(np.ndarray):
+    """ndarray that tolerates the torch idioms of the reference loop."""
+
+    def detach(self):
+        return self
+
+    def cpu(self):
+        return self
+
+    def numpy(self, force: bool = False):
+        return np.asarray(self)
+
+
+def _arr(a) -> _Arr:
+    return np.asarray(a).view(_Arr)
+
+
+class Boxes:
+    def __init__(self, xyxy: np.ndarray, conf: np.ndarray, cls: np.ndarray, ids: np.ndarray | None):
+        self._xyxy = np.asarray(xyxy, dtype=np.float32).reshape(-1, 4)
+        self._conf = np.asarray(conf, dtype=np.float32)
+        self._cls = np.asarray(cls, dtype=np.float32)
+        self._id = None if ids is None else np.asarray(ids, dtype=np.float32)
+
+    def __len__(self):
+        return len(self._conf)
+
+    @property
+    def xyxy(self):
+        return _arr(self._xyxy)
+
+    @property
+    def xywh(self):
+        b = self._xyxy
+        return _arr(np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
+                    .astype(np.float32) if len(b) else np.zeros((0, 4), np.float32))
+
+    @property
+    def conf(self):
+        return _arr(self._conf)
+
+    @property
+    def cls(self):
+        return _arr(self._cls)
+
+    @property
+    def id(self):
+        return None if self._id is None else _arr(self._id)
+
+    @property
+    def is_track(self):
+        return self._id is not None
+
+
+class Results:
+    def __init__(self, boxes: Boxes, speed: dict, orig_shape: tuple, names: dict):
+        self.boxes, self.speed, self.orig_shape, self.names = boxes, speed, orig_shape, names
+
+    def __len__(self):
+        return len(self.boxes)
+
+
+_PREDICT_KEYS = ("imgsz", "conf", "iou", "max_det", "classes", "agnostic_nms", "half", "rect")
+
+
+class YOLO:
+    def __init__(self, model, task: str = "detect", ctx: _lib.Context | None = None):
+        """model: path to a ``.safetensors`` weight file (see tools/convert_weights.py) or a dict of
+        tensors. An ultralytics ``.pt`` pickle cannot be read without ultralytics."""
+        if task not in (None, "detect"):
+            raise NotImplementedError(f"task='{task}': only 'detect' is implemented")
+        self.ctx = ctx
+        self.names: dict[int, str] = {}
+        if isinstance(model, dict):
+            self.tensors = model
+            self.model_path = None
+        else:
+            p = Path(model)
+            if p.suffix == ".pt":
+                raise ValueError(f"'{p}' is an ultralytics pickle; convert it once with tools/convert_weights.py "
+                                 "(needs ultralytics) and point cfg -> extraction -> model at the .safetensors file")
+            self.tensors = load_weights(p)
+            self.model_path = p
+            side = p.with_suffix(".names.yaml")
+            if side.is_file():
+                self.names = {int(k): str(v) for k, v in yaml.safe_load(side.read_text()).items()}
+        nc = int(self.tensors["model.22.cv3.0.2.weight"].shape[0])
+        if not self.names:
+            self.names = {i: str(i) for i in range(nc)}
+        self.model = self            # ultralytics exposes .model.yaml_file; keep attribute access harmless
+        self.yaml_file = "yolov8.yaml"
+        self._det: Detector | None = None
+        self._det_key = None
+        self._tracker: Tracker | None = None
+        self._tracker_key = None
+
+    # ---- lazy construction, like ultralytics' predictor setup on the first call
+    def _detector(self, frame_hw, kw) -> Detector:
+        key = (tuple(frame_hw),) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
+        if self._det is None or key != self._det_key:
+            if self._det is not None:
+                self._det.close()
+            imgsz = kw.get("imgsz", 640)
+            if isinstance(imgsz, (list, tuple)):
+                imgsz = max(imgsz)
+            self._det = Detector(self.tensors, frame_hw, imgsz=int(imgsz), conf=float(kw.get("conf") or 0.1),
+                                 iou=float(kw.get("iou", 0.7)), max_det=int(kw.get("max_det", 300)), classes=kw.get("classes"),
+                                 agnostic_nms=bool(kw.get("agnostic_nms", False)), half=bool(kw.get("half", False)),
+                                 rect=bool(kw.get("rect", True)), ctx=self.ctx)
+            self._det_key = key
+        return self._det
+
+    def _make_tracker(self, spec) -> Tracker:
+        if isinstance(spec, (str, Path)):
+            params = yaml.safe_load(Path(spec).read_text())
+        else:
+            params = dict(spec or {})
+        ttype = params.get("tracker_type", "botsort")
+        if ttype not in TRACKER_TYPES:
+            raise NotImplementedError(f"tracker_type '{ttype}' is not implemented (available: {sorted(TRACKER_TYPES)})")
+        if ttype == "botsort":
+            if params.get("with_reid"):
+                raise NotImplementedError("BoT-SORT ReID is not implemented")
+            if params.get("gmc_method", "none") not in ("none", None):
+                logger.warning("BoT-SORT gmc_method '%s' is not implemented on this path yet; camera motion compensation "
+                               "inside the tracker is skipped (identity).", params.get("gmc_method"))
+        return Tracker(ttype, **{k: v for k, v in params.items() if k in (
+            "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score")})
+
+    # ---- ultralytics-style entry points
+    def predict(self, source: np.ndarray, **kwargs) -> list[Results]:
+        frame = np.ascontiguousarray(source, dtype=np.uint8)
+        det = self._detector(frame.shape[:2], kwargs)
+        d = det.detect(frame)
+        return [Results(Boxes(d.xyxy, d.conf, d.cls, None), d.speed, frame.shape[:2], self.names)]
+
+    def track(self, source: np.ndarray, persist: bool = False, **kwargs) -> list[Results]:
+        spec = kwargs.get("tracker", {"tracker_type": "botsort"})
+        tkey = repr(spec)
+        if self._tracker is None or tkey != self._tracker_key:
+            self._tracker, self._tracker_key = self._make_tracker(spec), tkey
+        elif not persist:
+            self._tracker.reset()
+        kwargs = dict(kwargs)
+        kwargs["conf"] = kwargs.get("conf") or 0.1      # ultralytics Model.track default
+        res = self.predict(source, **kwargs)[0]
+        if len(res.boxes) == 0:
+            return [res]
+        b = res.boxes
+        xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32))
+        if len(ids) == 0:
+            return [res]
+        res.boxes = Boxes(xyxy, score, cls, ids)
+        return [res]
+
+    @property
+    def detector(self) -> Detector | None:
+        return self._det

@@ -1,0 +1,172 @@
+"""The whole extract path on the GPU (reader -> HIP detector -> C++ tracker -> HIP stabilizer ->
+post-processing -> writers) against the same chain assembled from the oracle modules, on a short
+seeded sequence, plus the output-file contract of the reference (column layout, %g / %.16g
+formats, frame-0 rule, metadata file)."""
+import argparse
+import logging
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+logger = logging.getLogger("test_extract")
+
+H, W, NF, IMGSZ = 432, 768, 6, 384
+STAB = dict(downsample_ratio=0.5, max_features=500, ref_multiplier=2.0, filter_ratio=0.9, ransac_epipolar_threshold=2.0,
+            ransac_max_iter=5000, mask_use=True, mask_margin_ratio=0.15, detector_name="orb", matcher_name="bf",
+            filter_type="ratio", transformation_type="projective", clahe=False)
+
+
+def _cfg_file(tmp_path, tracker="bytetrack", half=False):
+    import yaml
+    from geotrax_amd.config_utils import DEFAULT_CFG
+
+    cfg = yaml.safe_load(DEFAULT_CFG.read_text())
+    cfg["ultralytics"].update(imgsz=IMGSZ, half=half, max_det=300)
+    cfg["stabilo"].update(STAB)
+    cfg["tracker"]["active"] = tracker
+    cfg["extraction"]["model"] = "synthetic:1"
+    cfg["extraction"]["min_track_length"] = 2
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    return p, cfg
+
+
+def _oracle_chain(frames, weights, cfg, pattern):
+    """detect -> track -> stabilize with the oracle modules, following extract.py:145-197."""
+    from oracle.bytetrack_ref import ByteTrackRef
+    from oracle.stabilo_ref import StabilizerRef
+    from oracle.yolov8_ref import YoloV8Ref, detect
+
+    u = cfg["ultralytics"]
+    model = YoloV8Ref(weights, emulate_half=False)
+    trk = ByteTrackRef(**{k: v for k, v in cfg["tracker"]["bytetrack"].items() if k != "tracker_type"})
+    scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
+                ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
+    stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
+    rows, transforms = [], []
+    for f, frame in enumerate(frames):
+        xyxy, conf, cls = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"])
+        if len(conf):
+            t = trk.update(xyxy, conf, cls)
+            if len(t):
+                bx, ids, sc, cl = t[:, :4], t[:, 4], t[:, 5], t[:, 6]
+            else:
+                bx, ids, sc, cl = xyxy, np.full(len(conf), -1.0), conf, cls
+            xywh = np.stack([(bx[:, 0] + bx[:, 2]) / 2, (bx[:, 1] + bx[:, 3]) / 2, bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1).astype(np.float32)
+        else:
+            xywh = None
+        if f == 0:
+            stab.set_ref_frame(frame, xywh)
+            sb = xywh
+        else:
+            Hm, _ = stab.stabilize(frame, xywh)
+            if Hm is not None:
+                transforms.append(np.r_[f, Hm.ravel()])
+            sb = None
+            if xywh is not None:
+                sb = xywh.copy()
+                if Hm is not None:
+                    for k, (cx, cy, w, h) in enumerate(xywh.astype(np.float64)):
+                        c = np.array([[cx - w / 2, cy - h / 2, 1], [cx + w / 2, cy - h / 2, 1], [cx + w / 2, cy + h / 2, 1], [cx - w / 2, cy + h / 2, 1]]).T
+                        p = Hm @ c
+                        p = p[:2] / p[2]
+                        sb[k] = [(p[0].min() + p[0].max()) / 2, (p[1].min() + p[1].max()) / 2, np.ptp(p[0]), np.ptp(p[1])]
+        if xywh is not None:
+            for k in range(len(xywh)):
+                rows.append([f, ids[k], *xywh[k], *sb[k], cl[k], sc[k]])
+    t = np.asarray(rows, dtype=np.float32)
+    return t[t[:, 1] != -1], np.asarray(transforms)
+
+
+def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path):
+    from geotrax_amd import extract as ex
+    from geotrax_amd.config_utils import load_config_all
+    from geotrax_amd.stabilizer import Stabilizer
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.weights import synthetic_yolov8
+
+    scene = make_scene(seed=2, h=H, w=W)
+    frames = np.stack([scene.render(t, 150) for t in range(0, NF * 12, 12)])
+    src = tmp_path / "clip.npy"
+    np.save(src, frames)
+    cfg_path, cfg = _cfg_file(tmp_path)
+    args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
+                              class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
+    model = ex.load_detector(args, logger)
+    config = load_config_all(args, logger, model_names=model.names)
+    args.cut_frame_left, args.cut_frame_right = 0, None
+    tracks, transforms = ex.track_with_model(model, config, logger)
+
+    pattern = Stabilizer((H, W), ctx=gtx_ctx).pattern()
+    ref_tracks, ref_transforms = _oracle_chain(frames, synthetic_yolov8(seed=1, nc=4), cfg, pattern)
+
+    assert tracks.dtype == np.float32 and tracks.shape[1] == 12 and len(tracks) > 20
+    assert tracks.shape == ref_tracks.shape
+    np.testing.assert_array_equal(tracks[:, :2], ref_tracks[:, :2])           # frame, id
+    np.testing.assert_array_equal(tracks[:, 10], ref_tracks[:, 10])           # class
+    np.testing.assert_allclose(tracks[:, 11], ref_tracks[:, 11], atol=1e-5)   # confidence
+    np.testing.assert_allclose(tracks[:, 2:6], ref_tracks[:, 2:6], atol=2e-2)  # tracker boxes (px)
+    np.testing.assert_allclose(tracks[:, 6:10], ref_tracks[:, 6:10], atol=2e-2)  # stabilized boxes (px)
+    assert transforms.shape == ref_transforms.shape == (NF - 1, 10)
+    np.testing.assert_array_equal(transforms[:, 0], np.arange(1, NF))
+    for a, b in zip(transforms, ref_transforms):
+        Ha, Hb = a[1:].reshape(3, 3), b[1:].reshape(3, 3)
+        g = np.array([[0, 0, 1], [W, 0, 1], [0, H, 1], [W, H, 1.0]]).T
+        pa, pb = Ha @ g, Hb @ g
+        assert np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max() < 1e-3
+    # frame 0: stabilized boxes are the raw boxes (extract.py:178-179)
+    f0 = tracks[tracks[:, 0] == 0]
+    np.testing.assert_array_equal(f0[:, 2:6], f0[:, 6:10])
+
+
+def test_extract_cli_writes_reference_files(gtx_ctx, tmp_path):
+    import yaml
+    from geotrax_amd import extract as ex
+
+    cfg_path, _ = _cfg_file(tmp_path, tracker="botsort", half=True)
+    src = f"synthetic://?seed=4&frames=5&h={H}&w={W}"
+    out = tmp_path / "out"
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        ex.main([src, "--cfg", str(cfg_path), "--output-folder", str(out), "--cut-frame-right", "3", "--interpolate"])
+    finally:
+        os.chdir(cwd)
+    txt, tr = out / "synthetic.txt", out / "synthetic_vid_transf.txt"
+    assert txt.is_file() and tr.is_file() and (tmp_path / "synthetic.yaml").is_file()
+    t = np.loadtxt(txt, delimiter=",", ndmin=2)
+    assert t.shape[1] == 15                                     # 14 columns + is_interpolated
+    assert set(np.unique(t[:, 0])) <= {0, 1, 2, 3} and t[:, 0].max() == 3   # --cut-frame-right honoured
+    first = txt.read_text().splitlines()[0].split(",")
+    assert all(len(tok.replace("-", "").replace(".", "").lstrip("0")) <= 12 for tok in first)  # %g: <= 6 significant digits
+    m = np.loadtxt(tr, delimiter=",", ndmin=2)
+    assert m.shape == (3, 10) and list(m[:, 0]) == [1, 2, 3] and np.all(np.abs(m[:, 9] - 1) < 1e-12)
+    meta = yaml.safe_load((tmp_path / "synthetic.yaml").read_text())
+    assert {"run", "model", "class_names", "extraction", "processing", "output", "detection", "tracker", "stabilo", "georef"} <= set(meta)
+    assert meta["tracker"]["active"] == "botsort" and meta["detection"]["imgsz"] == IMGSZ
+
+
+def test_error_in_loop_voids_the_video(gtx_ctx, tmp_path, caplog):
+    """extract.py:198-200: one exception -> logged once, empty tables, no partial output."""
+    from geotrax_amd import extract as ex
+    from geotrax_amd.config_utils import load_config_all
+
+    cfg_path, _ = _cfg_file(tmp_path)
+    bad = np.zeros((3, H // 2, W, 3), np.uint8)     # wrong frame height after the first frame is fine; make frame 1 differ
+    frames = [np.zeros((H, W, 3), np.uint8), np.zeros((H // 2, W, 3), np.uint8)]
+    d = tmp_path / "frames"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        np.save(d / f"{i:03d}.npy", f)
+    args = argparse.Namespace(source=str(d), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
+                              class_names=None, conf=None, classes=None, cut_frame_left=0, cut_frame_right=None, interpolate=False)
+    model = ex.load_detector(args, logger)
+    config = load_config_all(args, logger, model_names=model.names)
+    with caplog.at_level(logging.ERROR):
+        tracks, transforms = ex.track_with_model(model, config, logger)
+    assert tracks.shape == (0, 12) and transforms.shape == (0, 10)
+    assert any("Error processing" in r.message for r in caplog.records)
+    del bad
