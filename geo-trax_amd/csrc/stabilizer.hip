@@ -746,8 +746,9 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   const int ref_features = (int)std::lround(cfg.max_features * (double)cfg.ref_multiplier);
   S.plan(S.lev_cur, cfg.max_features, S.slots_cur);
   S.plan(S.lev_ref, ref_features, S.slots_ref);
-  const Level& last = S.lev_ref.l[S.lev_ref.n - 1];
-  GTX_CHECK(last.w > 2 * kBorder + 8 && last.h > 2 * kBorder + 8, "stabilizer: image too small for %d pyramid levels", cfg.n_levels);
+  // Levels smaller than the keypoint border simply yield no keypoints (as in OpenCV's ORB).
+  const Level& l0 = S.lev_ref.l[0];
+  GTX_CHECK(l0.w > 2 * kBorder + 8 && l0.h > 2 * kBorder + 8, "stabilizer: %dx%d working image is too small", l0.w, l0.h);
   const int slots = std::max(S.slots_ref, S.slots_cur);
   S.d_pyr.alloc(S.pyr_bytes);
   S.d_score.alloc(S.pyr_bytes);

@@ -327,7 +327,10 @@ def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float
         H = _denorm(np.append(hvec, 1.0).reshape(3, 3), cx, cy, sc)
         if not abs(H[2, 2]) > 1e-12:
             continue
-        e = np.minimum(_errors(H, p, q), thr2)
+        w = H[2, 0] * p[:, 0] + H[2, 1] * p[:, 1] + H[2, 2]
+        ok = np.abs(w) > 1e-12                      # points on the line at infinity cost the full threshold
+        with np.errstate(all="ignore"):
+            e = np.where(ok, np.minimum(_errors(H, p, q), thr2), thr2)
         cost = int(np.floor(e * 1024.0 + 0.5).sum())
         if best_cost is None or cost < best_cost:
             best_cost, best_H = cost, H

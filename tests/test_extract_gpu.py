@@ -18,15 +18,36 @@ STAB = dict(downsample_ratio=0.5, max_features=500, ref_multiplier=2.0, filter_r
             filter_type="ratio", transformation_type="projective", clahe=False)
 
 
-def _cfg_file(tmp_path, tracker="bytetrack", half=False):
+def _weights_file(tmp_path, gtx_ctx, probe_frame, half=False):
+    """Seeded weights whose class bias is calibrated on the probe frame so that ~60 anchors clear
+    conf -- a few dozen boxes per frame, so that the foreground mask leaves the stabilizer most of
+    the 384x216 working image (seeded weights know nothing about vehicles), stored as the .safetensors file + names
+    side-car the model loader reads."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import calibrate_cls_bias, save_weights, synthetic_yolov8
+
+    w = synthetic_yolov8(seed=1, nc=4)
+    det = Detector(w, (H, W), imgsz=IMGSZ, half=half, rect=True, ctx=gtx_ctx)
+    det.detect(probe_frame)
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 60)
+    det.close()
+    path = tmp_path / "weights.safetensors"
+    save_weights(w, path)
+    path.with_suffix(".names.yaml").write_text("{0: car, 1: bus, 2: truck, 3: motorcycle}\n")
+    return path, w
+
+
+def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False):
     import yaml
     from geotrax_amd.config_utils import DEFAULT_CFG
 
     cfg = yaml.safe_load(DEFAULT_CFG.read_text())
-    cfg["ultralytics"].update(imgsz=IMGSZ, half=half, max_det=300)
+    # rect=True: minimal letterbox padding. Seeded weights fire anywhere, also inside the grey bars of
+    # a square letterbox, and such boxes clip to zero height (NaN aspect ratio in any XYAH tracker).
+    cfg["ultralytics"].update(imgsz=IMGSZ, half=half, max_det=300, rect=True)
     cfg["stabilo"].update(STAB)
     cfg["tracker"]["active"] = tracker
-    cfg["extraction"]["model"] = "synthetic:1"
+    cfg["extraction"]["model"] = str(model_path)
     cfg["extraction"]["min_track_length"] = 2
     p = tmp_path / "cfg.yaml"
     p.write_text(yaml.safe_dump(cfg))
@@ -85,13 +106,13 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path):
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.stabilizer import Stabilizer
     from geotrax_amd.synth import make_scene
-    from geotrax_amd.weights import synthetic_yolov8
 
     scene = make_scene(seed=2, h=H, w=W)
     frames = np.stack([scene.render(t, 150) for t in range(0, NF * 12, 12)])
     src = tmp_path / "clip.npy"
     np.save(src, frames)
-    cfg_path, cfg = _cfg_file(tmp_path)
+    wpath, weights = _weights_file(tmp_path, gtx_ctx, frames[0])
+    cfg_path, cfg = _cfg_file(tmp_path, wpath)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
                               class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
     model = ex.load_detector(args, logger)
@@ -100,15 +121,27 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path):
     tracks, transforms = ex.track_with_model(model, config, logger)
 
     pattern = Stabilizer((H, W), ctx=gtx_ctx).pattern()
-    ref_tracks, ref_transforms = _oracle_chain(frames, synthetic_yolov8(seed=1, nc=4), cfg, pattern)
+    ref_tracks, ref_transforms = _oracle_chain(frames, weights, cfg, pattern)
+    assert model.names[0] == "car"
 
     assert tracks.dtype == np.float32 and tracks.shape[1] == 12 and len(tracks) > 20
     assert tracks.shape == ref_tracks.shape
-    np.testing.assert_array_equal(tracks[:, :2], ref_tracks[:, :2])           # frame, id
-    np.testing.assert_array_equal(tracks[:, 10], ref_tracks[:, 10])           # class
-    np.testing.assert_allclose(tracks[:, 11], ref_tracks[:, 11], atol=1e-5)   # confidence
-    np.testing.assert_allclose(tracks[:, 2:6], ref_tracks[:, 2:6], atol=2e-2)  # tracker boxes (px)
-    np.testing.assert_allclose(tracks[:, 6:10], ref_tracks[:, 6:10], atol=2e-2)  # stabilized boxes (px)
+    np.testing.assert_array_equal(tracks[:, 0], ref_tracks[:, 0])             # frames
+    # Two detections whose confidences differ by less than fp32 summation noise may swap places in
+    # the NMS output and therefore swap the ids they are born with; everything else must agree.
+    # Align rows per frame by box position and require the id relabelling to be a bijection.
+    id_map = {}
+    for f in np.unique(tracks[:, 0]):
+        a, b = tracks[tracks[:, 0] == f], ref_tracks[ref_tracks[:, 0] == f]
+        a, b = a[np.lexsort((a[:, 3], a[:, 2]))], b[np.lexsort((b[:, 3], b[:, 2]))]
+        np.testing.assert_allclose(a[:, 2:6], b[:, 2:6], atol=2e-2)           # tracker boxes (px)
+        np.testing.assert_allclose(a[:, 6:10], b[:, 6:10], atol=2e-2)         # stabilized boxes (px)
+        np.testing.assert_array_equal(a[:, 10], b[:, 10])                     # class
+        np.testing.assert_allclose(a[:, 11], b[:, 11], atol=1e-5)             # confidence
+        for ia, ib in zip(a[:, 1], b[:, 1]):
+            assert id_map.setdefault(int(ia), int(ib)) == int(ib)
+    assert len(set(id_map.values())) == len(id_map)
+    assert sum(k != v for k, v in id_map.items()) <= 4
     assert transforms.shape == ref_transforms.shape == (NF - 1, 10)
     np.testing.assert_array_equal(transforms[:, 0], np.arange(1, NF))
     for a, b in zip(transforms, ref_transforms):
@@ -125,7 +158,10 @@ def test_extract_cli_writes_reference_files(gtx_ctx, tmp_path):
     import yaml
     from geotrax_amd import extract as ex
 
-    cfg_path, _ = _cfg_file(tmp_path, tracker="botsort", half=True)
+    from geotrax_amd.synth import make_scene
+
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, make_scene(seed=4, h=H, w=W).render(0), half=True)
+    cfg_path, _ = _cfg_file(tmp_path, wpath, tracker="botsort", half=True)
     src = f"synthetic://?seed=4&frames=5&h={H}&w={W}"
     out = tmp_path / "out"
     import os
@@ -154,7 +190,7 @@ def test_error_in_loop_voids_the_video(gtx_ctx, tmp_path, caplog):
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
 
-    cfg_path, _ = _cfg_file(tmp_path)
+    cfg_path, _ = _cfg_file(tmp_path, "synthetic:1")
     bad = np.zeros((3, H // 2, W, 3), np.uint8)     # wrong frame height after the first frame is fine; make frame 1 differ
     frames = [np.zeros((H, W, 3), np.uint8), np.zeros((H // 2, W, 3), np.uint8)]
     d = tmp_path / "frames"
