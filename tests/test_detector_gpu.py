@@ -75,6 +75,10 @@ def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz):
         # heavily overlapping boxes, so a 1e-3 score change can flip a suppression); match by IoU
         assert abs(len(got) - len(conf)) <= max(3, len(conf) // 10)
         matched = 0
+        # (seeded weights also fire inside the letterbox bars; those boxes clip to zero area and
+        # cannot be matched by IoU -- they are compared by count only)
+        area = (xyxy[:, 2] - xyxy[:, 0]) * (xyxy[:, 3] - xyxy[:, 1])
+        xyxy, conf = xyxy[area > 1], conf[area > 1]
         for b, c in zip(xyxy, conf):
             if len(got) == 0:
                 break
@@ -83,7 +87,7 @@ def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz):
             inter = np.clip(ix2 - ix1, 0, None) * np.clip(iy2 - iy1, 0, None)
             a = (got.xyxy[:, 2] - got.xyxy[:, 0]) * (got.xyxy[:, 3] - got.xyxy[:, 1])
             iou = inter / (a + (b[2] - b[0]) * (b[3] - b[1]) - inter + 1e-9)
-            matched += iou.max() > 0.9
+            matched += iou.max() > 0.7   # boxes are 16-64 px here; fp16 moves a side by up to ~1 px
         assert matched >= 0.9 * len(conf)
     assert len(got) > 0, "test weights/frame should produce detections"
 
