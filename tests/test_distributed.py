@@ -1,0 +1,116 @@
+"""Frame sharding across ranks (geotrax_amd/distributed.py): world-size-2 gloo processes on CPU
+must produce exactly what one process produces. Detector and stabilizer are stood in by
+deterministic numpy functions of the frame (the sharding logic does not care what computes them);
+the tracker is the real C++ one."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from geotrax_amd.distributed import extract_sharded, pack_frame_record, shard_range, unpack_frame_record
+
+N_FRAMES, MAX_DET = 23, 40
+
+
+def _frame(i):
+    rng = np.random.default_rng(1000 + i)
+    return rng.integers(0, 255, (8, 8, 3), dtype=np.uint8), i
+
+
+def _fake_detect(frame):
+    _, i = frame
+    rng = np.random.default_rng(7)                      # same objects every frame, drifting
+    c = rng.uniform(100, 900, (12, 2)) + 1.5 * i
+    s = rng.uniform(20, 60, (12, 2))
+    xyxy = np.c_[c - s / 2, c + s / 2].astype(np.float32)
+    conf = np.sort(rng.uniform(0.3, 0.9, 12))[::-1].astype(np.float32)
+    keep = np.ones(12, bool)
+    keep[(i * 5) % 12] = i % 3 != 0                     # occasional miss
+    return xyxy[keep], conf[keep], (np.arange(12) % 4).astype(np.int32)[keep]
+
+
+class _FakeStab:
+    def set_ref(self, frame, boxes):
+        self.ref = frame[1]
+
+    def stabilize(self, frame, boxes):
+        i = frame[1]
+        if i % 7 == 3:
+            return None                                 # a frame without a transform (extract.py:185)
+        return np.array([[1, 0, -0.1 * (i - self.ref)], [0, 1, 0.2 * (i - self.ref)], [0, 0, 1.0]])
+
+
+def _run(dist_mod):
+    from geotrax_amd.geometry import warp_boxes
+    from geotrax_amd.tracker import Tracker
+
+    stab = _FakeStab()
+    return extract_sharded(N_FRAMES, 2, _frame, _fake_detect, stab.set_ref, stab.stabilize, Tracker("bytetrack"), warp_boxes,
+                           MAX_DET, dist=dist_mod)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = _run(dist)
+        if rank == 0:
+            q.put([[np.asarray(a) for a in lst] for lst in out])
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_equals_single_process():
+    single = _run(None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    multi = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(single) == len(multi) == 7
+    for a, b in zip(single, multi):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x), y)
+    frames = np.concatenate(single[0])[:, 0]
+    assert frames.min() == 2 and frames.max() == N_FRAMES - 1
+    assert len(single[6]) == sum(1 for i in range(3, N_FRAMES) if i % 7 != 3)
+
+
+def test_shard_ranges_partition_the_frames():
+    for n, first, world in [(150, 0, 8), (7, 0, 8), (23, 2, 2), (1, 0, 4), (0, 0, 3), (100, 99, 5)]:
+        seen = []
+        for r in range(world):
+            s, e = shard_range(n, r, world, first)
+            assert s <= e
+            seen += list(range(s, e))
+        assert seen == list(range(first, n))
+        sizes = [shard_range(n, r, world, first)[1] - shard_range(n, r, world, first)[0] for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_frame_record_round_trip():
+    rng = np.random.default_rng(0)
+    xyxy, conf, cls = rng.uniform(0, 3840, (5, 4)).astype(np.float32), rng.uniform(0, 1, 5).astype(np.float32), np.arange(5, dtype=np.int32)
+    H = rng.normal(size=(3, 3))
+    rec = pack_frame_record(8, xyxy, conf, cls, H)
+    a, b, c, d = unpack_frame_record(rec, 8)
+    np.testing.assert_array_equal(a, xyxy)
+    np.testing.assert_array_equal(b, conf)
+    np.testing.assert_array_equal(c, cls)
+    np.testing.assert_array_equal(d, H)
+    a, b, c, d = unpack_frame_record(pack_frame_record(8, xyxy[:0], conf[:0], cls[:0], None), 8)
+    assert len(a) == 0 and d is None
