@@ -10,10 +10,9 @@
 //
 // The LAP: lap.lapjv(cost, extend_cost=True, cost_limit=t) minimises the assignment cost where
 // leaving a row or a column unmatched costs t/2 each, i.e. a pair is only worth matching when
-// cost < t. Pairs at or above the limit can therefore be dropped up front, the bipartite graph
-// falls apart into small connected components (vehicles rarely overlap), and every component is
-// solved exactly with a dense Hungarian on its own extended matrix. Same optimum, ~100x less
-// work than one (n+m)^2 problem per frame.
+// cost < t. Pairs at or above the limit are dropped up front and the remaining sparse problem is
+// solved exactly by successive shortest augmenting paths (see linear_assignment below): same
+// optimum as the dense (n+m)^2 extended problem, a tiny fraction of the work.
 #include "tracker.hpp"
 
 #include <algorithm>
@@ -21,6 +20,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <functional>
 #include <unordered_set>
 #include <vector>
 
@@ -133,108 +133,101 @@ struct Track {
   int frame_id = 0, start_frame = 0, tracklet_len = 0;
 };
 
-// ---- exact small LAP: Hungarian (Kuhn-Munkres with potentials) on a square matrix ----
-// Returns col assigned to each row.
-void hungarian(const std::vector<double>& a, int n, std::vector<int>& row_to_col) {
-  const double INF = std::numeric_limits<double>::infinity();
-  std::vector<double> u(n + 1, 0), v(n + 1, 0), minv(n + 1);
-  std::vector<int> p(n + 1, 0), way(n + 1, 0);
-  std::vector<char> used(n + 1);
-  for (int i = 1; i <= n; ++i) {
-    p[0] = i;
-    int j0 = 0;
-    std::fill(minv.begin(), minv.end(), INF);
-    std::fill(used.begin(), used.end(), 0);
-    do {
-      used[j0] = 1;
-      const int i0 = p[j0];
-      double delta = INF;
-      int j1 = 0;
-      for (int j = 1; j <= n; ++j) {
-        if (used[j]) continue;
-        const double cur = a[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
-        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
-      }
-      for (int j = 0; j <= n; ++j) {
-        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
-        else minv[j] -= delta;
-      }
-      j0 = j1;
-    } while (p[j0] != 0);
-    do {
-      const int j1 = way[j0];
-      p[j0] = p[j1];
-      j0 = j1;
-    } while (j0);
-  }
-  row_to_col.assign(n, -1);
-  for (int j = 1; j <= n; ++j)
-    if (p[j]) row_to_col[p[j] - 1] = j - 1;
-}
-
-// lap.lapjv(cost, extend_cost=True, cost_limit=limit) semantics. cost: rows x cols, row-major
-// float32 (as numpy hands it over). x[r] = matched col or -1, y[c] = matched row or -1.
+// ---- exact sparse LAP ----
+// lap.lapjv(cost, extend_cost=True, cost_limit=L) semantics: minimise the sum of matched costs
+// where leaving a row or a column unmatched costs L/2 each. Up to a constant that is
+//     minimise  sum over matched (c_ij - L),   every row either matched or "skipped" at cost 0,
+// so only pairs with c_ij < L can ever be matched. Solved exactly by successive shortest
+// augmenting paths (Dijkstra on reduced costs with row/column potentials) over the sparse list of
+// feasible pairs; every row owns a private zero-cost skip column, so a search never leaves the
+// row's connected component. On traffic scenes components are a handful of boxes; the cost is
+// O(E log E) in the number of feasible pairs even when hundreds of boxes overlap.
+// cost: rows x cols, row-major float32 (as numpy hands it to lapjv). x[r] = matched col or -1,
+// y[c] = matched row or -1.
 void linear_assignment(const std::vector<float>& cost, int rows, int cols, double limit, std::vector<int>& x,
                        std::vector<int>& y) {
   x.assign(rows, -1);
   y.assign(cols, -1);
   if (rows == 0 || cols == 0) return;
-  // union-find over rows [0,rows) and cols [rows, rows+cols) along feasible edges
-  std::vector<int> parent(rows + cols);
-  std::iota(parent.begin(), parent.end(), 0);
-  auto find = [&](int a) {
-    while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; }
-    return a;
-  };
-  std::vector<char> row_has(rows, 0);
-  for (int r = 0; r < rows; ++r)
-    for (int c = 0; c < cols; ++c)
-      if ((double)cost[(size_t)r * cols + c] < limit) {
-        row_has[r] = 1;
-        const int a = find(r), b = find(rows + c);
-        if (a != b) parent[a] = b;
-      }
-  // group members per root
-  std::vector<int> root_of(rows + cols);
-  for (int i = 0; i < rows + cols; ++i) root_of[i] = find(i);
-  std::vector<int> order(rows + cols);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return root_of[a] < root_of[b]; });
-  std::vector<int> rr, cc, r2c;
-  std::vector<double> ext;
-  size_t i = 0;
-  while (i < order.size()) {
-    size_t j = i;
-    rr.clear();
-    cc.clear();
-    while (j < order.size() && root_of[order[j]] == root_of[order[i]]) {
-      const int m = order[j];
-      if (m < rows) rr.push_back(m); else cc.push_back(m - rows);
-      ++j;
+  // CSR adjacency of feasible pairs, weights w = c - L (< 0)
+  std::vector<int> start(rows + 1, 0), adj;
+  std::vector<double> w;
+  for (int r = 0; r < rows; ++r) {
+    for (int c = 0; c < cols; ++c) {
+      const double v = (double)cost[(size_t)r * cols + c];
+      if (v < limit) { adj.push_back(c); w.push_back(v - limit); }
     }
-    i = j;
-    if (rr.empty() || cc.empty()) continue;
-    const int nr = (int)rr.size(), nc = (int)cc.size();
-    if (nr == 1 && nc == 1) {
-      x[rr[0]] = cc[0];
-      y[cc[0]] = rr[0];
-      continue;
-    }
-    // extended (nr+nc)^2 matrix exactly as lapjv builds it
-    const int n = nr + nc;
-    ext.assign((size_t)n * n, limit / 2.0);
-    for (int a = nr; a < n; ++a)
-      for (int b = nc; b < n; ++b) ext[(size_t)a * n + b] = 0.0;
-    for (int a = 0; a < nr; ++a)
-      for (int b = 0; b < nc; ++b) ext[(size_t)a * n + b] = (double)cost[(size_t)rr[a] * cols + cc[b]];
-    hungarian(ext, n, r2c);
-    for (int a = 0; a < nr; ++a)
-      if (r2c[a] >= 0 && r2c[a] < nc) {
-        x[rr[a]] = cc[r2c[a]];
-        y[cc[r2c[a]]] = rr[a];
-      }
+    start[r + 1] = (int)adj.size();
   }
+  const int ncol = cols + rows;                       // real columns, then one skip column per row
+  std::vector<double> u(rows, 0.0), v(ncol, 0.0), dist(ncol);
+  std::vector<int> col_match(ncol, -1), row_match(rows, -1), parent(ncol), seen_list;
+  std::vector<char> done(ncol, 0), touched(ncol, 0);
+  for (int r = 0; r < rows; ++r) {                    // feasible start: reduced costs >= 0
+    double m = 0.0;
+    for (int e = start[r]; e < start[r + 1]; ++e) m = std::min(m, w[e]);
+    u[r] = m;
+  }
+  using Item = std::pair<double, int>;
+  std::vector<Item> heap;
+  auto push = [&](double d, int j) { heap.emplace_back(d, j); std::push_heap(heap.begin(), heap.end(), std::greater<Item>()); };
+  for (int i = 0; i < rows; ++i) {
+    if (start[i] == start[i + 1]) continue;           // no feasible pair: stays unmatched
+    heap.clear();
+    seen_list.clear();
+    auto relax_row = [&](int r, double base, int via_col) {
+      for (int e = start[r]; e < start[r + 1]; ++e) {
+        const int j = adj[e];
+        if (done[j]) continue;
+        const double nd = base + (w[e] - u[r] - v[j]);
+        if (!touched[j] || nd < dist[j]) {
+          if (!touched[j]) { touched[j] = 1; seen_list.push_back(j); }
+          dist[j] = nd; parent[j] = via_col; push(nd, j);
+        }
+      }
+      const int sj = cols + r;                         // the row's own skip column, weight 0
+      if (!done[sj]) {
+        const double nd = base + (0.0 - u[r] - v[sj]);
+        if (!touched[sj] || nd < dist[sj]) {
+          if (!touched[sj]) { touched[sj] = 1; seen_list.push_back(sj); }
+          dist[sj] = nd; parent[sj] = via_col; push(nd, sj);
+        }
+      }
+    };
+    relax_row(i, 0.0, -1);
+    int jf = -1;
+    double D = 0.0;
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), std::greater<Item>());
+      const Item it = heap.back();
+      heap.pop_back();
+      const int j = it.second;
+      if (done[j] || it.first > dist[j]) continue;
+      done[j] = 1;
+      if (col_match[j] < 0) { jf = j; D = dist[j]; break; }
+      relax_row(col_match[j], dist[j], j);
+    }
+    // potentials: finalised columns and the rows matched to them (plus the start row)
+    u[i] += D;
+    for (int j : seen_list) {
+      if (done[j] && j != jf) {
+        const double delta = D - dist[j];
+        v[j] -= delta;
+        u[col_match[j]] += delta;
+      }
+    }
+    // augment along the parent chain
+    for (int j = jf; j >= 0;) {
+      const int pj = parent[j];
+      const int r = pj < 0 ? i : col_match[pj];
+      col_match[j] = r;
+      row_match[r] = j;
+      j = pj;
+    }
+    for (int j : seen_list) { done[j] = 0; touched[j] = 0; }
+  }
+  for (int r = 0; r < rows; ++r)
+    if (row_match[r] >= 0 && row_match[r] < cols) { x[r] = row_match[r]; y[row_match[r]] = r; }
 }
 
 inline void xyxy_of(const Track& t, bool xywh_state, float out[4]) {

@@ -112,14 +112,14 @@ def yolov8_layer_specs(scale: str = "s", nc: int = 4) -> list[tuple[str, tuple[i
 
 
 def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: float = -4.0,
-                     gain: float = 1.7, box_decay: float = 0.7) -> dict[str, np.ndarray]:
+                     gain: float = 1.7, box_decay: float = 0.3) -> dict[str, np.ndarray]:
     """Seeded random fused weights of the YOLOv8 architecture (no checkpoint is reachable here).
 
     Conv weights ~ N(0, gain^2 / fan_in) so activations keep O(1) scale through the SiLU stack;
     biases ~ N(0, 0.05^2). ``cls_bias`` shifts the class logits so that only a few percent of the
     anchors clear the confidence threshold, which is the load the decode/NMS stage sees on real
     footage. The box branch's final bias decays over the 16 DFL bins
-    (-box_decay * bin) and its weights are damped, so decoded boxes span about two strides per
+    (-box_decay * bin) and its weights are damped, so decoded boxes span about six strides per
     side -- vehicle-sized, localised boxes instead of the frame-filling ones uniform DFL logits
     give -- which keeps NMS, the tracker and the stabilizer mask in a realistic regime."""
     rng = np.random.default_rng(seed)

@@ -67,6 +67,21 @@ def test_tracker_matches_oracle(kind, seed):
     assert n_rows > 1000
 
 
+def test_tracker_dense_overlaps_match_oracle():
+    """120 objects on an 800x500 patch: association graphs with large connected components, the
+    regime where the sparse LAP has to agree with lapjv's dense extended problem."""
+    from geotrax_amd.tracker import Tracker
+    from oracle.bytetrack_ref import ByteTrackRef
+
+    trk, ref = Tracker("bytetrack"), ByteTrackRef()
+    for t, (xyxy, conf, cls) in enumerate(_stream(11, n_obj=120, n_frames=25, w=800, h=500, jitter=2.0)):
+        b, i, s, c, d = trk.update(xyxy, conf, cls)
+        r = ref.update(xyxy, conf, cls)
+        np.testing.assert_array_equal(i, r[:, 4].astype(np.int32), err_msg=f"frame {t}")
+        np.testing.assert_array_equal(d, r[:, 7].astype(np.int32))
+        np.testing.assert_allclose(b, r[:, :4], atol=2e-3)
+
+
 def test_tracker_first_frame_ids_follow_detection_order():
     """Golden track file property (data/results-pixel/U_video_cut.txt): on the first frame ids are
     1..N in detection order (descending confidence) and boxes equal the detections."""
