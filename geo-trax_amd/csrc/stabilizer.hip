@@ -41,12 +41,27 @@ struct Level {
   int n_want;       // keypoints to keep
   int kp_off;       // first output keypoint slot
   float scale;      // level pixel -> level-0 pixel
+  int tiles_x;      // 64x4-pixel tiles across
+  int tile_begin;   // first flattened tile of this level
 };
 
 struct Levels {
   Level l[kPyrLevels];
   int n;
+  int n_tiles;      // over all levels
 };
+
+// Flattened tile id -> (level, x, y) of this thread; 256 threads cover a 64x4 pixel tile.
+__device__ __forceinline__ int tile_coords(const Levels& L, int tile, int tid, int& x, int& y) {
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < kPyrLevels; ++i)
+    if (i < L.n && tile >= L.l[i].tile_begin) li = i;
+  const int t = tile - L.l[li].tile_begin;
+  x = (t % L.l[li].tiles_x) * 64 + (tid & 63);
+  y = (t / L.l[li].tiles_x) * 4 + (tid >> 6);
+  return li;
+}
 
 // ------------------------------------------------------------------ gray / pyramid
 __device__ __forceinline__ int bgr2gray_u8(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
@@ -87,54 +102,52 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
   dst[(size_t)y * dw + x] = (uint8_t)(((long)top * (2048 - fy) + (long)bot * fy + (1 << 21)) >> 22);
 }
 
-// Foreground mask at level-0 resolution: 255 = usable, 0 = inside a (grown) vehicle box.
-__global__ __launch_bounds__(256) void mask_fill_kernel(uint8_t* mask, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) mask[i] = 255;
-}
-__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* mask, int w, int h, const int4* __restrict__ rects, int n) {
-  const int b = blockIdx.x;
-  if (b >= n) return;
-  const int4 r = rects[b];
-  const int rw = r.z - r.x + 1, rh = r.w - r.y + 1;
-  for (int i = threadIdx.x; i < rw * rh; i += blockDim.x) {
-    const int x = r.x + i % rw, y = r.y + i / rw;
-    mask[(size_t)y * w + x] = 0;
-  }
-}
-
 // ------------------------------------------------------------------ FAST-9/16 score
 __constant__ int c_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, {3, 1}, {2, 2}, {1, 3},
                                     {0, 3}, {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
 
 // score = max over the 16 arcs of 9 contiguous circle pixels of min(I_i - p) (bright) or
 // min(p - I_i) (dark); the pixel is a corner at threshold t iff score > t.
+// Any arc of 9 contains at least two of the four compass pixels (0, 4, 8, 12), so a pixel with
+// fewer than two compass pixels beyond the threshold on one side cannot be a corner: that test
+// rejects most of the image after 5 loads. The arc minima are built by doubling (1,2,4,8,+1).
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
                                                          const Levels L, int thr) {
-  const Level lv = L.l[blockIdx.z];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  int x, y;
+  const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
+  const Level lv = L.l[li];
   if (x >= lv.w || y >= lv.h) return;
   uint8_t out = 0;
   if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) {
-    const uint8_t* img = pyr + lv.off;
-    const int p = img[(size_t)y * lv.w + x];
-    // quick reject: at least one of each opposite pair must differ by more than thr
-    int d[16];
+    const uint8_t* c = pyr + lv.off + (size_t)y * lv.w + x;
+    const int p = c[0];
+    const int d0 = (int)c[-3 * lv.w] - p, d4 = (int)c[3] - p, d8 = (int)c[3 * lv.w] - p, d12 = (int)c[-3] - p;
+    const int nb = (d0 > thr) + (d4 > thr) + (d8 > thr) + (d12 > thr);
+    const int nd = (d0 < -thr) + (d4 < -thr) + (d8 < -thr) + (d12 < -thr);
+    if (nb >= 2 || nd >= 2) {
+      int d[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = (int)img[(size_t)(y + c_circle[i][1]) * lv.w + x + c_circle[i][0]] - p;
-    int best = 0;
+      for (int i = 0; i < 16; ++i) d[i] = (int)c[c_circle[i][1] * lv.w + c_circle[i][0]] - p;
+      int lo[16], hi[16];   // running min / max over windows of length 1,2,4,8 starting at k
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      int mb = d[k], md = -d[k];
+      for (int k = 0; k < 16; ++k) { lo[k] = d[k]; hi[k] = d[k]; }
 #pragma unroll
-      for (int j = 1; j < 9; ++j) {
-        const int v = d[(k + j) & 15];
-        mb = min(mb, v);
-        md = min(md, -v);
+      for (int step = 1; step <= 4; step <<= 1) {
+        int l2[16], h2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { l2[k] = min(lo[k], lo[(k + step) & 15]); h2[k] = max(hi[k], hi[(k + step) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { lo[k] = l2[k]; hi[k] = h2[k]; }
       }
-      best = max(best, max(mb, md));
+      int best = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int mb = min(lo[k], d[(k + 8) & 15]);       // min over 9 -> bright arc strength
+        const int md = -max(hi[k], d[(k + 8) & 15]);      // min over 9 of (p - I) -> dark arc strength
+        best = max(best, max(mb, md));
+      }
+      if (best > thr) out = (uint8_t)min(best, 255);
     }
-    if (best > thr) out = (uint8_t)min(best, 255);
   }
   score[lv.off + (size_t)y * lv.w + x] = out;
 }
@@ -145,15 +158,21 @@ struct Cand {
   int pad;
 };
 
-// 3x3 non-maximum suppression on the score image (strictly greater than all 8 neighbours), mask
-// test, Harris response -> per-level candidate list (atomic append; order is irrelevant, the
-// selection below is by (key, pix)).
-__global__ __launch_bounds__(256) void fast_nms_harris_kernel(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ score,
-                                                              const uint8_t* __restrict__ mask, int w0, int h0,
-                                                              const Levels L, Cand* __restrict__ cand, int* __restrict__ cand_n) {
-  const int li = blockIdx.z;
+// 3x3 non-maximum suppression on the score image (strictly greater than all 8 neighbours) and
+// foreground test: the keypoint's level-0 pixel must lie outside every (grown) vehicle rectangle
+// (rectangles staged in LDS). Survivors are appended to the level's candidate list (order is
+// irrelevant, the selection below is by (key, pix)); their Harris keys are filled in by the next
+// kernel, one wave per candidate.
+constexpr int kMaxRects = 1024;
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, const int4* __restrict__ rects,
+                                                       int n_rects, int w0, int h0, const Levels L,
+                                                       Cand* __restrict__ cand, int* __restrict__ cand_n) {
+  __shared__ int4 s_rect[kMaxRects];
+  for (int i = threadIdx.x; i < n_rects; i += blockDim.x) s_rect[i] = rects[i];
+  if (n_rects > 0) __syncthreads();
+  int x, y;
+  const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
   const Level lv = L.l[li];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x < kBorder || x >= lv.w - kBorder || y < kBorder || y >= lv.h - kBorder) return;
   const uint8_t* sc = score + lv.off;
   const int s = sc[(size_t)y * lv.w + x];
@@ -162,32 +181,53 @@ __global__ __launch_bounds__(256) void fast_nms_harris_kernel(const uint8_t* __r
   const uint8_t* r1 = r0 + lv.w;
   const uint8_t* r2 = r1 + lv.w;
   if (!(s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1])) return;
-  if (mask) {
-    const int x0 = (int)(((long)x * w0 + lv.w / 2) / lv.w), y0 = (int)(((long)y * h0 + lv.h / 2) / lv.h);
-    if (mask[(size_t)min(y0, h0 - 1) * w0 + min(x0, w0 - 1)] == 0) return;
-  }
-  const uint8_t* img = pyr + lv.off;
-  long a = 0, b = 0, c = 0;
-  for (int dy = -3; dy <= 3; ++dy) {
-    const uint8_t* p0 = img + (size_t)(y + dy - 1) * lv.w + x;
-    const uint8_t* p1 = p0 + lv.w;
-    const uint8_t* p2 = p1 + lv.w;
-    for (int dx = -3; dx <= 3; ++dx) {
-      const int ix = (p0[dx + 1] + 2 * p1[dx + 1] + p2[dx + 1]) - (p0[dx - 1] + 2 * p1[dx - 1] + p2[dx - 1]);
-      const int iy = (p2[dx - 1] + 2 * p2[dx] + p2[dx + 1]) - (p0[dx - 1] + 2 * p0[dx] + p0[dx + 1]);
-      a += ix * ix;
-      b += iy * iy;
-      c += ix * iy;
+  if (n_rects > 0) {
+    const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
+    for (int i = 0; i < n_rects; ++i) {
+      const int4 r = s_rect[i];
+      if (x0 >= r.x && x0 <= r.z && y0 >= r.y && y0 <= r.w) return;
     }
   }
-  const long key = 25 * (a * b - c * c) - (a + b) * (a + b);
   const int slot = atomicAdd(&cand_n[li], 1);
   if (slot < lv.cand_cap) {
     Cand cd;
-    cd.key = key;
+    cd.key = 0;
     cd.pix = y * lv.w + x;
     cd.pad = 0;
     cand[lv.cand_off + slot] = cd;
+  }
+}
+
+// Harris response of every candidate: lanes 0..48 take one pixel of the 7x7 block each (3x3
+// Sobel), the three sums are reduced over the wave in exact integers.
+__global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ pyr, const Levels L, Cand* __restrict__ cand,
+                                                     const int* __restrict__ cand_n) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int li = 0; li < L.n; ++li) {
+    const Level lv = L.l[li];
+    const int n = min(cand_n[li], lv.cand_cap);
+    const uint8_t* img = pyr + lv.off;
+    for (int i = wave; i < n; i += nwaves) {
+      const int pix = cand[lv.cand_off + i].pix;
+      const int x = pix % lv.w, y = pix / lv.w;
+      long a = 0, b = 0, c = 0;
+      if (lane < 49) {
+        const uint8_t* p1 = img + (size_t)(y + lane / 7 - 3) * lv.w + x + lane % 7 - 3;
+        const uint8_t* p0 = p1 - lv.w;
+        const uint8_t* p2 = p1 + lv.w;
+        const int ix = (p0[1] + 2 * p1[1] + p2[1]) - (p0[-1] + 2 * p1[-1] + p2[-1]);
+        const int iy = (p2[-1] + 2 * p2[0] + p2[1]) - (p0[-1] + 2 * p0[0] + p0[1]);
+        a = ix * ix; b = iy * iy; c = ix * iy;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+        c += __shfl_xor(c, o, 64);
+      }
+      if (lane == 0) cand[lv.cand_off + i].key = 25 * (a * b - c * c) - (a + b) * (a + b);
+    }
   }
 }
 
@@ -205,22 +245,25 @@ struct KeyPoint {
 __device__ __forceinline__ unsigned long long flip_key(long k) { return (unsigned long long)k ^ 0x8000000000000000ull; }
 
 __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
-                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n,
-                                                           unsigned long long* __restrict__ sel_key, int* __restrict__ sel_pix) {
+                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_need, s_nsel, s_ntie_take;
+  __shared__ int s_need, s_nsel;
+  __shared__ unsigned long long s_key[1024];   // selected set (n_want <= 1024 per level)
+  __shared__ int s_pix[1024];
   const int li = blockIdx.x;
   const Level lv = L.l[li];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int n = min(cand_n[li], lv.cand_cap);
   const Cand* c = cand + lv.cand_off;
-  const int want = min(lv.n_want, n);
+  const int want = min(min(lv.n_want, n), 1024);
   if (want == 0) {
     if (tid == 0) kp_n[li] = 0;
     return;
   }
-  // ---- radix select: find the key of rank `want` (1-based, descending)
+  // ---- radix select: find the key of rank `want` (1-based, descending). Harris keys share their
+  // leading bytes, so in the first passes every lane of a wave hits the same bin: one LDS atomic per
+  // wave when the wave agrees on the digit, per-lane atomics otherwise.
   if (tid == 0) { s_prefix = 0ull; s_need = want; }
   __syncthreads();
   for (int pass = 0; pass < 8; ++pass) {
@@ -229,9 +272,23 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restric
     __syncthreads();
     const unsigned long long prefix = s_prefix;
     const unsigned long long pmask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-    for (int i = tid; i < n; i += blockDim.x) {
-      const unsigned long long k = flip_key(c[i].key);
-      if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      int digit = -1;
+      if (i < n) {
+        const unsigned long long k = flip_key(c[i].key);
+        if ((k & pmask) == prefix) digit = (int)((k >> shift) & 255);
+      }
+      const unsigned long long live = __ballot(digit >= 0);
+      if (live) {
+        const int first = __shfl(digit, __ffsll((long long)live) - 1, 64);
+        const unsigned long long same = __ballot(digit == first);
+        if (same == live) {
+          if (lane == __ffsll((long long)live) - 1) atomicAdd(&hist[first], __popcll(live));
+        } else if (digit >= 0) {
+          atomicAdd(&hist[digit], 1);
+        }
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -248,36 +305,33 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restric
   const unsigned long long kth = s_prefix;   // key of the want-th best
   const int tie_take = s_need;               // how many candidates with key == kth to keep
   // ---- gather: all keys > kth, plus the `tie_take` smallest-pix candidates with key == kth
-  unsigned long long* okey = sel_key + lv.kp_off;
-  int* opix = sel_pix + lv.kp_off;
-  if (tid == 0) { s_nsel = 0; s_ntie_take = 0; }
+  if (tid == 0) s_nsel = 0;
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) {
     const unsigned long long k = flip_key(c[i].key);
     bool take = k > kth;
     if (k == kth) {
-      // rank among ties by pix (ties are rare: count smaller pix with the same key)
-      int r = 0;
+      int r = 0;   // rank among the (rare) ties by pixel index
       for (int j = 0; j < n; ++j)
         if (flip_key(c[j].key) == kth && c[j].pix < c[i].pix) ++r;
       take = r < tie_take;
     }
     if (take) {
-      const int s = atomicAdd(&s_nsel, 1);
-      okey[s] = k;
-      opix[s] = c[i].pix;
+      const int sl = atomicAdd(&s_nsel, 1);
+      s_key[sl] = k;
+      s_pix[sl] = c[i].pix;
     }
   }
   __syncthreads();
   const int m = s_nsel;   // == want
   // ---- deterministic order: rank by (key desc, pix asc)
   for (int i = tid; i < m; i += blockDim.x) {
-    const unsigned long long k = okey[i];
-    const int p = opix[i];
+    const unsigned long long k = s_key[i];
+    const int p = s_pix[i];
     int r = 0;
     for (int j = 0; j < m; ++j) {
-      const unsigned long long kj = okey[j];
-      r += (kj > k || (kj == k && opix[j] < p)) ? 1 : 0;
+      const unsigned long long kj = s_key[j];
+      r += (kj > k || (kj == k && s_pix[j] < p)) ? 1 : 0;
     }
     KeyPoint kp;
     kp.x = p % lv.w;
@@ -419,46 +473,64 @@ __global__ __launch_bounds__(256) void compact_kernel(const Levels L, const int*
 }
 
 // ------------------------------------------------------------------ matching
-// Brute-force Hamming 2-NN: one thread per query descriptor, train descriptors tiled through LDS.
+// Brute-force Hamming 2-NN. Grid = (query tiles of 256) x (train chunks of 256): a block stages its
+// train chunk in LDS and every thread scans it for its query, leaving a partial (best, second,
+// index) per chunk; the ratio kernel below merges the chunks of a query in chunk order, which
+// preserves the "lowest index wins ties" rule.
+constexpr int kMatchChunk = 256;
 __global__ __launch_bounds__(256) void match_kernel(const unsigned long long* __restrict__ q, const int* __restrict__ nq_p,
                                                     const unsigned long long* __restrict__ t, const int* __restrict__ nt_p,
-                                                    int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d) {
-  __shared__ unsigned long long s_t[256 * 4];
+                                                    int max_q, int* __restrict__ part_idx, int* __restrict__ part_d1,
+                                                    int* __restrict__ part_d2) {
+  __shared__ unsigned long long s_t[kMatchChunk * 4];
   const int nq = *nq_p, nt = *nt_p;
+  const int t0 = blockIdx.y * kMatchChunk;
+  if (blockIdx.x * blockDim.x >= nq || t0 >= nt) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x * blockDim.x >= nq) return;
-  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  if (i < nq) { a0 = q[(size_t)i * 4]; a1 = q[(size_t)i * 4 + 1]; a2 = q[(size_t)i * 4 + 2]; a3 = q[(size_t)i * 4 + 3]; }
-  int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
-  for (int t0 = 0; t0 < nt; t0 += 256) {
-    const int j = t0 + threadIdx.x;
-    if (j < nt) {
+  const int j = t0 + threadIdx.x;
+  if (j < nt) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s_t[threadIdx.x * 4 + k] = t[(size_t)j * 4 + k];
-    }
-    __syncthreads();
-    const int lim = min(256, nt - t0);
-    for (int k = 0; k < lim; ++k) {
-      const int d = __popcll(a0 ^ s_t[k * 4]) + __popcll(a1 ^ s_t[k * 4 + 1]) + __popcll(a2 ^ s_t[k * 4 + 2]) +
-                    __popcll(a3 ^ s_t[k * 4 + 3]);
-      if (d < b1) { b2 = b1; b1 = d; bi = t0 + k; }
-      else if (d < b2) b2 = d;
-    }
-    __syncthreads();
+    for (int k = 0; k < 4; ++k) s_t[threadIdx.x * 4 + k] = t[(size_t)j * 4 + k];
   }
-  if (i < nq) { best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2; }
+  __syncthreads();
+  if (i >= nq) return;
+  const unsigned long long a0 = q[(size_t)i * 4], a1 = q[(size_t)i * 4 + 1], a2 = q[(size_t)i * 4 + 2], a3 = q[(size_t)i * 4 + 3];
+  int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
+  const int lim = min(kMatchChunk, nt - t0);
+  for (int k = 0; k < lim; ++k) {
+    const int d = __popcll(a0 ^ s_t[k * 4]) + __popcll(a1 ^ s_t[k * 4 + 1]) + __popcll(a2 ^ s_t[k * 4 + 2]) +
+                  __popcll(a3 ^ s_t[k * 4 + 3]);
+    if (d < b1) { b2 = b1; b1 = d; bi = t0 + k; }
+    else if (d < b2) b2 = d;
+  }
+  const size_t o = (size_t)blockIdx.y * max_q + i;
+  part_idx[o] = bi; part_d1[o] = b1; part_d2[o] = b2;
 }
 
-// Lowe ratio test + ordered compaction (single workgroup, queries in index order).
-__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ nq_p, const int* __restrict__ nt_p,
-                                                             const int* __restrict__ best_idx, const int* __restrict__ best_d,
-                                                             const int* __restrict__ second_d, float ratio,
+// Merge of the per-chunk partials + Lowe ratio test + ordered compaction (single workgroup, queries
+// in index order).
+__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ nq_p, const int* __restrict__ nt_p, int max_q,
+                                                             const int* __restrict__ part_idx, const int* __restrict__ part_d1,
+                                                             const int* __restrict__ part_d2, float ratio,
                                                              const float2* __restrict__ q_xy, const float2* __restrict__ t_xy,
+                                                             int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d,
                                                              int* __restrict__ m_q, int* __restrict__ m_t, int* __restrict__ m_d,
                                                              float4* __restrict__ m_pts, int* __restrict__ n_match) {
   __shared__ int s_cnt[1024];
   const int nq = *nq_p, nt = *nt_p;
+  const int nchunk = (nt + kMatchChunk - 1) / kMatchChunk;
   const int tid = threadIdx.x;
+  for (int i = tid; i < nq; i += blockDim.x) {
+    int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
+    for (int c = 0; c < nchunk; ++c) {
+      const size_t o = (size_t)c * max_q + i;
+      const int d1 = part_d1[o], d2 = part_d2[o];
+      if (d1 < b1) { b2 = min(b1, d2); b1 = d1; bi = part_idx[o]; }
+      else b2 = min(b2, d1);
+    }
+    best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2;
+  }
+  __syncthreads();
   const int per = (nq + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, nq);
   int c = 0;
@@ -522,24 +594,17 @@ __device__ bool homography4(const double* px, const double* py, const double* qx
   return true;
 }
 
-// One wave per hypothesis: lane 0 draws 4 distinct matches (counter-based hash of seed,
-// hypothesis and draw) and solves for H; all lanes then score the matches with the truncated
-// squared reprojection error (MSAC), quantised to 1/1024 px^2 so that the sum is an exact
-// integer regardless of the reduction order.
-__global__ __launch_bounds__(256) void ransac_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, unsigned seed,
-                                                     int n_hyp, double cx, double cy, double sc, float thr2,
-                                                     double* __restrict__ Hout, long* __restrict__ cost) {
-  const int n = *n_p;
-  const int lane = threadIdx.x & 63;
-  const int hyp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+// Hypothesis generation, one thread per hypothesis: 4 distinct matches drawn by a counter-based
+// hash of (seed, hypothesis, draw), exact 4-point solve in normalised coordinates, de-normalised H.
+__global__ __launch_bounds__(256) void ransac_solve_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, unsigned seed,
+                                                           int n_hyp, double cx, double cy, double sc,
+                                                           double* __restrict__ Hout, int* __restrict__ ok_out) {
+  const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
   if (hyp >= n_hyp) return;
-  if (n < 4) {
-    if (lane == 0) cost[hyp] = 0x7fffffffffffffffl;
-    return;
-  }
-  double H[9];
+  const int n = *n_p;
   int ok = 0;
-  if (lane == 0) {
+  double H[9];
+  if (n >= 4) {
     int idx[4];
     unsigned ctr = 0;
     for (int k = 0; k < 4; ++k) {
@@ -576,13 +641,28 @@ __global__ __launch_bounds__(256) void ransac_kernel(const float4* __restrict__ 
       if (!(fabs(H[8]) > 1e-12)) ok = 0;
     }
   }
-  ok = __shfl(ok, 0, 64);
-  if (!ok) {
+  ok_out[hyp] = ok;
+  if (ok)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hout[(size_t)hyp * 9 + k] = H[k];
+}
+
+// Scoring, one wave per hypothesis: truncated squared reprojection error (MSAC) over all matches,
+// quantised to 1/1024 px^2 so that the sum is an exact integer regardless of the reduction order.
+__global__ __launch_bounds__(256) void ransac_score_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, int n_hyp,
+                                                           float thr2, const double* __restrict__ Hin, const int* __restrict__ ok_in,
+                                                           long* __restrict__ cost) {
+  const int n = *n_p;
+  const int lane = threadIdx.x & 63;
+  const int hyp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (hyp >= n_hyp) return;
+  if (!ok_in[hyp]) {
     if (lane == 0) cost[hyp] = 0x7fffffffffffffffl;
     return;
   }
+  double H[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) H[k] = __shfl(H[k], 0, 64);
+  for (int k = 0; k < 9; ++k) H[k] = Hin[(size_t)hyp * 9 + k];
   long acc = 0;
   for (int i = lane; i < n; i += 64) {
     const float4 p = pts[i];
@@ -599,11 +679,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(const float4* __restrict__ 
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) {
-    cost[hyp] = acc;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Hout[(size_t)hyp * 9 + k] = H[k];
-  }
+  if (lane == 0) cost[hyp] = acc;
 }
 
 __global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ cost, int n, int* __restrict__ best) {
@@ -678,12 +754,12 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_score, d_mask, d_rects, d_cand, d_cand_n, d_kp_n, d_kps, d_desc, d_xy, d_selkey, d_selpix, d_pattern;
+  DevBuf d_frame, d_pyr, d_score, d_rects, d_cand, d_cand_n, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
   } ref, cur;
-  DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_mpts, d_nmatch, d_H, d_cost, d_best;
+  DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_mpts, d_nmatch, d_H, d_cost, d_best, d_hok, d_pidx, d_pd1, d_pd2;
   bool have_ref = false;
   // last results
   double H[9];
@@ -722,7 +798,11 @@ void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
     }
     lv.kp_off = koff;
     koff += lv.n_want;
+    lv.tiles_x = cdiv(lv.w, 64);
+    lv.tile_begin = i == 0 ? 0 : L.l[i - 1].tile_begin + L.l[i - 1].tiles_x * cdiv(L.l[i - 1].h, 4);
   }
+  L.n_tiles = L.l[L.n - 1].tile_begin + L.l[L.n - 1].tiles_x * cdiv(L.l[L.n - 1].h, 4);
+  GTX_CHECK(max_features * 0.25 < 1024, "stabilizer: at most ~4000 features per image are supported");
   pyr_bytes = off;
   cand_total = coff;
   slots = koff;
@@ -752,16 +832,13 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   const int slots = std::max(S.slots_ref, S.slots_cur);
   S.d_pyr.alloc(S.pyr_bytes);
   S.d_score.alloc(S.pyr_bytes);
-  S.d_mask.alloc((size_t)S.gw * S.gh);
-  S.d_rects.alloc(sizeof(int4) * 4096);
+  S.d_rects.alloc(sizeof(int4) * kMaxRects);
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_cand_n.alloc(sizeof(int) * kPyrLevels);
   S.d_kp_n.alloc(sizeof(int) * kPyrLevels);
   S.d_kps.alloc(sizeof(KeyPoint) * slots);
   S.d_desc.alloc(32 * (size_t)slots);
   S.d_xy.alloc(sizeof(float2) * slots);
-  S.d_selkey.alloc(8 * (size_t)slots);
-  S.d_selpix.alloc(4 * (size_t)slots);
   for (Impl::Feat* f : {&S.ref, &S.cur}) {
     f->kps.alloc(sizeof(KeyPoint) * slots);
     f->desc.alloc(32 * (size_t)slots);
@@ -777,6 +854,11 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_H.alloc(sizeof(double) * 9 * S.n_hyp);
   S.d_cost.alloc(sizeof(long) * S.n_hyp);
   S.d_best.alloc(sizeof(int));
+  S.d_hok.alloc(sizeof(int) * S.n_hyp);
+  {
+    const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;
+    S.d_pidx.alloc(4 * parts); S.d_pd1.alloc(4 * parts); S.d_pd2.alloc(4 * parts);
+  }
   // rotated sampling patterns
   int8_t base[256][4];
   base_pattern(base);
@@ -802,7 +884,7 @@ Stabilizer::~Stabilizer() = default;
 void Stabilizer::Impl::build_rects(const float* boxes, int n, std::vector<int4>& rects) const {
   // stabilo masks each box grown by mask_margin_ratio of its size, drawn on the downsampled frame
   const float r = cfg.downsample_ratio, m = cfg.mask_margin_ratio;
-  for (int i = 0; i < n && (int)rects.size() < 4096; ++i) {
+  for (int i = 0; i < n && (int)rects.size() < kMaxRects; ++i) {
     const float cx = boxes[4 * i], cy = boxes[4 * i + 1], w = boxes[4 * i + 2] * (1.f + m), h = boxes[4 * i + 3] * (1.f + m);
     int x1 = (int)std::floor((cx - w / 2) * r), y1 = (int)std::floor((cy - h / 2) * r);
     int x2 = (int)std::ceil((cx + w / 2) * r), y2 = (int)std::ceil((cy + h / 2) * r);
@@ -830,25 +912,20 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
     hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 256), L.l[i].h), dim3(256), 0, s, pyr + L.l[i - 1].off,
                        L.l[i - 1].w, L.l[i - 1].h, pyr + L.l[i].off, L.l[i].w, L.l[i].h);
   }
-  const uint8_t* mask = nullptr;
+  int n_rects = 0;
   if (cfg.mask_use && boxes && n > 0) {
     std::vector<int4> rects;
     build_rects(boxes, n, rects);
-    hipLaunchKernelGGL(mask_fill_kernel, dim3(cdiv(gw * gh, 256)), dim3(256), 0, s, d_mask.as<uint8_t>(), gw * gh);
-    if (!rects.empty()) {
-      GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size()), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, gh,
-                         d_rects.as<int4>(), (int)rects.size());
-    }
-    mask = d_mask.as<uint8_t>();
+    n_rects = (int)rects.size();
+    if (n_rects) GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
   }
-  const dim3 grid(cdiv(L.l[0].w, 256), L.l[0].h, L.n);
-  hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, s, pyr, d_score.as<uint8_t>(), L, cfg.fast_threshold);
+  hipLaunchKernelGGL(fast_score_kernel, dim3(L.n_tiles), dim3(256), 0, s, pyr, d_score.as<uint8_t>(), L, cfg.fast_threshold);
   GTX_HIP(hipMemsetAsync(d_cand_n.p, 0, sizeof(int) * kPyrLevels, s));
-  hipLaunchKernelGGL(fast_nms_harris_kernel, grid, dim3(256), 0, s, pyr, d_score.as<uint8_t>(), mask, gw, gh, L,
+  hipLaunchKernelGGL(fast_nms_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), d_rects.as<int4>(), n_rects, gw, gh, L,
                      d_cand.as<Cand>(), d_cand_n.as<int>());
+  hipLaunchKernelGGL(harris_kernel, dim3(1024), dim3(256), 0, s, pyr, L, d_cand.as<Cand>(), d_cand_n.as<int>());
   hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_cand.as<Cand>(), d_cand_n.as<int>(), L,
-                     d_kps.as<KeyPoint>(), d_kp_n.as<int>(), d_selkey.as<unsigned long long>(), d_selpix.as<int>());
+                     d_kps.as<KeyPoint>(), d_kp_n.as<int>());
   hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, pyr, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
                      d_pattern.as<int8_t>(), d_desc.as<unsigned long long>(), d_xy.as<float2>(), 1.0f / cfg.downsample_ratio, slots);
   hipLaunchKernelGGL(compact_kernel, dim3(8), dim3(256), 0, s, L, d_kp_n.as<int>(), d_kps.as<KeyPoint>(),
@@ -999,15 +1076,20 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
 void Stabilizer::Impl::run_stabilize(double Hout[9], int* valid_out, int st[4]) {
   hipStream_t s = ctx->stream;
   const int slots = std::max(slots_ref, slots_cur);
-  hipLaunchKernelGGL(match_kernel, dim3(cdiv(slots_cur, 256)), dim3(256), 0, s, cur.desc.as<unsigned long long>(), cur.n.as<int>(),
-                     ref.desc.as<unsigned long long>(), ref.n.as<int>(), d_bidx.as<int>(), d_bd.as<int>(), d_sd.as<int>());
-  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, cur.n.as<int>(), ref.n.as<int>(), d_bidx.as<int>(),
-                     d_bd.as<int>(), d_sd.as<int>(), cfg.filter_ratio, cur.xy.as<float2>(), ref.xy.as<float2>(), d_mq.as<int>(),
-                     d_mt.as<int>(), d_md.as<int>(), d_mpts.as<float4>(), d_nmatch.as<int>());
+  const int max_q = slots_cur, n_chunks = cdiv(slots_ref, kMatchChunk);
+  hipLaunchKernelGGL(match_kernel, dim3(cdiv(slots_cur, 256), n_chunks), dim3(256), 0, s, cur.desc.as<unsigned long long>(),
+                     cur.n.as<int>(), ref.desc.as<unsigned long long>(), ref.n.as<int>(), max_q, d_pidx.as<int>(), d_pd1.as<int>(),
+                     d_pd2.as<int>());
+  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, cur.n.as<int>(), ref.n.as<int>(), max_q, d_pidx.as<int>(),
+                     d_pd1.as<int>(), d_pd2.as<int>(), cfg.filter_ratio, cur.xy.as<float2>(), ref.xy.as<float2>(), d_bidx.as<int>(),
+                     d_bd.as<int>(), d_sd.as<int>(), d_mq.as<int>(), d_mt.as<int>(), d_md.as<int>(), d_mpts.as<float4>(),
+                     d_nmatch.as<int>());
   const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
   const float thr2 = cfg.ransac_threshold * cfg.ransac_threshold;
-  hipLaunchKernelGGL(ransac_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), cfg.seed,
-                     n_hyp, cx, cy, sc, thr2, d_H.as<double>(), d_cost.as<long>());
+  hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), cfg.seed,
+                     n_hyp, cx, cy, sc, d_H.as<double>(), d_hok.as<int>());
+  hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), n_hyp,
+                     thr2, d_H.as<double>(), d_hok.as<int>(), d_cost.as<long>());
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_best.as<int>());
   GTX_HIP(hipGetLastError());
   int n_match = 0, best = -1;
