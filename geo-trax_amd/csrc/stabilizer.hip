@@ -32,8 +32,10 @@ constexpr int kBorder = 31;        // ORB edgeThreshold
 constexpr int kPatchR = 20;        // patch radius staged per keypoint: 17 (rotated pattern) + 3 (blur)
 constexpr int kPatchW = 2 * kPatchR + 1;
 constexpr int kAngleBins = 256;
+constexpr int kMaxRects = 1024;
 
 struct Level {
+  const uint8_t* img;   // this level's pixels (level 0 may live in a caller-owned buffer)
   int w, h;
   int off;          // byte offset of this level in the pyramid / score buffers
   int cand_off;     // first candidate slot of this level
@@ -111,15 +113,14 @@ __constant__ int c_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, 
 // Any arc of 9 contains at least two of the four compass pixels (0, 4, 8, 12), so a pixel with
 // fewer than two compass pixels beyond the threshold on one side cannot be a corner: that test
 // rejects most of the image after 5 loads. The arc minima are built by doubling (1,2,4,8,+1).
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
-                                                         const Levels L, int thr) {
+__global__ __launch_bounds__(256) void fast_score_kernel(uint8_t* __restrict__ score, const Levels L, int thr) {
   int x, y;
   const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
   const Level lv = L.l[li];
   if (x >= lv.w || y >= lv.h) return;
   uint8_t out = 0;
   if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) {
-    const uint8_t* c = pyr + lv.off + (size_t)y * lv.w + x;
+    const uint8_t* c = lv.img + (size_t)y * lv.w + x;
     const int p = c[0];
     const int d0 = (int)c[-3 * lv.w] - p, d4 = (int)c[3] - p, d8 = (int)c[3 * lv.w] - p, d12 = (int)c[-3] - p;
     const int nb = (d0 > thr) + (d4 > thr) + (d8 > thr) + (d12 > thr);
@@ -155,21 +156,26 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
 struct Cand {
   long key;   // Harris response 25(ab - c^2) - (a+b)^2, exact integer
   int pix;    // y * w + x at its level
-  int pad;
+  int score;  // FAST score (1..255)
 };
 
+// Foreground mask at level-0 resolution: 255 = usable, 0 = inside a (grown) vehicle box. One
+// block per (rectangle, slice of its rows); lanes run along x.
+__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* __restrict__ mask, int w, const int4* __restrict__ rects) {
+  const int4 r = rects[blockIdx.x];
+  const int rw = r.z - r.x + 1, rh = r.w - r.y + 1;
+  const int rows_per = (rh + gridDim.y - 1) / gridDim.y;
+  const int y0 = r.y + blockIdx.y * rows_per, y1 = min(y0 + rows_per, r.w + 1);
+  for (int y = y0 + (threadIdx.x >> 6); y < y1; y += 4)
+    for (int x = threadIdx.x & 63; x < rw; x += 64) mask[(size_t)y * w + r.x + x] = 0;
+}
+
 // 3x3 non-maximum suppression on the score image (strictly greater than all 8 neighbours) and
-// foreground test: the keypoint's level-0 pixel must lie outside every (grown) vehicle rectangle
-// (rectangles staged in LDS). Survivors are appended to the level's candidate list (order is
-// irrelevant, the selection below is by (key, pix)); their Harris keys are filled in by the next
-// kernel, one wave per candidate.
-constexpr int kMaxRects = 1024;
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, const int4* __restrict__ rects,
-                                                       int n_rects, int w0, int h0, const Levels L,
-                                                       Cand* __restrict__ cand, int* __restrict__ cand_n) {
-  __shared__ int4 s_rect[kMaxRects];
-  for (int i = threadIdx.x; i < n_rects; i += blockDim.x) s_rect[i] = rects[i];
-  if (n_rects > 0) __syncthreads();
+// foreground test. Survivors are appended to the level's candidate list (order is irrelevant: the
+// selection is by value) and counted in the level's 256-bin FAST-score histogram.
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, const uint8_t* __restrict__ mask,
+                                                       int w0, int h0, const Levels L, Cand* __restrict__ cand,
+                                                       int* __restrict__ cand_n, int* __restrict__ score_hist) {
   int x, y;
   const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
   const Level lv = L.l[li];
@@ -181,39 +187,53 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict
   const uint8_t* r1 = r0 + lv.w;
   const uint8_t* r2 = r1 + lv.w;
   if (!(s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1])) return;
-  if (n_rects > 0) {
+  if (mask) {
     const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
-    for (int i = 0; i < n_rects; ++i) {
-      const int4 r = s_rect[i];
-      if (x0 >= r.x && x0 <= r.z && y0 >= r.y && y0 <= r.w) return;
-    }
+    if (mask[(size_t)y0 * w0 + x0] == 0) return;
   }
   const int slot = atomicAdd(&cand_n[li], 1);
   if (slot < lv.cand_cap) {
     Cand cd;
     cd.key = 0;
     cd.pix = y * lv.w + x;
-    cd.pad = 0;
+    cd.score = s;
     cand[lv.cand_off + slot] = cd;
+    atomicAdd(&score_hist[li * 256 + s], 1);
   }
 }
 
-// Harris response of every candidate: lanes 0..48 take one pixel of the 7x7 block each (3x3
-// Sobel), the three sums are reduced over the wave in exact integers.
-__global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ pyr, const Levels L, Cand* __restrict__ cand,
-                                                     const int* __restrict__ cand_n) {
+// Stage 1 of the selection, as OpenCV's ORB does it: per level keep the 2*n_want candidates with
+// the best FAST score (all candidates tied with the last one included), i.e. those with
+// score >= cutoff where cutoff is read off the level's score histogram. Stage 2 input: the Harris
+// response of every kept candidate -- lanes 0..48 take one pixel of the 7x7 block each (3x3 Sobel),
+// the three sums are reduced over the wave in exact integers -- appended to the eligible list.
+__global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand* __restrict__ cand, const int* __restrict__ cand_n,
+                                                     const int* __restrict__ score_hist, Cand* __restrict__ elig,
+                                                     int* __restrict__ elig_n) {
+  __shared__ int s_cut[kPyrLevels];
+  if (threadIdx.x < L.n) {
+    const int li = threadIdx.x, need = 2 * L.l[li].n_want;
+    int acc = 0, cut = 1;
+    for (int b = 255; b >= 1; --b) {
+      acc += score_hist[li * 256 + b];
+      if (acc >= need) { cut = b; break; }
+    }
+    s_cut[li] = cut;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int li = 0; li < L.n; ++li) {
     const Level lv = L.l[li];
     const int n = min(cand_n[li], lv.cand_cap);
-    const uint8_t* img = pyr + lv.off;
+    const int cut = s_cut[li];
     for (int i = wave; i < n; i += nwaves) {
-      const int pix = cand[lv.cand_off + i].pix;
-      const int x = pix % lv.w, y = pix / lv.w;
+      const Cand cd = cand[lv.cand_off + i];
+      if (cd.score < cut) continue;
+      const int x = cd.pix % lv.w, y = cd.pix / lv.w;
       long a = 0, b = 0, c = 0;
       if (lane < 49) {
-        const uint8_t* p1 = img + (size_t)(y + lane / 7 - 3) * lv.w + x + lane % 7 - 3;
+        const uint8_t* p1 = lv.img + (size_t)(y + lane / 7 - 3) * lv.w + x + lane % 7 - 3;
         const uint8_t* p0 = p1 - lv.w;
         const uint8_t* p2 = p1 + lv.w;
         const int ix = (p0[1] + 2 * p1[1] + p2[1]) - (p0[-1] + 2 * p1[-1] + p2[-1]);
@@ -226,7 +246,12 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__
         b += __shfl_xor(b, o, 64);
         c += __shfl_xor(c, o, 64);
       }
-      if (lane == 0) cand[lv.cand_off + i].key = 25 * (a * b - c * c) - (a + b) * (a + b);
+      if (lane == 0) {
+        Cand out = cd;
+        out.key = 25 * (a * b - c * c) - (a + b) * (a + b);
+        const int slot = atomicAdd(&elig_n[li], 1);
+        if (slot < lv.cand_cap) elig[lv.cand_off + slot] = out;
+      }
     }
   }
 }
@@ -368,7 +393,7 @@ __device__ __forceinline__ int angle_bin(int m10, int m01) {
 // gives the orientation bin, the 35x35 interior is blurred (separable integer 7-tap Gaussian) in
 // LDS, and the 256 steered-BRIEF tests are evaluated 64 at a time: a ballot per group of 64 tests
 // is one 64-bit word of the descriptor.
-__global__ __launch_bounds__(256) void describe_kernel(const uint8_t* __restrict__ pyr, const Levels L,
+__global__ __launch_bounds__(256) void describe_kernel(const Levels L,
                                                        KeyPoint* __restrict__ kps, const int* __restrict__ kp_n,
                                                        const int8_t* __restrict__ pattern /*[bins][256][4]*/,
                                                        unsigned long long* __restrict__ desc /*[slot][4]*/,
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t* __restrict
   const Level lv = L.l[li];
   if (slot - lv.kp_off >= kp_n[li]) return;
   KeyPoint kp = kps[slot];
-  const uint8_t* img = pyr + lv.off;
+  const uint8_t* img = lv.img;
   uint8_t* P = s_patch[wv];
   for (int i = lane; i < kPatchW * kPatchW; i += 64) {
     const int u = i % kPatchW - kPatchR, v = i / kPatchW - kPatchR;
@@ -560,37 +585,37 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
   return x;
 }
 
-// Homography from 4 correspondences (x,y)->(u,v), coordinates pre-normalised to O(1):
-// 8x8 linear system with h33 = 1, Gaussian elimination with partial pivoting, f64.
+// Homography from 4 correspondences by the projective-basis construction: A maps the canonical
+// basis (e1, e2, e3, e1+e2+e3) to the four source points, B to the four destination points,
+// H = B * adj(A). Closed form, static indexing only (stays in registers), f64.
+__device__ __forceinline__ bool basis_matrix(const double* px, const double* py, double* M) {
+  // solve [p0 p1 p2] (l0,l1,l2)^T = p3 by Cramer's rule; columns then scaled by l
+  const double x0 = px[0], y0 = py[0], x1 = px[1], y1 = py[1], x2 = px[2], y2 = py[2], x3 = px[3], y3 = py[3];
+  const double det = x0 * (y1 - y2) - x1 * (y0 - y2) + x2 * (y0 - y1);
+  if (!(fabs(det) > 1e-9)) return false;
+  const double l0 = (x3 * (y1 - y2) - x1 * (y3 - y2) + x2 * (y3 - y1)) / det;
+  const double l1 = (x0 * (y3 - y2) - x3 * (y0 - y2) + x2 * (y0 - y3)) / det;
+  const double l2 = (x0 * (y1 - y3) - x1 * (y0 - y3) + x3 * (y0 - y1)) / det;
+  if (!(fabs(l0) > 1e-9 && fabs(l1) > 1e-9 && fabs(l2) > 1e-9)) return false;   // three points collinear
+  M[0] = l0 * x0; M[1] = l1 * x1; M[2] = l2 * x2;
+  M[3] = l0 * y0; M[4] = l1 * y1; M[5] = l2 * y2;
+  M[6] = l0;      M[7] = l1;      M[8] = l2;
+  return true;
+}
 __device__ bool homography4(const double* px, const double* py, const double* qx, const double* qy, double* H) {
-  double A[8][9];
-  for (int i = 0; i < 4; ++i) {
-    const double x = px[i], y = py[i], u = qx[i], v = qy[i];
-    double* r0 = A[2 * i];
-    double* r1 = A[2 * i + 1];
-    r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * x; r0[7] = -u * y; r0[8] = u;
-    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
-  }
-  for (int c = 0; c < 8; ++c) {
-    int piv = c;
-    double best = fabs(A[c][c]);
-    for (int r = c + 1; r < 8; ++r)
-      if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); piv = r; }
-    if (best < 1e-12) return false;
-    if (piv != c)
-      for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-    const double inv = 1.0 / A[c][c];
-    for (int r = c + 1; r < 8; ++r) {
-      const double f = A[r][c] * inv;
-      for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k];
-    }
-  }
-  for (int r = 7; r >= 0; --r) {
-    double s = A[r][8];
-    for (int k = r + 1; k < 8; ++k) s -= A[r][k] * H[k];
-    H[r] = s / A[r][r];
-  }
-  H[8] = 1.0;
+  double A[9], B[9];
+  if (!basis_matrix(px, py, A) || !basis_matrix(qx, qy, B)) return false;
+  const double adj[9] = {A[4] * A[8] - A[5] * A[7], A[2] * A[7] - A[1] * A[8], A[1] * A[5] - A[2] * A[4],
+                         A[5] * A[6] - A[3] * A[8], A[0] * A[8] - A[2] * A[6], A[2] * A[3] - A[0] * A[5],
+                         A[3] * A[7] - A[4] * A[6], A[1] * A[6] - A[0] * A[7], A[0] * A[4] - A[1] * A[3]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) H[r * 3 + c] = B[r * 3] * adj[c] + B[r * 3 + 1] * adj[3 + c] + B[r * 3 + 2] * adj[6 + c];
+  if (!(fabs(H[8]) > 1e-12)) return false;
+  const double inv = 1.0 / H[8];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) H[i] *= inv;
   return true;
 }
 
@@ -754,7 +779,7 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_score, d_rects, d_cand, d_cand_n, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
+  DevBuf d_frame, d_pyr, d_score, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
@@ -833,8 +858,10 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_pyr.alloc(S.pyr_bytes);
   S.d_score.alloc(S.pyr_bytes);
   S.d_rects.alloc(sizeof(int4) * kMaxRects);
+  S.d_mask.alloc((size_t)S.gw * S.gh);
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
-  S.d_cand_n.alloc(sizeof(int) * kPyrLevels);
+  S.d_elig.alloc(sizeof(Cand) * (size_t)S.cand_total);
+  S.d_counters.alloc(sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels));
   S.d_kp_n.alloc(sizeof(int) * kPyrLevels);
   S.d_kps.alloc(sizeof(KeyPoint) * slots);
   S.d_desc.alloc(32 * (size_t)slots);
@@ -904,29 +931,39 @@ void Stabilizer::Impl::gray_from_frame(const uint8_t* frame, int h, int w) {
 }
 
 // gray_dev == nullptr: level 0 is already in d_pyr.
-void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int n, const Levels& L, int slots, Feat& out) {
+void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int n, const Levels& Lplan, int slots, Feat& out) {
   hipStream_t s = ctx->stream;
   uint8_t* pyr = d_pyr.as<uint8_t>();
-  if (gray_dev) GTX_HIP(hipMemcpyAsync(pyr, gray_dev, (size_t)gw * gh, hipMemcpyDeviceToDevice, s));
+  Levels L = Lplan;   // level 0 is read in place from the caller's gray image when there is one
+  for (int i = 0; i < L.n; ++i) L.l[i].img = pyr + L.l[i].off;
+  if (gray_dev) L.l[0].img = gray_dev;
   for (int i = 1; i < L.n; ++i) {
-    hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 256), L.l[i].h), dim3(256), 0, s, pyr + L.l[i - 1].off,
+    hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 256), L.l[i].h), dim3(256), 0, s, L.l[i - 1].img,
                        L.l[i - 1].w, L.l[i - 1].h, pyr + L.l[i].off, L.l[i].w, L.l[i].h);
   }
-  int n_rects = 0;
+  const uint8_t* mask = nullptr;
   if (cfg.mask_use && boxes && n > 0) {
     std::vector<int4> rects;
     build_rects(boxes, n, rects);
-    n_rects = (int)rects.size();
-    if (n_rects) GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
+    if (!rects.empty()) {
+      GTX_HIP(hipMemsetAsync(d_mask.p, 255, (size_t)gw * gh, s));
+      GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size(), 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>());
+      mask = d_mask.as<uint8_t>();
+    }
   }
-  hipLaunchKernelGGL(fast_score_kernel, dim3(L.n_tiles), dim3(256), 0, s, pyr, d_score.as<uint8_t>(), L, cfg.fast_threshold);
-  GTX_HIP(hipMemsetAsync(d_cand_n.p, 0, sizeof(int) * kPyrLevels, s));
-  hipLaunchKernelGGL(fast_nms_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), d_rects.as<int4>(), n_rects, gw, gh, L,
-                     d_cand.as<Cand>(), d_cand_n.as<int>());
-  hipLaunchKernelGGL(harris_kernel, dim3(1024), dim3(256), 0, s, pyr, L, d_cand.as<Cand>(), d_cand_n.as<int>());
-  hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_cand.as<Cand>(), d_cand_n.as<int>(), L,
-                     d_kps.as<KeyPoint>(), d_kp_n.as<int>());
-  hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, pyr, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
+  // counters: [cand_n 8][elig_n 8][score histogram 8 x 256], cleared with one memset
+  int* cand_n = d_counters.as<int>();
+  int* elig_n = cand_n + kPyrLevels;
+  int* hist = elig_n + kPyrLevels;
+  GTX_HIP(hipMemsetAsync(d_counters.p, 0, sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels), s));
+  hipLaunchKernelGGL(fast_score_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), L, cfg.fast_threshold);
+  hipLaunchKernelGGL(fast_nms_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), mask, gw, gh, L, d_cand.as<Cand>(),
+                     cand_n, hist);
+  hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
+  hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
+                     d_kp_n.as<int>());
+  hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
                      d_pattern.as<int8_t>(), d_desc.as<unsigned long long>(), d_xy.as<float2>(), 1.0f / cfg.downsample_ratio, slots);
   hipLaunchKernelGGL(compact_kernel, dim3(8), dim3(256), 0, s, L, d_kp_n.as<int>(), d_kps.as<KeyPoint>(),
                      d_desc.as<unsigned long long>(), d_xy.as<float2>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(),

@@ -10,7 +10,7 @@ stabilo>=1.2.3 (pyproject.toml:59) and the OpenCV calls it makes (ORB_create, BF
 findHomography(USAC_MAGSAC)) are third-party code that is neither vendored in /root/reference nor
 installed here, and OpenCV's ORB sampling table and MAGSAC++ internals cannot be restated from
 memory bit for bit. This file therefore restates the *published algorithms* (Rublee et al. ORB:
-scale pyramid, FAST-9/16 with 3x3 non-maximum suppression, Harris ranking, intensity-centroid
+scale pyramid, FAST-9/16 with 3x3 non-maximum suppression, FAST-score pre-selection then Harris ranking, intensity-centroid
 orientation, steered BRIEF on a Gaussian-smoothed patch; Lowe's ratio test; RANSAC with an
 MSAC score and a robust iteratively re-weighted Gauss-Newton refit) in the integer-exact form the HIP kernels implement
 (geo-trax_amd/csrc/stabilizer.hip), so that every stage can be compared bit for bit. The BRIEF
@@ -176,6 +176,13 @@ def extract(gray: np.ndarray, boxes_xywh, cfg: dict, max_features: int, pattern:
             ys, xs = ys[ok], xs[ok]
         if len(xs) == 0 or n_want == 0:
             continue
+        # stage 1 (as OpenCV's ORB): the 2*n_want best FAST scores, everything tied with the last kept
+        fs = score[ys, xs]
+        if len(fs) > 2 * n_want:
+            cut = np.sort(fs)[::-1][2 * n_want - 1]
+            sel = fs >= cut
+            ys, xs = ys[sel], xs[sel]
+        # stage 2: the n_want best Harris responses, ties to the smaller pixel index
         keys = harris_keys(img, ys, xs)
         pix = ys.astype(np.int64) * w + xs
         order = np.lexsort((pix, -keys))[:n_want]
