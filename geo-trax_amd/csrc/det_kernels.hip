@@ -357,46 +357,60 @@ __device__ __forceinline__ int find_level(const HeadParams& hp, int a) {
   return l;
 }
 
-// Class branch: final 1x1 conv (nc x cc) + sigmoid + max over classes, per anchor.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<_Float16>(const _Float16* p, float (&v)[8]) {
+  const half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Class branch of Detect folded into the score gate: final 1x1 conv (nc x cc) + sigmoid + max
+// over classes + threshold + compaction. 16 lanes share an anchor, each owning 8-channel chunks of
+// its cls features (one fully coalesced 16-B load per lane per 128 channels), partial dot products
+// are combined with 4 xor-shuffles.
 template <typename T>
-__device__ __forceinline__ void anchor_cls(const HeadParams& hp, const HeadLevel& L, const T* f,
-                                           float& best, int& best_c) {
-  best = -1.f;
-  best_c = 0;
-  const T* fc = f + L.cb;
-  for (int c0 = 0; c0 < hp.nc; c0 += 8) {
-    float acc[8];
+__global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams hp, const NmsBuffers nb) {
+  const int sub = threadIdx.x & 15;
+  const int a = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int n = blockIdx.y;
+  const bool valid = a < hp.n_anchors;
+  const int l = find_level(hp, valid ? a : 0);
+  const HeadLevel& L = hp.lv[l];
+  const int la = (valid ? a : 0) - L.anchor_begin;
+  const T* fc = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride + L.cb;
+  const int chunks = L.cc >> 3;
+  float best = -1.f;
+  int best_c = 0;
+  for (int c0 = 0; c0 < hp.nc; c0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = sub; ch < chunks; ch += 16) {
+      float f[8];
+      load8<T>(fc + ch * 8, f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (c0 + j < hp.nc) ? L.bc[c0 + j] : 0.f;
-    for (int k = 0; k < L.cc; ++k) {
-      const float v = ldf(fc + k);
+      for (int j = 0; j < 4; ++j) {
+        if (c0 + j < hp.nc) {
+          float w[8];
+          load8<float>(L.wc + (size_t)(c0 + j) * L.cc + ch * 8, w);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (c0 + j < hp.nc) acc[j] = fmaf(v, L.wc[(c0 + j) * L.cc + k], acc[j]);
+          for (int e = 0; e < 8; ++e) acc[j] = fmaf(f[e], w[e], acc[j]);
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
       if (c0 + j < hp.nc) {
-        const float sc = 1.f / (1.f + expf(-acc[j]));
+        const float sc = 1.f / (1.f + expf(-(acc[j] + L.bc[c0 + j])));
         if (sc > best) { best = sc; best_c = c0 + j; }
       }
     }
   }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams hp, const NmsBuffers nb) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = blockIdx.y;
-  if (a >= hp.n_anchors) return;
-  const int l = find_level(hp, a);
-  const HeadLevel& L = hp.lv[l];
-  const int la = a - L.anchor_begin;
-  const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
-  float best;
-  int best_c;
-  anchor_cls<T>(hp, L, f, best, best_c);
-  if (best > hp.conf && ((hp.class_mask >> best_c) & 1ull)) {
+  if (valid && sub == 0 && best > hp.conf && ((hp.class_mask >> best_c) & 1ull)) {
     const int idx = atomicAdd(&nb.count[n], 1);
     if (idx < nb.cap) {
       const size_t o = (size_t)n * nb.cap + idx;
@@ -411,9 +425,15 @@ __global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams h
 // expectation per side, dist2bbox(xywh) * stride. Returns xywh in network pixels on every lane.
 template <typename T>
 __device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int la, int lane) {
+  // lane k holds box feature k (and k+64); the 64x cb mat-vec then takes each feature by shuffle and
+  // one coalesced 256-B line of the transposed weights [cb][64] per feature.
+  const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
+  const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
   float acc = L.bb[lane];
-  const float* wr = L.wb + lane;   // wb is stored transposed, [cb][64]: lanes read one 256-B line
-  for (int k = 0; k < L.cb; ++k) acc = fmaf(ldf(f + k), wr[(size_t)k * 64], acc);
+  const float* wr = L.wb + lane;
+  const int k0 = min(L.cb, 64);
+  for (int k = 0; k < k0; ++k) acc = fmaf(__shfl(f0, k, 64), wr[(size_t)k * 64], acc);
+  for (int k = 64; k < L.cb; ++k) acc = fmaf(__shfl(f1, k - 64, 64), wr[(size_t)k * 64], acc);
   // softmax over the 16 lanes of a side
   float m = acc;
 #pragma unroll
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, floa
 
 void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
   GTX_HIP(hipMemsetAsync(nb.count, 0, sizeof(int) * n, s));
-  dim3 grid(cdiv(hp.n_anchors, 256), n), block(256);
+  dim3 grid(cdiv(hp.n_anchors, 16), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(head_candidates_kernel<_Float16>, grid, block, 0, s, hp, nb);
   else hipLaunchKernelGGL(head_candidates_kernel<float>, grid, block, 0, s, hp, nb);
   GTX_HIP(hipGetLastError());
@@ -498,6 +518,9 @@ void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, bool lo
 }
 
 // ============================================================================ NMS
+constexpr int kSmallNms = 4096;    // candidates the single-workgroup path handles
+constexpr int kSmallKeep = 2048;   // max_det it handles
+
 // (1) rank: position of each candidate in (score desc, anchor asc) order = stable descending
 //     sort of the anchor-ordered candidate list, which is what torchvision.ops.nms applies to
 //     the boolean-mask-filtered predictions. O(n^2) counting, keys tiled through LDS.
@@ -506,8 +529,9 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int 
   __shared__ int s_an[256];
   const int n = blockIdx.y;
   const int cnt = min(nb.count[n], nb.cap);
+  if (cnt <= kSmallNms && nb.max_det <= kSmallKeep) return;   // nms_small_kernel did the image (sorted_n = 0)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) nb.sorted_n[n] = min(cnt, limit);  // also when cnt == 0
+  if (blockIdx.x == 0 && threadIdx.x == 0) nb.sorted_n[n] = min(cnt, limit);
   if (blockIdx.x * blockDim.x >= cnt) return;  // whole block idle
   const size_t base = (size_t)n * nb.cap;
   const bool act = i < cnt;
@@ -605,6 +629,7 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const NmsBuffers nb, 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  if (min(nb.count[n], nb.cap) <= kSmallNms && nb.max_det <= kSmallKeep) return;   // nms_small_kernel did the image
   const int cnt = nb.sorted_n[n];
   const int nblk = (cnt + 63) >> 6;
   const unsigned long long* mask = nb.mask + (size_t)n * nb.nms_cap * (nb.nms_cap >> 6);
@@ -676,19 +701,147 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const NmsBuffers nb, 
   }
 }
 
+// ---- small-n path: everything after the score gate in ONE workgroup per image -----------------
+// For n <= 4096 candidates (traffic scenes: a few hundred to ~2000): (1) stable rank by a bitonic
+// sort of 64-bit keys {score bits | inverted anchor | slot} in LDS, (2) boxes gathered into LDS in
+// rank order, (3) greedy NMS as the same in-order wave pipeline as nms_resolve_kernel, but with IoUs
+// computed on the fly against the list of kept boxes (also in LDS) instead of an n x n bit matrix,
+// (4) kept boxes written straight to their output slot. Larger n falls through to the general
+// rank / mask / resolve kernels (which exit immediately when this path applies).
+
+__device__ __forceinline__ bool iou_gt(const float4& a, float area_a, const float4& b, float thr) {
+  const float area_b = (b.z - b.x) * (b.w - b.y);
+  const float iw = fmaxf(0.f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+  const float ih = fmaxf(0.f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+  const float inter = iw * ih;
+  return inter / (area_a + area_b - inter) > thr;
+}
+
+__global__ __launch_bounds__(1024) void nms_small_kernel(const NmsBuffers nb, float thr, float cls_offset, float gain, float padx,
+                                                         float pady, float fw, float fh) {
+  __shared__ unsigned long long s_key[kSmallNms];
+  __shared__ float4 s_box[kSmallNms];
+  __shared__ float4 s_kbox[kSmallKeep];
+  __shared__ int s_nkeep, s_done;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  const int cnt = min(nb.count[n], nb.cap);
+  if (cnt > kSmallNms || nb.max_det > kSmallKeep) return;   // general path handles it
+  if (tid == 0) { nb.sorted_n[n] = 0; s_nkeep = 0; s_done = 0; }
+  const size_t base = (size_t)n * nb.cap;
+  int P = 64;
+  while (P < cnt) P <<= 1;
+  for (int i = tid; i < P; i += blockDim.x) {
+    unsigned long long k = 0ull;
+    if (i < cnt) {
+      const unsigned sb = __float_as_uint(nb.cand_score[base + i]);            // scores are positive: bits are monotone
+      k = ((unsigned long long)sb << 32) | ((unsigned long long)(0x7FFFFu - (unsigned)nb.cand_anchor[base + i]) << 12) | (unsigned)i;
+    }
+    s_key[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P / 2; t += blockDim.x) {
+        const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+        const bool desc = ((lo & k) == 0);
+        const unsigned long long a = s_key[lo], b = s_key[hi];
+        if ((a < b) == desc) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < cnt; i += blockDim.x) {
+    const int slot = (int)(s_key[i] & 0xFFFu);
+    float4 b = reinterpret_cast<const float4*>(nb.cand_box)[base + slot];
+    const float o = cls_offset * (float)nb.cand_cls[base + slot];
+    b.x += o; b.y += o; b.z += o; b.w += o;
+    s_box[i] = b;
+  }
+  __syncthreads();
+  volatile int* done = &s_done;
+  volatile int* nkeep = &s_nkeep;
+  const int nblk = (cnt + 63) >> 6;
+  float* rows = nb.out_rows + (size_t)n * nb.max_det * 6;
+  for (int b = wave; b < nblk; b += nwaves) {
+    const int i = b * 64 + lane;
+    const bool valid = i < cnt;
+    const float4 bi = valid ? s_box[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+    // overlaps inside the block (does not depend on earlier blocks: overlaps with their resolution)
+    unsigned long long d = 0ull;
+    const int jn = min(64, cnt - b * 64);
+    for (int j = 0; j < jn; ++j)
+      if (j < lane && valid && iou_gt(bi, ai, s_box[b * 64 + j], thr)) d |= 1ull << j;
+    // overlaps with boxes kept by earlier blocks, consumed as they are published
+    bool rem = false;
+    int checked = 0;
+    for (;;) {
+      const int dn = *done;
+      const int nk = *nkeep;
+      for (int j = checked; j < nk; ++j)
+        if (!rem && valid && iou_gt(bi, ai, s_kbox[j], thr)) rem = true;
+      checked = nk;
+      if (dn >= b) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned long long removed = __ballot(rem || !valid), kept = 0ull;
+    const unsigned long long me = 1ull << lane;
+    for (int round = 0; round < 64; ++round) {
+      const unsigned long long und = ~(kept | removed);
+      if (und == 0ull) break;
+      bool nk2 = false, nr = false;
+      if (und & me) {
+        if (d & kept) nr = true;
+        else if ((d & ~removed) == 0ull) nk2 = true;
+      }
+      kept |= __ballot(nk2);
+      removed |= __ballot(nr);
+    }
+    const int base_keep = checked;                 // == number kept by all earlier blocks
+    const int my_slot = base_keep + __popcll(kept & (me - 1ull));
+    if ((kept & me) && my_slot < nb.max_det) {
+      s_kbox[my_slot] = bi;
+      const int slot = (int)(s_key[i] & 0xFFFu);
+      float4 o = reinterpret_cast<const float4*>(nb.cand_box)[base + slot];
+      o.x = (o.x - padx) / gain; o.y = (o.y - pady) / gain;
+      o.z = (o.z - padx) / gain; o.w = (o.w - pady) / gain;
+      o.x = fminf(fmaxf(o.x, 0.f), fw); o.z = fminf(fmaxf(o.z, 0.f), fw);
+      o.y = fminf(fmaxf(o.y, 0.f), fh); o.w = fminf(fmaxf(o.w, 0.f), fh);
+      float* r = rows + (size_t)my_slot * 6;
+      r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = o.w;
+      r[4] = nb.cand_score[base + slot];
+      r[5] = (float)nb.cand_cls[base + slot];
+    }
+    __threadfence_block();
+    if (lane == 0) {
+      const int total = min(base_keep + __popcll(kept), nb.max_det);
+      *nkeep = total;
+      __threadfence_block();
+      *done = (total >= nb.max_det) ? nblk : b + 1;   // nothing beyond max_det can be output
+    }
+    if (*nkeep >= nb.max_det) break;
+  }
+  __syncthreads();
+  if (tid == 0) nb.out_n[n] = s_nkeep;
+}
+
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
                 const Letterbox& lb, hipStream_t s) {
   GTX_CHECK(nb.nms_cap <= kNmsWords * 64, "nms: capacity %d too large", nb.nms_cap);
   const int limit = std::min(max_nms, nb.nms_cap);
   const float cls_offset = agnostic ? 0.f : 7680.f;  // ultralytics max_wh
-  hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(nb.cap, 256), n), dim3(256), 0, s, nb, limit, cls_offset);
-  GTX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(256, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
-  GTX_HIP(hipGetLastError());
   // ultralytics scale_boxes: gain = min ratio, pad = round((net - src*gain)/2 - 0.1)
   const double gain = lb.gain;
   const float padx = (float)std::nearbyint((lb.net_w - lb.src_w * gain) / 2 - 0.1);
   const float pady = (float)std::nearbyint((lb.net_h - lb.src_h * gain) / 2 - 0.1);
+  hipLaunchKernelGGL(nms_small_kernel, dim3(n), dim3(1024), 0, s, nb, iou_thr, cls_offset, (float)gain, padx, pady,
+                     (float)lb.src_w, (float)lb.src_h);
+  GTX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(nb.cap, 256), n), dim3(256), 0, s, nb, limit, cls_offset);
+  GTX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(256, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
+  GTX_HIP(hipGetLastError());
   hipLaunchKernelGGL(nms_resolve_kernel, dim3(n), dim3(1024), 0, s, nb, (float)gain, padx, pady,
                      (float)lb.src_w, (float)lb.src_h);
   GTX_HIP(hipGetLastError());

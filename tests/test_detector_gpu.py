@@ -92,6 +92,36 @@ def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz):
     assert len(got) > 0, "test weights/frame should produce detections"
 
 
+def test_many_candidates_take_the_general_nms_path(gtx_ctx, weights):
+    """conf = 0.02 lets > 4096 anchors through: the single-workgroup NMS steps aside and the
+    general rank / bit-matrix / wave-pipeline kernels run; non-agnostic NMS adds the class offset.
+    Both must reproduce the oracle (torchvision order) exactly on the fp32 path."""
+    from geotrax_amd.detector import Detector
+    from oracle.yolov8_ref import YoloV8Ref, detect
+
+    frame = _frame(1, (640, 640))
+    ref_model = YoloV8Ref(weights)
+    probe = Detector(weights, (640, 640), imgsz=640, half=False, rect=False, conf=0.5, ctx=gtx_ctx)
+    probe.detect(frame)
+    top = np.sort(probe.raw_output()[:, 4:].max(1))[::-1]
+    probe.close()
+    conf_small = float(top[600])      # ~600 candidates: non-agnostic NMS on the single-workgroup path
+    for agnostic, conf in ((True, 0.02), (False, 0.02), (False, conf_small)):
+        det = Detector(weights, (640, 640), imgsz=640, half=False, rect=False, conf=conf, iou=0.6, max_det=300,
+                       classes=[0, 1, 3], agnostic_nms=agnostic, ctx=gtx_ctx)
+        got = det.detect(frame)
+        n_cand = int((det.raw_output()[:, 4:].max(1) > conf).sum())
+        assert (n_cand > 4096) == (conf < 0.1), n_cand
+        assert n_cand > 300
+        xyxy, cf, cls = detect(ref_model, frame, 640, False, conf, 0.6, [0, 1, 3], agnostic, 300)
+        assert len(got) == len(cf) > 10
+        np.testing.assert_array_equal(got.cls, cls)
+        np.testing.assert_allclose(got.conf, cf, atol=1e-5)
+        np.testing.assert_allclose(got.xyxy, xyxy, atol=1e-2)
+        assert set(np.unique(got.cls)) <= {0, 1, 3}
+        det.close()
+
+
 def test_detector_batch_equals_single(gtx_ctx, weights):
     from geotrax_amd.detector import Detector
 
