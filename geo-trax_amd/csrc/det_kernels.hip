@@ -230,8 +230,77 @@ __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ img, in
   }
 }
 
+typedef float floatx16_t __attribute__((ext_vector_type(16)));
+
+// fp16 stem on the matrix cores: implicit GEMM with K = 12 taps x 4 channels (RGB0; taps 9..11 and
+// channel 3 are zero weights), D[cout 32][pixel 32] += W[cout][k] X[k][pixel]. A wave takes 32
+// consecutive output pixels of a row; each lane gathers its B fragments straight from the NHWC4
+// image (two 8-byte pixels = 16 bytes = one k-step half), the weights stay in registers for all the
+// tiles a wave walks, the epilogue is bias + SiLU and 8-byte NHWC stores. No LDS.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restrict__ img, int h, int w,
+                                                        const _Float16* __restrict__ wpk /*[groups][3][64][8]*/,
+                                                        const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                        int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int n = blockIdx.y;
+  const _Float16* base = img + (size_t)n * h * w * 4;
+  for (int g = 0; g < groups; ++g) {
+    half8 wf[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wf[s] = *reinterpret_cast<const half8*>(wpk + (((size_t)g * 3 + s) * 64 + lane) * 8);
+    for (long t = wave; t < n_tiles; t += nwaves) {
+      const int oy = (int)(t / tiles_per_row), ox = (int)(t % tiles_per_row) * 32 + r;
+      floatx16_t acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        half8 xf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tap = 2 * (2 * s + hh) + q;
+          if (tap < 9) {
+            const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+            if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
+              const half4 px = *reinterpret_cast<const half4*>(base + ((size_t)iy * w + ix) * 4);
+              xf[4 * q] = px[0]; xf[4 * q + 1] = px[1]; xf[4 * q + 2] = px[2]; xf[4 * q + 3] = px[3];
+            }
+          }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], xf, acc, 0, 0, 0);
+      }
+      if (ox < wo) {
+        _Float16* o = out + (((size_t)n * ho + oy) * wo + ox) * c0 + g * 32;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 8 * g4 + 4 * hh;
+          if (g * 32 + cl < c0) {
+            half4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (_Float16)silu_f(acc[4 * g4 + i] + bias[g * 32 + cl + i]);
+            *reinterpret_cast<half4*>(o + cl) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
-                 int c0, void* out, int ho, int wo, hipStream_t s) {
+                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s) {
+  if (dtype == DT_F16 && wpk_f16) {
+    const int tiles_per_row = cdiv(wo, 32);
+    const long n_tiles = (long)tiles_per_row * ho;
+    const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(blocks, n), dim3(256), 0, s, (const _Float16*)img, h, w, (const _Float16*)wpk_f16,
+                       bias, (_Float16*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
+    GTX_HIP(hipGetLastError());
+    return;
+  }
   dim3 grid(cdiv(wo, 256), ho, n), block(256);
 #define GTX_STEM(C)                                                                              \
   if (c0 == C) {                                                                                 \
@@ -249,70 +318,101 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
   fail(-3, "stem: unsupported channel count %d", c0);
 }
 
+// Packs the stem weights for stem_mfma_kernel: [group of 32 couts][k-step 3][lane 64][8 halves],
+// lane (r = cout in group, hh) holds taps 2*(2s+hh) and 2*(2s+hh)+1, 4 channels each (RGB0).
+std::vector<uint16_t> pack_stem_weights_f16(const float* w27 /*[27][c0], (tap*3+ch) major*/, int c0) {
+  const int groups = cdiv(c0, 32);
+  std::vector<uint16_t> out((size_t)groups * 3 * 64 * 8, 0);
+  for (int g = 0; g < groups; ++g)
+    for (int s = 0; s < 3; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, hh = lane >> 5, co = g * 32 + r;
+        for (int q = 0; q < 2; ++q) {
+          const int tap = 2 * (2 * s + hh) + q;
+          for (int ch = 0; ch < 4; ++ch) {
+            float v = 0.f;
+            if (tap < 9 && ch < 3 && co < c0) v = w27[(size_t)(tap * 3 + ch) * c0 + co];
+            const _Float16 hv = (_Float16)v;
+            uint16_t bits;
+            memcpy(&bits, &hv, 2);
+            out[(((size_t)g * 3 + s) * 64 + lane) * 8 + 4 * q + ch] = bits;
+          }
+        }
+      }
+  return out;
+}
+
 // ============================================================================ SPPF pools
 template <typename T> struct Vec16;  // 16-byte vector of T
 template <> struct Vec16<_Float16> { using type = half8; static constexpr int N = 8; };
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 
+__device__ __forceinline__ half8 vmax(const half8& a, const half8& b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ float4 vmax(const float4& a, const float4& b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ half8 vneg_inf(half8) {
+  half8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (_Float16)(-INFINITY);
+  return v;
+}
+__device__ __forceinline__ float4 vneg_inf(float4) { return make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+
+// The three cascaded 5x5/s1/p2 max-pools of SPPF in one pass: a block takes a 16x16 spatial tile of
+// one 16-byte channel vector, stages the tile plus a 6-pixel halo in LDS (out-of-image = -inf,
+// which is what the framework's padding does at every stage) and runs the three pools as separable
+// row/column passes on shrinking regions (28 -> 24 -> 20 -> 16), storing the 5x5, 9x9 and 13x13
+// results of the centre.
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h, int w, int c) {
-  constexpr int VN = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N, TS = 16, R = 6, P = TS + 2 * R;   // 28
+  __shared__ V s_a[P * P], s_b[P * P];
   const int vecs = c / VN;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)gridDim.y * h * w * vecs;  // gridDim.y = batch handled via blockIdx.y
-  (void)total;
-  const int n = blockIdx.y;
-  if (gid >= (long)h * w * vecs) return;
-  const int v = (int)(gid % vecs);
-  const int pix = (int)(gid / vecs);
-  const int py = pix / w, px = pix % w;
-  const int cs = 4 * c;
-  T* img = x + (size_t)n * h * w * cs;
-  float m5[VN], m9[VN], m13[VN];
-#pragma unroll
-  for (int i = 0; i < VN; ++i) m5[i] = m9[i] = m13[i] = -INFINITY;
-  for (int dy = -6; dy <= 6; ++dy) {
-    const int yy = py + dy;
-    if (yy < 0 || yy >= h) continue;
-    for (int dx = -6; dx <= 6; ++dx) {
-      const int xx = px + dx;
-      if (xx < 0 || xx >= w) continue;
-      const T* src = img + ((size_t)yy * w + xx) * cs + v * VN;
-      float f[VN];
-      if constexpr (VN == 8) {
-        half8 hv = *reinterpret_cast<const half8*>(src);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = (float)hv[i];
-      } else {
-        float4 fv = *reinterpret_cast<const float4*>(src);
-        f[0] = fv.x; f[1] = fv.y; f[2] = fv.z; f[3] = fv.w;
-      }
-      const int ad = max(abs(dy), abs(dx));
-#pragma unroll
-      for (int i = 0; i < VN; ++i) {
-        m13[i] = fmaxf(m13[i], f[i]);
-        if (ad <= 4) m9[i] = fmaxf(m9[i], f[i]);
-        if (ad <= 2) m5[i] = fmaxf(m5[i], f[i]);
-      }
-    }
+  const int tiles_x = (w + TS - 1) / TS;
+  const int v = blockIdx.x % vecs, tile = blockIdx.x / vecs;
+  const int tx0 = (tile % tiles_x) * TS, ty0 = (tile / tiles_x) * TS;
+  const int n = blockIdx.y, cs = 4 * c;
+  T* img = x + (size_t)n * h * w * cs + v * VN;
+  const V ninf = vneg_inf(V());
+  for (int i = threadIdx.x; i < P * P; i += 256) {
+    const int yy = ty0 - R + i / P, xx = tx0 - R + i % P;
+    s_a[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? *reinterpret_cast<const V*>(img + ((size_t)yy * w + xx) * cs) : ninf;
   }
-  T* dst = img + ((size_t)py * w + px) * cs + v * VN;
-  if constexpr (VN == 8) {
-    store8<T>(dst + c, m5);
-    store8<T>(dst + 2 * c, m9);
-    store8<T>(dst + 3 * c, m13);
-  } else {
-    *reinterpret_cast<float4*>(dst + c) = make_float4(m5[0], m5[1], m5[2], m5[3]);
-    *reinterpret_cast<float4*>(dst + 2 * c) = make_float4(m9[0], m9[1], m9[2], m9[3]);
-    *reinterpret_cast<float4*>(dst + 3 * c) = make_float4(m13[0], m13[1], m13[2], m13[3]);
+  __syncthreads();
+  int lo = 0;   // valid region of s_a is [lo, P-lo) in both axes
+#pragma unroll 1
+  for (int stage = 0; stage < 3; ++stage) {
+    const int in_n = P - 2 * lo, out_n = in_n - 4;
+    // rows: s_b[y][x'] = max over 5 horizontal neighbours, for all in_n rows and out_n columns
+    for (int i = threadIdx.x; i < in_n * out_n; i += 256) {
+      const int y = lo + i / out_n, xo = lo + 2 + i % out_n;
+      const V* r = s_a + y * P + xo;
+      s_b[y * P + xo] = vmax(vmax(vmax(r[-2], r[-1]), vmax(r[0], r[1])), r[2]);
+    }
+    __syncthreads();
+    // columns, written back to s_a; positions outside the image become -inf again (padding of the next stage)
+    for (int i = threadIdx.x; i < out_n * out_n; i += 256) {
+      const int yo = lo + 2 + i / out_n, xo = lo + 2 + i % out_n;
+      const V* q = s_b + yo * P + xo;
+      V m = vmax(vmax(vmax(q[-2 * P], q[-P]), vmax(q[0], q[P])), q[2 * P]);
+      const int yy = ty0 - R + yo, xx = tx0 - R + xo;
+      const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      s_a[yo * P + xo] = inside ? m : ninf;
+      if (inside && yo >= R && yo < R + TS && xo >= R && xo < R + TS)
+        *reinterpret_cast<V*>(img + ((size_t)yy * w + xx) * cs + (stage + 1) * c) = m;
+    }
+    __syncthreads();
+    lo += 2;
   }
 }
 
 void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s) {
   const int vn = dtype == DT_F16 ? 8 : 4;
   GTX_CHECK(c % vn == 0, "sppf: channels %d not a multiple of %d", c, vn);
-  const long work = (long)h * w * (c / vn);
-  dim3 grid((unsigned)((work + 255) / 256), n), block(256);
+  const int tiles = cdiv(w, 16) * cdiv(h, 16);
+  dim3 grid((unsigned)(tiles * (c / vn)), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, grid, block, 0, s, (_Float16*)x, h, w, c);
   else hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, block, 0, s, (float*)x, h, w, c);
   GTX_HIP(hipGetLastError());
@@ -421,19 +521,9 @@ __global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams h
   }
 }
 
-// Box branch for one anchor by one wave: 64 box logits (lane = side*16 + bin), DFL softmax
+// DFL tail shared by the decode kernels: lane = side*16 + bin holds one box logit; softmax
 // expectation per side, dist2bbox(xywh) * stride. Returns xywh in network pixels on every lane.
-template <typename T>
-__device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int la, int lane) {
-  // lane k holds box feature k (and k+64); the 64x cb mat-vec then takes each feature by shuffle and
-  // one coalesced 256-B line of the transposed weights [cb][64] per feature.
-  const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
-  const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
-  float acc = L.bb[lane];
-  const float* wr = L.wb + lane;
-  const int k0 = min(L.cb, 64);
-  for (int k = 0; k < k0; ++k) acc = fmaf(__shfl(f0, k, 64), wr[(size_t)k * 64], acc);
-  for (int k = 64; k < L.cb; ++k) acc = fmaf(__shfl(f1, k - 64, 64), wr[(size_t)k * 64], acc);
+__device__ __forceinline__ float4 dfl_box(const HeadLevel& L, float acc, int la, int lane) {
   // softmax over the 16 lanes of a side
   float m = acc;
 #pragma unroll
@@ -453,14 +543,37 @@ __device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int
                      (y2 - y1) * L.stride);
 }
 
-// One wave per candidate.
+// Box branch for one anchor by one wave: 64 box logits (lane = side*16 + bin), DFL softmax
+// expectation per side, dist2bbox(xywh) * stride. Returns xywh in network pixels on every lane.
+template <typename T>
+__device__ __forceinline__ float4 anchor_box(const HeadLevel& L, const T* f, int la, int lane) {
+  // lane k holds box feature k (and k+64); the 64x cb mat-vec then takes each feature by shuffle and
+  // one coalesced 256-B line of the transposed weights [cb][64] per feature.
+  const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
+  const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
+  float acc = L.bb[lane];
+  const float* wr = L.wb + lane;
+  const int k0 = min(L.cb, 64);
+  for (int k = 0; k < k0; ++k) acc = fmaf(__shfl(f0, k, 64), wr[(size_t)k * 64], acc);
+  for (int k = 64; k < L.cb; ++k) acc = fmaf(__shfl(f1, k - 64, 64), wr[(size_t)k * 64], acc);
+  return dfl_box(L, acc, la, lane);
+}
+
+// One wave per candidate; the transposed box weights of every level ([cb][64] each) are staged in
+// LDS once per block, so the 64 x cb mat-vec reads one conflict-free LDS row per feature.
 template <typename T>
 __global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, const NmsBuffers nb) {
+  extern __shared__ __attribute__((aligned(16))) float s_wb[];   // [levels][cb][64]
   const int n = blockIdx.y;
-  const int lane = threadIdx.x & 63;
+  const int cnt = min(nb.count[n], nb.cap);
   const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int cnt = min(nb.count[n], nb.cap);
+  if ((int)(blockIdx.x * (blockDim.x >> 6)) >= cnt) return;      // no candidate for this block
+  const int cbmax = hp.lv[0].cb;
+  for (int l = 0; l < hp.n_levels; ++l)
+    for (int i = threadIdx.x; i < hp.lv[l].cb * 64; i += blockDim.x) s_wb[l * cbmax * 64 + i] = hp.lv[l].wb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
   for (int i = wave_g; i < cnt; i += nwaves) {
     const size_t o = (size_t)n * nb.cap + i;
     const int a = nb.cand_anchor[o];
@@ -468,7 +581,14 @@ __global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, co
     const HeadLevel& L = hp.lv[l];
     const int la = a - L.anchor_begin;
     const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
-    const float4 b = anchor_box<T>(L, f, la, lane);
+    const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
+    const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
+    float acc = L.bb[lane];
+    const float* wr = s_wb + l * cbmax * 64 + lane;
+    const int k0 = min(L.cb, 64);
+    for (int k = 0; k < k0; ++k) acc = fmaf(__shfl(f0, k, 64), wr[k * 64], acc);
+    for (int k = 64; k < L.cb; ++k) acc = fmaf(__shfl(f1, k - 64, 64), wr[k * 64], acc);
+    const float4 b = dfl_box(L, acc, la, lane);
     if (lane == 0) {
       const float hw = b.z / 2.f, hh = b.w / 2.f;   // xywh2xyxy
       reinterpret_cast<float4*>(nb.cand_box)[o] = make_float4(b.x - hw, b.y - hh, b.x + hw, b.y + hh);
@@ -505,8 +625,15 @@ void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuf
   else hipLaunchKernelGGL(head_candidates_kernel<float>, grid, block, 0, s, hp, nb);
   GTX_HIP(hipGetLastError());
   dim3 grid2(64, n);
-  if (dtype == DT_F16) hipLaunchKernelGGL(head_boxes_kernel<_Float16>, grid2, block, 0, s, hp, nb);
-  else hipLaunchKernelGGL(head_boxes_kernel<float>, grid2, block, 0, s, hp, nb);
+  const size_t lds = (size_t)hp.n_levels * hp.lv[0].cb * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_boxes_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 64 * 4));
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_boxes_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 64 * 4));
+    attr_set = true;
+  }
+  if (dtype == DT_F16) hipLaunchKernelGGL(head_boxes_kernel<_Float16>, grid2, block, lds, s, hp, nb);
+  else hipLaunchKernelGGL(head_boxes_kernel<float>, grid2, block, lds, s, hp, nb);
   GTX_HIP(hipGetLastError());
 }
 
@@ -710,11 +837,12 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const NmsBuffers nb, 
 // rank / mask / resolve kernels (which exit immediately when this path applies).
 
 __device__ __forceinline__ bool iou_gt(const float4& a, float area_a, const float4& b, float thr) {
+  const float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  const float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  if (!(iw > 0.f && ih > 0.f)) return false;        // disjoint: IoU is 0 (or NaN), never > thr
   const float area_b = (b.z - b.x) * (b.w - b.y);
-  const float iw = fmaxf(0.f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
-  const float ih = fmaxf(0.f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
   const float inter = iw * ih;
-  return inter / (area_a + area_b - inter) > thr;
+  return inter / (area_a + area_b - inter) > thr;   // torchvision's fp32 sequence
 }
 
 __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsBuffers nb, float thr, float cls_offset, float gain, float padx,

@@ -2,6 +2,8 @@
 // SPPF pooling, nearest upsample, head decode (final 1x1 convs + DFL + sigmoid + threshold +
 // compaction) and NMS. gfx950 only. Host launch wrappers; kernels live in det_kernels.hip.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 #include "conv_igemm.hpp"
 
@@ -24,8 +26,10 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
 
 // Stem: Conv(3, c0, k=3, s=2) + bias + SiLU on the RGB0 image. w: [27][c0] fp32 (tap-major:
 // (ky*3+kx)*3 + c), bias [c0]. c0 must be a multiple of 16 and <= 64.
+// wpk_f16: weights packed by pack_stem_weights_f16 (fp16 MFMA path) or null (VALU path).
 void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
-                 int c0, void* out, int ho, int wo, hipStream_t s);
+                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s);
+std::vector<uint16_t> pack_stem_weights_f16(const float* w27, int c0);
 
 // SPPF pools: channels [0,c) -> 5x5 / 9x9 / 13x13 clipped-window maxima at [c,2c) [2c,3c) [3c,4c).
 void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s);

@@ -175,6 +175,12 @@ void Detector::build_graph() {
     op.out = a0;
     op.w27 = dw;
     op.bias = db;
+    if (dtype_ == DT_F16) {
+      const std::vector<uint16_t> pk = pack_stem_weights_f16(w27.data(), c0);
+      void* dp = alloc(pk.size() * 2);
+      GTX_HIP(hipMemcpy(dp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+      op.wpk = dp;
+    }
     ops_.push_back(op);
     layer_views_["model.0.conv"] = a0;
   }
@@ -308,6 +314,8 @@ void Detector::build_graph() {
     };
     const HostTensor &wb = tensor(b2 + ".2.weight"), &wc = tensor(b3 + ".2.weight");
     GTX_CHECK(wb.shape[0] == 64 && (int)wb.shape[1] == cb, "Detect box head must have 4*16 outputs");
+    GTX_CHECK(cb <= 128 && cc % 8 == 0, "Detect head widths cb=%d cc=%d are outside what the decode kernels support", cb, cc);
+    GTX_CHECK(l == 0 || cb == head_.lv[0].cb, "Detect box branch width differs between levels");
     GTX_CHECK((int)wc.shape[0] == cfg_.nc && (int)wc.shape[1] == cc, "Detect cls head has %d outputs, nc=%d", (int)wc.shape[0], cfg_.nc);
     {
       std::vector<float> wbt((size_t)cb * 64);  // [cb][64]: the decode wave reads one output per lane
@@ -393,7 +401,7 @@ void Detector::run_op(const Op& op, int nb, hipStream_t s) {
   switch (op.kind) {
     case Op::CONV: conv_launch(op.grp, op.cfg, s); break;
     case Op::STEM:
-      launch_stem(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.out.c, op.out.ptr, op.out.h, op.out.w, s);
+      launch_stem(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.wpk, op.out.c, op.out.ptr, op.out.h, op.out.w, s);
       break;
     case Op::POOL: launch_sppf_pool(dtype_, op.out.ptr, nb, op.in.h, op.in.w, op.in.c, s); break;
     case Op::UPSAMPLE:

@@ -52,6 +52,7 @@ struct Op {
   View in, out;
   const float* w27 = nullptr;
   const float* bias = nullptr;
+  const void* wpk = nullptr;   // fp16 MFMA stem weights
   double flops = 0;      // algorithmic 2*MAC
   double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
 };

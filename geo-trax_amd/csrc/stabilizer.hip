@@ -43,7 +43,7 @@ struct Level {
   int n_want;       // keypoints to keep
   int kp_off;       // first output keypoint slot
   float scale;      // level pixel -> level-0 pixel
-  int tiles_x;      // 64x4-pixel tiles across
+  int tiles_x;      // 64x16-pixel tiles across
   int tile_begin;   // first flattened tile of this level
 };
 
@@ -52,18 +52,6 @@ struct Levels {
   int n;
   int n_tiles;      // over all levels
 };
-
-// Flattened tile id -> (level, x, y) of this thread; 256 threads cover a 64x4 pixel tile.
-__device__ __forceinline__ int tile_coords(const Levels& L, int tile, int tid, int& x, int& y) {
-  int li = 0;
-#pragma unroll
-  for (int i = 1; i < kPyrLevels; ++i)
-    if (i < L.n && tile >= L.l[i].tile_begin) li = i;
-  const int t = tile - L.l[li].tile_begin;
-  x = (t % L.l[li].tiles_x) * 64 + (tid & 63);
-  y = (t / L.l[li].tiles_x) * 4 + (tid >> 6);
-  return li;
-}
 
 // ------------------------------------------------------------------ gray / pyramid
 __device__ __forceinline__ int bgr2gray_u8(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14; }
@@ -108,49 +96,39 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
 __constant__ int c_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, {3, 1}, {2, 2}, {1, 3},
                                     {0, 3}, {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
 
-// score = max over the 16 arcs of 9 contiguous circle pixels of min(I_i - p) (bright) or
+// FAST-9/16 score: max over the 16 arcs of 9 contiguous circle pixels of min(I_i - p) (bright) or
 // min(p - I_i) (dark); the pixel is a corner at threshold t iff score > t.
 // Any arc of 9 contains at least two of the four compass pixels (0, 4, 8, 12), so a pixel with
 // fewer than two compass pixels beyond the threshold on one side cannot be a corner: that test
 // rejects most of the image after 5 loads. The arc minima are built by doubling (1,2,4,8,+1).
-__global__ __launch_bounds__(256) void fast_score_kernel(uint8_t* __restrict__ score, const Levels L, int thr) {
-  int x, y;
-  const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
-  const Level lv = L.l[li];
-  if (x >= lv.w || y >= lv.h) return;
-  uint8_t out = 0;
-  if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) {
-    const uint8_t* c = lv.img + (size_t)y * lv.w + x;
-    const int p = c[0];
-    const int d0 = (int)c[-3 * lv.w] - p, d4 = (int)c[3] - p, d8 = (int)c[3 * lv.w] - p, d12 = (int)c[-3] - p;
-    const int nb = (d0 > thr) + (d4 > thr) + (d8 > thr) + (d12 > thr);
-    const int nd = (d0 < -thr) + (d4 < -thr) + (d8 < -thr) + (d12 < -thr);
-    if (nb >= 2 || nd >= 2) {
-      int d[16];
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int w, int thr) {
+  const int p = c[0];
+  const int d0 = (int)c[-3 * w] - p, d4 = (int)c[3] - p, d8 = (int)c[3 * w] - p, d12 = (int)c[-3] - p;
+  const int nb = (d0 > thr) + (d4 > thr) + (d8 > thr) + (d12 > thr);
+  const int nd = (d0 < -thr) + (d4 < -thr) + (d8 < -thr) + (d12 < -thr);
+  if (nb < 2 && nd < 2) return 0;
+  int d[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) d[i] = (int)c[c_circle[i][1] * lv.w + c_circle[i][0]] - p;
-      int lo[16], hi[16];   // running min / max over windows of length 1,2,4,8 starting at k
+  for (int i = 0; i < 16; ++i) d[i] = (int)c[c_circle[i][1] * w + c_circle[i][0]] - p;
+  int lo[16], hi[16];   // running min / max over windows of length 1,2,4,8 starting at k
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { lo[k] = d[k]; hi[k] = d[k]; }
+  for (int k = 0; k < 16; ++k) { lo[k] = d[k]; hi[k] = d[k]; }
 #pragma unroll
-      for (int step = 1; step <= 4; step <<= 1) {
-        int l2[16], h2[16];
+  for (int step = 1; step <= 4; step <<= 1) {
+    int l2[16], h2[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { l2[k] = min(lo[k], lo[(k + step) & 15]); h2[k] = max(hi[k], hi[(k + step) & 15]); }
+    for (int k = 0; k < 16; ++k) { l2[k] = min(lo[k], lo[(k + step) & 15]); h2[k] = max(hi[k], hi[(k + step) & 15]); }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { lo[k] = l2[k]; hi[k] = h2[k]; }
-      }
-      int best = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int mb = min(lo[k], d[(k + 8) & 15]);       // min over 9 -> bright arc strength
-        const int md = -max(hi[k], d[(k + 8) & 15]);      // min over 9 of (p - I) -> dark arc strength
-        best = max(best, max(mb, md));
-      }
-      if (best > thr) out = (uint8_t)min(best, 255);
-    }
+    for (int k = 0; k < 16; ++k) { lo[k] = l2[k]; hi[k] = h2[k]; }
   }
-  score[lv.off + (size_t)y * lv.w + x] = out;
+  int best = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int mb = min(lo[k], d[(k + 8) & 15]);       // min over 9 -> bright arc strength
+    const int md = -max(hi[k], d[(k + 8) & 15]);      // min over 9 of (p - I) -> dark arc strength
+    best = max(best, max(mb, md));
+  }
+  return best > thr ? min(best, 255) : 0;
 }
 
 struct Cand {
@@ -170,43 +148,60 @@ __global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* __restrict__ m
     for (int x = threadIdx.x & 63; x < rw; x += 64) mask[(size_t)y * w + r.x + x] = 0;
 }
 
-// 3x3 non-maximum suppression on the score image (strictly greater than all 8 neighbours) and
-// foreground test. Survivors are appended to the level's candidate list (order is irrelevant: the
-// selection is by value) and counted in the level's 256-bin FAST-score histogram.
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ score, const uint8_t* __restrict__ mask,
-                                                       int w0, int h0, const Levels L, Cand* __restrict__ cand,
-                                                       int* __restrict__ cand_n, int* __restrict__ score_hist) {
-  int x, y;
-  const int li = tile_coords(L, blockIdx.x, threadIdx.x, x, y);
+// FAST score + 3x3 non-maximum suppression + foreground test in one pass: a block scores its
+// 64x16 tile plus a 1-pixel ring into LDS (the score image never exists in memory), keeps the
+// pixels whose score is strictly greater than all 8 neighbours and whose level-0 position is not
+// masked, appends them to the level's candidate list (order is irrelevant: the selection is by
+// value) and counts them in the level's 256-bin FAST-score histogram.
+constexpr int kTileW = 64, kTileH = 16;
+__global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restrict__ mask, int w0, int h0, const Levels L, int thr,
+                                                          Cand* __restrict__ cand, int* __restrict__ cand_n, int* __restrict__ score_hist) {
+  __shared__ uint8_t s_sc[(kTileH + 2) * (kTileW + 2)];
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < kPyrLevels; ++i)
+    if (i < L.n && (int)blockIdx.x >= L.l[i].tile_begin) li = i;
   const Level lv = L.l[li];
-  if (x < kBorder || x >= lv.w - kBorder || y < kBorder || y >= lv.h - kBorder) return;
-  const uint8_t* sc = score + lv.off;
-  const int s = sc[(size_t)y * lv.w + x];
-  if (s == 0) return;
-  const uint8_t* r0 = sc + (size_t)(y - 1) * lv.w + x;
-  const uint8_t* r1 = r0 + lv.w;
-  const uint8_t* r2 = r1 + lv.w;
-  if (!(s > r0[-1] && s > r0[0] && s > r0[1] && s > r1[-1] && s > r1[1] && s > r2[-1] && s > r2[0] && s > r2[1])) return;
-  if (mask) {
-    const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
-    if (mask[(size_t)y0 * w0 + x0] == 0) return;
+  const int t = blockIdx.x - lv.tile_begin;
+  const int tx0 = (t % lv.tiles_x) * kTileW, ty0 = (t / lv.tiles_x) * kTileH;
+  for (int i = threadIdx.x; i < (kTileH + 2) * (kTileW + 2); i += 256) {
+    const int x = tx0 - 1 + i % (kTileW + 2), y = ty0 - 1 + i / (kTileW + 2);
+    int sc = 0;
+    if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) sc = fast_score_at(lv.img + (size_t)y * lv.w + x, lv.w, thr);
+    s_sc[i] = (uint8_t)sc;
   }
-  const int slot = atomicAdd(&cand_n[li], 1);
-  if (slot < lv.cand_cap) {
-    Cand cd;
-    cd.key = 0;
-    cd.pix = y * lv.w + x;
-    cd.score = s;
-    cand[lv.cand_off + slot] = cd;
-    atomicAdd(&score_hist[li * 256 + s], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) {
+    const int lx = i % kTileW, ly = i / kTileW;
+    const uint8_t* c = s_sc + (ly + 1) * (kTileW + 2) + lx + 1;
+    const int sv = c[0];
+    if (sv == 0) continue;
+    constexpr int S = kTileW + 2;
+    if (!(sv > c[-S - 1] && sv > c[-S] && sv > c[-S + 1] && sv > c[-1] && sv > c[1] && sv > c[S - 1] && sv > c[S] && sv > c[S + 1])) continue;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (mask) {
+      const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
+      if (mask[(size_t)y0 * w0 + x0] == 0) continue;
+    }
+    const int slot = atomicAdd(&cand_n[li], 1);
+    if (slot < lv.cand_cap) {
+      Cand cd;
+      cd.key = 0;
+      cd.pix = y * lv.w + x;
+      cd.score = sv;
+      cand[lv.cand_off + slot] = cd;
+      atomicAdd(&score_hist[li * 256 + sv], 1);
+    }
   }
 }
 
 // Stage 1 of the selection, as OpenCV's ORB does it: per level keep the 2*n_want candidates with
 // the best FAST score (all candidates tied with the last one included), i.e. those with
 // score >= cutoff where cutoff is read off the level's score histogram. Stage 2 input: the Harris
-// response of every kept candidate -- lanes 0..48 take one pixel of the 7x7 block each (3x3 Sobel),
-// the three sums are reduced over the wave in exact integers -- appended to the eligible list.
+// response of every kept candidate (7x7 block of 3x3 Sobel derivatives, exact integers), appended
+// to the eligible list. One thread per candidate: the 9x9 neighbourhood streams through a 3-row
+// register window, so a candidate costs 81 byte loads and ~600 integer ops with no cross-lane
+// traffic, and thousands of candidates are in flight at once.
 __global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand* __restrict__ cand, const int* __restrict__ cand_n,
                                                      const int* __restrict__ score_hist, Cand* __restrict__ elig,
                                                      int* __restrict__ elig_n) {
@@ -221,37 +216,39 @@ __global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand*
     s_cut[li] = cut;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
   for (int li = 0; li < L.n; ++li) {
     const Level lv = L.l[li];
     const int n = min(cand_n[li], lv.cand_cap);
     const int cut = s_cut[li];
-    for (int i = wave; i < n; i += nwaves) {
-      const Cand cd = cand[lv.cand_off + i];
+    for (int i = gtid; i < n; i += nthreads) {
+      Cand cd = cand[lv.cand_off + i];
       if (cd.score < cut) continue;
       const int x = cd.pix % lv.w, y = cd.pix / lv.w;
-      long a = 0, b = 0, c = 0;
-      if (lane < 49) {
-        const uint8_t* p1 = lv.img + (size_t)(y + lane / 7 - 3) * lv.w + x + lane % 7 - 3;
-        const uint8_t* p0 = p1 - lv.w;
-        const uint8_t* p2 = p1 + lv.w;
-        const int ix = (p0[1] + 2 * p1[1] + p2[1]) - (p0[-1] + 2 * p1[-1] + p2[-1]);
-        const int iy = (p2[-1] + 2 * p2[0] + p2[1]) - (p0[-1] + 2 * p0[0] + p0[1]);
-        a = ix * ix; b = iy * iy; c = ix * iy;
-      }
+      const uint8_t* base = lv.img + (size_t)(y - 4) * lv.w + x - 4;
+      int r0[9], r1[9], r2[9];
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-        c += __shfl_xor(c, o, 64);
+      for (int k = 0; k < 9; ++k) { r0[k] = base[k]; r1[k] = base[lv.w + k]; }
+      long a = 0, b = 0, c = 0;
+#pragma unroll
+      for (int row = 2; row < 9; ++row) {
+        const uint8_t* rp = base + (size_t)row * lv.w;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r2[k] = rp[k];
+        int sa = 0, sb = 0, sc = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+          const int ix = (r0[k + 1] + 2 * r1[k + 1] + r2[k + 1]) - (r0[k - 1] + 2 * r1[k - 1] + r2[k - 1]);
+          const int iy = (r2[k - 1] + 2 * r2[k] + r2[k + 1]) - (r0[k - 1] + 2 * r0[k] + r0[k + 1]);
+          sa += ix * ix; sb += iy * iy; sc += ix * iy;
+        }
+        a += sa; b += sb; c += sc;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
       }
-      if (lane == 0) {
-        Cand out = cd;
-        out.key = 25 * (a * b - c * c) - (a + b) * (a + b);
-        const int slot = atomicAdd(&elig_n[li], 1);
-        if (slot < lv.cand_cap) elig[lv.cand_off + slot] = out;
-      }
+      cd.key = 25 * (a * b - c * c) - (a + b) * (a + b);
+      const int slot = atomicAdd(&elig_n[li], 1);
+      if (slot < lv.cand_cap) elig[lv.cand_off + slot] = cd;
     }
   }
 }
@@ -269,6 +266,60 @@ struct KeyPoint {
 
 __device__ __forceinline__ unsigned long long flip_key(long k) { return (unsigned long long)k ^ 0x8000000000000000ull; }
 
+constexpr int kSortCap = 8192;   // eligible candidates the in-LDS sort handles (more: radix-select path)
+
+// Stage 2 of the selection: the n_want best Harris keys of the eligible set, ordered by
+// (key desc, pix asc). Usual case (n <= 8192): one bitonic sort of {key, pix} pairs in LDS.
+__global__ __launch_bounds__(1024) void select_sort_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
+                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_raw);        // [kSortCap]
+  int* s_pix = reinterpret_cast<int*>(s_raw + sizeof(unsigned long long) * kSortCap);  // [kSortCap]
+  const int li = blockIdx.x;
+  const Level lv = L.l[li];
+  const int tid = threadIdx.x;
+  const int n = min(cand_n[li], lv.cand_cap);
+  if (n > kSortCap) return;                       // select_topn_kernel takes this level
+  const int want = min(lv.n_want, n);
+  if (want == 0) {
+    if (tid == 0) kp_n[li] = 0;
+    return;
+  }
+  int P = 64;
+  while (P < n) P <<= 1;
+  const Cand* c = cand + lv.cand_off;
+  for (int i = tid; i < P; i += blockDim.x) {
+    s_key[i] = i < n ? flip_key(c[i].key) : 0ull;
+    s_pix[i] = i < n ? c[i].pix : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P / 2; t += blockDim.x) {
+        const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+        const bool first_block = ((lo & k) == 0);  // this pair sorts "best first"
+        const unsigned long long ka = s_key[lo], kb = s_key[hi];
+        const int pa = s_pix[lo], pb = s_pix[hi];
+        const bool a_before_b = ka > kb || (ka == kb && pa < pb);
+        if (a_before_b != first_block) { s_key[lo] = kb; s_key[hi] = ka; s_pix[lo] = pb; s_pix[hi] = pa; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < want; i += blockDim.x) {
+    KeyPoint kp;
+    kp.x = s_pix[i] % lv.w;
+    kp.y = s_pix[i] / lv.w;
+    kp.level = li;
+    kp.bin = 0;
+    kps[lv.kp_off + i] = kp;
+  }
+  if (tid == 0) kp_n[li] = want;
+}
+
+// General case (more than kSortCap eligible candidates on a level): 8-pass MSB radix select on the
+// (sign-flipped) 64-bit key finds the key of the n-th best candidate; candidates above it are kept,
+// ties on the boundary key are broken by the smaller pixel index; the kept set is then ordered by
+// (key desc, pix asc) with a counting rank.
 __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
                                                            const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
   __shared__ int hist[256];
@@ -280,6 +331,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restric
   const Level lv = L.l[li];
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = min(cand_n[li], lv.cand_cap);
+  if (n <= kSortCap) return;                      // select_sort_kernel did this level
   const Cand* c = cand + lv.cand_off;
   const int want = min(min(lv.n_want, n), 1024);
   if (want == 0) {
@@ -779,7 +831,7 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_score, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
+  DevBuf d_frame, d_pyr, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
@@ -824,9 +876,9 @@ void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
     lv.kp_off = koff;
     koff += lv.n_want;
     lv.tiles_x = cdiv(lv.w, 64);
-    lv.tile_begin = i == 0 ? 0 : L.l[i - 1].tile_begin + L.l[i - 1].tiles_x * cdiv(L.l[i - 1].h, 4);
+    lv.tile_begin = i == 0 ? 0 : L.l[i - 1].tile_begin + L.l[i - 1].tiles_x * cdiv(L.l[i - 1].h, 16);
   }
-  L.n_tiles = L.l[L.n - 1].tile_begin + L.l[L.n - 1].tiles_x * cdiv(L.l[L.n - 1].h, 4);
+  L.n_tiles = L.l[L.n - 1].tile_begin + L.l[L.n - 1].tiles_x * cdiv(L.l[L.n - 1].h, 16);
   GTX_CHECK(max_features * 0.25 < 1024, "stabilizer: at most ~4000 features per image are supported");
   pyr_bytes = off;
   cand_total = coff;
@@ -856,7 +908,6 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   GTX_CHECK(l0.w > 2 * kBorder + 8 && l0.h > 2 * kBorder + 8, "stabilizer: %dx%d working image is too small", l0.w, l0.h);
   const int slots = std::max(S.slots_ref, S.slots_cur);
   S.d_pyr.alloc(S.pyr_bytes);
-  S.d_score.alloc(S.pyr_bytes);
   S.d_rects.alloc(sizeof(int4) * kMaxRects);
   S.d_mask.alloc((size_t)S.gw * S.gh);
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
@@ -901,6 +952,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   }
   S.d_pattern.alloc(S.pattern.size());
   GTX_HIP(hipMemcpy(S.d_pattern.p, S.pattern.data(), S.pattern.size(), hipMemcpyHostToDevice));
+  GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 12));
   long tans[32];
   for (int j = 0; j < 32; ++j) tans[j] = std::lround(std::tan((j + 0.5) * 2.0 * M_PI / kAngleBins) * 16777216.0);
   GTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tan), tans, sizeof tans));
@@ -957,10 +1009,11 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
   int* elig_n = cand_n + kPyrLevels;
   int* hist = elig_n + kPyrLevels;
   GTX_HIP(hipMemsetAsync(d_counters.p, 0, sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels), s));
-  hipLaunchKernelGGL(fast_score_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), L, cfg.fast_threshold);
-  hipLaunchKernelGGL(fast_nms_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_score.as<uint8_t>(), mask, gw, gh, L, d_cand.as<Cand>(),
+  hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, mask, gw, gh, L, cfg.fast_threshold, d_cand.as<Cand>(),
                      cand_n, hist);
   hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
+  hipLaunchKernelGGL(select_sort_kernel, dim3(L.n), dim3(1024), kSortCap * 12, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
+                     d_kp_n.as<int>());
   hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
                      d_kp_n.as<int>());
   hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
