@@ -158,31 +158,56 @@ def main():
     order = list(range(n_pool)) + list(range(n_pool - 2, 0, -1))   # ping-pong: continuous motion
     extract = args.workload == "extract"
     tracker = Tracker(args.tracker)
-    stab = Stabilizer((H, W), ctx=ctx) if extract else None
+    ctx_stab = _lib.Context(local)                              # second stream: stabilize(t) overlaps detect(t+1)
+    stab = Stabilizer((H, W), ctx=ctx_stab) if extract else None
     if extract:                                                  # every rank registers against frame 0 of the clip
         d0 = det.detect(ref_frame)
         g = det.gray_dptr(0)
+        ctx.synchronize()
         stab.set_ref_gray_dev(g[0], g[1], g[2], d0.xywh if len(d0) else None)
     max_det = 1000
     records = []
     empty = (np.zeros((0, 4), np.float32), np.zeros(0, np.int32))
 
-    def step(i, sharded):
-        d = det.detect_dev(dptrs[order[i % len(order)]], 1)[0]
+    def run(i0, n_steps, sharded):
+        """n_steps frames through the software pipeline: while the GPU runs detect(t+1) on the detector's
+        stream, the host drives tracker(t) and the stabilizer's stream works on stabilize(t); stabilize(t)
+        is collected (host refit + box warp) one iteration later. Per-frame results are identical to the
+        serial order: only the issue order of independent work changes."""
         if not extract:
-            return len(d)
-        g = det.gray_dptr(0)
-        if sharded:                                              # shard rank: mask from raw detections, tracker later
-            stab.stabilize_gray_dev(g[0], g[1], g[2], d.xywh if len(d) else None)
-            records.append(pack_frame_record(max_det, d.xyxy, d.conf, d.cls, stab.get_cur_trans_matrix()))
-            return len(d)
-        bx, ids = tracker.update(d.xyxy, d.conf, d.cls)[:2] if len(d) else empty
-        xywh = xywh_of(bx)
-        stab.stabilize_gray_dev(g[0], g[1], g[2], xywh)
-        Hm = stab.get_cur_trans_matrix()
-        if xywh is not None and Hm is not None:
-            warp_boxes(Hm, xywh)
-        return len(ids)
+            n = 0
+            for k in range(n_steps):
+                n = len(det.detect_dev(dptrs[order[(i0 + k) % len(order)]], 1)[0])
+            return n
+        pending = None
+        n_rows = 0
+
+        def finish(p):
+            stab.collect()
+            Hm = stab.get_cur_trans_matrix()
+            if sharded:
+                records.append(pack_frame_record(max_det, p.xyxy, p.conf, p.cls, Hm))
+            elif p is not None and Hm is not None:
+                warp_boxes(Hm, p)
+
+        det.submit_dev(dptrs[order[i0 % len(order)]], 1)
+        for k in range(n_steps):
+            d = det.collect()[0]
+            g = det.gray_dptr(0)
+            if k + 1 < n_steps:
+                det.submit_dev(dptrs[order[(i0 + k + 1) % len(order)]], 1)
+            if sharded:                                          # shard rank: mask from raw detections, tracker later
+                xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
+            else:
+                bx, ids = tracker.update(d.xyxy, d.conf, d.cls)[:2] if len(d) else empty
+                xywh = xywh_of(bx)
+                keep, n_rows = xywh, len(ids)
+            if pending is not None:
+                finish(pending[0])
+            stab.submit_gray_dev(g[0], g[1], g[2], xywh)
+            pending = (keep,)
+        finish(pending[0])
+        return n_rows
 
     def replay_tracker(all_records):
         n_rows = 0
@@ -198,8 +223,8 @@ def main():
 
     sharded = world > 1
     n_tracks = 0
-    for i in range(args.warmup):
-        n_tracks = step(i, sharded)
+    if args.warmup > 0:
+        n_tracks = run(0, args.warmup, sharded)
     records.clear()
     tracker.reset()
 
@@ -213,8 +238,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        n_tracks = step(i, sharded)
+    n_tracks = run(args.warmup, args.steps, sharded)
     ctx.synchronize()
     if sharded and extract:
         import torch
@@ -248,6 +272,7 @@ def main():
                 "weights": "seeded synthetic YOLOv8s, class bias calibrated on one frame (no checkpoint reachable)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
                 "frames_per_rank_in_hbm": n_pool,
+                "pipeline": "detect(t+1) in flight while tracker(t)/stabilize(t) run (2 HIP streams, submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
                             "frames over ranks; records gathered to rank 0 (RCCL), tracker replayed there",
             },

@@ -371,7 +371,7 @@ void Detector::finalize() {
   const int N = cfg_.max_batch;
   gray_h_ = cfg_.frame_h / 2;
   gray_w_ = cfg_.frame_w / 2;
-  gray_.alloc((size_t)N * gray_h_ * gray_w_);
+  gray_.alloc((size_t)kGrayRing * N * gray_h_ * gray_w_);
   // NMS workspace. Candidate capacity = every anchor; sort/NMS capacity = ultralytics max_nms.
   nms_ = NmsBuffers{};
   nms_.cap = head_.n_anchors;
@@ -422,23 +422,39 @@ void Detector::run_post(int nb, hipStream_t s) {
   GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
 }
 
-void Detector::detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
-                          int* cls, float speed_ms[3]) {
+// Asynchronous half: enqueue preprocess -> forward -> decode/NMS -> D2H of the result rows on the
+// context's stream and return. Results are picked up by collect(). The gray image of this batch
+// goes to the next slot of a 3-deep ring so that a consumer on another stream (the stabilizer) can
+// still read the images of the two previous batches while this one is being produced.
+void Detector::submit_dev(const void* frames, int nb, int h, int w) {
   GTX_CHECK(finalized_, "detector not finalized");
+  GTX_CHECK(!in_flight_, "submit while a batch is in flight: call collect first");
   GTX_CHECK(nb >= 1 && nb <= cfg_.max_batch, "batch %d outside [1,%d]", nb, cfg_.max_batch);
   GTX_CHECK(h == cfg_.frame_h && w == cfg_.frame_w, "frame is %dx%d, detector was created for %dx%d", w, h, cfg_.frame_w, cfg_.frame_h);
   GTX_HIP(hipSetDevice(ctx_->device));
   hipStream_t s = ctx_->stream;
   set_batch(nb);
   cur_frames_ = frames;
+  gray_slot_ = (gray_slot_ + 1) % kGrayRing;
+  uint8_t* gray = gray_.as<uint8_t>() + (size_t)gray_slot_ * cfg_.max_batch * gray_h_ * gray_w_;
   GTX_HIP(hipEventRecord(ev_[0], s));
-  launch_preprocess(dtype_, (const uint8_t*)frames, nb, lb_, img_.ptr, gray_.as<uint8_t>(), gray_h_, gray_w_, s);
+  launch_preprocess(dtype_, (const uint8_t*)frames, nb, lb_, img_.ptr, gray, gray_h_, gray_w_, s);
   GTX_HIP(hipEventRecord(ev_[1], s));
   run_forward(nb, s);
   GTX_HIP(hipEventRecord(ev_[2], s));
   run_post(nb, s);
   GTX_HIP(hipEventRecord(ev_[3], s));
-  GTX_HIP(hipStreamSynchronize(s));
+  in_flight_ = true;
+  flight_nb_ = nb;
+}
+
+void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) {
+  GTX_CHECK(in_flight_, "collect without a submitted batch");
+  GTX_HIP(hipSetDevice(ctx_->device));
+  GTX_HIP(hipEventSynchronize(ev_[3]));
+  in_flight_ = false;
+  collected_gray_slot_ = gray_slot_;
+  const int nb = flight_nb_;
   for (int b = 0; b < nb; ++b) {
     const int n = h_out_n_[b];
     n_out[b] = n;
@@ -453,6 +469,12 @@ void Detector::detect_dev(const void* frames, int nb, int h, int w, int* n_out, 
   if (speed_ms) {
     for (int i = 0; i < 3; ++i) GTX_HIP(hipEventElapsedTime(&speed_ms[i], ev_[i], ev_[i + 1]));
   }
+}
+
+void Detector::detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
+                          int* cls, float speed_ms[3]) {
+  submit_dev(frames, nb, h, w);
+  collect(n_out, xyxy, conf, cls, speed_ms);
 }
 
 void Detector::detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf, int* cls,
@@ -476,7 +498,8 @@ const void* Detector::gray(int b, int* gh, int* gw) const {
   if (gh) *gh = gray_h_;
   if (gw) *gw = gray_w_;
   if (b < 0 || b >= cfg_.max_batch) return nullptr;
-  return gray_.as<uint8_t>() + (size_t)b * gray_h_ * gray_w_;
+  // the image of the most recently *collected* batch (a newer batch may already be in flight)
+  return gray_.as<uint8_t>() + ((size_t)collected_gray_slot_ * cfg_.max_batch + b) * gray_h_ * gray_w_;
 }
 
 void Detector::raw_output(int b, float* out, int* n_anchors, bool logits) {

@@ -68,6 +68,9 @@ class Detector {
   // frames: device pointer, nb frames [h][w][3] u8 back to back. Outputs sized [nb][max_det].
   void detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
                   int* cls, float speed_ms[3]);
+  // asynchronous pair: submit enqueues the whole pass, collect waits for it and unpacks
+  void submit_dev(const void* frames, int nb, int h, int w);
+  void collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]);
   void detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf,
                    int* cls, float speed_ms[3]);
   const void* gray(int b, int* gh, int* gw) const;
@@ -109,6 +112,10 @@ class Detector {
   DevBuf gray_;              // [N][gh][gw] u8
   int gray_h_ = 0, gray_w_ = 0;
   const void* cur_frames_ = nullptr;
+  static constexpr int kGrayRing = 3;
+  int gray_slot_ = 0, collected_gray_slot_ = 0;
+  bool in_flight_ = false;
+  int flight_nb_ = 0;
 
   HeadParams head_{};
   NmsBuffers nms_{};

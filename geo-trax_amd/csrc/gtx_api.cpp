@@ -312,6 +312,15 @@ int gtx_detector_detect_batch_dev(gtx_detector* det, const void* frames_dptr, in
     det->impl->detect_dev(frames_dptr, nb, h, w, n_out, xyxy, conf, cls, speed_ms);
   });
 }
+int gtx_detector_submit_dev(gtx_detector* det, const void* frames_dptr, int nb, int h, int w) {
+  return guarded([&] { need(det, "det"); need(frames_dptr, "frames"); det->impl->submit_dev(frames_dptr, nb, h, w); });
+}
+int gtx_detector_collect(gtx_detector* det, int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) {
+  return guarded([&] {
+    need(det, "det"); need(n_out, "n_out"); need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls");
+    det->impl->collect(n_out, xyxy, conf, cls, speed_ms);
+  });
+}
 const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w) {
   if (!det) return nullptr;
   return det->impl->gray(b, gray_h, gray_w);
@@ -399,6 +408,12 @@ int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr,
     need(st, "st"); need(gray_dptr, "gray"); need(H, "H"); need(valid, "valid");
     st->impl->stabilize_gray_dev(gray_dptr, gh, gw, boxes_xywh, n, H, valid, stats);
   });
+}
+int gtx_stabilizer_submit_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw, const float* boxes_xywh, int n) {
+  return guarded([&] { need(st, "st"); need(gray_dptr, "gray"); st->impl->submit_gray_dev(gray_dptr, gh, gw, boxes_xywh, n); });
+}
+int gtx_stabilizer_collect(gtx_stabilizer* st, double H[9], int* valid, int stats[4]) {
+  return guarded([&] { need(st, "st"); need(H, "H"); need(valid, "valid"); st->impl->collect(H, valid, stats); });
 }
 int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc) {
   return guarded([&] { need(st, "st"); need(n, "n"); st->impl->keypoints(which, cap, n, xy, level, angle_bin, desc); });

@@ -759,7 +759,15 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const float4* __restr
   if (lane == 0) cost[hyp] = acc;
 }
 
-__global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ cost, int n, int* __restrict__ best) {
+// Device-side result record of one stabilize pass, fetched with a single D2H copy.
+struct StabResult {
+  int n_match, best, n_cur, pad;
+  double H[9];
+};
+
+__global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ cost, int n, const double* __restrict__ Hin,
+                                                      const int* __restrict__ n_match, const int* __restrict__ n_cur,
+                                                      StabResult* __restrict__ res) {
   __shared__ long s_c[1024];
   __shared__ int s_i[1024];
   long bc = 0x7fffffffffffffffl;
@@ -780,7 +788,13 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ c
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *best = s_i[0];
+  if (threadIdx.x == 0) {
+    const int b = s_c[0] == 0x7fffffffffffffffl ? -1 : s_i[0];
+    res->n_match = *n_match;
+    res->n_cur = *n_cur;
+    res->best = b;
+    for (int k = 0; k < 9; ++k) res->H[k] = b >= 0 ? Hin[(size_t)b * 9 + k] : 0.0;
+  }
 }
 
 }  // namespace
@@ -837,6 +851,11 @@ struct Stabilizer::Impl {
     int host_n = 0;
   } ref, cur;
   DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_mpts, d_nmatch, d_H, d_cost, d_best, d_hok, d_pidx, d_pd1, d_pd2;
+  DevBuf d_res;
+  StabResult* h_res = nullptr;   // pinned
+  float4* h_pts = nullptr;       // pinned
+  hipEvent_t done_ev = nullptr;
+  bool pending = false;
   bool have_ref = false;
   // last results
   double H[9];
@@ -847,7 +866,8 @@ struct Stabilizer::Impl {
   void build_rects(const float* boxes, int n, std::vector<int4>& rects) const;
   void extract(const uint8_t* gray_dev, const float* boxes, int n, const Levels& L, int slots, Feat& out);
   void gray_from_frame(const uint8_t* frame, int h, int w);
-  void run_stabilize(double Hout[9], int* valid_out, int st[4]);
+  void submit_match();
+  void collect(double Hout[9], int* valid_out, int st[4]);
 };
 
 void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
@@ -932,6 +952,10 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_H.alloc(sizeof(double) * 9 * S.n_hyp);
   S.d_cost.alloc(sizeof(long) * S.n_hyp);
   S.d_best.alloc(sizeof(int));
+  S.d_res.alloc(sizeof(StabResult));
+  GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(StabResult)));
+  GTX_HIP(hipHostMalloc((void**)&S.h_pts, sizeof(float4) * slots));
+  GTX_HIP(hipEventCreate(&S.done_ev));
   S.d_hok.alloc(sizeof(int) * S.n_hyp);
   {
     const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;
@@ -958,7 +982,13 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   GTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tan), tans, sizeof tans));
 }
 
-Stabilizer::~Stabilizer() = default;
+Stabilizer::~Stabilizer() {
+  if (impl_) {
+    if (impl_->h_res) (void)hipHostFree(impl_->h_res);
+    if (impl_->h_pts) (void)hipHostFree(impl_->h_pts);
+    if (impl_->done_ev) (void)hipEventDestroy(impl_->done_ev);
+  }
+}
 
 void Stabilizer::Impl::build_rects(const float* boxes, int n, std::vector<int4>& rects) const {
   // stabilo masks each box grown by mask_margin_ratio of its size, drawn on the downsampled frame
@@ -1022,7 +1052,6 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
                      d_desc.as<unsigned long long>(), d_xy.as<float2>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(),
                      out.xy.as<float2>(), out.n.as<int>());
   GTX_HIP(hipGetLastError());
-  GTX_HIP(hipMemcpyAsync(&out.host_n, out.n.p, sizeof(int), hipMemcpyDeviceToHost, s));
 }
 
 namespace {
@@ -1163,9 +1192,10 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
 
 }  // namespace
 
-void Stabilizer::Impl::run_stabilize(double Hout[9], int* valid_out, int st[4]) {
+// Asynchronous half of a stabilize pass: match -> ratio -> RANSAC on the stream, then two D2H
+// copies (result record, match points) into pinned memory and an event.
+void Stabilizer::Impl::submit_match() {
   hipStream_t s = ctx->stream;
-  const int slots = std::max(slots_ref, slots_cur);
   const int max_q = slots_cur, n_chunks = cdiv(slots_ref, kMatchChunk);
   hipLaunchKernelGGL(match_kernel, dim3(cdiv(slots_cur, 256), n_chunks), dim3(256), 0, s, cur.desc.as<unsigned long long>(),
                      cur.n.as<int>(), ref.desc.as<unsigned long long>(), ref.n.as<int>(), max_q, d_pidx.as<int>(), d_pd1.as<int>(),
@@ -1180,22 +1210,29 @@ void Stabilizer::Impl::run_stabilize(double Hout[9], int* valid_out, int st[4]) 
                      n_hyp, cx, cy, sc, d_H.as<double>(), d_hok.as<int>());
   hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), n_hyp,
                      thr2, d_H.as<double>(), d_hok.as<int>(), d_cost.as<long>());
-  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_best.as<int>());
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_nmatch.as<int>(),
+                     cur.n.as<int>(), d_res.as<StabResult>());
   GTX_HIP(hipGetLastError());
-  int n_match = 0, best = -1;
-  GTX_HIP(hipMemcpyAsync(&n_match, d_nmatch.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  GTX_HIP(hipMemcpyAsync(&best, d_best.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  GTX_HIP(hipStreamSynchronize(s));
-  (void)slots;
-  stats[0] = ref.host_n; stats[1] = cur.host_n; stats[2] = n_match; stats[3] = 0;
+  GTX_HIP(hipMemcpyAsync(h_res, d_res.p, sizeof(StabResult), hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipMemcpyAsync(h_pts, d_mpts.p, sizeof(float4) * slots_cur, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipEventRecord(done_ev, s));
+  pending = true;
+}
+
+// Blocking half: wait for the pass, then the robust refit on the host (f64).
+void Stabilizer::Impl::collect(double Hout[9], int* valid_out, int st[4]) {
+  GTX_CHECK(pending, "stabilizer: collect without a submitted frame");
+  GTX_HIP(hipEventSynchronize(done_ev));
+  pending = false;
+  const StabResult& R = *h_res;
+  const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
+  cur.host_n = R.n_cur;
+  stats[0] = ref.host_n; stats[1] = R.n_cur; stats[2] = R.n_match; stats[3] = 0;
   valid = false;
-  if (n_match >= 4 && best >= 0) {
-    std::vector<float4> pts(n_match);
-    double Hb[9];
-    GTX_HIP(hipMemcpy(pts.data(), d_mpts.p, sizeof(float4) * n_match, hipMemcpyDeviceToHost));
-    GTX_HIP(hipMemcpy(Hb, d_H.as<double>() + (size_t)best * 9, sizeof Hb, hipMemcpyDeviceToHost));
+  if (R.n_match >= 4 && R.best >= 0) {
+    std::vector<float4> pts(h_pts, h_pts + R.n_match);
     double Hc[9];
-    std::memcpy(Hc, Hb, sizeof Hc);
+    std::memcpy(Hc, R.H, sizeof Hc);
     const double inv = 1.0 / Hc[8];
     for (double& v : Hc) v *= inv;
     int n_inl = 0;
@@ -1215,6 +1252,7 @@ void Stabilizer::set_ref_frame(const uint8_t* frame_bgr, int h, int w, const flo
   GTX_HIP(hipSetDevice(S.ctx->device));
   S.gray_from_frame(frame_bgr, h, w);
   S.extract(nullptr, boxes_xywh, n, S.lev_ref, S.slots_ref, S.ref);
+  GTX_HIP(hipMemcpyAsync(&S.ref.host_n, S.ref.n.p, sizeof(int), hipMemcpyDeviceToHost, S.ctx->stream));
   GTX_HIP(hipStreamSynchronize(S.ctx->stream));
   S.have_ref = true;
 }
@@ -1224,6 +1262,7 @@ void Stabilizer::set_ref_gray_dev(const void* gray, int gh, int gw, const float*
   GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
   GTX_HIP(hipSetDevice(S.ctx->device));
   S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_ref, S.slots_ref, S.ref);
+  GTX_HIP(hipMemcpyAsync(&S.ref.host_n, S.ref.n.p, sizeof(int), hipMemcpyDeviceToHost, S.ctx->stream));
   GTX_HIP(hipStreamSynchronize(S.ctx->stream));
   S.have_ref = true;
 }
@@ -1234,16 +1273,28 @@ void Stabilizer::stabilize(const uint8_t* frame_bgr, int h, int w, const float* 
   GTX_HIP(hipSetDevice(S.ctx->device));
   S.gray_from_frame(frame_bgr, h, w);
   S.extract(nullptr, boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
-  S.run_stabilize(H, valid, stats);
+  S.submit_match();
+  S.collect(H, valid, stats);
 }
 
-void Stabilizer::stabilize_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]) {
+void Stabilizer::submit_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n) {
   Impl& S = *impl_;
   if (!S.have_ref) fail(GTX_ERR_STATE, "stabilize called before set_ref_frame");
+  GTX_CHECK(!S.pending, "stabilizer: a frame is already in flight");
   GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
   GTX_HIP(hipSetDevice(S.ctx->device));
   S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
-  S.run_stabilize(H, valid, stats);
+  S.submit_match();
+}
+
+void Stabilizer::collect(double H[9], int* valid, int stats[4]) {
+  GTX_HIP(hipSetDevice(impl_->ctx->device));
+  impl_->collect(H, valid, stats);
+}
+
+void Stabilizer::stabilize_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]) {
+  submit_gray_dev(gray, gh, gw, boxes_xywh, n);
+  collect(H, valid, stats);
 }
 
 void Stabilizer::keypoints(int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc) {

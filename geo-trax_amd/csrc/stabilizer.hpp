@@ -16,6 +16,9 @@ class Stabilizer {
   void set_ref_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n);
   void stabilize(const uint8_t* frame_bgr, int h, int w, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]);
   void stabilize_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n, double H[9], int* valid, int stats[4]);
+  // asynchronous pair: enqueue the whole pass for a gray image in HBM / wait for it and refit
+  void submit_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n);
+  void collect(double H[9], int* valid, int stats[4]);
   void keypoints(int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc);
   void matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist);
   // rotated sampling pattern table [256 bins][256 tests][ax, ay, bx, by] int8 (data, for the oracle)

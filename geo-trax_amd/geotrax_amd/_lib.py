@@ -81,6 +81,8 @@ _SIGNATURES = {
     "gtx_detector_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "gtx_detector_detect_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "gtx_detector_detect_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "gtx_detector_submit_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "gtx_detector_collect": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "gtx_detector_gray": (_P, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_raw_output": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
     "gtx_detector_raw_logits": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
@@ -96,6 +98,8 @@ _SIGNATURES = {
     "gtx_stabilizer_set_ref_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "gtx_stabilizer_stabilize": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
     "gtx_stabilizer_stabilize_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
+    "gtx_stabilizer_submit_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "gtx_stabilizer_collect": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "gtx_stabilizer_keypoints": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "gtx_stabilizer_matches": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
     "gtx_stabilizer_pattern": (C.c_int, [_P, _P]),

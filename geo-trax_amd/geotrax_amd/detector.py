@@ -103,6 +103,17 @@ class Detector:
                                                          ptr(self._xyxy), ptr(self._conf), ptr(self._cls), ptr(self._speed)))
         return self._collect(nb)
 
+    def submit_dev(self, frames_dptr: int, nb: int = 1) -> None:
+        """Enqueue a batch (frames resident in HBM) and return at once; pair with collect()."""
+        h, w = self.frame_hw
+        check(self.ctx.lib.gtx_detector_submit_dev(self.handle, C.c_void_p(frames_dptr), nb, h, w))
+        self._flight = nb
+
+    def collect(self) -> list[Detections]:
+        check(self.ctx.lib.gtx_detector_collect(self.handle, ptr(self._n), ptr(self._xyxy), ptr(self._conf), ptr(self._cls),
+                                                ptr(self._speed)))
+        return self._collect(self._flight)
+
     def gray_dptr(self, b: int = 0) -> tuple[int, int, int]:
         gh, gw = C.c_int(), C.c_int()
         p = self.ctx.lib.gtx_detector_gray(self.handle, b, C.byref(gh), C.byref(gw))

@@ -35,6 +35,7 @@ from .config_utils import backfill_args_from_config, load_config_all
 from .frames import get_video_dimensions, open_source, source_exists
 from .model import YOLO
 from .postprocess import aggregate_results, postprocess_tracks
+from . import _lib
 from .stabilizer import Stabilizer
 
 _INFERENCE_KEYS = {'conf', 'iou', 'imgsz', 'max_det', 'classes', 'augment', 'agnostic_nms', 'half', 'device',
@@ -85,10 +86,12 @@ class _Collector:
             self.transforms.append(np.hstack((np.array([[frame_num]]), H.flatten().reshape(1, -1))))
 
 
-def _stabilize_step(stabilizer: Stabilizer, model: YOLO, frame: np.ndarray, xywh, is_ref: bool, use_dev_gray: bool):
-    """Registers `frame` against the reference frame (or makes it the reference). The gray image the
-    detector's preprocess pass left in HBM is used when the stabilizer works at half resolution.
-    Returns (stabilized boxes or None, 3x3 matrix or None)."""
+def _stabilize_submit(stabilizer: Stabilizer, model: YOLO, frame: np.ndarray, xywh, is_ref: bool, use_dev_gray: bool) -> bool:
+    """Starts registering `frame` against the reference frame (or makes it the reference). The gray
+    image the detector's preprocess pass left in HBM is used when the stabilizer works at half
+    resolution; that path is asynchronous (own HIP stream) and is completed by _stabilize_finish one
+    frame later, so the stabilizer's GPU work overlaps the next frame's read, upload and detection.
+    Returns True when a result is pending."""
     gray = model.detector.gray_dptr(0) if (use_dev_gray and model.detector is not None) else None
     on_dev = gray is not None and bool(gray[0])
     if on_dev and stabilizer.handle is None:
@@ -98,11 +101,18 @@ def _stabilize_step(stabilizer: Stabilizer, model: YOLO, frame: np.ndarray, xywh
             stabilizer.set_ref_gray_dev(gray[0], gray[1], gray[2], xywh)
         else:
             stabilizer.set_ref_frame(frame, xywh)
-        return xywh, None                                   # frame 0 is copied through (extract.py:178-179)
+        return False                                        # frame 0 is copied through (extract.py:178-179)
     if on_dev:
-        stabilizer.stabilize_gray_dev(gray[0], gray[1], gray[2], xywh)
-    else:
-        stabilizer.stabilize(frame, xywh)
+        stabilizer.submit_gray_dev(gray[0], gray[1], gray[2], xywh)
+        return True
+    stabilizer.stabilize(frame, xywh)
+    return False
+
+
+def _stabilize_result(stabilizer: Stabilizer, xywh, pending: bool):
+    """(stabilized boxes or None, 3x3 matrix or None) of the frame last given to _stabilize_submit."""
+    if pending:
+        stabilizer.collect()
     return (stabilizer.transform_cur_boxes() if xywh is not None else None), stabilizer.get_cur_trans_matrix()
 
 
@@ -111,13 +121,23 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
     Any exception voids the whole video (empty tables), exactly like the reference (:198-200)."""
     args = config['main']['args']
     reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
-    stabilizer = Stabilizer(**{k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')})
+    # own context = own HIP stream: the stabilizer's kernels overlap the next frame's detection
+    stabilizer = Stabilizer(**{k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')},
+                            ctx=_lib.Context(0))
     use_dev_gray = float(config['stabilo'].get('downsample_ratio', 0.5)) == 0.5
     do_stab = config['main']['extraction']['stabilize']
     track_kw = {k: v for k, v in config['ultralytics'].items() if k != 'model'}
     first, last = args.cut_frame_left, args.cut_frame_right
     out, yolo_ms, stab_ms = _Collector(), [], []
     t_wall = time.time()
+    in_flight = None
+
+    def finish(num, xywh, pending):
+        stab_boxes, H = _stabilize_result(stabilizer, xywh, pending)
+        if stab_boxes is not None:
+            out.stab.append(stab_boxes)
+        out.add_transform(num, H)
+
     try:
         frame_num = 0
         while reader.isOpened():
@@ -129,17 +149,28 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
                 break
             res = model.track(frame, **track_kw, persist=True)[0]
             yolo_ms.append(sum(res.speed.values()))
+            if in_flight is not None:                       # frame t-1's registration ran beside this detection
+                t0 = time.time()
+                finish(*in_flight)
+                in_flight = None
+                stab_ms[-1] += 1000 * (time.time() - t0)
             xywh = out.add_boxes(frame_num, res.boxes)
             if do_stab:
                 t0 = time.time()
-                stab_boxes, H = _stabilize_step(stabilizer, model, frame, xywh, frame_num == first, use_dev_gray)
-                if stab_boxes is not None:
-                    out.stab.append(stab_boxes)
-                out.add_transform(frame_num, H)
+                if frame_num == first:
+                    _stabilize_submit(stabilizer, model, frame, xywh, True, use_dev_gray)
+                    if xywh is not None:
+                        out.stab.append(xywh)
+                elif _stabilize_submit(stabilizer, model, frame, xywh, False, use_dev_gray):
+                    in_flight = (frame_num, xywh, True)
+                else:
+                    finish(frame_num, xywh, False)
                 stab_ms.append(1000 * (time.time() - t0))
             if last is not None and frame_num >= last:
                 break
             frame_num += 1
+        if in_flight is not None:
+            finish(*in_flight)
     except Exception as e:
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return np.empty((0, 12), dtype=np.float32), np.empty((0, 10))

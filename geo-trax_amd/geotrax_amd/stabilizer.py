@@ -112,6 +112,17 @@ class Stabilizer:
                                                              C.byref(valid), ptr(self._stats)))
         self._finish(H, valid, b)
 
+    def submit_gray_dev(self, gray_dptr: int, gh: int, gw: int, boxes=None) -> None:
+        """Asynchronous stabilize: enqueue on the stabilizer's stream; pair with collect()."""
+        b, n = self._boxes(boxes)
+        check(self.ctx.lib.gtx_stabilizer_submit_gray_dev(self.handle, C.c_void_p(gray_dptr), gh, gw, ptr(b), n))
+        self._pending_boxes = b
+
+    def collect(self) -> None:
+        H, valid = np.zeros(9, np.float64), C.c_int()
+        check(self.ctx.lib.gtx_stabilizer_collect(self.handle, ptr(H), C.byref(valid), ptr(self._stats)))
+        self._finish(H, valid, self._pending_boxes)
+
     def get_cur_trans_matrix(self) -> np.ndarray | None:
         """3x3 float64 mapping current-frame pixels to reference-frame pixels, or None."""
         return None if self._H is None else self._H.copy()

@@ -157,9 +157,16 @@ int gtx_detector_detect_dev(gtx_detector* det, const void* frame_dptr, int h, in
 int gtx_detector_detect_batch_dev(gtx_detector* det, const void* frames_dptr, int nb, int h, int w,
                                   int* n_out, float* xyxy, float* conf, int* cls,
                                   float speed_ms[3]);
-/* Device pointer of the half-resolution gray image the preprocess pass of the last detect
- * call wrote (batch slot b), or NULL if disabled. The stabilizer consumes it so the frame is
- * read from HBM once. */
+/* Asynchronous pair for pipelining: _submit_dev enqueues the whole pass for nb frames resident in
+ * HBM on the context's stream and returns; _collect waits for that batch and fills the outputs
+ * ([nb][max_det] arrays). One batch may be in flight per detector. While it runs the caller can
+ * drive the tracker and the stabilizer (another context / stream) on the previous batch. */
+int gtx_detector_submit_dev(gtx_detector* det, const void* frames_dptr, int nb, int h, int w);
+int gtx_detector_collect(gtx_detector* det, int* n_out, float* xyxy, float* conf, int* cls,
+                         float speed_ms[3]);
+/* Device pointer of the half-resolution gray image the preprocess pass wrote for batch slot b of
+ * the most recently *collected* batch (the images live in a 3-deep ring, so a newer batch may
+ * already be in flight), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
 const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w);
 /* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
  * pixels + sigmoid class scores), like the tensor ultralytics' Detect returns. */
@@ -243,6 +250,11 @@ int gtx_stabilizer_stabilize(gtx_stabilizer* st, const uint8_t* frame_bgr, int h
 int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
                                       const float* boxes_xywh, int n, double H[9], int* valid,
                                       int stats[4]);
+/* Asynchronous pair of _stabilize_gray_dev for pipelining: _submit enqueues keypoints, matching and
+ * RANSAC on the stabilizer's stream and returns; _collect waits and runs the host refit. */
+int gtx_stabilizer_submit_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
+                                   const float* boxes_xywh, int n);
+int gtx_stabilizer_collect(gtx_stabilizer* st, double H[9], int* valid, int stats[4]);
 /* Keypoints / descriptors of the last processed image (for parity tests): xy in full-res
  * pixels, level, angle bin, 32-byte descriptors. */
 int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which /*0 ref, 1 cur*/, int cap, int* n,

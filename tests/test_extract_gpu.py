@@ -206,3 +206,89 @@ def test_error_in_loop_voids_the_video(gtx_ctx, tmp_path, caplog):
     assert tracks.shape == (0, 12) and transforms.shape == (0, 10)
     assert any("Error processing" in r.message for r in caplog.records)
     del bad
+
+
+def test_pipelined_submit_collect_equals_serial_order(gtx_ctx):
+    """The asynchronous C-ABI pairs (gtx_detector_submit_dev/_collect, gtx_stabilizer_submit_gray_dev/
+    _collect; two HIP streams, gray images in a 3-deep ring) must give exactly the per-frame results of
+    the blocking calls, and misuse must be refused."""
+    from geotrax_amd import _lib
+    from geotrax_amd._lib import GtxError
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.stabilizer import Stabilizer
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.weights import synthetic_yolov8
+
+    hw = (720, 1280)
+    sc = make_scene(seed=5, h=hw[0], w=hw[1])
+    frames = [sc.render(t) for t in range(0, 60, 10)]
+    from geotrax_amd.weights import calibrate_cls_bias
+
+    w = synthetic_yolov8(seed=2, nc=4)
+    det = Detector(w, hw, imgsz=640, half=True, rect=True, ctx=gtx_ctx, conf=0.25, max_det=300)
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 80)
+    det.close()
+    det = Detector(w, hw, imgsz=640, half=True, rect=True, ctx=gtx_ctx, conf=0.25, max_det=300)
+    ctx2 = _lib.Context(0)
+    kw = dict(max_features=600, seed=0)
+    dptrs = []
+    for f in frames:
+        p = gtx_ctx.dev_alloc(f.nbytes)
+        gtx_ctx.dev_upload(p, f)
+        dptrs.append(p)
+    try:
+        # serial
+        st = Stabilizer(hw, ctx=gtx_ctx, **kw)
+        serial = []
+        for i, p in enumerate(dptrs):
+            d = det.detect_dev(p, 1)[0]
+            g = det.gray_dptr(0)
+            bx = d.xywh if len(d) else None
+            if i == 0:
+                st.set_ref_gray_dev(g[0], g[1], g[2], bx)
+                serial.append((d, None))
+            else:
+                st.stabilize_gray_dev(g[0], g[1], g[2], bx)
+                serial.append((d, st.get_cur_trans_matrix()))
+        # pipelined: detect(t+1) in flight while stabilize(t) runs on the second stream, collected late
+        st2 = Stabilizer(hw, ctx=ctx2, **kw)
+        piped, pend = [], None
+        det.submit_dev(dptrs[0], 1)
+        with pytest.raises(GtxError):
+            det.submit_dev(dptrs[1], 1)                     # one batch in flight per detector
+        for i in range(len(dptrs)):
+            d = det.collect()[0]
+            g = det.gray_dptr(0)
+            if i + 1 < len(dptrs):
+                det.submit_dev(dptrs[i + 1], 1)
+            if pend is not None:
+                st2.collect()
+                piped.append((pend, st2.get_cur_trans_matrix()))
+                pend = None
+            bx = d.xywh if len(d) else None
+            if i == 0:
+                st2.set_ref_gray_dev(g[0], g[1], g[2], bx)
+                piped.append((d, None))
+            else:
+                st2.submit_gray_dev(g[0], g[1], g[2], bx)
+                pend = d
+        st2.collect()
+        piped.append((pend, st2.get_cur_trans_matrix()))
+        with pytest.raises(GtxError):
+            st2.collect()                                   # nothing in flight
+        with pytest.raises(GtxError):
+            det.collect()
+        assert len(serial) == len(piped) == len(frames)
+        assert sum(len(d) for d, _ in serial) > 0
+        for (ds, Hs), (dp, Hp) in zip(serial, piped):
+            np.testing.assert_array_equal(ds.xyxy, dp.xyxy)
+            np.testing.assert_array_equal(ds.conf, dp.conf)
+            np.testing.assert_array_equal(ds.cls, dp.cls)
+            assert (Hs is None) == (Hp is None)
+            if Hs is not None:
+                np.testing.assert_array_equal(Hs, Hp)
+    finally:
+        for p in dptrs:
+            gtx_ctx.dev_free(p)
+        det.close()
