@@ -4,8 +4,11 @@
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one 3840x2160 synthetic frame per rank, the frame already
-resident in HBM when the timed region starts:
+A step = one pass of the hot path over one batch of --batch consecutive 3840x2160 synthetic frames
+per rank (default 4; --batch 1 is the frame-at-a-time pass), the frames already resident in HBM when
+the timed region starts. Frames of a batch share the detector launches (every kernel covers the whole
+batch); tracker and stabilizer take them one by one in clip order, so per-frame results do not depend
+on the batch size (tests/test_detector_gpu.py::test_detector_batch_equals_single):
 
   N = 1   the reference's per-frame order (geotrax/extract.py:145-197): HIP detector -> host C++
           tracker -> HIP stabilizer (mask from the tracker's boxes) -> box warp.
@@ -19,6 +22,7 @@ Weak scaling: per-rank work is fixed, value = N*K frames / max-over-ranks time. 
 from __future__ import annotations
 
 import argparse
+import collections
 import json
 import os
 import sys
@@ -48,6 +52,8 @@ def parse():
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
     ap.add_argument("--tracker", default="bytetrack", choices=["bytetrack", "botsort"])
+    ap.add_argument("--batch", type=int, default=4, help="frames per detector pass (= per step)")
+    ap.add_argument("--stab-streams", type=int, default=3, help="stabilizer instances (own HIP stream each) working on consecutive frames")
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM per rank (played ping-pong)")
     ap.add_argument("--detections", type=int, default=132, help="boxes per frame the seeded weights are calibrated to (golden clip: 132)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -67,7 +73,7 @@ def calibrated_detector(ctx, frame, args, target):
     from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
 
     kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
-              half=bool(args.half), rect=bool(args.rect), max_batch=1, ctx=ctx)
+              half=bool(args.half), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
     base = synthetic_yolov8(seed=0, nc=4, scale="s")
     det = Detector(base, (H, W), **kw)
     det.detect(frame)
@@ -150,63 +156,83 @@ def main():
     frames = [scene.render(t, 150) for t in pool_t]
     ref_frame = frames[0] if rank == 0 else scene.render(0, 150)
     det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
-    dptrs = []
-    for f in frames:
-        p = ctx.dev_alloc(f.nbytes)
-        ctx.dev_upload(p, f)
-        dptrs.append(p)
-    order = list(range(n_pool)) + list(range(n_pool - 2, 0, -1))   # ping-pong: continuous motion
+    # the ping-pong playback (0..n-1, n-2..1: continuous motion) laid out contiguously in HBM, plus the
+    # first B-1 frames again, so that every batch of B consecutive frames is one contiguous range
+    B = max(args.batch, 1)
+    order = list(range(n_pool)) + list(range(n_pool - 2, 0, -1))
+    seq = order + [order[i % len(order)] for i in range(B - 1)]
+    fbytes = frames[0].nbytes
+    pool = ctx.dev_alloc(fbytes * len(seq))
+    for i, t in enumerate(seq):
+        ctx.dev_upload(pool + i * fbytes, frames[t])
+
+    def batch_ptr(k):                                            # batch k = frames k*B .. k*B+B-1 of the playback
+        return pool + ((k * B) % len(order)) * fbytes
+
     extract = args.workload == "extract"
     tracker = Tracker(args.tracker)
-    ctx_stab = _lib.Context(local)                              # second stream: stabilize(t) overlaps detect(t+1)
-    stab = Stabilizer((H, W), ctx=ctx_stab) if extract else None
+    # stabilizer instances on their own streams: stabilize(t), stabilize(t+1), .. overlap each other and detect(batch k+1)
+    n_stab = min(max(args.stab_streams, 1), 4 * B)               # gray images stay valid for 4 further batches
+    stabs = [Stabilizer((H, W), ctx=_lib.Context(local)) for _ in range(n_stab)] if extract else []
+    stab = stabs[0] if extract else None
     if extract:                                                  # every rank registers against frame 0 of the clip
         d0 = det.detect(ref_frame)
         g = det.gray_dptr(0)
         ctx.synchronize()
-        stab.set_ref_gray_dev(g[0], g[1], g[2], d0.xywh if len(d0) else None)
+        for st in stabs:                                         # same reference image -> identical reference keypoints
+            st.set_ref_gray_dev(g[0], g[1], g[2], d0.xywh if len(d0) else None)
     max_det = 1000
     records = []
     empty = (np.zeros((0, 4), np.float32), np.zeros(0, np.int32))
 
-    def run(i0, n_steps, sharded):
-        """n_steps frames through the software pipeline: while the GPU runs detect(t+1) on the detector's
-        stream, the host drives tracker(t) and the stabilizer's stream works on stabilize(t); stabilize(t)
-        is collected (host refit + box warp) one iteration later. Per-frame results are identical to the
-        serial order: only the issue order of independent work changes."""
+    def run(k0, n_steps, sharded):
+        """n_steps batches through the software pipeline: while the GPU runs detect(batch k+1) on the
+        detector's stream, the host drives the tracker over the frames of batch k and the stabilizer's
+        stream registers them; stabilize(t) is collected (host refit + box warp) one frame later. Per-frame
+        results are identical to the serial order: only the issue order of independent work changes."""
         if not extract:
             n = 0
+            det.submit_dev(batch_ptr(k0), B)
             for k in range(n_steps):
-                n = len(det.detect_dev(dptrs[order[(i0 + k) % len(order)]], 1)[0])
+                d = det.collect()
+                if k + 1 < n_steps:
+                    det.submit_dev(batch_ptr(k0 + k + 1), B)
+                n = len(d[-1])
             return n
-        pending = None
+        pending = collections.deque()
         n_rows = 0
+        t = 0
 
-        def finish(p):
-            stab.collect()
-            Hm = stab.get_cur_trans_matrix()
+        def finish():
+            st, p = pending.popleft()
+            st.collect()
+            Hm = st.get_cur_trans_matrix()
             if sharded:
                 records.append(pack_frame_record(max_det, p.xyxy, p.conf, p.cls, Hm))
             elif p is not None and Hm is not None:
                 warp_boxes(Hm, p)
 
-        det.submit_dev(dptrs[order[i0 % len(order)]], 1)
+        det.submit_dev(batch_ptr(k0), B)
         for k in range(n_steps):
-            d = det.collect()[0]
-            g = det.gray_dptr(0)
+            dets = det.collect()
+            grays = [det.gray_dptr(b) for b in range(B)]
             if k + 1 < n_steps:
-                det.submit_dev(dptrs[order[(i0 + k + 1) % len(order)]], 1)
-            if sharded:                                          # shard rank: mask from raw detections, tracker later
-                xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
-            else:
-                bx, ids = tracker.update(d.xyxy, d.conf, d.cls)[:2] if len(d) else empty
-                xywh = xywh_of(bx)
-                keep, n_rows = xywh, len(ids)
-            if pending is not None:
-                finish(pending[0])
-            stab.submit_gray_dev(g[0], g[1], g[2], xywh)
-            pending = (keep,)
-        finish(pending[0])
+                det.submit_dev(batch_ptr(k0 + k + 1), B)
+            for d, g in zip(dets, grays):
+                if sharded:                                      # shard rank: mask from raw detections, tracker later
+                    xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
+                else:
+                    bx, ids = tracker.update(d.xyxy, d.conf, d.cls)[:2] if len(d) else empty
+                    xywh = xywh_of(bx)
+                    keep, n_rows = xywh, len(ids)
+                if len(pending) == n_stab:                       # results are taken in frame order
+                    finish()
+                st = stabs[t % n_stab]
+                st.submit_gray_dev(g[0], g[1], g[2], xywh)
+                pending.append((st, keep))
+                t += 1
+        while pending:
+            finish()
         return n_rows
 
     def replay_tracker(all_records):
@@ -260,34 +286,34 @@ def main():
     if rank == 0:
         dt = "f16" if args.half else "f32"
         out = {
-            "metric": "4K frames/sec through detect+stabilize+track", "value": args.steps * world / elapsed, "unit": "frames/s",
+            "metric": "4K frames/sec through detect+stabilize+track", "value": args.steps * B * world / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
             "config": {
-                "workload": ("full extract: YOLOv8s + ByteTrack + homography stabilization on 3840x2160 frames, 1 frame per step "
-                             "(BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
-                             "YOLOv8s HIP inference only, 3840x2160 frames, batch=1 (BASELINE configs[1])"),
+                "workload": ("full extract: YOLOv8s + ByteTrack + homography stabilization on 3840x2160 frames, "
+                             f"{B} frame(s) per step (BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
+                             f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
                 "tracker": args.tracker, "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s, class bias calibrated on one frame (no checkpoint reachable)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
-                "frames_per_rank_in_hbm": n_pool,
-                "pipeline": "detect(t+1) in flight while tracker(t)/stabilize(t) run (2 HIP streams, submit/collect C ABI)",
+                "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),
+                "pipeline": f"detect(batch k+1) in flight while tracker/stabilizer work through batch k; {n_stab} stabilizer streams (submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
                             "frames over ranks; records gathered to rank 0 (RCCL), tracker replayed there",
             },
         }
         if not args.no_profile:
-            fam = det.profile(nb=1, iters=5)
+            fam = det.profile(nb=B, iters=5)
             fam.sort(key=lambda d: -d["total_ms"])
             top = fam[0]
             ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dt],
                                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dt], "traffic": None,
                                "avg_launch_us": 1000.0 * top["total_ms"] / top["launches"],
-                               "launches_per_frame": top["launches"] // 5,
+                               "launches_per_step": top["launches"] // 5,
                                "flops_per_launch": top["flops"] / top["launches"]}
-            out["kernels"] = [{"kernel": d["kernel"], "launches_per_frame": d["launches"] // 5, "ms_per_frame": d["total_ms"] / 5,
+            out["kernels"] = [{"kernel": d["kernel"], "launches_per_step": d["launches"] // 5, "ms_per_step": d["total_ms"] / 5,
                                "tflops": (d["flops"] / (d["total_ms"] * 1e-3) / 1e12) if d["total_ms"] > 0 else 0.0,
                                "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                               for d in fam]

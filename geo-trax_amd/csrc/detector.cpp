@@ -424,8 +424,8 @@ void Detector::run_post(int nb, hipStream_t s) {
 
 // Asynchronous half: enqueue preprocess -> forward -> decode/NMS -> D2H of the result rows on the
 // context's stream and return. Results are picked up by collect(). The gray image of this batch
-// goes to the next slot of a 3-deep ring so that a consumer on another stream (the stabilizer) can
-// still read the images of the two previous batches while this one is being produced.
+// goes to the next slot of a 6-deep ring so that consumers on other streams (stabilizers) can
+// still read the images of the four batches before the newest collected one.
 void Detector::submit_dev(const void* frames, int nb, int h, int w) {
   GTX_CHECK(finalized_, "detector not finalized");
   GTX_CHECK(!in_flight_, "submit while a batch is in flight: call collect first");

@@ -53,7 +53,9 @@ int gtx_device_count(void) {
   return n;
 }
 
-int gtx_ctx_create(int device, gtx_ctx** out) {
+int gtx_ctx_create(int device, gtx_ctx** out) { return gtx_ctx_create_prio(device, 0, out); }
+
+int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out) {
   return guarded([&] {
     need(out, "out");
     int n = 0;
@@ -65,7 +67,13 @@ int gtx_ctx_create(int device, gtx_ctx** out) {
     GTX_HIP(hipGetDeviceProperties(&c->prop, device));
     if (std::string(c->prop.gcnArchName).find("gfx950") == std::string::npos)
       gtx::fail(GTX_ERR_UNSUPPORTED, "libgtx is built for gfx950 only; device %d is %s", device, c->prop.gcnArchName);
-    GTX_HIP(hipStreamCreate(&c->stream));
+    if (high_priority) {
+      int least = 0, greatest = 0;   // numerically lower = higher priority
+      GTX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      GTX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, greatest));
+    } else {
+      GTX_HIP(hipStreamCreate(&c->stream));
+    }
     *out = c.release();
   });
 }

@@ -283,23 +283,36 @@ struct ByteTracker::Impl {
     std::vector<float> ab(a.size() * 4), bb(b.size() * 4);
     for (size_t i = 0; i < a.size(); ++i) xyxy_of(*a[i], kf.xywh, &ab[i * 4]);
     for (size_t j = 0; j < b.size(); ++j) xyxy_of(*b[j], kf.xywh, &bb[j * 4]);
+    const size_t nb = b.size();
+    std::vector<float> barea(nb), bscore(nb);
+    for (size_t j = 0; j < nb; ++j) {
+      const float* q = &bb[j * 4];
+      barea[j] = (q[2] - q[0]) * (q[3] - q[1]);
+      bscore[j] = b[j]->score;
+    }
     for (size_t i = 0; i < a.size(); ++i) {
       const float* p = &ab[i * 4];
       const float a1 = (p[2] - p[0]) * (p[3] - p[1]);
-      for (size_t j = 0; j < b.size(); ++j) {
+      float* row = &d[i * nb];
+      for (size_t j = 0; j < nb; ++j) {
         const float* q = &bb[j * 4];
+        // disjoint boxes (the vast majority): iw or ih clamps to 0, so iou = 0 / den = 0 and the cost
+        // (fused or not) is exactly 1 for every positive finite den -- skip the arithmetic
+        const float den0 = barea[j] + a1 + 1e-7f;
+        // bitwise | on purpose: one well-predicted branch instead of four data-dependent ones
+        const bool skip = ((q[0] >= p[2]) | (q[2] <= p[0]) | (q[1] >= p[3]) | (q[3] <= p[1])) &
+                          (den0 > 0.f) & (den0 < std::numeric_limits<float>::infinity());
+        if (skip) { row[j] = 1.f; continue; }
         const float iw = std::max(0.f, std::min(p[2], q[2]) - std::max(p[0], q[0]));
         const float ih = std::max(0.f, std::min(p[3], q[3]) - std::max(p[1], q[1]));
         const float inter = iw * ih;
-        float area = (q[2] - q[0]) * (q[3] - q[1]);
-        area = area + a1 - inter;
-        const float iou = inter / (area + 1e-7f);
+        const float iou = inter / (barea[j] + a1 - inter + 1e-7f);
         float cost = 1.f - iou;
         if (fuse) {
-          const float sim = (1.f - cost) * b[j]->score;
+          const float sim = (1.f - cost) * bscore[j];
           cost = 1.f - sim;
         }
-        d[i * b.size() + j] = cost;
+        row[j] = cost;
       }
     }
     return d;

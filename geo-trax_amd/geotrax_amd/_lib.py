@@ -62,6 +62,7 @@ _SIGNATURES = {
     "gtx_last_error": (C.c_char_p, []),
     "gtx_device_count": (C.c_int, []),
     "gtx_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gtx_ctx_create_prio": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_ctx_destroy": (None, [_P]),
     "gtx_ctx_synchronize": (C.c_int, [_P]),
     "gtx_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -143,12 +144,12 @@ def ptr(a: np.ndarray | None):
 
 
 class Context:
-    """One context per GPU (include/gtx.h: gtx_ctx_create)."""
+    """A device + one HIP stream (include/gtx.h: gtx_ctx_create[_prio])."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, high_priority: bool = False):
         self.lib = load()
         h = C.c_void_p()
-        check(self.lib.gtx_ctx_create(device, C.byref(h)))
+        check(self.lib.gtx_ctx_create_prio(device, int(high_priority), C.byref(h)))
         self.handle = h
         self.device = device
 

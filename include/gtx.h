@@ -62,6 +62,9 @@ int gtx_device_count(void);
 /* One context per GPU. Replaces the implicit torch device selection the reference leaves to
  * ultralytics (cfg ultralytics.device, geotrax/cfg/default.yaml:236). */
 int gtx_ctx_create(int device, gtx_ctx** out);
+/* Same, the context's stream gets the device's highest priority when high_priority != 0: for the
+ * short kernels of a latency-critical consumer (the stabilizer) running beside the detector. */
+int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out);
 void gtx_ctx_destroy(gtx_ctx* ctx);
 int gtx_ctx_synchronize(gtx_ctx* ctx);
 /* Raw device memory for callers that keep inputs resident in HBM (bench.py). */
@@ -165,8 +168,8 @@ int gtx_detector_submit_dev(gtx_detector* det, const void* frames_dptr, int nb, 
 int gtx_detector_collect(gtx_detector* det, int* n_out, float* xyxy, float* conf, int* cls,
                          float speed_ms[3]);
 /* Device pointer of the half-resolution gray image the preprocess pass wrote for batch slot b of
- * the most recently *collected* batch (the images live in a 3-deep ring, so a newer batch may
- * already be in flight), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
+ * the most recently *collected* batch (the images live in a 6-deep ring: an image stays valid until
+ * four more batches have been submitted after the one that follows it), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
 const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w);
 /* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
  * pixels + sigmoid class scores), like the tensor ultralytics' Detect returns. */
