@@ -38,6 +38,8 @@ struct ConvProblem {
   int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8)
   int n_ct;             // cout tiles (Cout / BN)
   int block_begin;      // first logical block of this problem inside a grouped launch
+  int in_blocked;       // EXPERIMENT: read the input as [C/16][H][W][16]
+  const void* zero;     // >= 256 B of zeros in HBM (out-of-image patch pixels of the LDS-DMA kernels)
 };
 
 constexpr int kMaxGroup = 8;
@@ -54,6 +56,9 @@ struct ConvConfig {
   int stride;  // 1 or 2
   int bn;      // cout tile: 32, 64 or 128
   int kc;      // cin elements staged per K chunk
+  int variant; // 0 = register-staged kernel (conv_igemm.hip, fp16 + exact fp32), 1 = LDS-DMA ring (conv_igemm2.hip, fp16)
+  int ns;      // variant 1: ring depth
+  int th, tw;  // variant 1: output pixel tile (rows x cols; 1x1 convs: 1 x 256 of the linearised pixel index)
 };
 
 // Picks the tile configuration used for a layer shape.
@@ -71,6 +76,9 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 
 // Algorithmic FLOPs (2*MAC) of a problem.
 double conv_flops(const ConvProblem& p, int ks);
+
+// conv_igemm2.hip
+void conv2_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 
 // Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
 const char* conv_kernel_name(const ConvConfig& cfg);

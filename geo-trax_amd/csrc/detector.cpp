@@ -294,7 +294,8 @@ void Detector::build_graph() {
     ops_.resize(mark);
     if (l == 0) { st1.cfg = o1.cfg; st2.cfg = o2.cfg; }
     auto same = [](const ConvConfig& a, const ConvConfig& b) {
-      return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc;
+      return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc &&
+             a.variant == b.variant && a.ns == b.ns && a.th == b.th && a.tw == b.tw;
     };
     GTX_CHECK(same(st1.cfg, o1.cfg) && same(st2.cfg, o2.cfg) && same(st2.cfg, o3.cfg),
               "Detect level %d does not share a kernel configuration with level 0", l);
