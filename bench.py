@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch of --batch consecutive 3840x2160 synthetic frames
-per rank (default 4; --batch 1 is the frame-at-a-time pass), the frames already resident in HBM when
+per rank (default 2; --batch 1 is the frame-at-a-time pass), the frames already resident in HBM when
 the timed region starts. Frames of a batch share the detector launches (every kernel covers the whole
 batch); tracker and stabilizer take them one by one in clip order, so per-frame results do not depend
 on the batch size (tests/test_detector_gpu.py::test_detector_batch_equals_single):
@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
     ap.add_argument("--tracker", default="bytetrack", choices=["bytetrack", "botsort"])
-    ap.add_argument("--batch", type=int, default=4, help="frames per detector pass (= per step)")
-    ap.add_argument("--stab-streams", type=int, default=3, help="stabilizer instances (own HIP stream each) working on consecutive frames")
+    ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
+    ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")
+    ap.add_argument("--stab-streams", type=int, default=4, help="stabilizer instances (own HIP stream each) working on consecutive frames")
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM per rank (played ping-pong)")
     ap.add_argument("--detections", type=int, default=132, help="boxes per frame the seeded weights are calibrated to (golden clip: 132)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,7 +173,10 @@ def main():
     extract = args.workload == "extract"
     tracker = Tracker(args.tracker)
     # stabilizer instances on their own streams: stabilize(t), stabilize(t+1), .. overlap each other and detect(batch k+1)
-    n_stab = min(max(args.stab_streams, 1), 4 * B)               # gray images stay valid for 4 further batches
+    # a gray image stays valid until its detector has submitted 5 more batches: the frames in flight in
+    # the stabilizers must stay below 4 * detectors * batch
+    n_det_streams = max(args.det_streams, 1)
+    n_stab = max(1, min(args.stab_streams, 4 * n_det_streams * B - 2))
     stabs = [Stabilizer((H, W), ctx=_lib.Context(local)) for _ in range(n_stab)] if extract else []
     stab = stabs[0] if extract else None
     if extract:                                                  # every rank registers against frame 0 of the clip
@@ -182,6 +186,12 @@ def main():
         for st in stabs:                                         # same reference image -> identical reference keypoints
             st.set_ref_gray_dev(g[0], g[1], g[2], d0.xywh if len(d0) else None)
     max_det = 1000
+    from geotrax_amd.detector import Detector
+
+    dets_ = [det]                                                # batch k goes to detector k % n; same weights, own stream
+    for _ in range(1, n_det_streams):
+        dets_.append(Detector(weights, (H, W), imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3],
+                              agnostic_nms=True, half=bool(args.half), rect=bool(args.rect), max_batch=B, ctx=_lib.Context(local)))
     records = []
     empty = (np.zeros((0, 4), np.float32), np.zeros(0, np.int32))
 
@@ -192,11 +202,13 @@ def main():
         results are identical to the serial order: only the issue order of independent work changes."""
         if not extract:
             n = 0
-            det.submit_dev(batch_ptr(k0), B)
+            for k in range(min(n_det_streams, n_steps)):
+                dets_[k % n_det_streams].submit_dev(batch_ptr(k0 + k), B)
             for k in range(n_steps):
-                d = det.collect()
-                if k + 1 < n_steps:
-                    det.submit_dev(batch_ptr(k0 + k + 1), B)
+                dk = dets_[k % n_det_streams]
+                d = dk.collect()
+                if k + n_det_streams < n_steps:
+                    dk.submit_dev(batch_ptr(k0 + k + n_det_streams), B)
                 n = len(d[-1])
             return n
         pending = collections.deque()
@@ -212,12 +224,14 @@ def main():
             elif p is not None and Hm is not None:
                 warp_boxes(Hm, p)
 
-        det.submit_dev(batch_ptr(k0), B)
+        for k in range(min(n_det_streams, n_steps)):
+            dets_[k % n_det_streams].submit_dev(batch_ptr(k0 + k), B)
         for k in range(n_steps):
-            dets = det.collect()
-            grays = [det.gray_dptr(b) for b in range(B)]
-            if k + 1 < n_steps:
-                det.submit_dev(batch_ptr(k0 + k + 1), B)
+            dk = dets_[k % n_det_streams]
+            dets = dk.collect()
+            grays = [dk.gray_dptr(b) for b in range(B)]
+            if k + n_det_streams < n_steps:
+                dk.submit_dev(batch_ptr(k0 + k + n_det_streams), B)
             for d, g in zip(dets, grays):
                 if sharded:                                      # shard rank: mask from raw detections, tracker later
                     xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
@@ -298,7 +312,7 @@ def main():
                 "weights": "seeded synthetic YOLOv8s, class bias calibrated on one frame (no checkpoint reachable)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),
-                "pipeline": f"detect(batch k+1) in flight while tracker/stabilizer work through batch k; {n_stab} stabilizer streams (submit/collect C ABI)",
+                "pipeline": f"{n_det_streams} detector stream(s) take batches round-robin and stay in flight while tracker/stabilizers work through the collected batch; {n_stab} stabilizer streams (submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
                             "frames over ranks; records gathered to rank 0 (RCCL), tracker replayed there",
             },

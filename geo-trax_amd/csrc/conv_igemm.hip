@@ -255,9 +255,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGroup g) {
 // ------------------------------------------------------------------------------------------
 
 namespace {
-// GTX_CONV_V1=1 forces the register-staged kernel for every layer (A/B measurements).
+// GTX_CONV_V2=1 selects the LDS-DMA ring kernel (conv_igemm2.hip) for fp16 layers: measured equal or
+// slower than the register-staged kernel on every YOLOv8s layer, kept for A/B runs.
 bool force_v1() {
-  static const bool v = [] { const char* e = getenv("GTX_CONV_V1"); return e && e[0] == '1'; }();
+  static const bool v = [] { const char* e = getenv("GTX_CONV_V2"); return !(e && e[0] == '1'); }();
   return v;
 }
 int env_int(const char* name, int dflt) {
@@ -374,7 +375,7 @@ void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
   for (int i = 0; i < g.count; ++i) {
     ConvProblem& p = g.p[i];
     p.zero = zp;
-    p.in_blocked = getenv("GTX_CONV_FAKE_BLOCKED") ? 1 : 0;
+    p.in_blocked = 0;
     p.n_ct = p.Cout / cfg.bn;
     p.block_begin = total;
     if (cfg.variant == 1 && cfg.ks == 1) {       // linearised pixel index
