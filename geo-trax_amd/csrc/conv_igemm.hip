@@ -60,7 +60,9 @@ struct ConvTile {
   static constexpr int W_CHUNKS = KS * KS * BN * CPR;
   static constexpr int W_SLOTS = (W_CHUNKS + 255) / 256;
   static constexpr int PATCH_BYTES = NPIX * RB;
-  static constexpr int LDS_BYTES = PATCH_BYTES + KS * KS * BN * RB;
+  static constexpr int STAGE_BYTES = PATCH_BYTES + KS * KS * BN * RB;
+  static constexpr int EPI_BYTES = sizeof(T) == 2 ? 4 * 32 * (BN * 2 + 16) : 0;   // fp16 epilogue transpose
+  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   static constexpr int ROWS_PER_BANKROW = 256 / RB;  // 4 (RB=64) or 2 (RB=128)
   static __host__ __device__ constexpr int swz(int row) {
     return (row / ROWS_PER_BANKROW) & (CPR - 1);
@@ -219,14 +221,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGroup g) {
     }
   }
 
-  // ---- epilogue: bias + SiLU (+ residual) -> NHWC store, 4 consecutive channels per lane ----
+  // ---- epilogue: bias + SiLU (+ residual) -> NHWC store ----
+  // After the MFMAs a lane holds 4 consecutive channels of one pixel (8 B in fp16). Storing those
+  // directly makes 8 partial writes per 128-B line; in the HBM-bound layers L2 evicts such lines before
+  // they are complete and the memory side sees up to 3x the bytes (rocprofv3 WRITE_SIZE). fp16 path:
+  // each wave transposes its 32 pixels x BN channels through LDS and stores 16 B per lane, whole
+  // lines per pixel. The values are the same bits either way (rounded to fp16 before staging).
   const int oy = oy0 + trow, ox = ox0 + tcol;
-  if (oy < P.Ho && ox < P.Wo) {
+  const bool wide = sizeof(T) == 2 && (P.out_cstride % 8) == 0 && (P.out_coff % 8) == 0;
+  const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
+  if (wide) {
+    constexpr int PITCH = BN * 2 + 16;          // bytes per staged pixel row; +16 keeps ds_write_b64 conflict free
+    __syncthreads();                            // every wave is done with the staging buffers
+    char* stg = smem + wave * (32 * PITCH);
+    const bool inside = oy < P.Ho && ox < P.Wo;
+    const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
+    const T* __restrict__ res =
+        (P.res && inside) ? static_cast<const T*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = 32 * j + 8 * g4 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[j][4 * g4 + i] + (bias ? bias[cl + i] : 0.f);
+          if (P.act) v[i] = silu(v[i]);
+        }
+        if (res) {
+          float rv[4];
+          load4<T>(res + cl, rv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += rv[i];
+        }
+        store4<T>(reinterpret_cast<T*>(stg + prow * PITCH) + cl, v);
+      }
+    }
+    // wave-private buffer: the wave's own LDS writes are ordered before its reads (lgkmcnt)
+    constexpr int LPP = BN / 8;                 // lanes per pixel (16 B each)
+    constexpr int PPI = 64 / LPP;               // pixels per store instruction
+#pragma unroll
+    for (int it = 0; it < 32 / PPI; ++it) {
+      const int p = it * PPI + lane / LPP, q = lane % LPP;
+      const int py = oy0 + 2 * wave + (p >> 4), px = ox0 + (p & 15);
+      const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
+      if (py < P.Ho && px < P.Wo) {
+        T* dst = static_cast<T*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 8;
+        *reinterpret_cast<uint4*>(dst) = val;
+      }
+    }
+  } else if (oy < P.Ho && ox < P.Wo) {
     const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
     T* __restrict__ out = static_cast<T*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
     const T* __restrict__ res =
         P.res ? static_cast<const T*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
-    const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
 #pragma unroll

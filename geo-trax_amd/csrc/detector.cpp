@@ -29,6 +29,8 @@ Detector::~Detector() {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_up_)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : trace_ev_)
+    if (e) (void)hipEventDestroy(e);
 }
 
 void Detector::set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape) {
@@ -412,8 +414,53 @@ void Detector::run_op(const Op& op, int nb, hipStream_t s) {
   }
 }
 
-void Detector::run_forward(int nb, hipStream_t s) {
-  for (const Op& op : ops_) run_op(op, nb, s);
+void Detector::run_forward(int nb, hipStream_t s, bool traced) {
+  if (!traced) {
+    for (const Op& op : ops_) run_op(op, nb, s);
+    return;
+  }
+  for (size_t i = 0; i < ops_.size(); ++i) {
+    GTX_HIP(hipEventRecord(trace_ev_[i], s));
+    run_op(ops_[i], nb, s);
+  }
+  GTX_HIP(hipEventRecord(trace_ev_[ops_.size()], s));
+}
+
+void Detector::set_trace(int every_n) {
+  GTX_CHECK(finalized_ && every_n >= 0, "set_trace: detector not finalized or bad period");
+  GTX_CHECK(!in_flight_, "set_trace while a batch is in flight");
+  trace_every_ = every_n;
+  trace_count_ = 0;
+  if (every_n > 0 && trace_ev_.empty()) {
+    trace_ev_.resize(ops_.size() + 1);
+    for (auto& e : trace_ev_) GTX_HIP(hipEventCreate(&e));
+  }
+  trace_ms_.assign(ops_.size(), 0.0);
+  trace_n_.assign(ops_.size(), 0);
+}
+
+void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
+                            std::vector<double>& flops, std::vector<double>& bytes) {
+  std::map<std::string, size_t> idx;
+  for (size_t i = 0; i < ops_.size() && i < trace_n_.size(); ++i) {
+    if (trace_n_[i] == 0) continue;
+    auto it = idx.find(ops_[i].family);
+    size_t k;
+    if (it == idx.end()) {
+      k = names.size();
+      idx[ops_[i].family] = k;
+      names.push_back(ops_[i].family);
+      launches.push_back(0); ms.push_back(0.f); flops.push_back(0.0); bytes.push_back(0.0);
+    } else {
+      k = it->second;
+    }
+    launches[k] += trace_n_[i];
+    ms[k] += (float)trace_ms_[i];
+    flops[k] += ops_[i].flops * trace_n_[i];     // ops_[i].flops is for the current batch size
+    bytes[k] += ops_[i].bytes * trace_n_[i];
+  }
+  trace_ms_.assign(ops_.size(), 0.0);
+  trace_n_.assign(ops_.size(), 0);
 }
 
 void Detector::run_post(int nb, hipStream_t s) {
@@ -441,7 +488,8 @@ void Detector::submit_dev(const void* frames, int nb, int h, int w) {
   GTX_HIP(hipEventRecord(ev_[0], s));
   launch_preprocess(dtype_, (const uint8_t*)frames, nb, lb_, img_.ptr, gray, gray_h_, gray_w_, s);
   GTX_HIP(hipEventRecord(ev_[1], s));
-  run_forward(nb, s);
+  flight_traced_ = trace_every_ > 0 && (trace_count_++ % trace_every_) == 0;
+  run_forward(nb, s, flight_traced_);
   GTX_HIP(hipEventRecord(ev_[2], s));
   run_post(nb, s);
   GTX_HIP(hipEventRecord(ev_[3], s));
@@ -455,6 +503,15 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
   GTX_HIP(hipEventSynchronize(ev_[3]));
   in_flight_ = false;
   collected_gray_slot_ = gray_slot_;
+  if (flight_traced_) {
+    for (size_t i = 0; i < ops_.size(); ++i) {
+      float t = 0.f;
+      GTX_HIP(hipEventElapsedTime(&t, trace_ev_[i], trace_ev_[i + 1]));
+      trace_ms_[i] += t;
+      trace_n_[i] += 1;
+    }
+    flight_traced_ = false;
+  }
   const int nb = flight_nb_;
   for (int b = 0; b < nb; ++b) {
     const int n = h_out_n_[b];

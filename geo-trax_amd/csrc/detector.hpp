@@ -78,6 +78,12 @@ class Detector {
   void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c);
   void profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
                std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes);
+  // Live tracing: every `every_n`-th submitted pass gets a HIP event in front of every launch of the
+  // forward graph (on the launch stream); collect() folds the elapsed times into per-op totals that
+  // trace_report() returns per kernel family and clears. every_n = 0 switches tracing off.
+  void set_trace(int every_n);
+  void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
+                    std::vector<double>& flops, std::vector<double>& bytes);
   int max_det() const { return cfg_.max_det; }
 
  private:
@@ -91,7 +97,7 @@ class Detector {
   View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice);
   void build_graph();
   void run_op(const Op& op, int nb, hipStream_t s);
-  void run_forward(int nb, hipStream_t s);
+  void run_forward(int nb, hipStream_t s, bool traced = false);
   void run_post(int nb, hipStream_t s);
   void set_batch(int nb);
 
@@ -123,6 +129,11 @@ class Detector {
   int* h_out_n_ = nullptr;   // pinned
   float* h_out_rows_ = nullptr;
   hipEvent_t ev_[4]{};
+  int trace_every_ = 0, trace_count_ = 0;
+  bool flight_traced_ = false;
+  std::vector<hipEvent_t> trace_ev_;      // one per op + 1
+  std::vector<double> trace_ms_;          // per op
+  std::vector<int> trace_n_;
   hipEvent_t ev_up_[2]{};
 };
 

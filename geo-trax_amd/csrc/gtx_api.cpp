@@ -342,6 +342,9 @@ int gtx_detector_raw_logits(gtx_detector* det, int b, float* out, int* n_anchors
 int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out, int* h, int* w, int* c) {
   return guarded([&] { need(det, "det"); need(layer, "layer"); det->impl->layer_output(b, layer, out, h, w, c); });
 }
+int gtx_detector_trace(gtx_detector* det, int every_n) {
+  return guarded([&] { need(det, "det"); det->impl->set_trace(every_n); });
+}
 int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* names, int* launches, float* total_ms,
                          double* flops, double* bytes, int* n_families) {
   return guarded([&] {
@@ -351,7 +354,8 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
     std::vector<int> la;
     std::vector<float> ms;
     std::vector<double> fl, by;
-    det->impl->profile(nb, iters, nm, la, ms, fl, by);
+    if (iters <= 0) det->impl->trace_report(nm, la, ms, fl, by);   // iters = 0: the live trace totals
+    else det->impl->profile(nb, iters, nm, la, ms, fl, by);
     const int n = std::min<int>(cap, (int)nm.size());
     for (int i = 0; i < n; ++i) {
       std::strncpy(names + (size_t)i * 96, nm[i].c_str(), 95);

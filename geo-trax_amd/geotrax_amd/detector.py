@@ -138,6 +138,14 @@ class Detector:
         check(self.ctx.lib.gtx_detector_layer_output(self.handle, b, layer.encode(), ptr(out), C.byref(h), C.byref(w), C.byref(c)))
         return out
 
+    def trace(self, every_n: int) -> None:
+        """Time every launch of every `every_n`-th submitted pass with HIP events (0 = off)."""
+        check(self.ctx.lib.gtx_detector_trace(self.handle, every_n))
+
+    def trace_report(self) -> list[dict]:
+        """Per-kernel-family totals of the traced passes since the last report."""
+        return self.profile(nb=0, iters=0)
+
     def profile(self, nb: int = 1, iters: int = 5) -> list[dict]:
         """Per-kernel-family totals of `iters` forward passes (HIP events around every launch)."""
         cap = 64

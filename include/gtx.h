@@ -182,6 +182,11 @@ int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float
 /* Per-kernel-family profile of one forward pass: launches, total ms (HIP events around every
  * launch on the launch stream, graph disabled) and algorithmic FLOPs / bytes. `names` receives
  * up to cap entries of 96 chars. Feeds bench.py's roofline object. */
+/* Live variant: after gtx_detector_trace(det, n) every n-th submitted pass carries a HIP event in
+ * front of every launch of its forward graph; gtx_detector_profile(det, 0, 0, ...) then returns (and
+ * clears) the per-family totals of the traced passes, i.e. kernel durations as they were inside the
+ * running pipeline. n = 0 switches tracing off. */
+int gtx_detector_trace(gtx_detector* det, int every_n);
 int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* names,
                          int* launches, float* total_ms, double* flops, double* bytes,
                          int* n_families);
