@@ -172,7 +172,7 @@ void Detector::build_graph() {
     Op op;
     op.kind = Op::STEM;
     op.name = "model.0.conv";
-    op.family = "stem_kernel";
+    op.family = dtype_ == DT_F16 ? "stem_mfma_kernel" : "stem_kernel";
     op.in = img_;
     op.out = a0;
     op.w27 = dw;
