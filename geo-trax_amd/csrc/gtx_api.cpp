@@ -10,6 +10,7 @@
 #include "det_kernels.hpp"
 #include "detector.hpp"
 #include "geometry.hpp"
+#include "match_l2.hpp"
 #include "stabilizer.hpp"
 #include "tracker.hpp"
 
@@ -247,6 +248,43 @@ int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const
     gtx::launch_upsample2x(dtype, dx.p, n, h, w, c, in_cstride, in_coff, dy.p, out_cstride, out_coff, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
     GTX_HIP(hipMemcpy(y, dy.p, yb, hipMemcpyDeviceToHost));
+  });
+}
+
+int gtx_op_match_2nn(gtx_ctx* ctx, const float* query, int nq, const float* train, int nt, int* idx1, int* idx2, float* d1,
+                     float* d2, int iters, float* ms_per_pass) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(query, "query"); need(train, "train"); need(idx1, "idx1"); need(idx2, "idx2"); need(d1, "d1"); need(d2, "d2");
+    if (nq < 0 || nt < 0) gtx::fail(GTX_ERR_INVALID, "negative descriptor count");
+    GTX_HIP(hipSetDevice(ctx->device));
+    if (nq == 0) return;
+    hipStream_t s = ctx->stream;
+    const size_t qn = (size_t)nq * 128, tn = (size_t)std::max(nt, 1) * 128;
+    gtx::DevBuf qf(qn * 4), tf(tn * 4), qh(qn * 2), th(tn * 2), ws(gtx::match2nn_workspace_bytes(nq, nt));
+    gtx::DevBuf i1(nq * 4), i2(nq * 4), e1(nq * 4), e2(nq * 4);
+    GTX_HIP(hipMemcpy(qf.p, query, qn * 4, hipMemcpyHostToDevice));
+    if (nt > 0) GTX_HIP(hipMemcpy(tf.p, train, (size_t)nt * 128 * 4, hipMemcpyHostToDevice));
+    gtx::descriptors_to_half(qf.as<float>(), qh.p, qn, s);
+    gtx::descriptors_to_half(tf.as<float>(), th.p, (size_t)nt * 128, s);
+    gtx::match2nn(qh.p, qf.as<float>(), nq, th.p, tf.as<float>(), nt, ws.p, i1.as<int>(), i2.as<int>(), e1.as<float>(), e2.as<float>(), s);
+    GTX_HIP(hipStreamSynchronize(s));
+    if (iters > 0 && ms_per_pass) {
+      hipEvent_t a, b;
+      GTX_HIP(hipEventCreate(&a)); GTX_HIP(hipEventCreate(&b));
+      GTX_HIP(hipEventRecord(a, s));
+      for (int i = 0; i < iters; ++i)
+        gtx::match2nn(qh.p, qf.as<float>(), nq, th.p, tf.as<float>(), nt, ws.p, i1.as<int>(), i2.as<int>(), e1.as<float>(), e2.as<float>(), s);
+      GTX_HIP(hipEventRecord(b, s));
+      GTX_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      GTX_HIP(hipEventElapsedTime(&ms, a, b));
+      *ms_per_pass = ms / iters;
+      (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+    GTX_HIP(hipMemcpy(idx1, i1.p, nq * 4, hipMemcpyDeviceToHost));
+    GTX_HIP(hipMemcpy(idx2, i2.p, nq * 4, hipMemcpyDeviceToHost));
+    GTX_HIP(hipMemcpy(d1, e1.p, nq * 4, hipMemcpyDeviceToHost));
+    GTX_HIP(hipMemcpy(d2, e2.p, nq * 4, hipMemcpyDeviceToHost));
   });
 }
 

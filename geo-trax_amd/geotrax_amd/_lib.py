@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gtx_op_conv2d_time": (C.c_int, [_P, C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "gtx_op_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gtx_op_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "gtx_op_match_2nn": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "gtx_op_preprocess": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
     "gtx_detector_create": (C.c_int, [_P, C.POINTER(DetConfig), C.POINTER(_P)]),
     "gtx_detector_destroy": (None, [_P]),

@@ -89,3 +89,18 @@ def preprocess(frame_bgr: np.ndarray, net_h: int, net_w: int, dtype=np.float32, 
     check(ctx.lib.gtx_op_preprocess(ctx.handle, _dt(img), ptr(frame), h, w, net_h, net_w, ptr(img), ptr(gray),
                                     h // 2, w // 2))
     return img, gray
+
+
+def match_2nn(query: np.ndarray, train: np.ndarray, iters: int = 0, ctx: _lib.Context | None = None):
+    """2 nearest train rows (L2) of every query row; unit-norm [n,128] fp32 descriptors.
+    -> (idx1, idx2, d1, d2[, ms_per_pass when iters > 0])."""
+    ctx = ctx or _lib.default_context()
+    q = np.ascontiguousarray(query, np.float32).reshape(-1, 128)
+    t = np.ascontiguousarray(train, np.float32).reshape(-1, 128)
+    nq, nt = len(q), len(t)
+    i1, i2 = np.full(nq, -1, np.int32), np.full(nq, -1, np.int32)
+    d1, d2 = np.zeros(nq, np.float32), np.zeros(nq, np.float32)
+    ms = C.c_float()
+    check(ctx.lib.gtx_op_match_2nn(ctx.handle, ptr(q), nq, ptr(t if nt else np.zeros((1, 128), np.float32)), nt, ptr(i1), ptr(i2),
+                                   ptr(d1), ptr(d2), iters, C.byref(ms)))
+    return (i1, i2, d1, d2, ms.value) if iters > 0 else (i1, i2, d1, d2)

@@ -109,6 +109,15 @@ int gtx_op_sppf_pool(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, void* 
 int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const void* x,
                       int in_cstride, int in_coff, void* y, int out_cstride, int out_coff);
 
+/* Brute-force L2 2-nearest-neighbour search of unit-norm 128-d float descriptors (RootSIFT): what
+ * cv2.BFMatcher(NORM_L2).knnMatch(query, train, k=2) returns inside stabilo for the orthophoto
+ * registration (geotrax/utils/registration.py:59-85, matcher_name='bf'). query [nq][128], train
+ * [nt][128] fp32 host arrays; idx1/idx2 = nearest / second nearest train row (-1 if absent), d1/d2
+ * their L2 distances (exact fp32; the search itself runs on fp16 MFMA). iters > 0 also times the
+ * device passes (ms_per_pass, for bench/roofline). */
+int gtx_op_match_2nn(gtx_ctx* ctx, const float* query, int nq, const float* train, int nt,
+                     int* idx1, int* idx2, float* d1, float* d2, int iters, float* ms_per_pass);
+
 /* LetterBox + BGR->RGB + /255 (ultralytics predictor preprocess, reached from
  * extract.py:153) fused with the stabilizer's gray + resize (stabilo, extract.py:177,181).
  * frame: BGR u8 [h,w,3]. out_img: [net_h,net_w,4] dtype (RGB0). out_gray: u8
