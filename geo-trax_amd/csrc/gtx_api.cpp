@@ -11,6 +11,8 @@
 #include "detector.hpp"
 #include "geometry.hpp"
 #include "match_l2.hpp"
+#include "register.hpp"
+#include "sift.hpp"
 #include "stabilizer.hpp"
 #include "tracker.hpp"
 
@@ -248,6 +250,58 @@ int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const
     gtx::launch_upsample2x(dtype, dx.p, n, h, w, c, in_cstride, in_coff, dy.p, out_cstride, out_coff, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
     GTX_HIP(hipMemcpy(y, dy.p, yb, hipMemcpyDeviceToHost));
+  });
+}
+
+struct gtx_sift {
+  gtx_ctx* ctx;
+  std::unique_ptr<gtx::Sift> impl;
+};
+
+int gtx_register_images(gtx_ctx* ctx, const gtx_reg_config* cfg, const uint8_t* src, int sh, int sw, const uint8_t* dst, int dh, int dw,
+                        double H[9], int* valid, int stats[4], float timings_ms[4]) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(cfg, "cfg"); need(src, "src"); need(dst, "dst"); need(H, "H"); need(valid, "valid"); need(stats, "stats");
+    gtx::register_images(ctx, *cfg, src, sh, sw, dst, dh, dw, H, valid, stats, timings_ms);
+  });
+}
+int gtx_sift_create(gtx_ctx* ctx, int max_h, int max_w, gtx_sift** out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(out, "out");
+    std::unique_ptr<gtx_sift> s(new gtx_sift);
+    s->ctx = ctx;
+    s->impl.reset(new gtx::Sift(ctx->device, ctx->stream, max_h, max_w));
+    *out = s.release();
+  });
+}
+void gtx_sift_destroy(gtx_sift* s) { delete s; }
+int gtx_sift_detect(gtx_sift* s, const uint8_t* image, int h, int w, int max_features, int root, float root_eps, int cap, int* n,
+                    float* kp5, int* octave, float* desc) {
+  return guarded([&] {
+    need(s, "sift"); need(image, "image"); need(n, "n");
+    s->impl->detect_and_compute(image, h, w, max_features, root != 0, root_eps);
+    std::vector<gtx::SiftKeypoint> k;
+    std::vector<float> d;
+    s->impl->download(k, d);
+    *n = (int)k.size();
+    const int m = std::min<int>(cap, (int)k.size());
+    for (int i = 0; i < m; ++i) {
+      if (kp5) { kp5[5 * i] = k[i].x; kp5[5 * i + 1] = k[i].y; kp5[5 * i + 2] = k[i].size; kp5[5 * i + 3] = k[i].angle; kp5[5 * i + 4] = k[i].response; }
+      if (octave) octave[i] = k[i].octave;
+    }
+    if (desc && m > 0) std::memcpy(desc, d.data(), (size_t)m * 128 * sizeof(float));
+  });
+}
+int gtx_sift_pyramid(gtx_sift* s, int kind, int octave, int layer, int cap, float* out, int* h, int* w, int* n_octaves) {
+  return guarded([&] {
+    need(s, "sift"); need(h, "h"); need(w, "w");
+    if (n_octaves) *n_octaves = s->impl->n_octaves();
+    std::vector<float> img;
+    s->impl->pyramid_image(kind, octave, layer, img, h, w);
+    if (out) {
+      if ((size_t)cap < img.size()) gtx::fail(GTX_ERR_INVALID, "pyramid image has %zu pixels, buffer holds %d", img.size(), cap);
+      std::memcpy(out, img.data(), img.size() * sizeof(float));
+    }
   });
 }
 

@@ -1329,4 +1329,37 @@ void Stabilizer::matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist)
 
 void Stabilizer::pattern(int8_t* out) const { std::memcpy(out, impl_->pattern.data(), impl_->pattern.size()); }
 
+// Blocking robust homography from matched point pairs already in HBM (registration path): the same
+// hypothesis / MSAC-score / argmin kernels as the per-frame stabilizer, then the host IRLS refit.
+bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_match, unsigned seed, int n_hyp, int frame_w, int frame_h,
+                       float threshold, double H[9], int* n_inliers) {
+  *n_inliers = 0;
+  if (n_match < 4) return false;
+  GTX_HIP(hipSetDevice(device));
+  DevBuf d_n(sizeof(int) * 2), d_H(sizeof(double) * 9 * n_hyp), d_ok(sizeof(int) * n_hyp), d_cost(sizeof(long) * n_hyp), d_res(sizeof(StabResult));
+  const int two[2] = {n_match, n_match};
+  GTX_HIP(hipMemcpyAsync(d_n.p, two, sizeof two, hipMemcpyHostToDevice, s));
+  const double cx = frame_w / 2.0, cy = frame_h / 2.0, sc = 2.0 / frame_w;
+  hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), seed, n_hyp, cx, cy, sc,
+                     d_H.as<double>(), d_ok.as<int>());
+  hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), n_hyp, threshold * threshold,
+                     d_H.as<double>(), d_ok.as<int>(), d_cost.as<long>());
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_n.as<int>(), d_n.as<int>() + 1,
+                     d_res.as<StabResult>());
+  GTX_HIP(hipGetLastError());
+  StabResult R;
+  std::vector<float4> pts(n_match);
+  GTX_HIP(hipMemcpyAsync(&R, d_res.p, sizeof R, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipMemcpyAsync(pts.data(), d_pts, sizeof(float4) * n_match, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipStreamSynchronize(s));
+  if (R.best < 0) return false;
+  double Hc[9];
+  std::memcpy(Hc, R.H, sizeof Hc);
+  const double inv = 1.0 / Hc[8];
+  for (double& v : Hc) v *= inv;
+  if (!refine_homography(pts, cx, cy, sc, (double)threshold, Hc, n_inliers)) return false;
+  std::memcpy(H, Hc, sizeof Hc);
+  return true;
+}
+
 }  // namespace gtx

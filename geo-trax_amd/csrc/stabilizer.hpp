@@ -1,5 +1,7 @@
 // GPU homography stabilizer (ORB-style keypoints + Hamming matching + RANSAC homography).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <memory>
 
 #include "../../include/gtx.h"
@@ -28,6 +30,11 @@ class Stabilizer {
   struct Impl;
   std::unique_ptr<Impl> impl_;
 };
+
+// Robust homography (MSAC hypotheses on the GPU + IRLS refit on the host, f64) from n_match point pairs
+// (x, y) -> (z, w) in HBM; threshold in pixels of the destination. false: no model.
+bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_match, unsigned seed, int n_hyp, int frame_w, int frame_h,
+                       float threshold, double H[9], int* n_inliers);
 }  // namespace gtx
 
 struct gtx_stabilizer {

@@ -44,6 +44,12 @@ class TrackerConfig(C.Structure):
     ]
 
 
+class RegConfig(C.Structure):
+    """gtx_reg_config (include/gtx.h)."""
+    _fields_ = [("max_features", C.c_int), ("filter_ratio", C.c_float), ("ransac_threshold", C.c_float), ("ransac_max_iter", C.c_int),
+                ("ransac_confidence", C.c_float), ("rsift_eps", C.c_float), ("seed", C.c_int)]
+
+
 class StabConfig(C.Structure):
     _fields_ = [
         ("downsample_ratio", C.c_float), ("max_features", C.c_int), ("ref_multiplier", C.c_float),
@@ -73,6 +79,11 @@ _SIGNATURES = {
     "gtx_op_conv2d_time": (C.c_int, [_P, C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "gtx_op_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gtx_op_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "gtx_register_images": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P, _P]),
+    "gtx_sift_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gtx_sift_destroy": (None, [_P]),
+    "gtx_sift_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
+    "gtx_sift_pyramid": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_op_match_2nn": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "gtx_op_preprocess": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),
     "gtx_detector_create": (C.c_int, [_P, C.POINTER(DetConfig), C.POINTER(_P)]),

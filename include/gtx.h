@@ -284,6 +284,40 @@ int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, in
  * tests][ax, ay, bx, by] int8 = 262144 bytes. Data hand-over for the parity tests. */
 int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out);
 
+/* ------------------------------------------------------------------ registration (once per video)
+ * Replaces estimate_homography() of geotrax/utils/registration.py:21-95 -- stabilo.Stabilizer with
+ * detector_name='rsift', matcher_name='bf', filter_type='ratio', projective model, no mask, no
+ * downsampling -- as used by the georeference stage for frame <-> master frame <-> orthophoto
+ * (SURVEY.md K11). RootSIFT keypoints/descriptors on the GPU, brute-force L2 2-NN on MFMA, Lowe
+ * ratio, robust homography (MSAC hypotheses + IRLS refit; the reference uses MAGSAC++). */
+typedef struct gtx_reg_config {
+  int max_features;         /* SIFT nfeatures: strongest responses kept (reference default 250000) */
+  float filter_ratio;       /* Lowe ratio (reference default 0.55) */
+  float ransac_threshold;   /* reprojection threshold in destination pixels (3.0) */
+  int ransac_max_iter;      /* hypotheses (10000; clamped to [256, 16384]) */
+  float ransac_confidence;  /* accepted for interface parity; the hypothesis count is fixed */
+  float rsift_eps;          /* RootSIFT L1-normalisation epsilon (1e-8) */
+  int seed;
+} gtx_reg_config;
+/* src/dst: BGR u8 [h][w][3] host images. H (row-major 3x3 f64) maps src pixels to dst pixels;
+ * stats = {n_src_keypoints, n_dst_keypoints, n_good_matches, n_inliers}; *valid = 0 when no model
+ * was found (the reference then retries with half the features, registration.py:87-91);
+ * timings_ms (may be NULL) = {detect+describe both images, matching, ratio filter, robust fit}. */
+int gtx_register_images(gtx_ctx* ctx, const gtx_reg_config* cfg, const uint8_t* src_bgr, int src_h,
+                        int src_w, const uint8_t* dst_bgr, int dst_h, int dst_w, double H[9],
+                        int* valid, int stats[4], float timings_ms[4]);
+/* The detector stage on its own (cv2.SIFT_create(nfeatures, enable_precise_upscale=True)
+ * .detectAndCompute + stabilo's RootSIFT conversion when root != 0), for parity tests: keypoints as
+ * rows {x, y, size, angle, response} + the packed octave word, descriptors [n][128] fp32. */
+typedef struct gtx_sift gtx_sift;
+int gtx_sift_create(gtx_ctx* ctx, int max_h, int max_w, gtx_sift** out);
+void gtx_sift_destroy(gtx_sift* s);
+int gtx_sift_detect(gtx_sift* s, const uint8_t* image_bgr, int h, int w, int max_features, int root,
+                    float root_eps, int cap, int* n, float* kp5, int* octave, float* desc);
+/* Gaussian (kind 0) or DoG (kind 1) image of the last detect call, [h][w] fp32. */
+int gtx_sift_pyramid(gtx_sift* s, int kind, int octave, int layer, int cap, float* out, int* h, int* w,
+                     int* n_octaves);
+
 /* Stabilizer.transform_cur_boxes(): maps the 4 corners of each xywh box through H and
  * returns the axis-aligned bounding rectangle as xywh (rule pinned on the reference's golden
  * output). Pure host arithmetic, f64 inside, f32 out. */
