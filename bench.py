@@ -12,10 +12,11 @@ on the batch size (tests/test_detector_gpu.py::test_detector_batch_equals_single
 
   N = 1   the reference's per-frame order (geotrax/extract.py:145-197): HIP detector -> host C++
           tracker -> HIP stabilizer (mask from the tracker's boxes) -> box warp.
-  N > 1   frames of the clip are sharded over the ranks: every rank detects and
-          stabilizes its K frames (mask from the raw detections), the fixed-stride per-frame
-          records are gathered to rank 0 over RCCL, and rank 0 replays the tracker over all N*K
-          frames and warps the boxes -- all inside the timed region. No other collective.
+  N > 1   the clip's batches are dealt round-robin to the ranks (global batch g goes to
+          rank g % N): every rank detects and stabilizes its K batches (mask from the raw detections);
+          every --gather-every steps the fixed-stride per-frame records of those steps are gathered to
+          rank 0 over RCCL, where a second host thread runs the tracker over them in clip order and
+          warps the boxes while the GPUs carry on -- all inside the timed region. No other collective.
 
 Weak scaling: per-rank work is fixed, value = N*K frames / max-over-ranks time. ONE JSON line (rank 0).
 """
@@ -25,7 +26,9 @@ import argparse
 import collections
 import json
 import os
+import queue
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -58,6 +61,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM per rank (played ping-pong)")
     ap.add_argument("--detections", type=int, default=132, help="boxes per frame the seeded weights are calibrated to (golden clip: 132)")
     ap.add_argument("--trace-every", type=int, default=4, help="HIP-event timing of every launch on every n-th detector pass inside the timed region (roofline); 0 = off")
+    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps between two gathers of per-frame records to rank 0")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU to test the sharded path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -152,13 +158,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("GTX_BENCH_FORCE_DIST") == "1"   # test hook: the N > 1 code path with one rank
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:                                                   # test mode: ranks may share a GPU, collectives on the host
+            local = local % max(torch.cuda.device_count(), 1)
+            dist.init_process_group("gloo")
 
+    cdev = f"cuda:{local}" if args.backend == "nccl" else "cpu"     # where the collectives' tensors live
     from geotrax_amd import _lib
     from geotrax_amd.distributed import pack_frame_record, unpack_frame_record
     from geotrax_amd.geometry import warp_boxes
@@ -169,9 +181,8 @@ def main():
     ctx = _lib.Context(local)
     scene = make_scene(seed=0, h=H, w=W)                       # one clip; ranks take different frames of it
     n_pool = max(args.frames, 2)
-    pool_t = [rank * n_pool + i for i in range(n_pool)]
-    frames = [scene.render(t, 150) for t in pool_t]
-    ref_frame = frames[0] if rank == 0 else scene.render(0, 150)
+    frames = [scene.render(t, 150) for t in range(n_pool)]    # every rank holds the clip; it processes its own batches of it
+    ref_frame = frames[0]
     det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
     # the ping-pong playback (0..n-1, n-2..1: continuous motion) laid out contiguously in HBM, plus the
     # first B-1 frames again, so that every batch of B consecutive frames is one contiguous range
@@ -183,8 +194,9 @@ def main():
     for i, t in enumerate(seq):
         ctx.dev_upload(pool + i * fbytes, frames[t])
 
-    def batch_ptr(k):                                            # batch k = frames k*B .. k*B+B-1 of the playback
-        return pool + ((k * B) % len(order)) * fbytes
+    def batch_ptr(k):                                            # local step k -> global batch k * world + rank of the playback
+        g = k * world + rank
+        return pool + ((g * B) % len(order)) * fbytes
 
     extract = args.workload == "extract"
     tracker = Tracker(args.tracker)
@@ -237,6 +249,8 @@ def main():
             Hm = st.get_cur_trans_matrix()
             if sharded:
                 records.append(pack_frame_record(max_det, p.xyxy, p.conf, p.cls, Hm))
+                if live[0]:
+                    gather_ready()
             elif p is not None and Hm is not None:
                 warp_boxes(Hm, p)
 
@@ -265,8 +279,48 @@ def main():
             finish()
         return n_rows
 
+    # ---- N > 1: chunked gather to rank 0 + tracker replay on a second host thread
+    sent = [0]                                                   # steps of this rank already handed to a gather
+    replay_q = queue.Queue()
+    replay_rows = [0]
+    comm_stream = None
+    if dist is not None and args.backend == "nccl":
+        import torch
+
+        comm_stream = torch.cuda.Stream()                        # non-blocking: torch copies/collectives never touch the kernels' streams
+
+    def gather_ready(final=False):
+        """Hands every complete chunk of --gather-every steps (all of the rest when final) to one gather."""
+        import contextlib
+
+        import torch
+
+        chunk = max(args.gather_every, 1)
+        while True:
+            done_steps = len(records) // B
+            n = min(chunk, done_steps - sent[0])
+            if n <= 0 or (n < chunk and not final):
+                return
+            block = np.stack(records[sent[0] * B:(sent[0] + n) * B])          # [n*B, stride], step-major
+            sent[0] += n
+            with (torch.cuda.stream(comm_stream) if comm_stream is not None else contextlib.nullcontext()):
+                t = torch.from_numpy(block).to(cdev)
+                bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                dist.gather(t, bufs, dst=0)
+                if rank == 0:
+                    host = np.stack([b.cpu().numpy() for b in bufs])            # [world, n*B, stride]
+                    # clip order: step-major, then rank, then frame within the batch
+                    replay_q.put(host.reshape(world, n, B, -1).transpose(1, 0, 2, 3).reshape(world * n * B, -1))
+
+    def replay_worker():
+        while True:
+            item = replay_q.get()
+            if item is None:
+                return
+            replay_rows[0] = replay_tracker(item)
+
     def replay_tracker(all_records):
-        n_rows = 0
+        n_last = 0
         for rec in all_records:
             xyxy, conf, cls, Hm = unpack_frame_record(rec, max_det)
             if len(conf) == 0:
@@ -274,11 +328,12 @@ def main():
             bx, ids = tracker.update(xyxy, conf, cls)[:2]
             if len(ids) and Hm is not None:
                 warp_boxes(Hm, xywh_of(bx))
-            n_rows += len(ids)
-        return n_rows
+            n_last = len(ids)
+        return n_last
 
-    sharded = world > 1
+    sharded = world > 1 or force_dist
     n_tracks = 0
+    live = [False]                                               # gathers only inside the timed region
     if args.warmup > 0:
         n_tracks = run(0, args.warmup, sharded)
     records.clear()
@@ -290,28 +345,33 @@ def main():
             import torch
 
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
 
     if rank == 0 and not args.no_profile:
         for d in dets_:
             d.trace(args.trace_every)
+    worker = None
+    if sharded and extract:
+        live[0] = True
+        if rank == 0:
+            worker = threading.Thread(target=replay_worker, daemon=True)
+            worker.start()
     barrier()
     t0 = time.perf_counter()
     n_tracks = run(args.warmup, args.steps, sharded)
     ctx.synchronize()
     if sharded and extract:
-        import torch
-
-        t = torch.from_numpy(np.stack(records)).to(f"cuda:{local}")
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-        dist.gather(t, bufs, dst=0)
-        if rank == 0:
-            replay_tracker(np.concatenate([b.cpu().numpy() for b in bufs]))
+        gather_ready(final=True)                                 # the steps since the last full chunk
+        if worker is not None:
+            replay_q.put(None)
+            worker.join()                                        # the tracker has seen every frame of every rank
+            n_tracks = replay_rows[0]
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device=f"cuda:{local}")
+        t = torch.tensor([elapsed], device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     barrier()
@@ -333,7 +393,8 @@ def main():
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),
                 "pipeline": f"{n_det_streams} detector stream(s) take batches round-robin and stay in flight while tracker/stabilizers work through the collected batch; {n_stab} stabilizer streams (submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
-                            "frames over ranks; records gathered to rank 0 (RCCL), tracker replayed there",
+                            f"batches dealt round-robin to ranks; records gathered to rank 0 every {args.gather_every} steps (RCCL), "
+                            "tracker replayed there on a second host thread",
             },
         }
         if not args.no_profile:

@@ -16,6 +16,8 @@
 #include "tracker.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -27,6 +29,19 @@
 namespace gtx {
 
 namespace {
+// -DGTX_TRK_PROF: per-phase wall time of update(), printed when the library unloads (tuning only)
+#ifdef GTX_TRK_PROF
+struct ProfAcc {
+  double t[16] = {0}; const char* n[16] = {nullptr}; int calls = 0;
+  ~ProfAcc() { if (calls) for (int i = 0; i < 16; ++i) if (n[i]) fprintf(stderr, "trk %-10s %8.1f us/call\n", n[i], 1e6 * t[i] / calls); }
+};
+static ProfAcc g_prof;
+#define PROF_T0 auto prof_t = std::chrono::steady_clock::now(); int prof_i = 0; g_prof.calls++;
+#define PROF_MARK(name) { auto now__ = std::chrono::steady_clock::now(); g_prof.t[prof_i] += std::chrono::duration<double>(now__ - prof_t).count(); g_prof.n[prof_i++] = #name; prof_t = now__; }
+#else
+#define PROF_T0
+#define PROF_MARK(name)
+#endif
 
 enum State { kNew = 0, kTracked = 1, kLost = 2, kRemoved = 3 };
 
@@ -144,21 +159,36 @@ struct Track {
 // O(E log E) in the number of feasible pairs even when hundreds of boxes overlap.
 // cost: rows x cols, row-major float32 (as numpy hands it to lapjv). x[r] = matched col or -1,
 // y[c] = matched row or -1.
+struct SparseCost {                    // feasible pairs (cost < limit) of a rows x cols problem, CSR by row, columns ascending
+  int rows = 0, cols = 0;
+  std::vector<int> start, adj;
+  std::vector<double> w;             // cost - limit (< 0)
+};
+
+void linear_assignment_sparse(const SparseCost& P, std::vector<int>& x, std::vector<int>& y);
+
 void linear_assignment(const std::vector<float>& cost, int rows, int cols, double limit, std::vector<int>& x,
                        std::vector<int>& y) {
-  x.assign(rows, -1);
-  y.assign(cols, -1);
-  if (rows == 0 || cols == 0) return;
-  // CSR adjacency of feasible pairs, weights w = c - L (< 0)
-  std::vector<int> start(rows + 1, 0), adj;
-  std::vector<double> w;
+  SparseCost P;
+  P.rows = rows; P.cols = cols;
+  P.start.assign(rows + 1, 0);
   for (int r = 0; r < rows; ++r) {
     for (int c = 0; c < cols; ++c) {
       const double v = (double)cost[(size_t)r * cols + c];
-      if (v < limit) { adj.push_back(c); w.push_back(v - limit); }
+      if (v < limit) { P.adj.push_back(c); P.w.push_back(v - limit); }
     }
-    start[r + 1] = (int)adj.size();
+    P.start[r + 1] = (int)P.adj.size();
   }
+  linear_assignment_sparse(P, x, y);
+}
+
+void linear_assignment_sparse(const SparseCost& P, std::vector<int>& x, std::vector<int>& y) {
+  const int rows = P.rows, cols = P.cols;
+  const std::vector<int>&start = P.start, &adj = P.adj;
+  const std::vector<double>& w = P.w;
+  x.assign(rows, -1);
+  y.assign(cols, -1);
+  if (rows == 0 || cols == 0) return;
   const int ncol = cols + rows;                       // real columns, then one skip column per row
   std::vector<double> u(rows, 0.0), v(ncol, 0.0), dist(ncol);
   std::vector<int> col_match(ncol, -1), row_match(rows, -1), parent(ncol), seen_list;
@@ -318,6 +348,70 @@ struct ByteTracker::Impl {
     return d;
   }
 
+  // Feasible pairs of the IoU(+score) cost, i.e. the entries of dists(a, b, fuse) below `limit`, without
+  // forming the dense matrix: a pair of disjoint boxes costs exactly 1 (see dists) and every limit used is
+  // below 1, so only boxes that overlap can qualify. Boxes are swept in x order; the cost of an
+  // overlapping pair is the same float32 expression as in dists().
+  SparseCost sparse_costs(const std::vector<Track*>& a, const std::vector<Track*>& b, bool fuse, double limit) const {
+    SparseCost P;
+    const int na = (int)a.size(), nb = (int)b.size();
+    P.rows = na; P.cols = nb;
+    P.start.assign(na + 1, 0);
+    if (na == 0 || nb == 0) return P;
+    std::vector<float> ab((size_t)na * 4), bb((size_t)nb * 4);
+    for (int i = 0; i < na; ++i) xyxy_of(*a[i], kf.xywh, &ab[(size_t)i * 4]);
+    for (int j = 0; j < nb; ++j) xyxy_of(*b[j], kf.xywh, &bb[(size_t)j * 4]);
+    bool regular = true;           // the sweep needs finite, non-inverted boxes; anything else takes the dense path
+    for (float v : ab) regular &= std::isfinite(v);
+    for (float v : bb) regular &= std::isfinite(v);
+    for (int i = 0; i < na && regular; ++i) regular &= ab[i * 4 + 2] >= ab[i * 4] && ab[i * 4 + 3] >= ab[i * 4 + 1];
+    for (int j = 0; j < nb && regular; ++j) regular &= bb[j * 4 + 2] >= bb[j * 4] && bb[j * 4 + 3] >= bb[j * 4 + 1];
+    if (!regular || limit > 1.0) {
+      const std::vector<float> d = dists(a, b, fuse);
+      for (int r = 0; r < na; ++r) {
+        for (int c = 0; c < nb; ++c) {
+          const double v = (double)d[(size_t)r * nb + c];
+          if (v < limit) { P.adj.push_back(c); P.w.push_back(v - limit); }
+        }
+        P.start[r + 1] = (int)P.adj.size();
+      }
+      return P;
+    }
+    std::vector<int> ob(nb);
+    for (int j = 0; j < nb; ++j) ob[j] = j;
+    std::sort(ob.begin(), ob.end(), [&](int p, int q) { return bb[p * 4] < bb[q * 4]; });
+    std::vector<float> bx1(nb);
+    for (int j = 0; j < nb; ++j) bx1[j] = bb[ob[j] * 4];
+    std::vector<std::pair<int, float>> rowbuf;
+    for (int i = 0; i < na; ++i) {
+      const float* p = &ab[(size_t)i * 4];
+      const float a1 = (p[2] - p[0]) * (p[3] - p[1]);
+      rowbuf.clear();
+      // candidates: x1_b < x2_a (sorted prefix), then x2_b > x1_a and y overlap
+      const int hi = (int)(std::lower_bound(bx1.begin(), bx1.end(), p[2]) - bx1.begin());
+      for (int k = 0; k < hi; ++k) {
+        const int j = ob[k];
+        const float* q = &bb[(size_t)j * 4];
+        if (q[2] <= p[0] || q[1] >= p[3] || q[3] <= p[1]) continue;
+        const float iw = std::max(0.f, std::min(p[2], q[2]) - std::max(p[0], q[0]));
+        const float ih = std::max(0.f, std::min(p[3], q[3]) - std::max(p[1], q[1]));
+        const float inter = iw * ih;
+        const float barea = (q[2] - q[0]) * (q[3] - q[1]);
+        const float iou = inter / (barea + a1 - inter + 1e-7f);
+        float cost = 1.f - iou;
+        if (fuse) {
+          const float sim = (1.f - cost) * b[j]->score;
+          cost = 1.f - sim;
+        }
+        if ((double)cost < limit) rowbuf.emplace_back(j, cost);
+      }
+      std::sort(rowbuf.begin(), rowbuf.end());
+      for (const auto& e : rowbuf) { P.adj.push_back(e.first); P.w.push_back((double)e.second - limit); }
+      P.start[i + 1] = (int)P.adj.size();
+    }
+    return P;
+  }
+
   void activate(Track& t) {
     t.id = new_id();
     double z[4];
@@ -368,6 +462,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   Impl& S = *impl_;
   const gtx_tracker_config& A = S.cfg;
   S.frame_id += 1;
+  PROF_T0
 
   // detections -> candidate tracks (xyxy2xywh then xywh2ltwh in float32)
   std::vector<Track> det_hi, det_lo;
@@ -383,6 +478,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     else if (conf[i] > A.track_low_thresh) det_lo.push_back(t);
   }
 
+  PROF_MARK(dets)
   std::vector<Track*> unconfirmed, confirmed;
   for (Track& t : S.tracked) (t.activated ? confirmed : unconfirmed).push_back(&t);
   // pool = joint(confirmed, lost)
@@ -393,6 +489,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     for (Track& t : S.lost)
       if (!ids.count(t.id)) { ids.insert(t.id); pool.push_back(&t); }
   }
+  PROF_MARK(pool)
   // Kalman predict (velocity of the size/aspect state is zeroed for non-tracked tracks)
   for (Track* t : pool) {
     if (t->state != kTracked) {
@@ -428,6 +525,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     for (Track* t : unconfirmed) apply(t);
   }
 
+  PROF_MARK(predict)
   std::vector<Track> activated_new;             // tracks created this frame
   std::vector<Track*> activated, refind, lost_now, removed_now;
   std::vector<int> x, y;
@@ -435,8 +533,8 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   // ---- first association: pool vs high-score detections ----
   std::vector<Track*> dh;
   for (Track& d : det_hi) dh.push_back(&d);
-  std::vector<float> c1 = S.dists(pool, dh, A.fuse_score != 0);
-  linear_assignment(c1, (int)pool.size(), (int)dh.size(), A.match_thresh, x, y);
+  linear_assignment_sparse(S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh), x, y);
+  PROF_MARK(assoc1)
   std::vector<int> u_track, u_det;
   for (size_t i = 0; i < pool.size(); ++i) {
     if (x[i] >= 0) {
@@ -448,13 +546,13 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (size_t j = 0; j < dh.size(); ++j)
     if (y[j] < 0) u_det.push_back((int)j);
 
+  PROF_MARK(absorb1)
   // ---- second association: remaining tracked tracks vs low-score detections (plain IoU, 0.5) ----
   std::vector<Track*> r_tracked, dl;
   for (int i : u_track)
     if (pool[i]->state == kTracked) r_tracked.push_back(pool[i]);
   for (Track& d : det_lo) dl.push_back(&d);
-  std::vector<float> c2 = S.dists(r_tracked, dl, false);
-  linear_assignment(c2, (int)r_tracked.size(), (int)dl.size(), 0.5, x, y);
+  linear_assignment_sparse(S.sparse_costs(r_tracked, dl, false, 0.5), x, y);
   for (size_t i = 0; i < r_tracked.size(); ++i) {
     Track* t = r_tracked[i];
     if (x[i] >= 0) {
@@ -466,11 +564,11 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     }
   }
 
+  PROF_MARK(second)
   // ---- unconfirmed tracks vs leftover high-score detections (0.7) ----
   std::vector<Track*> dleft;
   for (int j : u_det) dleft.push_back(dh[j]);
-  std::vector<float> c3 = S.dists(unconfirmed, dleft, A.fuse_score != 0);
-  linear_assignment(c3, (int)unconfirmed.size(), (int)dleft.size(), 0.7, x, y);
+  linear_assignment_sparse(S.sparse_costs(unconfirmed, dleft, A.fuse_score != 0, 0.7), x, y);
   for (size_t i = 0; i < unconfirmed.size(); ++i) {
     if (x[i] >= 0) { S.absorb(*unconfirmed[i], *dleft[x[i]], false); activated.push_back(unconfirmed[i]); }
     else { unconfirmed[i]->state = kRemoved; removed_now.push_back(unconfirmed[i]); }
@@ -487,9 +585,11 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (Track& t : S.lost)
     if (S.frame_id - t.frame_id > S.max_time_lost) { t.state = kRemoved; removed_now.push_back(&t); }
 
+  PROF_MARK(third)
   // ---- state update (order of the lists is part of the output contract) ----
   auto has_ptr = [](const std::vector<Track*>& v, const Track* p) { return std::find(v.begin(), v.end(), p) != v.end(); };
   std::vector<Track> new_tracked, new_lost;
+  new_tracked.reserve(S.tracked.size() + 16);
   std::unordered_set<int> ids;
   for (Track& t : S.tracked)
     if (t.state == kTracked) { new_tracked.push_back(t); ids.insert(t.id); }
@@ -517,27 +617,32 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
       if (!removed_ids.count(t.id)) keep.push_back(t);
     new_lost.swap(keep);
   }
+  PROF_MARK(lists)
   // duplicates between tracked and lost (IoU distance < 0.15): keep the older track
   {
     std::vector<Track*> pa, pb;
     for (Track& t : new_tracked) pa.push_back(&t);
     for (Track& t : new_lost) pb.push_back(&t);
-    std::vector<float> pd = S.dists(pa, pb, false);
+    const SparseCost pd = S.sparse_costs(pa, pb, false, (double)0.15f);   // pairs with 1 - IoU < 0.15
     std::vector<char> dupa(pa.size(), 0), dupb(pb.size(), 0);
     for (size_t p = 0; p < pa.size(); ++p)
-      for (size_t q = 0; q < pb.size(); ++q)
-        if (pd[p * pb.size() + q] < 0.15f) {
-          const int tp = pa[p]->frame_id - pa[p]->start_frame, tq = pb[q]->frame_id - pb[q]->start_frame;
-          if (tp > tq) dupb[q] = 1; else dupa[p] = 1;
-        }
-    std::vector<Track> ta, tb;
-    for (size_t p = 0; p < pa.size(); ++p) if (!dupa[p]) ta.push_back(*pa[p]);
-    for (size_t q = 0; q < pb.size(); ++q) if (!dupb[q]) tb.push_back(*pb[q]);
-    new_tracked.swap(ta);
-    new_lost.swap(tb);
+      for (int e = pd.start[p]; e < pd.start[p + 1]; ++e) {
+        const int q = pd.adj[e];
+        const int tp = pa[p]->frame_id - pa[p]->start_frame, tq = pb[q]->frame_id - pb[q]->start_frame;
+        if (tp > tq) dupb[q] = 1; else dupa[p] = 1;
+      }
+    if (!pd.adj.empty()) {               // usual frame: no duplicates, nothing to rebuild
+      std::vector<Track> ta, tb;
+      ta.reserve(pa.size()); tb.reserve(pb.size());
+      for (size_t p = 0; p < pa.size(); ++p) if (!dupa[p]) ta.push_back(*pa[p]);
+      for (size_t q = 0; q < pb.size(); ++q) if (!dupb[q]) tb.push_back(*pb[q]);
+      new_tracked.swap(ta);
+      new_lost.swap(tb);
+    }
   }
   // lost tracks that were marked removed this frame stay in `lost` until the next frame's
   // subtraction (upstream behaviour); keep their state so they never match again.
+  PROF_MARK(dups)
   S.tracked.swap(new_tracked);
   S.lost.swap(new_lost);
   S.removed.swap(removed_all);
@@ -557,6 +662,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     }
     ++k;
   }
+  PROF_MARK(out)
   *n_out = std::min(k, cap);
 }
 
