@@ -10,6 +10,7 @@
 #include "det_kernels.hpp"
 #include "detector.hpp"
 #include "geometry.hpp"
+#include "gmc.hpp"
 #include "match_l2.hpp"
 #include "register.hpp"
 #include "sift.hpp"
@@ -251,6 +252,42 @@ int gtx_op_upsample2x(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, const
     GTX_HIP(hipStreamSynchronize(ctx->stream));
     GTX_HIP(hipMemcpy(y, dy.p, yb, hipMemcpyDeviceToHost));
   });
+}
+
+struct gtx_gmc {
+  gtx_ctx* ctx;
+  std::unique_ptr<gtx::Gmc> impl;
+};
+
+int gtx_gmc_create(gtx_ctx* ctx, int frame_h, int frame_w, int seed, gtx_gmc** out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(out, "out");
+    GTX_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<gtx_gmc> g(new gtx_gmc);
+    g->ctx = ctx;
+    g->impl.reset(new gtx::Gmc(ctx->device, ctx->stream, frame_h / 2, frame_w / 2, seed));
+    *out = g.release();
+  });
+}
+void gtx_gmc_destroy(gtx_gmc* g) { delete g; }
+int gtx_gmc_reset(gtx_gmc* g) {
+  return guarded([&] { need(g, "gmc"); g->impl->reset(); });
+}
+int gtx_gmc_apply(gtx_gmc* g, const uint8_t* frame_bgr, int h, int w, double A[6], int* valid, int stats[3]) {
+  return guarded([&] {
+    need(g, "gmc"); need(frame_bgr, "frame"); need(A, "A");
+    g->impl->submit_frame(frame_bgr, h, w);
+    g->impl->collect(A, valid, stats);
+  });
+}
+int gtx_gmc_submit_gray_dev(gtx_gmc* g, const void* gray_dptr, int gh, int gw) {
+  return guarded([&] { need(g, "gmc"); need(gray_dptr, "gray"); g->impl->submit_gray_dev(gray_dptr, gh, gw); });
+}
+int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]) {
+  return guarded([&] { need(g, "gmc"); need(A, "A"); g->impl->collect(A, valid, stats); });
+}
+int gtx_gmc_points(gtx_gmc* g, int which, int cap, int* n, float* xy, int* status) {
+  return guarded([&] { need(g, "gmc"); need(n, "n"); g->impl->debug_points(which, cap, n, xy, status); });
 }
 
 struct gtx_sift {

@@ -79,6 +79,13 @@ _SIGNATURES = {
     "gtx_op_conv2d_time": (C.c_int, [_P, C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "gtx_op_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gtx_op_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "gtx_gmc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gtx_gmc_destroy": (None, [_P]),
+    "gtx_gmc_reset": (C.c_int, [_P]),
+    "gtx_gmc_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P]),
+    "gtx_gmc_submit_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gtx_gmc_collect": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
+    "gtx_gmc_points": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P]),
     "gtx_register_images": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P, _P]),
     "gtx_sift_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_sift_destroy": (None, [_P]),

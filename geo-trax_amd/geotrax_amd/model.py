@@ -128,6 +128,8 @@ class YOLO:
         self._det_key = None
         self._tracker: Tracker | None = None
         self._tracker_key = None
+        self._gmc = None
+        self._gmc_method = None
 
     # ---- lazy construction, like ultralytics' predictor setup on the first call
     def _detector(self, frame_hw, kw) -> Detector:
@@ -156,9 +158,16 @@ class YOLO:
         if ttype == "botsort":
             if params.get("with_reid"):
                 raise NotImplementedError("BoT-SORT ReID is not implemented")
-            if params.get("gmc_method", "none") not in ("none", None):
-                logger.warning("BoT-SORT gmc_method '%s' is not implemented on this path yet; camera motion compensation "
-                               "inside the tracker is skipped (identity).", params.get("gmc_method"))
+            gm = params.get("gmc_method", "none")
+            if gm in ("none", None):
+                self._gmc_method = None
+            elif gm == "sparseOptFlow":
+                self._gmc_method = gm                         # GPU corners + pyramidal LK + RANSAC similarity (gmc.py)
+            else:
+                raise NotImplementedError(f"BoT-SORT gmc_method '{gm}': only 'sparseOptFlow' and 'none' are implemented")
+        else:
+            self._gmc_method = None
+        self._gmc = None
         return Tracker(ttype, **{k: v for k, v in params.items() if k in (
             "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score")})
 
@@ -176,13 +185,28 @@ class YOLO:
             self._tracker, self._tracker_key = self._make_tracker(spec), tkey
         elif not persist:
             self._tracker.reset()
+            if self._gmc is not None:
+                self._gmc.reset_params()
         kwargs = dict(kwargs)
         kwargs["conf"] = kwargs.get("conf") or 0.1      # ultralytics Model.track default
         res = self.predict(source, **kwargs)[0]
         if len(res.boxes) == 0:
             return [res]
         b = res.boxes
-        xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32))
+        warp = None
+        if self._gmc_method is not None:                    # BOTSORT.update: camera motion first, on this frame's gray image
+            frame = np.asarray(source)
+            if self._gmc is None or self._gmc.frame_hw != tuple(frame.shape[:2]):
+                from .gmc import GMC
+
+                self._gmc = GMC(frame.shape[:2], method=self._gmc_method, ctx=self.ctx)
+            g = self._det.gray_dptr(0) if self._det is not None else (0, 0, 0)
+            if g[0] and (g[1], g[2]) == (frame.shape[0] // 2, frame.shape[1] // 2):
+                self._gmc.submit_gray_dev(g[0], g[1], g[2])  # the half-resolution gray the detector left in HBM
+                warp = self._gmc.collect()
+            else:
+                warp = self._gmc.apply(frame)
+        xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32), gmc=warp)
         if len(ids) == 0:
             return [res]
         res.boxes = Boxes(xyxy, score, cls, ids)

@@ -284,6 +284,25 @@ int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, in
  * tests][ax, ay, bx, by] int8 = 262144 bytes. Data hand-over for the parity tests. */
 int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out);
 
+/* ------------------------------------------------------------------ global motion compensation
+ * BoT-SORT's camera-motion estimate, gmc_method 'sparseOptFlow' (geotrax/cfg/default.yaml:374), the
+ * per-frame step ultralytics' BOTSORT.update runs before association (reached from extract.py:153):
+ * Shi-Tomasi corners of the half-resolution gray frame, pyramidal Lucas-Kanade against the previous
+ * frame, RANSAC similarity. A = row-major 2x3 f64 mapping previous-frame to current-frame pixels
+ * (full resolution); feed it to gtx_tracker_update(gmc). Identity (valid = 0) on the first frame or
+ * when fewer than 5 corners could be tracked. stats = {corners of the previous frame, tracked, inliers}. */
+typedef struct gtx_gmc gtx_gmc;
+int gtx_gmc_create(gtx_ctx* ctx, int frame_h, int frame_w, int seed, gtx_gmc** out);
+void gtx_gmc_destroy(gtx_gmc* g);
+int gtx_gmc_reset(gtx_gmc* g);
+int gtx_gmc_apply(gtx_gmc* g, const uint8_t* frame_bgr, int h, int w, double A[6], int* valid, int stats[3]);
+/* Asynchronous pair on the half-resolution gray image the detector left in HBM (gtx_detector_gray). */
+int gtx_gmc_submit_gray_dev(gtx_gmc* g, const void* gray_dptr, int gray_h, int gray_w);
+int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]);
+/* Parity hook: which 0 = corners of the last frame, 1 = corners of the frame before, 2 = where LK put
+ * those in the last frame (+ status). xy in half-resolution pixels. */
+int gtx_gmc_points(gtx_gmc* g, int which, int cap, int* n, float* xy, int* status);
+
 /* ------------------------------------------------------------------ registration (once per video)
  * Replaces estimate_homography() of geotrax/utils/registration.py:21-95 -- stabilo.Stabilizer with
  * detector_name='rsift', matcher_name='bf', filter_type='ratio', projective model, no mask, no

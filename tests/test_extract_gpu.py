@@ -60,9 +60,16 @@ def _oracle_chain(frames, weights, cfg, pattern):
     from oracle.stabilo_ref import StabilizerRef
     from oracle.yolov8_ref import YoloV8Ref, detect
 
+    from oracle.gmc_ref import GmcRef
+    from oracle.yolov8_ref import bgr2gray_half
+
     u = cfg["ultralytics"]
     model = YoloV8Ref(weights, emulate_half=False)
-    trk = ByteTrackRef(**{k: v for k, v in cfg["tracker"]["bytetrack"].items() if k != "tracker_type"})
+    active = cfg["tracker"]["active"]
+    tp = cfg["tracker"][active]
+    trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
+                                                                             "track_buffer", "match_thresh", "fuse_score")})
+    gmc = GmcRef(seed=0) if active == "botsort" and tp.get("gmc_method") == "sparseOptFlow" else None
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
@@ -70,7 +77,8 @@ def _oracle_chain(frames, weights, cfg, pattern):
     for f, frame in enumerate(frames):
         xyxy, conf, cls = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"])
         if len(conf):
-            t = trk.update(xyxy, conf, cls)
+            warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
+            t = trk.update(xyxy, conf, cls, gmc=warp)
             if len(t):
                 bx, ids, sc, cl = t[:, :4], t[:, 4], t[:, 5], t[:, 6]
             else:
@@ -101,7 +109,8 @@ def _oracle_chain(frames, weights, cfg, pattern):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path):
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.stabilizer import Stabilizer
@@ -112,7 +121,9 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path):
     src = tmp_path / "clip.npy"
     np.save(src, frames)
     wpath, weights = _weights_file(tmp_path, gtx_ctx, frames[0])
-    cfg_path, cfg = _cfg_file(tmp_path, wpath)
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker)
+    if tracker == "botsort":
+        assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
                               class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
     model = ex.load_detector(args, logger)
