@@ -200,6 +200,11 @@ def main():
 
     extract = args.workload == "extract"
     tracker = Tracker(args.tracker)
+    gmc = None
+    if extract and args.tracker == "botsort" and world == 1 and not force_dist:
+        from geotrax_amd.gmc import GMC                       # BoT-SORT: camera motion per frame (default.yaml:374), own stream
+
+        gmc = GMC((H, W), ctx=_lib.Context(local))
     # stabilizer instances on their own streams: stabilize(t), stabilize(t+1), .. overlap each other and detect(batch k+1)
     # a gray image stays valid until its detector has submitted 5 more batches: the frames in flight in
     # the stabilizers must stay below 4 * detectors * batch
@@ -262,11 +267,15 @@ def main():
             grays = [dk.gray_dptr(b) for b in range(B)]
             if k + n_det_streams < n_steps:
                 dk.submit_dev(batch_ptr(k0 + k + n_det_streams), B)
-            for d, g in zip(dets, grays):
+            if gmc is not None:                                  # the whole batch queues on the GMC stream, results in order
+                for g in grays:
+                    gmc.submit_gray_dev(*g)
+            for b, (d, g) in enumerate(zip(dets, grays)):
+                warp = gmc.collect() if gmc is not None else None
                 if sharded:                                      # shard rank: mask from raw detections, tracker later
                     xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
                 else:
-                    bx, ids = tracker.update(d.xyxy, d.conf, d.cls)[:2] if len(d) else empty
+                    bx, ids = tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)[:2] if len(d) else empty
                     xywh = xywh_of(bx)
                     keep, n_rows = xywh, len(ids)
                 if len(pending) == n_stab:                       # results are taken in frame order
@@ -338,6 +347,8 @@ def main():
         n_tracks = run(0, args.warmup, sharded)
     records.clear()
     tracker.reset()
+    if gmc is not None:
+        gmc.reset_params()
 
     def barrier():
         ctx.synchronize()
@@ -387,7 +398,7 @@ def main():
                              f"{B} frame(s) per step (BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
                              f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
-                "tracker": args.tracker, "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
+                "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s, class bias calibrated on one frame (no checkpoint reachable)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),

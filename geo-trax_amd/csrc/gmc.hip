@@ -73,32 +73,70 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ g, int w, i
   dy = (k - a) + 2 * (l - b) + (m - c);
 }
 
+// reflect-101 for indices at most a few pixels outside [0, n)
+__device__ __forceinline__ int refl_near(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// 64x16 output tile: gray (+2 ring) -> LDS, Sobel at the (+1 ring) positions -> LDS, 3x3 box sums.
+// All sums fit int32 (|d| <= 1020, 9 d^2 <= 9.4e6); the eigenvalue is f64.
+constexpr int kRT_W = 64, kRT_H = 16;
 __global__ __launch_bounds__(256) void response_kernel(const uint8_t* __restrict__ g, int w, int h, double* __restrict__ lam,
                                                        unsigned long long* __restrict__ max_bits) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  double v = 0.0;
-  if (x < w) {
-    long a = 0, b = 0, c = 0;
+  __shared__ uint8_t s_g[(kRT_H + 4) * (kRT_W + 4)];
+  __shared__ short s_dx[(kRT_H + 2) * (kRT_W + 2)], s_dy[(kRT_H + 2) * (kRT_W + 2)];
+  const int x0 = blockIdx.x * kRT_W, y0 = blockIdx.y * kRT_H;
+  // The box sum at (y, x) uses Sobel values at reflect(y+i), reflect(x+j); the Sobel there uses gray at
+  // reflect(. +-1) of THAT position. Away from the image border both are plain offsets; at the border the
+  // tile is filled per Sobel position, so stage the Sobel values directly.
+  for (int i = threadIdx.x; i < (kRT_H + 4) * (kRT_W + 4); i += 256) {
+    const int ty = i / (kRT_W + 4), tx = i % (kRT_W + 4);
+    s_g[i] = g[(size_t)refl_near(min(y0 + ty - 2, h + 1), h) * w + refl_near(min(x0 + tx - 2, w + 1), w)];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (kRT_H + 2) * (kRT_W + 2); i += 256) {
+    const int ty = i / (kRT_W + 2), tx = i % (kRT_W + 2);
+    // Sobel position in image coordinates (may be one outside: reflect it, then its neighbours reflect again)
+    const int py = refl_near(min(y0 + ty - 1, h), h), px = refl_near(min(x0 + tx - 1, w), w);
+    int dx, dy;
+    const bool interior = py >= 1 && py < h - 1 && px >= 1 && px < w - 1 && py == y0 + ty - 1 && px == x0 + tx - 1;
+    if (interior) {
+      const uint8_t* c = s_g + (ty + 1) * (kRT_W + 4) + tx + 1;
+      constexpr int S = kRT_W + 4;
+      dx = (c[-S + 1] - c[-S - 1]) + 2 * (c[1] - c[-1]) + (c[S + 1] - c[S - 1]);
+      dy = (c[S - 1] - c[-S - 1]) + 2 * (c[S] - c[-S]) + (c[S + 1] - c[-S + 1]);
+    } else {
+      long ldx, ldy;
+      sobel_at(g, w, h, py, px, ldx, ldy);
+      dx = (int)ldx; dy = (int)ldy;
+    }
+    s_dx[i] = (short)dx; s_dy[i] = (short)dy;
+  }
+  __syncthreads();
+  double m = 0.0;
+  for (int i = threadIdx.x; i < kRT_H * kRT_W; i += 256) {
+    const int ty = i / kRT_W, tx = i % kRT_W;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= w || y >= h) continue;
+    int a = 0, b = 0, c = 0;
 #pragma unroll
-    for (int i = -1; i <= 1; ++i)
+    for (int di = 0; di < 3; ++di)
 #pragma unroll
-      for (int j = -1; j <= 1; ++j) {
-        long dx, dy;
-        sobel_at(g, w, h, refl101(y + i, h), refl101(x + j, w), dx, dy);
+      for (int dj = 0; dj < 3; ++dj) {
+        const int q = (ty + di) * (kRT_W + 2) + tx + dj;
+        const int dx = s_dx[q], dy = s_dy[q];
         a += dx * dx; b += dx * dy; c += dy * dy;
       }
-    v = 0.5 * (double)(a + c) - sqrt(0.25 * ((double)(a - c) * (double)(a - c)) + (double)b * (double)b);
+    const double v = 0.5 * (double)(a + c) - sqrt(0.25 * ((double)(a - c) * (double)(a - c)) + (double)b * (double)b);
     lam[(size_t)y * w + x] = v;
+    m = fmax(m, v);
   }
   // block max -> global max (bit pattern of a non-negative double is order preserving)
-  double m = v > 0.0 ? v : 0.0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(m));
 }
 
 __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam, int w, int h, const unsigned long long* __restrict__ max_bits,
-                                                  Cand* __restrict__ cand, int* __restrict__ n_cand, int cap) {
+                                                  Cand* __restrict__ cand, int* __restrict__ n_cand, int cap, int* __restrict__ hist16) {
   const int x = 1 + blockIdx.x * 256 + threadIdx.x, y = 1 + blockIdx.y;
   if (x >= w - 1 || y >= h - 1) return;
   const double thr = __longlong_as_double((long long)*max_bits) * kQuality;
@@ -114,95 +152,98 @@ __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam
     }
   if (v == mx) {
     const int slot = atomicAdd(n_cand, 1);
-    if (slot < cap) cand[slot] = Cand{v, y * w + x, 0};
+    if (slot < cap) {
+      cand[slot] = Cand{v, y * w + x, 0};
+      atomicAdd(&hist16[(unsigned long long)__double_as_longlong(v) >> 48], 1);   // sign + exponent + 4 mantissa bits
+    }
   }
 }
 
-// top-kMaxCorners by (val desc, pix desc), sorted; one workgroup of 1024 threads
+// top-kMaxCorners by (val desc, pix desc), sorted; one workgroup of 1024 threads.
+// The candidates' histogram over the top 16 key bits (filled by nms_kernel) gives the bucket the 1000th
+// strongest falls into; one sweep then gathers everything above that bucket plus the bucket itself
+// (a 6 %-wide value range: a few hundred candidates) into LDS, where a bitonic sort of (key, pix)
+// finishes the job. A bucket too full for LDS is narrowed by further 8-bit radix passes first.
+constexpr int kSelCap = 4096;
 __global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ cand, const int* __restrict__ n_cand, int cap, int w,
-                                                      float2* __restrict__ pts, int* __restrict__ n_pts) {
-  __shared__ unsigned long long s_key[1024];
-  __shared__ int s_pix[1024];
+                                                      const int* __restrict__ hist16, float2* __restrict__ pts, int* __restrict__ n_pts) {
+  __shared__ unsigned long long s_key[kSelCap];
+  __shared__ int s_pix[kSelCap];
+  __shared__ int s_part[1024];
   __shared__ int s_hist[256];
-  __shared__ unsigned long long s_prefix;
-  __shared__ int s_need, s_cnt;
+  __shared__ unsigned long long s_lo;       // keys >= s_lo are gathered
+  __shared__ int s_cnt, s_bucket, s_above, s_need;
   const int tid = threadIdx.x;
   const int n = min(*n_cand, cap);
   const int want = min(n, kMaxCorners);
-  unsigned long long cut_key = 0;     // keys > cut_key are all kept
-  int cut_pix = -1;                   // among key == cut_key: pix >= cut_pix kept
-  if (n > kMaxCorners) {
-    // radix select the want-th largest key, MSB first
-    if (tid == 0) { s_prefix = 0; s_need = want; }
+  if (tid == 0) { s_lo = 0; s_cnt = 0; }
+  __syncthreads();
+  if (n > kSelCap) {
+    // bucket of the want-th strongest: scan the 65536-bin histogram from the top, 64 bins per thread
+    int part = 0;
+    if (tid >= 512)                          // keys are non-negative doubles: the top half of the bins is empty
+      for (int k = 0; k < 64; ++k) part += hist16[65535 - (tid * 64 + k)];
+    s_part[tid] = part;
     __syncthreads();
-    for (int pass = 7; pass >= 0; --pass) {
+    if (tid == 0) {
+      int acc = 0, t = 0;
+      for (; t < 1024; ++t) { if (acc + s_part[t] >= want) break; acc += s_part[t]; }
+      int bkt = 65535 - t * 64;
+      for (int k = 0; k < 64; ++k, --bkt) { const int c = hist16[bkt]; if (acc + c >= want) break; acc += c; }
+      s_bucket = bkt; s_above = acc; s_need = want - acc;
+    }
+    __syncthreads();
+    unsigned long long lo = (unsigned long long)s_bucket << 48;
+    int population = hist16[s_bucket];
+    // narrow an over-full bucket: 8 more key bits per pass, keeping the part that still holds the cut
+    for (int shift = 40; population + s_above > kSelCap - 64 && shift >= 0; shift -= 8) {
       if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
-      const unsigned long long prefix = s_prefix;
-      const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+      const unsigned long long mask = ~0ull << (shift + 8);
       for (int i = tid; i < n; i += 1024) {
         const unsigned long long k = (unsigned long long)__double_as_longlong(cand[i].val);
-        if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> (8 * pass)) & 255], 1);
+        if ((k & mask) == lo) atomicAdd(&s_hist[(k >> shift) & 255], 1);
       }
       __syncthreads();
       if (tid == 0) {
-        int need = s_need, b = 255;
-        for (; b > 0; --b) { if (s_hist[b] >= need) break; need -= s_hist[b]; }
-        s_need = need;
-        s_prefix = prefix | ((unsigned long long)b << (8 * pass));
+        int need = s_need, b2 = 255;
+        for (; b2 > 0; --b2) { if (s_hist[b2] >= need) break; need -= s_hist[b2]; s_above += s_hist[b2]; }
+        s_need = need; s_bucket = b2; s_cnt = s_hist[b2];
       }
+      __syncthreads();
+      lo |= (unsigned long long)s_bucket << shift;
+      population = s_cnt;
       __syncthreads();
     }
-    cut_key = s_prefix;
-    // among key == cut_key keep the s_need largest pixel indices: radix select on pix (4 passes)
-    const int need_eq = s_need;
+    if (tid == 0) { s_lo = lo; s_cnt = 0; }
     __syncthreads();
-    if (tid == 0) { s_prefix = 0; s_need = need_eq; }
-    __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {
-      if (tid < 256) s_hist[tid] = 0;
-      __syncthreads();
-      const unsigned prefix = (unsigned)s_prefix;
-      const unsigned mask = pass == 3 ? 0u : (~0u << (8 * (pass + 1)));
-      for (int i = tid; i < n; i += 1024) {
-        if ((unsigned long long)__double_as_longlong(cand[i].val) != cut_key) continue;
-        const unsigned k = (unsigned)cand[i].pix;
-        if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> (8 * pass)) & 255], 1);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int need = s_need, b = 255;
-        for (; b > 0; --b) { if (s_hist[b] >= need) break; need -= s_hist[b]; }
-        s_need = need;
-        s_prefix = (unsigned long long)(prefix | ((unsigned)b << (8 * pass)));
-      }
-      __syncthreads();
-    }
-    cut_pix = (int)(unsigned)s_prefix;
   }
-  // gather the selected set into LDS (order irrelevant, sorted next)
-  if (tid == 0) s_cnt = 0;
-  s_key[tid] = 0; s_pix[tid] = -1;
+  for (int i = tid; i < kSelCap; i += 1024) { s_key[i] = 0; s_pix[i] = -1; }
   __syncthreads();
+  const unsigned long long lo = s_lo;
   for (int i = tid; i < n; i += 1024) {
     const unsigned long long k = (unsigned long long)__double_as_longlong(cand[i].val);
-    const int px = cand[i].pix;
-    if (k > cut_key || (k == cut_key && px >= cut_pix)) {
+    if (k >= lo) {
       const int slot = atomicAdd(&s_cnt, 1);
-      if (slot < 1024) { s_key[slot] = k; s_pix[slot] = px; }
+      if (slot < kSelCap) { s_key[slot] = k; s_pix[slot] = cand[i].pix; }
     }
   }
   __syncthreads();
-  // bitonic sort, descending by (key, pix); empty slots (key 0, pix -1) sink to the end
-  for (int k2 = 2; k2 <= 1024; k2 <<= 1)
+  // bitonic sort of the occupied slots (padded to a power of two), descending by (key, pix); empty
+  // slots (key 0, pix -1) sink to the end
+  int m = 1024;
+  while (m < min(s_cnt, kSelCap)) m <<= 1;
+  for (int k2 = 2; k2 <= m; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      const int ixj = tid ^ j;
-      if (ixj > tid) {
-        const unsigned long long ka = s_key[tid], kb = s_key[ixj];
-        const int pa = s_pix[tid], pb = s_pix[ixj];
-        const bool a_before_b = ka > kb || (ka == kb && pa > pb);   // a should precede b in descending order
-        const bool desc = (tid & k2) == 0;
-        if (desc ? !a_before_b : a_before_b) { s_key[tid] = kb; s_key[ixj] = ka; s_pix[tid] = pb; s_pix[ixj] = pa; }
+      for (int t = tid; t < m; t += 1024) {
+        const int ixj = t ^ j;
+        if (ixj > t) {
+          const unsigned long long ka = s_key[t], kb = s_key[ixj];
+          const int pa = s_pix[t], pb = s_pix[ixj];
+          const bool a_first = ka > kb || (ka == kb && pa > pb);
+          const bool desc = (t & k2) == 0;
+          if (desc ? !a_first : a_first) { s_key[t] = kb; s_key[ixj] = ka; s_pix[t] = pb; s_pix[ixj] = pa; }
+        }
       }
       __syncthreads();
     }
@@ -432,13 +473,18 @@ struct Gmc::Impl {
   hipStream_t s;
   int w, h;                    // half-resolution gray size
   unsigned seed;
-  DevBuf frame, gray, pyr[2], lam, cand, counters, pts[2], npts[2], next, status, pairs, res, model, count;
+  DevBuf frame, gray, pyr[2], lam, cand, counters, hist16, pts[2], npts[2], next, status, pairs, res, model, count;
   Pyr P[2]{};
   int cur = 0;                 // index of the buffers the next frame is written to
-  bool have_prev = false, pending = false, pending_first = false;
-  GmcResult* h_res = nullptr;  // pinned
-  float4* h_pairs = nullptr;   // pinned
-  hipEvent_t done = nullptr;
+  bool have_prev = false;
+  // results of up to kRing submitted frames wait in pinned memory, one event each (stream order
+  // makes the device-side buffers reusable from one frame to the next)
+  static constexpr int kRing = 16;
+  GmcResult* h_res = nullptr;  // pinned [kRing]
+  float4* h_pairs = nullptr;   // pinned [kRing][1024]
+  hipEvent_t done[kRing] = {};
+  bool first[kRing] = {};
+  int head = 0, pending = 0;   // oldest pending slot, number pending
   int cand_cap = 0;
   int stats[3] = {0, 0, 0};
 };
@@ -464,11 +510,12 @@ Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : imp
   S.cand_cap = gray_w * gray_h / 4;
   S.cand.alloc(sizeof(Cand) * S.cand_cap);
   S.counters.alloc(16);
+  S.hist16.alloc(sizeof(int) * 65536);
   S.next.alloc(sizeof(float2) * 1024); S.status.alloc(sizeof(int) * 1024); S.pairs.alloc(sizeof(float4) * 1024);
   S.res.alloc(sizeof(GmcResult)); S.model.alloc(sizeof(double4) * kHyp); S.count.alloc(sizeof(int) * kHyp);
-  GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(GmcResult)));
-  GTX_HIP(hipHostMalloc((void**)&S.h_pairs, sizeof(float4) * 1024));
-  GTX_HIP(hipEventCreate(&S.done));
+  GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(GmcResult) * Impl::kRing));
+  GTX_HIP(hipHostMalloc((void**)&S.h_pairs, sizeof(float4) * 1024 * Impl::kRing));
+  for (auto& e : S.done) GTX_HIP(hipEventCreate(&e));
   GTX_HIP(hipDeviceSynchronize());
 }
 
@@ -476,19 +523,21 @@ Gmc::~Gmc() {
   if (impl_) {
     if (impl_->h_res) (void)hipHostFree(impl_->h_res);
     if (impl_->h_pairs) (void)hipHostFree(impl_->h_pairs);
-    if (impl_->done) (void)hipEventDestroy(impl_->done);
+    for (auto& e : impl_->done)
+      if (e) (void)hipEventDestroy(e);
   }
 }
 
 void Gmc::reset() {
-  GTX_CHECK(!impl_->pending, "gmc: reset while a frame is in flight");
+  GTX_CHECK(impl_->pending == 0, "gmc: reset while a frame is in flight");
   impl_->have_prev = false;
 }
 
 void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
   Impl& S = *impl_;
   GTX_CHECK(gray && gh == S.h && gw == S.w, "gmc: gray image is %dx%d, expected %dx%d", gw, gh, S.w, S.h);
-  GTX_CHECK(!S.pending, "gmc: a frame is already in flight");
+  GTX_CHECK(S.pending < Impl::kRing, "gmc: %d frames already in flight, collect first", S.pending);
+  const int slot = (S.head + S.pending) % Impl::kRing;
   GTX_HIP(hipSetDevice(S.device));
   hipStream_t s = S.s;
   const int c = S.cur, p = c ^ 1;
@@ -500,13 +549,15 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
                        const_cast<uint8_t*>(Pc.img[l]), Pc.w[l], Pc.h[l]);
   // corners of the current frame
   GTX_HIP(hipMemsetAsync(S.counters.p, 0, 16, s));
+  GTX_HIP(hipMemsetAsync(S.hist16.p, 0, sizeof(int) * 65536, s));
   unsigned long long* max_bits = S.counters.as<unsigned long long>();
   int* n_cand = reinterpret_cast<int*>(max_bits + 1);
-  hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam.as<double>(), max_bits);
+  hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, kRT_W), cdiv(S.h, kRT_H)), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam.as<double>(), max_bits);
   hipLaunchKernelGGL(nms_kernel, dim3(cdiv(S.w - 2, 256), S.h - 2), dim3(256), 0, s, S.lam.as<double>(), S.w, S.h, max_bits, S.cand.as<Cand>(),
-                     n_cand, S.cand_cap);
-  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand.as<Cand>(), n_cand, S.cand_cap, S.w, S.pts[c].as<float2>(), S.npts[c].as<int>());
-  S.pending_first = !S.have_prev;
+                     n_cand, S.cand_cap, S.hist16.as<int>());
+  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand.as<Cand>(), n_cand, S.cand_cap, S.w, S.hist16.as<int>(), S.pts[c].as<float2>(),
+                     S.npts[c].as<int>());
+  S.first[slot] = !S.have_prev;
   if (S.have_prev) {
     hipLaunchKernelGGL(lk_kernel, dim3(cdiv(kMaxCorners, 4)), dim3(256), 0, s, S.P[p], Pc, S.pts[p].as<float2>(), S.npts[p].as<int>(),
                        S.next.as<float2>(), S.status.as<int>());
@@ -515,12 +566,12 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
     hipLaunchKernelGGL(ransac_kernel, dim3(kHyp / 4), dim3(256), 0, s, S.pairs.as<float4>(), S.res.as<GmcResult>(), S.seed, S.model.as<double4>(),
                        S.count.as<int>());
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(kHyp), 0, s, S.model.as<double4>(), S.count.as<int>(), S.res.as<GmcResult>());
-    GTX_HIP(hipMemcpyAsync(S.h_res, S.res.p, sizeof(GmcResult), hipMemcpyDeviceToHost, s));
-    GTX_HIP(hipMemcpyAsync(S.h_pairs, S.pairs.p, sizeof(float4) * 1024, hipMemcpyDeviceToHost, s));
+    GTX_HIP(hipMemcpyAsync(S.h_res + slot, S.res.p, sizeof(GmcResult), hipMemcpyDeviceToHost, s));
+    GTX_HIP(hipMemcpyAsync(S.h_pairs + (size_t)slot * 1024, S.pairs.p, sizeof(float4) * 1024, hipMemcpyDeviceToHost, s));
   }
   GTX_HIP(hipGetLastError());
-  GTX_HIP(hipEventRecord(S.done, s));
-  S.pending = true;
+  GTX_HIP(hipEventRecord(S.done[slot], s));
+  S.pending += 1;
   S.have_prev = true;
   S.cur = p;       // the next frame overwrites what is now "previous"
 }
@@ -528,7 +579,7 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
 void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
   Impl& S = *impl_;
   GTX_CHECK(frame_bgr && h / 2 == S.h && w / 2 == S.w, "gmc: frame is %dx%d, created for %dx%d", w, h, 2 * S.w, 2 * S.h);
-  GTX_CHECK(!S.pending, "gmc: a frame is already in flight");
+  GTX_CHECK(S.pending == 0, "gmc: the host-frame path keeps one frame in flight");
   GTX_HIP(hipSetDevice(S.device));
   const size_t bytes = (size_t)h * w * 3;
   if (S.frame.bytes < bytes) S.frame.alloc(bytes);
@@ -540,19 +591,22 @@ void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
 
 void Gmc::collect(double A[6], int* valid, int stats[3]) {
   Impl& S = *impl_;
-  GTX_CHECK(S.pending, "gmc: collect without a submitted frame");
+  GTX_CHECK(S.pending > 0, "gmc: collect without a submitted frame");
   GTX_HIP(hipSetDevice(S.device));
-  GTX_HIP(hipEventSynchronize(S.done));
-  S.pending = false;
+  const int slot = S.head;
+  GTX_HIP(hipEventSynchronize(S.done[slot]));
+  S.head = (S.head + 1) % Impl::kRing;
+  S.pending -= 1;
   const double I6[6] = {1, 0, 0, 0, 1, 0};
   std::memcpy(A, I6, sizeof I6);
   if (valid) *valid = 0;
   S.stats[0] = S.stats[1] = S.stats[2] = 0;
-  if (!S.pending_first) {
-    const GmcResult& R = *S.h_res;
+  if (!S.first[slot]) {
+    const GmcResult& R = S.h_res[slot];
     S.stats[0] = R.n_prev; S.stats[1] = R.n_valid;
     if (R.n_valid > 4 && R.best_count >= 0) {
-      std::vector<float4> pr(S.h_pairs, S.h_pairs + R.n_valid);
+      const float4* hp = S.h_pairs + (size_t)slot * 1024;
+      std::vector<float4> pr(hp, hp + R.n_valid);
       double M[6] = {R.a, -R.b, R.tx, R.b, R.a, R.ty};
       std::vector<char> inl(pr.size());
       int n_inl = 0;
@@ -579,7 +633,7 @@ void Gmc::collect(double A[6], int* valid, int stats[3]) {
 
 void Gmc::debug_points(int which, int cap, int* n, float* xy, int* status) const {
   const Impl& S = *impl_;
-  GTX_CHECK(!S.pending, "gmc: debug read while a frame is in flight");
+  GTX_CHECK(S.pending == 0, "gmc: debug read while a frame is in flight");
   GTX_HIP(hipSetDevice(S.device));
   GTX_HIP(hipStreamSynchronize(S.s));
   // which 0: corners of the last submitted frame; 1: corners of the frame before; 2: their LK positions in the last frame

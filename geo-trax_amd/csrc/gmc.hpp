@@ -15,7 +15,8 @@ class Gmc {
   Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed);
   ~Gmc();
   void reset();                                               // forget the previous frame
-  // asynchronous pair: corners + flow against the previous frame + RANSAC on the stream / refit on the host
+  // asynchronous pair: corners + flow against the previous frame + RANSAC on the stream / refit on the host.
+  // Up to 16 frames may be submitted ahead; collect() returns them in submission order.
   void submit_gray_dev(const void* gray, int gh, int gw);
   // BGR u8 host frame [2*gray_h][2*gray_w][3]: gray + 2x2 mean on the GPU, then as above
   void submit_frame(const uint8_t* frame_bgr, int h, int w);

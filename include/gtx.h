@@ -296,7 +296,9 @@ int gtx_gmc_create(gtx_ctx* ctx, int frame_h, int frame_w, int seed, gtx_gmc** o
 void gtx_gmc_destroy(gtx_gmc* g);
 int gtx_gmc_reset(gtx_gmc* g);
 int gtx_gmc_apply(gtx_gmc* g, const uint8_t* frame_bgr, int h, int w, double A[6], int* valid, int stats[3]);
-/* Asynchronous pair on the half-resolution gray image the detector left in HBM (gtx_detector_gray). */
+/* Asynchronous pair on the half-resolution gray image the detector left in HBM (gtx_detector_gray).
+ * Up to 16 frames may be submitted ahead (the image is copied at submit); _collect returns their warps
+ * in submission order. */
 int gtx_gmc_submit_gray_dev(gtx_gmc* g, const void* gray_dptr, int gray_h, int gray_w);
 int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]);
 /* Parity hook: which 0 = corners of the last frame, 1 = corners of the frame before, 2 = where LK put
