@@ -129,6 +129,8 @@ class Detector {
   int* h_out_n_ = nullptr;   // pinned
   float* h_out_rows_ = nullptr;
   hipEvent_t ev_[4]{};
+  hipGraphExec_t graph_exec_ = nullptr;   // captured forward graph for batch size graph_nb_
+  int graph_nb_ = 0;
   int trace_every_ = 0, trace_count_ = 0;
   bool flight_traced_ = false;
   std::vector<hipEvent_t> trace_ev_;      // one per op + 1
