@@ -16,6 +16,11 @@ Two kinds of fixture, both *data* (inputs + expected outputs), never reference s
    of the detect/track/stabilize chain), stored compactly:
    `U_video_cut.txt.gz`, `U_video_cut_vid_transf.txt`, `U_video_cut_geo_transf.txt`,
    `U_video_cut_csv_cols.npz` (the CSV columns the georeference parity check uses).
+3. `georeference_vectors.npz` + `georeference_table.csv` -- seeded track tables pushed through the
+   reference's own per-track georeference functions (geotrax/georeference.py:683-866: visibility,
+   kinematics with both filters, gap interpolation, table formatting / rounding / minimum-trajectory
+   filter), imported with stubs for cv2 / geopandas / shapely / tqdm. CRS reprojection and lane lookup need
+   pyproj / shapely themselves and are pinned on the reference tests' known answers instead.
 """
 import argparse
 import gzip
@@ -162,7 +167,70 @@ def copy_reference_goldens():
     print("copied reference golden outputs")
 
 
+def import_reference_georeference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules.setdefault(name, m)
+        return sys.modules[name]
+
+    import_reference_extract()                       # installs the cv2 / ultralytics / stabilo stubs
+    sys.modules["cv2"].USAC_MAGSAC = 38              # default argument of registration.estimate_homography
+    stub("geopandas", GeoDataFrame=object, points_from_xy=lambda *a, **k: None, sjoin=lambda *a, **k: None)
+    stub("shapely")
+    stub("shapely.geometry", Polygon=object, Point=object)
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        stub("PIL", Image=object, TiffImagePlugin=object)
+    import geotrax.georeference as gr
+
+    return gr
+
+
+def make_georeference_vectors(gr):
+    rng = np.random.default_rng(20260701)
+    logger = logging.getLogger("golden")
+    out = {}
+    # a track table with gaps, some rows outside the frame, some interpolated rows
+    tracks = random_tracks(rng, 40, 60, with_gaps=True)
+    tid, frame = tracks[:, 1].astype(np.int64), tracks[:, 0].astype(np.int64)
+    bbox = tracks[:, 2:6].astype(np.float64)
+    bbox[rng.random(len(bbox)) < 0.08, 0] = rng.uniform(0, 30)          # near the left edge
+    out["track_id"], out["frame"], out["bbox"] = tid, frame, bbox
+    vis = gr.calculate_visibility(tid, bbox, (2160, 3840), 4)
+    out["visibility"] = vis
+    out["visibility_m10"] = gr.calculate_visibility(tid, bbox, (2160, 3840), 10)
+    x_local = 200000 + 0.0268 * tracks[:, 6].astype(np.float64) + rng.normal(0, 0.01, len(tid))
+    y_local = 540000 - 0.0268 * tracks[:, 7].astype(np.float64) + rng.normal(0, 0.01, len(tid))
+    out["x_local"], out["y_local"] = x_local, y_local
+    is_interp = (rng.random(len(tid)) < 0.1).astype(np.int64)
+    out["is_interpolated"] = is_interp
+    for name, ft, ks, interp in (("gauss14", "gaussian", 14, None), ("gauss3_interp", "gaussian", 3, is_interp),
+                                 ("savgol7", "savgol", 7, None), ("savgol8_interp", "savgol", 8, is_interp)):
+        v, a = gr.compute_kinematics(tid, frame, x_local, y_local, vis, 29.97, ft, ks, is_interpolated=interp)
+        out[f"speed_{name}"], out[f"accel_{name}"] = v, a
+    fr = np.array([3, 4, 7, 8, 12])
+    xi, yi, present = gr.interpolate_missing_points(fr, np.array([0.0, 1.0, 5.5, 6.0, 9.0]), np.array([2.0, 2.5, 1.0, 0.0, -4.0]))
+    out["interp_x"], out["interp_y"], out["interp_present"] = np.asarray(xi), np.asarray(yi), present
+    # the formatted table (rounding rules, column order, min_traj_length filter on really-detected rows)
+    v, a = out["speed_gauss3_interp"], out["accel_gauss3_interp"]
+    lat, lon = 37.38 + 1e-6 * tracks[:, 7].astype(np.float64), 126.66 + 1e-6 * tracks[:, 6].astype(np.float64)
+    lane = np.where(rng.random(len(tid)) < 0.3, np.nan, rng.integers(1, 5, len(tid)).astype(np.float64))
+    section = np.where(np.isnan(lane), None, "A").astype(object)
+    out["lat"], out["lon"], out["lane"] = lat, lon, lane
+    out["veh_len"], out["veh_wid"] = rng.uniform(3.5, 12, len(tid)), rng.uniform(1.5, 2.6, len(tid))
+    df = gr.create_and_format_georeferenced_df(tid, np.array([]), frame, tracks[:, 6].astype(np.float64) * 3.7123, tracks[:, 7].astype(np.float64) * 3.7123,
+                                               x_local, y_local, lat, lon, (out["veh_len"], out["veh_wid"]), tracks[:, 10].astype(np.int64),
+                                               v, a, section, lane, vis, 15, is_interpolated=is_interp, logger=logger)
+    df.to_csv(OUT / "georeference_table.csv", index=False)
+    out["stab_x"], out["stab_y"], out["cls"] = tracks[:, 6].astype(np.float64), tracks[:, 7].astype(np.float64), tracks[:, 10].astype(np.int64)
+    np.savez_compressed(OUT / "georeference_vectors.npz", **out)
+    print("georeference_vectors.npz:", len(out), "arrays;", len(df), "table rows")
+
+
 if __name__ == "__main__":
     ex = import_reference_extract()
     make_postprocess_vectors(ex)
     copy_reference_goldens()
+    make_georeference_vectors(import_reference_georeference())
