@@ -206,7 +206,14 @@ class Context:
 _default_ctx: dict[int, Context] = {}
 
 
-def default_context(device: int = 0) -> Context:
+def default_device() -> int:
+    """GPU of this process: $GTX_DEVICE (set per rank by the batch launcher), else 0."""
+    return int(os.environ.get("GTX_DEVICE", "0") or 0)
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = default_device()
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]

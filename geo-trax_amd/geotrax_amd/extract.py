@@ -123,7 +123,7 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
     reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
     # own context = own HIP stream: the stabilizer's kernels overlap the next frame's detection
     stabilizer = Stabilizer(**{k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')},
-                            ctx=_lib.Context(0, high_priority=True))
+                            ctx=_lib.Context(_lib.default_device(), high_priority=True))
     use_dev_gray = float(config['stabilo'].get('downsample_ratio', 0.5)) == 0.5
     do_stab = config['main']['extraction']['stabilize']
     track_kw = {k: v for k, v in config['ultralytics'].items() if k != 'model'}

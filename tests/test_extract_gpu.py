@@ -303,3 +303,23 @@ def test_pipelined_submit_collect_equals_serial_order(gtx_ctx):
         for p in dptrs:
             gtx_ctx.dev_free(p)
         det.close()
+
+
+def test_batch_processes_a_directory_and_skips_existing(gtx_ctx, tmp_path):
+    """geotrax_amd.batch over two tiny clips on the GPU: results written next to each clip, second run skips."""
+    from geotrax_amd import batch
+    from geotrax_amd.synth import make_scene
+
+    scene = make_scene(seed=4, h=H, w=W)
+    for name, t0 in (("north/clip_a.npy", 0), ("south/clip_b.npy", 30)):
+        p = tmp_path / name
+        p.parent.mkdir(parents=True)
+        np.save(p, np.stack([scene.render(t0 + 12 * k, 150) for k in range(3)]))
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, scene.render(0, 150), half=True)
+    cfg_path, _ = _cfg_file(tmp_path, wpath, half=True)
+    args = batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path), "--exclude-patterns", "weights"])
+    counts = batch.process_input(args, logger)
+    assert counts["done"] == 2 and counts["failed"] == 0
+    for name in ("north/results/clip_a.txt", "south/results/clip_b.txt", "north/results/clip_a_vid_transf.txt"):
+        assert (tmp_path / name).exists(), name
+    assert batch.process_input(batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path)]), logger)["skipped"] == 2
