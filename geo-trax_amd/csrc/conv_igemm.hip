@@ -316,7 +316,7 @@ int env_int(const char* name, int dflt) {
 }
 }  // namespace
 
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout) {
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc) {
   ConvConfig c{};
   c.dtype = dtype;
   c.ks = ks;
@@ -334,6 +334,10 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout) {
   const int epc = dtype == DT_F16 ? 8 : 4;
   int cpr = 4;
   if (ks == 1 && cin % (8 * epc) == 0) cpr = 8;
+  // 3x3 fp16: 16-channel chunks for the shallow layers (half the LDS -> twice the resident workgroups,
+  // which matters when a tile has only 2-8 chunks to pipeline), 32-channel chunks for Cin > 128
+  if (ks == 3 && dtype == DT_F16) cpr = env_int("GTX_CONV_CPR3", cin <= 128 ? 2 : 4);
+  if (force_kc > 0) cpr = force_kc / epc;    // members of a grouped launch must share one instantiation
   c.kc = cpr * epc;
   c.bn = (cout % 64 == 0) ? 64 : 32;
   c.th = 8; c.tw = 16;
@@ -465,7 +469,7 @@ void launch_dt(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
   const int wn = c.bn / 32;
 #define GTX_CASE(KS, ST, WN, CPR) \
   if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR) return launch_t<T, KS, ST, WN, CPR>(g, s);
-  GTX_CASE(3, 1, 1, 4) GTX_CASE(3, 1, 2, 4)
+  GTX_CASE(3, 1, 1, 4) GTX_CASE(3, 1, 2, 4) GTX_CASE(3, 1, 1, 2) GTX_CASE(3, 1, 2, 2) GTX_CASE(3, 2, 2, 2) GTX_CASE(3, 2, 1, 2)
   GTX_CASE(3, 2, 1, 4) GTX_CASE(3, 2, 2, 4)
   GTX_CASE(1, 1, 1, 4) GTX_CASE(1, 1, 2, 4)
   GTX_CASE(1, 1, 1, 8) GTX_CASE(1, 1, 2, 8)

@@ -99,7 +99,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(dtype_, ks, stride, cin, cout);
+  op.cfg = conv_pick_config(dtype_, ks, stride, cin, cout, force_kc_);
   const std::vector<float> ohwi = to_ohwi(w);
   const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg);
   void* dw = alloc(packed.size());
@@ -286,11 +286,13 @@ void Detector::build_graph() {
     bs.data.insert(bs.data.end(), b30.begin(), b30.end());
     tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
     const size_t mark = ops_.size();
+    force_kc_ = dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
     View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
     View h2 = new_view(h1.h, h1.w, cb + cc);
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
     conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
     conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
+    force_kc_ = 0;
     // move the three freshly built single-problem ops into the two grouped stage ops
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
