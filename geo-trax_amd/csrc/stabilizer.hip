@@ -157,6 +157,7 @@ constexpr int kTileW = 64, kTileH = 16;
 __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restrict__ mask, int w0, int h0, const Levels L, int thr,
                                                           Cand* __restrict__ cand, int* __restrict__ cand_n, int* __restrict__ score_hist) {
   __shared__ uint8_t s_sc[(kTileH + 2) * (kTileW + 2)];
+  __shared__ uint8_t s_px[(kTileH + 8) * (kTileW + 8)];   // tile + 4: 1 (NMS ring) + 3 (circle radius)
   int li = 0;
 #pragma unroll
   for (int i = 1; i < kPyrLevels; ++i)
@@ -164,10 +165,17 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
   const Level lv = L.l[li];
   const int t = blockIdx.x - lv.tile_begin;
   const int tx0 = (t % lv.tiles_x) * kTileW, ty0 = (t / lv.tiles_x) * kTileH;
+  constexpr int PP = kTileW + 8;
+  for (int i = threadIdx.x; i < (kTileH + 8) * PP; i += 256) {
+    const int x = min(max(tx0 - 4 + i % PP, 0), lv.w - 1), y = min(max(ty0 - 4 + i / PP, 0), lv.h - 1);
+    s_px[i] = lv.img[(size_t)y * lv.w + x];     // clamped addresses; clamped pixels are never used by a scored pixel
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < (kTileH + 2) * (kTileW + 2); i += 256) {
-    const int x = tx0 - 1 + i % (kTileW + 2), y = ty0 - 1 + i / (kTileW + 2);
+    const int lx = i % (kTileW + 2), ly = i / (kTileW + 2);
+    const int x = tx0 - 1 + lx, y = ty0 - 1 + ly;
     int sc = 0;
-    if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) sc = fast_score_at(lv.img + (size_t)y * lv.w + x, lv.w, thr);
+    if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) sc = fast_score_at(s_px + (ly + 3) * PP + lx + 3, PP, thr);
     s_sc[i] = (uint8_t)sc;
   }
   __syncthreads();
