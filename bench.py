@@ -183,7 +183,38 @@ def main():
     n_pool = max(args.frames, 2)
     frames = [scene.render(t, 150) for t in range(n_pool)]    # every rank holds the clip; it processes its own batches of it
     ref_frame = frames[0]
-    det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
+    if dist is None:
+        det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
+    else:
+        # rank 0 prepares the weights (here: calibrates the seeded set) and broadcasts them, one flat fp32 buffer
+        # over RCCL (~44 MB); every rank then builds its detector from the same bytes
+        import torch
+        from geotrax_amd.detector import Detector
+        from geotrax_amd.weights import synthetic_yolov8
+
+        template = synthetic_yolov8(seed=0, nc=4, scale="s")
+        names = sorted(template)
+        meta = torch.zeros(2, dtype=torch.int64)
+        if rank == 0:
+            det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
+            det.close()
+            flat = torch.from_numpy(np.concatenate([np.asarray(weights[k], np.float32).ravel() for k in names]))
+            meta[0], meta[1] = n_det, n_cand
+        else:
+            flat = torch.empty(sum(int(np.asarray(template[k]).size) for k in names), dtype=torch.float32)
+        flat, meta = flat.to(cdev), meta.to(cdev)
+        dist.broadcast(flat, src=0)
+        dist.broadcast(meta, src=0)
+        host = flat.cpu().numpy()
+        weights, off = {}, 0
+        for k in names:
+            shp = np.asarray(template[k]).shape
+            n = int(np.prod(shp))
+            weights[k] = host[off:off + n].reshape(shp).copy()
+            off += n
+        n_det, n_cand = int(meta[0]), int(meta[1])
+        det = Detector(weights, (H, W), imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
+                       half=bool(args.half), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
     # the ping-pong playback (0..n-1, n-2..1: continuous motion) laid out contiguously in HBM, plus the
     # first B-1 frames again, so that every batch of B consecutive frames is one contiguous range
     B = max(args.batch, 1)
