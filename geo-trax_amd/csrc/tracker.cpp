@@ -82,53 +82,57 @@ struct Kalman {
     for (int i = 0; i < 8; ++i) cov[i * 9] += s[i] * s[i];
   }
 
+  // Measurement update with H = [I4 0]: S = P[:4,:4] + R, K = P[:, :4] S^-1, mean += K (z - mean[:4]),
+  // P -= K S K^T = P[:, :4] K^T ... computed as P - K P[:4, :]. S^-1 comes from one Cholesky factorisation
+  // (4 square roots, 4 reciprocals); everything else is multiply-add.
   void update(double* mean, double* cov, const double z[4]) const {
     double s[8];
     stds(mean, 1, 1, 1e-1, 0, s);
-    // S = H cov H^T + R (4x4), H = [I 0]
     double S[16];
     for (int i = 0; i < 4; ++i)
       for (int j = 0; j < 4; ++j) S[i * 4 + j] = cov[i * 8 + j] + (i == j ? s[i] * s[i] : 0.0);
-    // Cholesky S = L L^T
-    double L[16] = {0};
+    // Cholesky S = L L^T, then Linv = L^-1 (lower triangular), Sinv = Linv^T Linv
+    double L[16] = {0}, rd[4];
     for (int i = 0; i < 4; ++i)
       for (int j = 0; j <= i; ++j) {
         double v = S[i * 4 + j];
         for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
-        L[i * 4 + j] = (i == j) ? std::sqrt(v) : v / L[j * 4 + j];
+        if (i == j) { L[i * 4 + i] = std::sqrt(v); rd[i] = 1.0 / L[i * 4 + i]; }
+        else L[i * 4 + j] = v * rd[j];
       }
-    // K = cov H^T S^-1  (8x4): solve S K^T = (cov H^T)^T column by column
-    double K[32];
-    for (int r = 0; r < 8; ++r) {
-      double y[4], x[4];
-      for (int i = 0; i < 4; ++i) {
-        double v = cov[r * 8 + i];
-        for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * y[k];
-        y[i] = v / L[i * 4 + i];
+    double Li[16] = {0};
+    for (int c = 0; c < 4; ++c) {
+      Li[c * 4 + c] = rd[c];
+      for (int r = c + 1; r < 4; ++r) {
+        double v = 0;
+        for (int k = c; k < r; ++k) v -= L[r * 4 + k] * Li[k * 4 + c];
+        Li[r * 4 + c] = v * rd[r];
       }
-      for (int i = 3; i >= 0; --i) {
-        double v = y[i];
-        for (int k = i + 1; k < 4; ++k) v -= L[k * 4 + i] * x[k];
-        x[i] = v / L[i * 4 + i];
-      }
-      for (int i = 0; i < 4; ++i) K[r * 4 + i] = x[i];
     }
+    double Si[16];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double v = 0;
+        for (int k = i; k < 4; ++k) v += Li[k * 4 + i] * Li[k * 4 + j];
+        Si[i * 4 + j] = Si[j * 4 + i] = v;
+      }
+    double K[32];
+    for (int r = 0; r < 8; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += cov[r * 8 + k] * Si[k * 4 + c];
+        K[r * 4 + c] = v;
+      }
     double innov[4];
     for (int i = 0; i < 4; ++i) innov[i] = z[i] - mean[i];
     for (int r = 0; r < 8; ++r)
       for (int i = 0; i < 4; ++i) mean[r] += innov[i] * K[r * 4 + i];
-    // cov -= K S K^T
-    double KS[32];
-    for (int r = 0; r < 8; ++r)
-      for (int j = 0; j < 4; ++j) {
-        double v = 0;
-        for (int k = 0; k < 4; ++k) v += K[r * 4 + k] * S[k * 4 + j];
-        KS[r * 4 + j] = v;
-      }
+    double top[32];                                  // P[:4, :] before it is overwritten
+    std::memcpy(top, cov, sizeof top);
     for (int r = 0; r < 8; ++r)
       for (int c = 0; c < 8; ++c) {
         double v = 0;
-        for (int k = 0; k < 4; ++k) v += KS[r * 4 + k] * K[c * 4 + k];
+        for (int k = 0; k < 4; ++k) v += K[r * 4 + k] * top[k * 8 + c];
         cov[r * 8 + c] -= v;
       }
   }
@@ -381,15 +385,17 @@ struct ByteTracker::Impl {
     for (int j = 0; j < nb; ++j) ob[j] = j;
     std::sort(ob.begin(), ob.end(), [&](int p, int q) { return bb[p * 4] < bb[q * 4]; });
     std::vector<float> bx1(nb);
-    for (int j = 0; j < nb; ++j) bx1[j] = bb[ob[j] * 4];
+    float bw_max = 0.f;                       // widest box of b: x2_b > x1_a implies x1_b > x1_a - bw_max
+    for (int j = 0; j < nb; ++j) { bx1[j] = bb[ob[j] * 4]; bw_max = std::max(bw_max, bb[j * 4 + 2] - bb[j * 4]); }
     std::vector<std::pair<int, float>> rowbuf;
     for (int i = 0; i < na; ++i) {
       const float* p = &ab[(size_t)i * 4];
       const float a1 = (p[2] - p[0]) * (p[3] - p[1]);
       rowbuf.clear();
-      // candidates: x1_b < x2_a (sorted prefix), then x2_b > x1_a and y overlap
+      // candidates: x1_a - bw_max < x1_b < x2_a (a band of the sorted list), then x2_b > x1_a and y overlap
       const int hi = (int)(std::lower_bound(bx1.begin(), bx1.end(), p[2]) - bx1.begin());
-      for (int k = 0; k < hi; ++k) {
+      const int lo = (int)(std::lower_bound(bx1.begin(), bx1.begin() + hi, p[0] - bw_max) - bx1.begin());
+      for (int k = lo; k < hi; ++k) {
         const int j = ob[k];
         const float* q = &bb[(size_t)j * 4];
         if (q[2] <= p[0] || q[1] >= p[3] || q[3] <= p[1]) continue;
@@ -483,11 +489,11 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (Track& t : S.tracked) (t.activated ? confirmed : unconfirmed).push_back(&t);
   // pool = joint(confirmed, lost)
   std::vector<Track*> pool = confirmed;
-  {
-    std::unordered_set<int> ids;
-    for (Track* t : confirmed) ids.insert(t->id);
-    for (Track& t : S.lost)
-      if (!ids.count(t.id)) { ids.insert(t.id); pool.push_back(&t); }
+  for (Track& t : S.lost) {           // joint_stracks: first occurrence of an id wins
+    bool seen = false;
+    for (Track* q : pool)
+      if (q->id == t.id) { seen = true; break; }
+    if (!seen) pool.push_back(&t);
   }
   PROF_MARK(pool)
   // Kalman predict (velocity of the size/aspect state is zeroed for non-tracked tracks)
@@ -533,7 +539,11 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   // ---- first association: pool vs high-score detections ----
   std::vector<Track*> dh;
   for (Track& d : det_hi) dh.push_back(&d);
-  linear_assignment_sparse(S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh), x, y);
+  {
+    const SparseCost c1 = S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh);
+    PROF_MARK(cost1)
+    linear_assignment_sparse(c1, x, y);
+  }
   PROF_MARK(assoc1)
   std::vector<int> u_track, u_det;
   for (size_t i = 0; i < pool.size(); ++i) {
