@@ -452,13 +452,23 @@ def main():
             fam = sorted(merged.values(), key=lambda d: -d["total_ms"])
             if fam:
                 top = fam[0]
-                ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dt],
-                                   "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dt], "traffic": pmc_traffic(top["kernel"], B),
+                tflops = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+                gbs = top["bytes"] / (top["total_ms"] * 1e-3) / 1e9
+                # which roof bounds the family: algorithmic intensity against the machine balance (peak FLOP/s / peak B/s)
+                balance = MFMA_PEAK_TFLOPS[dt] * 1e12 / (HBM_PEAK_GBS * 1e9)
+                hbm_bound = top["flops"] / max(top["bytes"], 1.0) < balance
+                out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": top["kernel"],
+                                   "achieved": gbs if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS[dt],
+                                   "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                                   "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_PEAK_TFLOPS[dt]),
+                                   "traffic": pmc_traffic(top["kernel"], B),
                                    "avg_launch_us": 1000.0 * top["total_ms"] / top["launches"],
                                    "launches_timed": top["launches"],
-                                   "flops_per_launch": top["flops"] / top["launches"],
-                                   "timing": f"HIP events around every launch of every {args.trace_every}th pass inside the timed region"}
+                                   "flops_per_launch": top["flops"] / top["launches"], "bytes_per_launch": top["bytes"] / top["launches"],
+                                   "intensity_flop_per_byte": top["flops"] / max(top["bytes"], 1.0), "machine_balance": balance,
+                                   "tflops": tflops, "algo_gbs": gbs,
+                                   "timing": f"HIP events around every launch of every {args.trace_every}th pass inside the timed region "
+                                             "(durations include the time a launch shares the GPU with the other streams)"}
                 out["kernels"] = [{"kernel": d["kernel"], "launches_timed": d["launches"],
                                    "avg_launch_us": 1000.0 * d["total_ms"] / d["launches"],
                                    "tflops": (d["flops"] / (d["total_ms"] * 1e-3) / 1e12) if d["total_ms"] > 0 else 0.0,
