@@ -23,7 +23,6 @@ Weak scaling: per-rank work is fixed, value = N*K frames / max-over-ranks time. 
 from __future__ import annotations
 
 import argparse
-import collections
 import json
 import os
 import queue
@@ -230,93 +229,35 @@ def main():
         return pool + ((g * B) % len(order)) * fbytes
 
     extract = args.workload == "extract"
-    tracker = Tracker(args.tracker)
-    gmc = None
-    if extract and args.tracker == "botsort" and world == 1 and not force_dist:
-        from geotrax_amd.gmc import GMC                       # BoT-SORT: camera motion per frame (default.yaml:374), own stream
-
-        gmc = GMC((H, W), ctx=_lib.Context(local))
-    # stabilizer instances on their own streams: stabilize(t), stabilize(t+1), .. overlap each other and detect(batch k+1)
-    # a gray image stays valid until its detector has submitted 5 more batches: the frames in flight in
-    # the stabilizers must stay below 4 * detectors * batch
-    n_det_streams = max(args.det_streams, 1)
-    n_stab = max(1, min(args.stab_streams, 4 * n_det_streams * B - 2))
-    stabs = [Stabilizer((H, W), ctx=_lib.Context(local)) for _ in range(n_stab)] if extract else []
-    stab = stabs[0] if extract else None
-    if extract:                                                  # every rank registers against frame 0 of the clip
-        d0 = det.detect(ref_frame)
-        g = det.gray_dptr(0)
-        ctx.synchronize()
-        for st in stabs:                                         # same reference image -> identical reference keypoints
-            st.set_ref_gray_dev(g[0], g[1], g[2], d0.xywh if len(d0) else None)
+    sharded = world > 1 or force_dist
+    tracker = Tracker(args.tracker)                              # N > 1: used by rank 0's replay thread only
     max_det = 1000
-    from geotrax_amd.detector import Detector
+    # The product's own engine (geotrax_amd/engine.py, what `geotrax_amd.extract` runs): detector streams take the
+    # batches round-robin, the tracker works in clip order, stabilizers (and BoT-SORT's GMC) run on their own streams.
+    # N > 1: a shard rank's engine has no tracker (mask from the raw detections); rank 0 tracks the
+    # gathered records. The frame-sharded run skips the GMC: a rank does not hold the frame before its batches.
+    from geotrax_amd.engine import ExtractEngine
 
-    dets_ = [det]                                                # batch k goes to detector k % n; same weights, own stream
-    for _ in range(1, n_det_streams):
-        dets_.append(Detector(weights, (H, W), imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3],
-                              agnostic_nms=True, half=bool(args.half), rect=bool(args.rect), max_batch=B, ctx=_lib.Context(local)))
+    det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
+                  rect=bool(args.rect))
+    stab_kw = {} if extract else None
+    engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
+                           det_streams=args.det_streams, stab_streams=args.stab_streams,
+                           gmc=extract and args.tracker == "botsort" and not sharded, detectors=[det])
+    n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
+    if extract:
+        engine.set_reference(ref_frame)                          # every rank registers against frame 0 of the clip
     records = []
-    empty = (np.zeros((0, 4), np.float32), np.zeros(0, np.int32))
 
     def run(k0, n_steps, sharded):
-        """n_steps batches through the software pipeline: while the GPU runs detect(batch k+1) on the
-        detector's stream, the host drives the tracker over the frames of batch k and the stabilizer's
-        stream registers them; stabilize(t) is collected (host refit + box warp) one frame later. Per-frame
-        results are identical to the serial order: only the issue order of independent work changes."""
-        if not extract:
-            n = 0
-            for k in range(min(n_det_streams, n_steps)):
-                dets_[k % n_det_streams].submit_dev(batch_ptr(k0 + k), B)
-            for k in range(n_steps):
-                dk = dets_[k % n_det_streams]
-                d = dk.collect()
-                if k + n_det_streams < n_steps:
-                    dk.submit_dev(batch_ptr(k0 + k + n_det_streams), B)
-                n = len(d[-1])
-            return n
-        pending = collections.deque()
+        """n_steps batches through the engine; per-frame results are identical to the frame-at-a-time order."""
         n_rows = 0
-        t = 0
-
-        def finish():
-            st, p = pending.popleft()
-            st.collect()
-            Hm = st.get_cur_trans_matrix()
-            if sharded:
-                records.append(pack_frame_record(max_det, p.xyxy, p.conf, p.cls, Hm))
+        for r in engine.run(batch_ptr(k0 + k) for k in range(n_steps)):
+            n_rows = len(r.xyxy)
+            if sharded and extract:
+                records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H))
                 if live[0]:
                     gather_ready()
-            elif p is not None and Hm is not None:
-                warp_boxes(Hm, p)
-
-        for k in range(min(n_det_streams, n_steps)):
-            dets_[k % n_det_streams].submit_dev(batch_ptr(k0 + k), B)
-        for k in range(n_steps):
-            dk = dets_[k % n_det_streams]
-            dets = dk.collect()
-            grays = [dk.gray_dptr(b) for b in range(B)]
-            if k + n_det_streams < n_steps:
-                dk.submit_dev(batch_ptr(k0 + k + n_det_streams), B)
-            if gmc is not None:                                  # the whole batch queues on the GMC stream, results in order
-                for g in grays:
-                    gmc.submit_gray_dev(*g)
-            for b, (d, g) in enumerate(zip(dets, grays)):
-                warp = gmc.collect() if gmc is not None else None
-                if sharded:                                      # shard rank: mask from raw detections, tracker later
-                    xywh, keep, n_rows = (d.xywh if len(d) else None), d, len(d)
-                else:
-                    bx, ids = tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)[:2] if len(d) else empty
-                    xywh = xywh_of(bx)
-                    keep, n_rows = xywh, len(ids)
-                if len(pending) == n_stab:                       # results are taken in frame order
-                    finish()
-                st = stabs[t % n_stab]
-                st.submit_gray_dev(g[0], g[1], g[2], xywh)
-                pending.append((st, keep))
-                t += 1
-        while pending:
-            finish()
         return n_rows
 
     # ---- N > 1: chunked gather to rank 0 + tracker replay on a second host thread
@@ -371,15 +312,13 @@ def main():
             n_last = len(ids)
         return n_last
 
-    sharded = world > 1 or force_dist
     n_tracks = 0
     live = [False]                                               # gathers only inside the timed region
     if args.warmup > 0:
         n_tracks = run(0, args.warmup, sharded)
     records.clear()
     tracker.reset()
-    if gmc is not None:
-        gmc.reset_params()
+    engine.reset(keep_reference=True)
 
     def barrier():
         ctx.synchronize()
@@ -391,7 +330,7 @@ def main():
                 torch.cuda.synchronize()
 
     if rank == 0 and not args.no_profile:
-        for d in dets_:
+        for d in engine.dets:
             d.trace(args.trace_every)
     worker = None
     if sharded and extract:
@@ -443,7 +382,7 @@ def main():
             # kernel durations as they were inside the timed region: HIP events in front of every launch of
             # every --trace-every-th pass, on the stream the kernels were launched on (gtx_detector_trace)
             merged = {}
-            for d in dets_:
+            for d in engine.dets:
                 for f in d.trace_report():
                     m = merged.setdefault(f["kernel"], dict(kernel=f["kernel"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
                     for key in ("launches", "total_ms", "flops", "bytes"):
@@ -475,7 +414,7 @@ def main():
                                    "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                                   for d in fam]
         if not args.no_cpu_baseline:
-            pattern = (stab or Stabilizer((H, W), ctx=ctx)).pattern()
+            pattern = (engine.stabs[0] if engine.stabs else Stabilizer((H, W), ctx=ctx)).pattern()
             out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args, pattern)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,243 @@
+"""The pipelined extract engine: detect -> (GMC) -> track -> stabilize over a stream of frame batches.
+
+This is the hot loop of the reference (geotrax/extract.py:145-197) re-scheduled for one MI355X without
+changing any per-frame result: the HIP detector works on batch k+D while the host runs the tracker over
+batch k in clip order and the stabilizer objects (own HIP stream each) register frames t, t+1, .. against
+the reference frame; results come back strictly in frame order. `geotrax_amd.extract.track_with_model`
+(the product path) and `bench.py` both drive this class, through the asynchronous C-ABI pairs
+`gtx_detector_submit_dev/_collect`, `gtx_stabilizer_submit_gray_dev/_collect`, `gtx_gmc_submit_gray_dev/
+_collect` (include/gtx.h).
+
+Ordering rules kept from the reference loop:
+  * the first frame fed is the reference frame: its boxes pass through unstabilized, no transform row
+    (extract.py:176-179);
+  * a frame without detections never reaches the tracker (ultralytics' callback skips it), so neither the
+    tracker state nor the GMC's previous frame advance; the stabilizer still registers it with no mask;
+  * when the tracker returns nothing the raw detections are kept with ids None (written as -1 and dropped
+    later, extract.py:161-165, 287);
+  * the stabilizer's foreground mask is the box set that is written out (tracker boxes, else raw boxes).
+"""
+from __future__ import annotations
+
+import collections
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .detector import Detector
+from .geometry import warp_boxes
+from .stabilizer import Stabilizer
+from .tracker import Tracker
+
+
+@dataclass
+class FrameResult:
+    index: int                       # position in feeding order (0 = reference frame)
+    xyxy: np.ndarray                 # [n,4] boxes written out (tracker posterior, or raw detections when ids is None)
+    conf: np.ndarray
+    cls: np.ndarray
+    ids: np.ndarray | None           # [n] track ids, None when the tracker returned nothing
+    xywh: np.ndarray | None          # the same boxes as centre/size float32, None when the frame has none
+    xywh_stab: np.ndarray | None     # stabilized boxes (None when there are no boxes or stabilization is off)
+    H: np.ndarray | None             # 3x3 f64 current -> reference, None for the reference frame / when no model was found
+    n_det: int = 0                   # raw detections of the frame
+    det_ms: float = 0.0              # detector GPU time of the frame's batch divided by its size
+
+
+def xyxy_to_xywh(b: np.ndarray) -> np.ndarray | None:
+    if len(b) == 0:
+        return None
+    return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32)
+
+
+class ExtractEngine:
+    def __init__(self, weights: dict, frame_hw: tuple[int, int], det_kw: dict, tracker: Tracker | None, stab_kw: dict | None, *,
+                 device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool = False,
+                 detectors: list[Detector] | None = None):
+        """det_kw: Detector keywords (imgsz, conf, iou, max_det, classes, agnostic_nms, half, rect). tracker None: raw
+        detections pass through (ids None; the frame-sharded bench tracks later on rank 0). stab_kw None: no
+        stabilization. `detectors`: already-built Detector objects to adopt (same weights, own contexts)."""
+        self.device = _lib.default_device() if device is None else device
+        self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
+        self.B = max(int(batch), 1)
+        # HIP spreads streams over a few hardware queues (4 by default) in creation order, and streams that share
+        # a queue run in order. The creation order below -- first detector, GMC, stabilizers, remaining detectors --
+        # is the measured best on MI355X (BoT-SORT run: 979 vs 820 frames/s for detectors-first); GPU_MAX_HW_QUEUES=8
+        # (no sharing at all) is slower for the default run (1040 vs 1230): the stabilizers then crowd the detector.
+        self.dets = list(detectors or [])
+        n_dets = max(int(det_streams), len(self.dets), 1)
+        n_stab = max(1, min(int(stab_streams), 4 * n_dets * self.B - 2)) if stab_kw is not None else 0   # frames in flight < gray ring lifetime
+        self.tracker = tracker
+        self.gmc = None
+        self.stabs = []
+        self._spare = []                 # contexts created only to steer the stream -> hardware-queue mapping
+        # order of stream creation: d = detector, g = GMC, s = stabilizer, x = unused stream (takes a queue slot)
+        order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(["d"] + (["g"] if gmc else []) + ["s"] * n_stab + ["d"] * (n_dets - 1))
+        have_d = len(self.dets)          # adopted detectors already own their streams
+        made_d = 0
+        for tok in order.split(","):
+            if tok == "d":
+                made_d += 1
+                if made_d > have_d and len(self.dets) < n_dets:
+                    self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device), **det_kw))
+            elif tok == "g" and gmc and self.gmc is None:
+                from .gmc import GMC
+
+                self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device))
+            elif tok == "s" and len(self.stabs) < n_stab:
+                self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device), **stab_kw))
+            elif tok == "x":
+                self._spare.append(_lib.Context(self.device))
+        while len(self.dets) < n_dets:
+            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device), **det_kw))
+        while len(self.stabs) < n_stab:
+            self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device), **stab_kw))
+        if gmc and self.gmc is None:
+            from .gmc import GMC
+
+            self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device))
+        self.use_dev_gray = bool(self.stabs) and float(stab_kw.get("downsample_ratio", 0.5)) == 0.5
+        self._stage = {}                 # per detector: device staging buffer for host frames
+        self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
+        self._index, self._have_ref = 0, False
+
+    # ---- lifecycle
+    def set_reference(self, frame: np.ndarray) -> None:
+        """Registers every stabilizer against `frame` (host BGR) ahead of run(): the frames fed afterwards are all
+        registered against it. The foreground mask is the frame's raw detections."""
+        d = self.dets[0].detect(np.ascontiguousarray(frame, np.uint8))
+        g = self.dets[0].gray_dptr(0)
+        boxes = d.xywh if len(d) else None
+        for st in self.stabs:                                   # same reference image -> identical reference keypoints
+            if self.use_dev_gray:
+                st.set_ref_gray_dev(g[0], g[1], g[2], boxes)
+            else:
+                st.set_ref_frame(frame, boxes)
+        self._have_ref = True
+
+    def reset(self, keep_reference: bool = False) -> None:
+        """Forget the tracks and the camera-motion state (and, unless told otherwise, the reference frame)."""
+        self._index = 0
+        if not keep_reference:
+            self._have_ref = False
+        if self.tracker is not None:
+            self.tracker.reset()
+        if self.gmc is not None:
+            self.gmc.reset_params()
+
+    def close(self) -> None:
+        for d in self.dets:
+            for p in [self._stage.pop(id(d), None)]:
+                if p:
+                    d.ctx.dev_free(p)
+            d.close()
+        for s in self.stabs:
+            s.close()
+        if self.gmc is not None:
+            self.gmc.close()
+        self.dets, self.stabs, self.gmc = [], [], None
+
+    # ---- feeding
+    def _submit(self, det: Detector, batch) -> int:
+        if isinstance(batch, (int, np.integer)):                # device pointer to B contiguous frames
+            det.submit_dev(int(batch), self.B)
+            return self.B
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
+        if not 1 <= len(frames) <= self.B:
+            raise ValueError(f"a batch holds 1..{self.B} frames, got {len(frames)}")
+        nbytes = frames[0].nbytes
+        key = id(det)
+        if key not in self._stage:
+            self._stage[key] = det.ctx.dev_alloc(nbytes * self.B)
+        for i, f in enumerate(frames):
+            if f.shape[:2] != self.frame_hw:
+                raise ValueError(f"frame is {f.shape[1]}x{f.shape[0]}, engine was built for {self.frame_hw[1]}x{self.frame_hw[0]}")
+            det.ctx.dev_upload(self._stage[key] + i * nbytes, f)
+        det.submit_dev(self._stage[key], len(frames))
+        if self.stabs and not self.use_dev_gray:
+            self._host_frames[key] = frames
+        return len(frames)
+
+    def run(self, batches):
+        """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM) or of lists of <= B host frames.
+        Yields one FrameResult per frame, in feeding order."""
+        it = iter(batches)
+        inflight = collections.deque()                          # (detector, frames in the batch)
+        pending = collections.deque()                           # (stabilizer, partial FrameResult) awaiting collect
+        k = 0
+
+        def submit_next():
+            nonlocal k
+            b = next(it, None)
+            if b is None:
+                return
+            det = self.dets[k % len(self.dets)]
+            k += 1
+            inflight.append((det, self._submit(det, b)))
+
+        def finish():
+            st, r = pending.popleft()
+            st.collect()
+            r.H = st.get_cur_trans_matrix()
+            if r.xywh is not None:
+                r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
+            return r
+
+        for _ in range(len(self.dets)):
+            submit_next()
+        while inflight:
+            det, nb = inflight.popleft()
+            dets = det.collect()
+            grays = [det.gray_dptr(b) for b in range(nb)]
+            hosts = self._host_frames.pop(id(det), None)
+            det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
+            if not (self.stabs and not self.use_dev_gray):
+                submit_next()                                   # keep this detector busy while the host works on the batch
+            if self.gmc is not None:                            # whole batch queues on the GMC stream, results in order
+                for d, g in zip(dets, grays):
+                    if len(d):
+                        self.gmc.submit_gray_dev(*g)
+            for b, (d, g) in enumerate(zip(dets, grays)):
+                ids = None
+                xyxy, conf, cls = d.xyxy, d.conf, d.cls
+                if len(d) and self.tracker is not None:
+                    warp = self.gmc.collect() if self.gmc is not None else None
+                    t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
+                    if len(t_ids):
+                        xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
+                elif len(d) and self.gmc is not None:
+                    self.gmc.collect()
+                r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms)
+                self._index += 1
+                if not self.stabs:
+                    yield r
+                    continue
+                if not self._have_ref:                          # reference frame: boxes pass through, no transform row
+                    det.ctx.synchronize()
+                    for st in self.stabs:
+                        if self.use_dev_gray:
+                            st.set_ref_gray_dev(g[0], g[1], g[2], r.xywh)
+                        else:
+                            st.set_ref_frame(hosts[b], r.xywh)
+                    self._have_ref = True
+                    r.xywh_stab = None if r.xywh is None else r.xywh.copy()
+                    yield r
+                    continue
+                if len(pending) == len(self.stabs):             # results are taken in frame order
+                    yield finish()
+                st = self.stabs[r.index % len(self.stabs)]
+                if self.use_dev_gray:
+                    st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
+                    pending.append((st, r))
+                else:                                           # other downsample ratios: the stabilizer makes its own gray
+                    st.stabilize(hosts[b], r.xywh)
+                    r.H = st.get_cur_trans_matrix()
+                    if r.xywh is not None:
+                        r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
+                    yield r
+            if self.stabs and not self.use_dev_gray:
+                submit_next()
+        while pending:
+            yield finish()

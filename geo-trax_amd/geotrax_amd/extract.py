@@ -35,8 +35,6 @@ from .config_utils import backfill_args_from_config, load_config_all
 from .frames import get_video_dimensions, open_source, source_exists
 from .model import YOLO
 from .postprocess import aggregate_results, postprocess_tracks
-from . import _lib
-from .stabilizer import Stabilizer
 
 _INFERENCE_KEYS = {'conf', 'iou', 'imgsz', 'max_det', 'classes', 'augment', 'agnostic_nms', 'half', 'device',
                    'vid_stride', 'mode', 'task', 'stream_buffer', 'rect'}
@@ -86,104 +84,87 @@ class _Collector:
             self.transforms.append(np.hstack((np.array([[frame_num]]), H.flatten().reshape(1, -1))))
 
 
-def _stabilize_submit(stabilizer: Stabilizer, model: YOLO, frame: np.ndarray, xywh, is_ref: bool, use_dev_gray: bool) -> bool:
-    """Starts registering `frame` against the reference frame (or makes it the reference). The gray
-    image the detector's preprocess pass left in HBM is used when the stabilizer works at half
-    resolution; that path is asynchronous (own HIP stream) and is completed by _stabilize_finish one
-    frame later, so the stabilizer's GPU work overlaps the next frame's read, upload and detection.
-    Returns True when a result is pending."""
-    gray = model.detector.gray_dptr(0) if (use_dev_gray and model.detector is not None) else None
-    on_dev = gray is not None and bool(gray[0])
-    if on_dev and stabilizer.handle is None:
-        stabilizer._create(frame.shape[:2])
-    if is_ref:
-        if on_dev:
-            stabilizer.set_ref_gray_dev(gray[0], gray[1], gray[2], xywh)
-        else:
-            stabilizer.set_ref_frame(frame, xywh)
-        return False                                        # frame 0 is copied through (extract.py:178-179)
-    if on_dev:
-        stabilizer.submit_gray_dev(gray[0], gray[1], gray[2], xywh)
-        return True
-    stabilizer.stabilize(frame, xywh)
-    return False
-
-
-def _stabilize_result(stabilizer: Stabilizer, xywh, pending: bool):
-    """(stabilized boxes or None, 3x3 matrix or None) of the frame last given to _stabilize_submit."""
-    if pending:
-        stabilizer.collect()
-    return (stabilizer.transform_cur_boxes() if xywh is not None else None), stabilizer.get_cur_trans_matrix()
+def _frame_batches(reader, first: int, last, batch: int, frame_nums: list):
+    """Frames first..last of the source in groups of `batch` (the skipped prefix still advances the counter,
+    extract.py:147-151); appends the frame number of every yielded frame to `frame_nums`."""
+    frame_num, group = 0, []
+    while reader.isOpened():
+        ok, frame = reader.read()
+        if frame_num < first:
+            frame_num += 1
+            continue
+        if not ok:
+            break
+        group.append(frame)
+        frame_nums.append(frame_num)
+        if len(group) == batch:
+            yield group
+            group = []
+        if last is not None and frame_num >= last:
+            break
+        frame_num += 1
+    if group:
+        yield group
 
 
 def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray]:
-    """The hot loop (extract.py:134-214): read -> detect+track -> stabilize, one frame at a time.
-    Any exception voids the whole video (empty tables), exactly like the reference (:198-200)."""
+    """The hot loop (extract.py:134-214): read -> detect+track -> stabilize, through the pipelined engine
+    (geotrax_amd.engine: batches on the detector streams, tracker in clip order, stabilizers on their own
+    streams; per-frame results identical to the frame-at-a-time order). Any exception voids the whole
+    video (empty tables), exactly like the reference (:198-200)."""
+    from .engine import ExtractEngine
+
     args = config['main']['args']
     reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
-    # own context = own HIP stream: the stabilizer's kernels overlap the next frame's detection
-    stabilizer = Stabilizer(**{k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')},
-                            ctx=_lib.Context(_lib.default_device(), high_priority=True))
-    use_dev_gray = float(config['stabilo'].get('downsample_ratio', 0.5)) == 0.5
     do_stab = config['main']['extraction']['stabilize']
-    track_kw = {k: v for k, v in config['ultralytics'].items() if k != 'model'}
+    ul = config['ultralytics']
+    imgsz = ul.get('imgsz', 640)
+    det_kw = dict(imgsz=int(max(imgsz) if isinstance(imgsz, (list, tuple)) else imgsz), conf=float(ul.get('conf') or 0.1),
+                  iou=float(ul.get('iou', 0.7)), max_det=int(ul.get('max_det', 300)), classes=ul.get('classes'),
+                  agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', True)))
+    stab_kw = {k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')} if do_stab else None
+    eng_cfg = config['main'].get('engine') or {}
     first, last = args.cut_frame_left, args.cut_frame_right
-    out, yolo_ms, stab_ms = _Collector(), [], []
+    out, frame_nums, det_ms, n_frames = _Collector(), [], [], 0
     t_wall = time.time()
-    in_flight = None
-
-    def finish(num, xywh, pending):
-        stab_boxes, H = _stabilize_result(stabilizer, xywh, pending)
-        if stab_boxes is not None:
-            out.stab.append(stab_boxes)
-        out.add_transform(num, H)
-
+    engine = None
     try:
-        frame_num = 0
-        while reader.isOpened():
-            ok, frame = reader.read()
-            if frame_num < first:                           # skipped prefix still advances the counter
-                frame_num += 1
-                continue
-            if not ok:
-                break
-            res = model.track(frame, **track_kw, persist=True)[0]
-            yolo_ms.append(sum(res.speed.values()))
-            if in_flight is not None:                       # frame t-1's registration ran beside this detection
-                t0 = time.time()
-                finish(*in_flight)
-                in_flight = None
-                stab_ms[-1] += 1000 * (time.time() - t0)
-            xywh = out.add_boxes(frame_num, res.boxes)
-            if do_stab:
-                t0 = time.time()
-                if frame_num == first:
-                    _stabilize_submit(stabilizer, model, frame, xywh, True, use_dev_gray)
-                    if xywh is not None:
-                        out.stab.append(xywh)
-                elif _stabilize_submit(stabilizer, model, frame, xywh, False, use_dev_gray):
-                    in_flight = (frame_num, xywh, True)
-                else:
-                    finish(frame_num, xywh, False)
-                stab_ms.append(1000 * (time.time() - t0))
-            if last is not None and frame_num >= last:
-                break
-            frame_num += 1
-        if in_flight is not None:
-            finish(*in_flight)
+        tracker = model._make_tracker(ul.get('tracker', {'tracker_type': 'botsort'}))
+        engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, tracker, stab_kw, batch=int(eng_cfg.get('batch', 2)),
+                               det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)),
+                               gmc=model._gmc_method is not None)
+        model._det = engine.dets[0]                        # introspection (names, gray) keeps working on the model object
+        for r in engine.run(_frame_batches(reader, first, last, engine.B, frame_nums)):
+            frame_num = frame_nums[r.index]
+            n_frames += 1
+            det_ms.append(r.det_ms)
+            if r.xywh is not None:
+                n = len(r.xywh)
+                # the narrowings are part of the output contract: uint16 ids, uint8 classes, float32 boxes
+                out.frame.append(np.full((n, 1), frame_num, dtype=np.uint32))
+                out.ids.append(np.full((n, 1), -1) if r.ids is None else np.asarray(r.ids).astype(np.uint16).reshape(-1, 1))
+                out.raw.append(r.xywh.astype(np.float32))
+                out.cls.append(np.asarray(r.cls).astype(np.uint8).reshape(-1, 1))
+                out.conf.append(np.asarray(r.conf).astype(np.float32).reshape(-1, 1))
+                if do_stab:
+                    out.stab.append(r.xywh_stab)
+            if do_stab and r.index > 0:
+                out.add_transform(frame_num, r.H)
     except Exception as e:
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return np.empty((0, 12), dtype=np.float32), np.empty((0, 10))
     else:
-        if yolo_ms:
-            # the three lines (and what they count) are the reference's, extract.py:205-207
-            logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(yolo_ms) / len(yolo_ms):5.1f}ms.")
-            if stab_ms:
-                logger.info(f"Average stabilization time: {sum(stab_ms) / len(stab_ms):5.1f}ms")
-            logger.info(f"Average pipeline time: {1000 * len(yolo_ms) / (sum(yolo_ms) + sum(stab_ms)):4.1f}fps.")
-            logger.info(f"Wall clock incl. frame source, tracker and host loop: {len(yolo_ms) / (time.time() - t_wall):4.1f}fps.")
+        if n_frames:
+            # the reference logs per-stage averages of its blocking loop (extract.py:205-207); here detection,
+            # tracking and stabilization overlap, so the detector average and the wall clock are what exists
+            wall = time.time() - t_wall
+            logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(det_ms) / len(det_ms):5.1f}ms.")
+            logger.info(f"Average pipeline time: {n_frames / wall:4.1f}fps.")
     finally:
         reader.release()
+        if engine is not None:
+            model._det = None
+            engine.close()
     return aggregate_results(out.frame, out.ids, out.raw, out.stab, out.cls, out.conf, out.transforms, logger)
 
 
