@@ -70,3 +70,20 @@ struct DevBuf {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace gtx
+
+#if defined(__HIPCC__)
+// Wave-aggregated list append: the lanes of a wave that want a slot (pred) reserve them with ONE atomic on
+// the counter instead of one each -- appends from thousands of waves to a single counter otherwise serialise
+// in L2 (measured: fast_detect 75 -> 33 us). Returns the lane's slot, or -1 for lanes with pred == false.
+// Every lane of the wave must call it (the ballot needs the whole wave), converged.
+__device__ __forceinline__ int gtx_wave_append(int* counter, bool pred) {
+  const unsigned long long m = __ballot(pred);
+  if (m == 0) return -1;
+  const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader);
+  return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+#endif
+

@@ -138,24 +138,28 @@ __global__ __launch_bounds__(256) void response_kernel(const uint8_t* __restrict
 __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam, int w, int h, const unsigned long long* __restrict__ max_bits,
                                                   Cand* __restrict__ cand, int* __restrict__ n_cand, int cap, int* __restrict__ hist16) {
   const int x = 1 + blockIdx.x * 256 + threadIdx.x, y = 1 + blockIdx.y;
-  if (x >= w - 1 || y >= h - 1) return;
   const double thr = __longlong_as_double((long long)*max_bits) * kQuality;
-  const double v = lam[(size_t)y * w + x];
-  if (!(v > thr)) return;
-  double mx = v;
+  bool keep = x < w - 1 && y < h - 1;
+  double v = 0.0;
+  if (keep) {
+    v = lam[(size_t)y * w + x];
+    keep = v > thr;
+  }
+  if (keep) {
+    double mx = v;
 #pragma unroll
-  for (int i = -1; i <= 1; ++i)
+    for (int i = -1; i <= 1; ++i)
 #pragma unroll
-    for (int j = -1; j <= 1; ++j) {
-      const double q = lam[(size_t)(y + i) * w + x + j];
-      mx = fmax(mx, q > thr ? q : 0.0);
-    }
-  if (v == mx) {
-    const int slot = atomicAdd(n_cand, 1);
-    if (slot < cap) {
-      cand[slot] = Cand{v, y * w + x, 0};
-      atomicAdd(&hist16[(unsigned long long)__double_as_longlong(v) >> 48], 1);   // sign + exponent + 4 mantissa bits
-    }
+      for (int j = -1; j <= 1; ++j) {
+        const double q = lam[(size_t)(y + i) * w + x + j];
+        mx = fmax(mx, q > thr ? q : 0.0);
+      }
+    keep = v == mx;
+  }
+  const int slot = gtx_wave_append(n_cand, keep);          // one reservation per wave, not per corner
+  if (keep && slot < cap) {
+    cand[slot] = Cand{v, y * w + x, 0};
+    atomicAdd(&hist16[(unsigned long long)__double_as_longlong(v) >> 48], 1);   // sign + exponent + 4 mantissa bits
   }
 }
 

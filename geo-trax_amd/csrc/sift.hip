@@ -130,24 +130,27 @@ __global__ __launch_bounds__(256) void extrema_kernel(const float* __restrict__ 
                                                       int w, int h, float thr, int o, int layer, Cand* __restrict__ cand,
                                                       int* __restrict__ n_cand, int cap) {
   const int x = kBorder + blockIdx.x * 256 + threadIdx.x, y = kBorder + blockIdx.y;
-  if (x >= w - kBorder || y >= h - kBorder) return;
-  const size_t p = (size_t)y * w + x;
-  const float v = cur[p];
-  if (!(fabsf(v) > thr)) return;
-  float mx = -INFINITY, mn = INFINITY;
+  bool is_ext = x < w - kBorder && y < h - kBorder;
+  if (is_ext) {
+    const size_t p = (size_t)y * w + x;
+    const float v = cur[p];
+    is_ext = fabsf(v) > thr;
+    if (is_ext) {
+      float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const size_t q = p + (long)dy * w + dx;
-      const float a = prv[q], b = nxt[q];
-      mx = fmaxf(mx, fmaxf(a, b)); mn = fminf(mn, fminf(a, b));
-      if (dy != 0 || dx != 0) { const float c = cur[q]; mx = fmaxf(mx, c); mn = fminf(mn, c); }
+        for (int dx = -1; dx <= 1; ++dx) {
+          const size_t q = p + (long)dy * w + dx;
+          const float a = prv[q], b = nxt[q];
+          mx = fmaxf(mx, fmaxf(a, b)); mn = fminf(mn, fminf(a, b));
+          if (dy != 0 || dx != 0) { const float c = cur[q]; mx = fmaxf(mx, c); mn = fminf(mn, c); }
+        }
+      is_ext = (v > 0.f && v >= mx) || (v < 0.f && v <= mn);
     }
-  if ((v > 0.f && v >= mx) || (v < 0.f && v <= mn)) {
-    const int slot = atomicAdd(n_cand, 1);
-    if (slot < cap) cand[slot] = Cand{o, layer, y, x};
   }
+  const int slot = gtx_wave_append(n_cand, is_ext);
+  if (is_ext && slot < cap) cand[slot] = Cand{o, layer, y, x};
 }
 
 // 3x3 solve, LU with partial pivoting, float32 (operation order of oracle/sift_ref.py::_solve3)

@@ -101,12 +101,17 @@ __constant__ int c_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, 
 // Any arc of 9 contains at least two of the four compass pixels (0, 4, 8, 12), so a pixel with
 // fewer than two compass pixels beyond the threshold on one side cannot be a corner: that test
 // rejects most of the image after 5 loads. The arc minima are built by doubling (1,2,4,8,+1).
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ c, int w, int thr) {
+__device__ __forceinline__ bool fast_pretest(const uint8_t* __restrict__ c, int w, int thr) {
   const int p = c[0];
   const int d0 = (int)c[-3 * w] - p, d4 = (int)c[3] - p, d8 = (int)c[3 * w] - p, d12 = (int)c[-3] - p;
   const int nb = (d0 > thr) + (d4 > thr) + (d8 > thr) + (d12 > thr);
   const int nd = (d0 < -thr) + (d4 < -thr) + (d8 < -thr) + (d12 < -thr);
-  if (nb < 2 && nd < 2) return 0;
+  return nb >= 2 || nd >= 2;
+}
+
+// The arc search proper (for pixels that passed fast_pretest).
+__device__ __forceinline__ int fast_score_full(const uint8_t* __restrict__ c, int w, int thr) {
+  const int p = c[0];
   int d[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) d[i] = (int)c[c_circle[i][1] * w + c_circle[i][0]] - p;
@@ -171,12 +176,28 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
     s_px[i] = lv.img[(size_t)y * lv.w + x];     // clamped addresses; clamped pixels are never used by a scored pixel
   }
   __syncthreads();
+  // phase A: the 5-load compass test on every pixel; the survivors (a scattered minority) are listed so that
+  // phase B runs the 16-pixel arc search densely instead of dragging whole waves through it
+  __shared__ unsigned short s_list[(kTileH + 2) * (kTileW + 2)];
+  __shared__ int s_nlist, s_ncand, s_base;
+  __shared__ int s_cpix[kTileH * kTileW];
+  __shared__ uint8_t s_csc[kTileH * kTileW];
+  __shared__ int s_hist[256];
+  s_hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_nlist = 0; s_ncand = 0; }
+  __syncthreads();
   for (int i = threadIdx.x; i < (kTileH + 2) * (kTileW + 2); i += 256) {
     const int lx = i % (kTileW + 2), ly = i / (kTileW + 2);
     const int x = tx0 - 1 + lx, y = ty0 - 1 + ly;
-    int sc = 0;
-    if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder) sc = fast_score_at(s_px + (ly + 3) * PP + lx + 3, PP, thr);
-    s_sc[i] = (uint8_t)sc;
+    s_sc[i] = 0;
+    if (x >= kBorder && x < lv.w - kBorder && y >= kBorder && y < lv.h - kBorder && fast_pretest(s_px + (ly + 3) * PP + lx + 3, PP, thr))
+      s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)i;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < s_nlist; k += 256) {
+    const int i = s_list[k];
+    const int lx = i % (kTileW + 2), ly = i / (kTileW + 2);
+    s_sc[i] = (uint8_t)fast_score_full(s_px + (ly + 3) * PP + lx + 3, PP, thr);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) {
@@ -191,16 +212,28 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
       const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
       if (mask[(size_t)y0 * w0 + x0] == 0) continue;
     }
-    const int slot = atomicAdd(&cand_n[li], 1);
-    if (slot < lv.cand_cap) {
+    const int k = atomicAdd(&s_ncand, 1);                    // workgroup-local list: one global reservation per tile
+    s_cpix[k] = y * lv.w + x;
+    s_csc[k] = (uint8_t)sv;
+  }
+  __syncthreads();
+  const int nloc = s_ncand;
+  if (nloc == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&cand_n[li], nloc);
+  __syncthreads();
+  const int base = s_base;
+  for (int k = threadIdx.x; k < nloc; k += 256) {
+    if (base + k < lv.cand_cap) {
       Cand cd;
       cd.key = 0;
-      cd.pix = y * lv.w + x;
-      cd.score = sv;
-      cand[lv.cand_off + slot] = cd;
-      atomicAdd(&score_hist[li * 256 + sv], 1);
+      cd.pix = s_cpix[k];
+      cd.score = s_csc[k];
+      cand[lv.cand_off + base + k] = cd;
+      atomicAdd(&s_hist[s_csc[k]], 1);
     }
   }
+  __syncthreads();
+  if (s_hist[threadIdx.x] != 0) atomicAdd(&score_hist[li * 256 + threadIdx.x], s_hist[threadIdx.x]);
 }
 
 // Stage 1 of the selection, as OpenCV's ORB does it: per level keep the 2*n_want candidates with
@@ -224,14 +257,17 @@ __global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand*
     s_cut[li] = cut;
   }
   __syncthreads();
-  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  const int nthreads = gridDim.x * blockDim.x;
   for (int li = 0; li < L.n; ++li) {
     const Level lv = L.l[li];
     const int n = min(cand_n[li], lv.cand_cap);
     const int cut = s_cut[li];
-    for (int i = gtid; i < n; i += nthreads) {
-      Cand cd = cand[lv.cand_off + i];
-      if (cd.score < cut) continue;
+    for (int ib = blockIdx.x * blockDim.x; ib < n; ib += nthreads) {     // block-uniform trip count: the append below is wave-wide
+      const int i = ib + (int)threadIdx.x;
+      Cand cd{};
+      bool take = i < n;
+      if (take) { cd = cand[lv.cand_off + i]; take = cd.score >= cut; }
+      if (take) {
       const int x = cd.pix % lv.w, y = cd.pix / lv.w;
       const uint8_t* base = lv.img + (size_t)(y - 4) * lv.w + x - 4;
       int r0[9], r1[9], r2[9];
@@ -255,8 +291,9 @@ __global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand*
         for (int k = 0; k < 9; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
       }
       cd.key = 25 * (a * b - c * c) - (a + b) * (a + b);
-      const int slot = atomicAdd(&elig_n[li], 1);
-      if (slot < lv.cand_cap) elig[lv.cand_off + slot] = cd;
+      }
+      const int slot = gtx_wave_append(&elig_n[li], take);
+      if (take && slot < lv.cand_cap) elig[lv.cand_off + slot] = cd;
     }
   }
 }
