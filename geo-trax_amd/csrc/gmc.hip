@@ -129,10 +129,19 @@ __global__ __launch_bounds__(256) void response_kernel(const uint8_t* __restrict
     lam[(size_t)y * w + x] = v;
     m = fmax(m, v);
   }
-  // block max -> global max (bit pattern of a non-negative double is order preserving)
+  // block max -> global max (bit pattern of a non-negative double is order preserving). Thousands of
+  // atomics on one address serialise in L2: reduce to one per workgroup and skip it when the value already
+  // published is at least as large (a plain read is enough for that: the maximum only grows).
+  __shared__ double s_m[4];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m > 0.0 && bits > __atomic_load_n(max_bits, __ATOMIC_RELAXED)) atomicMax(max_bits, bits);
+  }
 }
 
 __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam, int w, int h, const unsigned long long* __restrict__ max_bits,
@@ -159,7 +168,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam
   const int slot = gtx_wave_append(n_cand, keep);          // one reservation per wave, not per corner
   if (keep && slot < cap) {
     cand[slot] = Cand{v, y * w + x, 0};
-    atomicAdd(&hist16[(unsigned long long)__double_as_longlong(v) >> 48], 1);   // sign + exponent + 4 mantissa bits
+    // bucket = distance of the key's top 16 bits (exponent + 4 mantissa bits) below the maximum's: the
+    // candidates span a factor 100 (quality 0.01), i.e. ~107 of the 256 buckets
+    const int rel = (int)(*max_bits >> 48) - (int)((unsigned long long)__double_as_longlong(v) >> 48);
+    atomicAdd(&hist16[min(max(rel, 0), 255)], 1);
   }
 }
 
@@ -170,10 +182,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam
 // finishes the job. A bucket too full for LDS is narrowed by further 8-bit radix passes first.
 constexpr int kSelCap = 4096;
 __global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ cand, const int* __restrict__ n_cand, int cap, int w,
-                                                      const int* __restrict__ hist16, float2* __restrict__ pts, int* __restrict__ n_pts) {
+                                                      const int* __restrict__ hist16, const unsigned long long* __restrict__ max_bits_p,
+                                                      float2* __restrict__ pts, int* __restrict__ n_pts) {
   __shared__ unsigned long long s_key[kSelCap];
   __shared__ int s_pix[kSelCap];
-  __shared__ int s_part[1024];
   __shared__ int s_hist[256];
   __shared__ unsigned long long s_lo;       // keys >= s_lo are gathered
   __shared__ int s_cnt, s_bucket, s_above, s_need;
@@ -183,22 +195,17 @@ __global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ c
   if (tid == 0) { s_lo = 0; s_cnt = 0; }
   __syncthreads();
   if (n > kSelCap) {
-    // bucket of the want-th strongest: scan the 65536-bin histogram from the top, 64 bins per thread
-    int part = 0;
-    if (tid >= 512)                          // keys are non-negative doubles: the top half of the bins is empty
-      for (int k = 0; k < 64; ++k) part += hist16[65535 - (tid * 64 + k)];
-    s_part[tid] = part;
-    __syncthreads();
+    // bucket of the want-th strongest: the 256 relative buckets, strongest first
     if (tid == 0) {
-      int acc = 0, t = 0;
-      for (; t < 1024; ++t) { if (acc + s_part[t] >= want) break; acc += s_part[t]; }
-      int bkt = 65535 - t * 64;
-      for (int k = 0; k < 64; ++k, --bkt) { const int c = hist16[bkt]; if (acc + c >= want) break; acc += c; }
-      s_bucket = bkt; s_above = acc; s_need = want - acc;
+      int acc = 0, bkt = 0;
+      for (; bkt < 255; ++bkt) { const int c = hist16[bkt]; if (acc + c >= want) break; acc += c; }
+      s_bucket = (int)(*max_bits_p >> 48) - bkt;              // back to the absolute top-16-bit value
+      s_above = acc; s_need = want - acc; s_cnt = hist16[bkt];
     }
     __syncthreads();
     unsigned long long lo = (unsigned long long)s_bucket << 48;
-    int population = hist16[s_bucket];
+    int population = s_cnt;
+    __syncthreads();
     // narrow an over-full bucket: 8 more key bits per pass, keeping the part that still holds the cut
     for (int shift = 40; population + s_above > kSelCap - 64 && shift >= 0; shift -= 8) {
       if (tid < 256) s_hist[tid] = 0;
@@ -514,7 +521,7 @@ Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : imp
   S.cand_cap = gray_w * gray_h / 4;
   S.cand.alloc(sizeof(Cand) * S.cand_cap);
   S.counters.alloc(16);
-  S.hist16.alloc(sizeof(int) * 65536);
+  S.hist16.alloc(sizeof(int) * 256);
   S.next.alloc(sizeof(float2) * 1024); S.status.alloc(sizeof(int) * 1024); S.pairs.alloc(sizeof(float4) * 1024);
   S.res.alloc(sizeof(GmcResult)); S.model.alloc(sizeof(double4) * kHyp); S.count.alloc(sizeof(int) * kHyp);
   GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(GmcResult) * Impl::kRing));
@@ -553,13 +560,13 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
                        const_cast<uint8_t*>(Pc.img[l]), Pc.w[l], Pc.h[l]);
   // corners of the current frame
   GTX_HIP(hipMemsetAsync(S.counters.p, 0, 16, s));
-  GTX_HIP(hipMemsetAsync(S.hist16.p, 0, sizeof(int) * 65536, s));
+  GTX_HIP(hipMemsetAsync(S.hist16.p, 0, sizeof(int) * 256, s));
   unsigned long long* max_bits = S.counters.as<unsigned long long>();
   int* n_cand = reinterpret_cast<int*>(max_bits + 1);
   hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, kRT_W), cdiv(S.h, kRT_H)), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam.as<double>(), max_bits);
   hipLaunchKernelGGL(nms_kernel, dim3(cdiv(S.w - 2, 256), S.h - 2), dim3(256), 0, s, S.lam.as<double>(), S.w, S.h, max_bits, S.cand.as<Cand>(),
                      n_cand, S.cand_cap, S.hist16.as<int>());
-  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand.as<Cand>(), n_cand, S.cand_cap, S.w, S.hist16.as<int>(), S.pts[c].as<float2>(),
+  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand.as<Cand>(), n_cand, S.cand_cap, S.w, S.hist16.as<int>(), max_bits, S.pts[c].as<float2>(),
                      S.npts[c].as<int>());
   S.first[slot] = !S.have_prev;
   if (S.have_prev) {
