@@ -246,15 +246,37 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
 __global__ __launch_bounds__(256) void harris_kernel(const Levels L, const Cand* __restrict__ cand, const int* __restrict__ cand_n,
                                                      const int* __restrict__ score_hist, Cand* __restrict__ elig,
                                                      int* __restrict__ elig_n) {
+  // cutoff per level: smallest score whose suffix count reaches 2 * n_want. The histogram comes into LDS with
+  // one coalesced pass (a serial walk over global memory cost ~50 us of pure latency in every workgroup);
+  // wave w < L.n then scans level w: lane l owns bins 4l..4l+3, suffix sums by shuffles.
   __shared__ int s_cut[kPyrLevels];
-  if (threadIdx.x < L.n) {
-    const int li = threadIdx.x, need = 2 * L.l[li].n_want;
-    int acc = 0, cut = 1;
-    for (int b = 255; b >= 1; --b) {
-      acc += score_hist[li * 256 + b];
-      if (acc >= need) { cut = b; break; }
+  __shared__ int s_h[kPyrLevels * 256];
+  for (int i = threadIdx.x; i < L.n * 256; i += blockDim.x) s_h[i] = score_hist[i];
+  __syncthreads();
+  {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int li = wv; li < L.n; li += (int)(blockDim.x >> 6)) {
+      const int need = 2 * L.l[li].n_want;
+      const int* hh = s_h + li * 256 + 4 * lane;
+      const int c0 = lane == 0 ? 0 : hh[0], c1 = hh[1], c2 = hh[2], c3 = hh[3];     // bin 0 (no corner) is not counted
+      int suf = c0 + c1 + c2 + c3;                       // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_down(suf, o);
+        if (lane + o < 64) suf += v;
+      }
+      const int above = suf - (c0 + c1 + c2 + c3);       // counts of the bins above this lane's four
+      // largest bin b with count(bins >= b) >= need; bins inside the lane from the top
+      int cut = 0;
+      int acc = above + c3;
+      if (acc >= need) cut = 4 * lane + 3;
+      else if ((acc += c2) >= need) cut = 4 * lane + 2;
+      else if ((acc += c1) >= need) cut = 4 * lane + 1;
+      else if ((acc += c0) >= need) cut = 4 * lane;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) cut = max(cut, __shfl_xor(cut, o));
+      if (lane == 0) s_cut[li] = max(cut, 1);
     }
-    s_cut[li] = cut;
   }
   __syncthreads();
   const int nthreads = gridDim.x * blockDim.x;
