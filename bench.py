@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="extract", choices=["extract", "detect"],
-                    help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1])")
+    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register"],
+                    help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
+                         "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU)")
     ap.add_argument("--half", type=int, default=1, help="ultralytics.half: 1 = fp16 MFMA, 0 = fp32 MFMA (reference default)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
@@ -151,8 +152,55 @@ def cpu_baseline(weights, ref_frame, frame, args, pattern):
                        + ", ".join(f"{k}={v:.2f}" for k, v in parts.items()))
 
 
+def bench_register(args):
+    """--workload register: one step = estimate_homography's GPU path on a 4K frame pair (host images in, H out).
+    The roofline object prices the stage SURVEY 8d calls MFMA-bound, the brute-force 2-NN, at its stated size
+    (250 000 x 250 000 x 128): the synthetic frames only give ~10 k keypoints each."""
+    from geotrax_amd import _lib, ops
+    from geotrax_amd.registration import register_once
+    from geotrax_amd.synth import make_scene
+
+    ctx = _lib.Context(0)
+    scene = make_scene(seed=0, h=H, w=W)
+    a, b = scene.render(0, 150), scene.render(40, 150)
+    kw = dict(max_features=250000, filter_ratio=0.55, ransac_epipolar_threshold=3.0, ransac_max_iter=10000, ransac_confidence=0.999999,
+              rsift_eps=1e-8, ctx=ctx)
+    steps, warm = min(args.steps, 40), min(args.warmup, 4)
+    for _ in range(max(warm, 1)):
+        Hm, stats, tm = register_once(b, a, **kw)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        Hm, stats, tm = register_once(b, a, **kw)
+    elapsed = time.perf_counter() - t0
+    ys, xs = np.meshgrid(np.linspace(0, H - 1, 9), np.linspace(0, W - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    pa, pb = Hm @ P, np.linalg.inv(scene.camera(40, 150)) @ P
+    err = float(np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max())
+    rng = np.random.default_rng(0)
+    n = 250000
+    d = rng.gamma(0.6, 1.0, (n, 128)).astype(np.float32)
+    d /= d.sum(1, keepdims=True)
+    d = np.sqrt(d)
+    *_, ms = ops.match_2nn(d, d[rng.permutation(n)], iters=3, ctx=ctx)
+    flops = 2.0 * n * n * 128
+    out = {"metric": "4K frame-pair registrations/sec (RootSIFT + 2-NN + robust homography)", "value": steps / elapsed, "unit": "registrations/s",
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 keypoints/descriptors, f16 MFMA matching", "data": "synthetic",
+           "config": {"workload": "estimate_homography GPU path on two 3840x2160 frames (frame 40 -> frame 0 of the synthetic clip), host images in",
+                      "keypoints": [int(stats[0]), int(stats[1])], "good_matches": int(stats[2]), "inliers": int(stats[3]),
+                      "stage_ms": {"detect_describe": float(tm[0]), "match": float(tm[1]), "ratio": float(tm[2]), "fit": float(tm[3])},
+                      "max_grid_error_px_vs_known_camera": err},
+           "roofline": {"bound": "mfma", "kernel": "match2nn_kernel", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["f16"],
+                        "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f16"], "traffic": None,
+                        "avg_launch_us": 1000.0 * ms, "flops_per_launch": flops,
+                        "timing": "HIP events around 3 passes of 250000 x 250000 x 128 (gtx_op_match_2nn), incl. the exact-distance finish kernel"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "register":
+        return bench_register(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -2,6 +2,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "detector.hpp"
@@ -10,6 +12,34 @@
 #include "stabilizer.hpp"
 
 namespace gtx {
+
+namespace {
+// The pyramids of a 4K image are ~2 GB: allocating and freeing them per call costs far more than the
+// registration itself. Keep the last few Sift objects (keyed by context and image size) alive.
+struct SiftCache {
+  struct Entry { gtx_ctx* ctx; int h, w; std::unique_ptr<Sift> sift; unsigned long stamp; };
+  std::vector<Entry> entries;
+  unsigned long clock = 0;
+  std::mutex mu;
+  Sift* get(gtx_ctx* ctx, int h, int w, const Sift* other) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : entries)
+      if (e.ctx == ctx && e.h == h && e.w == w && e.sift.get() != other) { e.stamp = ++clock; return e.sift.get(); }
+    if (entries.size() >= 4) {
+      size_t victim = entries.size();
+      for (size_t i = 0; i < entries.size(); ++i)
+        if (entries[i].sift.get() != other && (victim == entries.size() || entries[i].stamp < entries[victim].stamp)) victim = i;
+      entries.erase(entries.begin() + (long)victim);
+    }
+    entries.push_back(Entry{ctx, h, w, std::unique_ptr<Sift>(new Sift(ctx->device, ctx->stream, h, w)), ++clock});
+    return entries.back().sift.get();
+  }
+};
+SiftCache& sift_cache() {
+  static SiftCache c;
+  return c;
+}
+}  // namespace
 
 void register_images(gtx_ctx* ctx, const gtx_reg_config& cfg, const uint8_t* src, int sh, int sw, const uint8_t* dst, int dh, int dw,
                      double H[9], int* valid, int stats[4], float timings_ms[4]) {
@@ -25,7 +55,8 @@ void register_images(gtx_ctx* ctx, const gtx_reg_config& cfg, const uint8_t* src
   float tm[4] = {0, 0, 0, 0};
 
   auto t0 = clk::now();
-  Sift sift_dst(ctx->device, s, dh, dw), sift_src(ctx->device, s, sh, sw);
+  Sift& sift_dst = *sift_cache().get(ctx, dh, dw, nullptr);
+  Sift& sift_src = *sift_cache().get(ctx, sh, sw, &sift_dst);
   sift_dst.detect_and_compute(dst, dh, dw, cfg.max_features, true, cfg.rsift_eps);     // reference = destination
   sift_src.detect_and_compute(src, sh, sw, cfg.max_features, true, cfg.rsift_eps);     // current = source (query)
   GTX_HIP(hipStreamSynchronize(s));
