@@ -323,3 +323,61 @@ def test_batch_processes_a_directory_and_skips_existing(gtx_ctx, tmp_path):
     for name in ("north/results/clip_a.txt", "south/results/clip_b.txt", "north/results/clip_a_vid_transf.txt"):
         assert (tmp_path / name).exists(), name
     assert batch.process_input(batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path)]), logger)["skipped"] == 2
+
+
+@pytest.mark.parametrize("ratio", [0.5, 1.0])
+def test_engine_host_frames_equal_blocking_calls(gtx_ctx, ratio):
+    """ExtractEngine fed with host frames (odd batch tail, both stabilizer input paths: the detector's
+    half-resolution gray in HBM for downsample_ratio 0.5, the stabilizer's own gray otherwise) against the
+    blocking per-frame calls of the same objects."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.stabilizer import Stabilizer
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    scene = make_scene(seed=6, h=H, w=W)
+    frames = [scene.render(12 * k, 150) for k in range(5)]
+    kw = dict(imgsz=IMGSZ, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=1, nc=4)
+    det = Detector(w, (H, W), ctx=gtx_ctx, **kw)
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 60)
+    det.close()
+    stab_kw = dict(max_features=500, downsample_ratio=ratio)
+    # blocking reference
+    det = Detector(w, (H, W), ctx=gtx_ctx, **kw)
+    trk, st = Tracker("bytetrack"), Stabilizer((H, W), ctx=gtx_ctx, **stab_kw)
+    want = []
+    for i, f in enumerate(frames):
+        d = det.detect(f)
+        bx, ids = (trk.update(d.xyxy, d.conf, d.cls)[:2]) if len(d) else (d.xyxy, np.zeros(0, np.int32))
+        xywh = None if len(bx) == 0 else np.stack([(bx[:, 0] + bx[:, 2]) / 2, (bx[:, 1] + bx[:, 3]) / 2, bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1).astype(np.float32)
+        if i == 0:
+            st.set_ref_frame(f, xywh)
+            want.append((ids, xywh, None))
+        else:
+            st.stabilize(f, xywh)
+            want.append((ids, xywh, st.get_cur_trans_matrix()))
+    det.close()
+    eng = ExtractEngine(w, (H, W), kw, Tracker("bytetrack"), stab_kw, batch=2, det_streams=2, stab_streams=3)
+    try:
+        got = list(eng.run([frames[0:2], frames[2:4], frames[4:5]]))             # last batch is short
+        assert [r.index for r in got] == list(range(5))
+        for r, (ids, xywh, Hm) in zip(got, want):
+            np.testing.assert_array_equal(r.ids if r.ids is not None else np.zeros(0, np.int32), ids)
+            if xywh is None:
+                assert r.xywh is None
+            else:
+                np.testing.assert_array_equal(r.xywh, xywh)
+            assert (r.H is None) == (Hm is None)
+            if Hm is not None:
+                np.testing.assert_array_equal(r.H, Hm)
+        assert got[0].H is None and got[0].xywh_stab is not None and sum(r.H is not None for r in got) == 4
+        with pytest.raises(ValueError):
+            list(eng.run([[frames[0][:100]]]))                                     # wrong frame size
+        with pytest.raises(ValueError):
+            list(eng.run([frames[:3]]))                                            # more frames than the batch size
+    finally:
+        eng.close()
