@@ -90,8 +90,22 @@ template <> __device__ __forceinline__ void load4<float>(const float* src, float
   v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
 }
 
+// Waves per SIMD the register allocator is asked to fit (VGPR + AGPR <= 512 / waves, 8-register granules).
+// Several instantiations sit within two registers of a boundary (3x3 stride 2, BN 64: 96 vs 98 VGPRs + 32 AGPRs
+// is 4 or 3 waves) and flip with unrelated edits when left to the default heuristics; these are the values
+// each one reaches without scratch.
 template <typename T, int KS, int STRIDE, int WN, int CPR>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGroup g) {
+constexpr int conv_min_waves() {
+  if (KS == 3 && CPR == 2) return WN == 1 ? (STRIDE == 1 ? 6 : 4) : 4;
+  if (KS == 3 && CPR == 4) return STRIDE == 1 ? (WN == 1 ? 4 : 3) : (WN == 1 ? 3 : 2);
+  if (KS == 1 && CPR == 4) return WN == 1 ? 8 : 5;
+  if (KS == 1 && CPR == 8) return WN == 1 ? 7 : 5;
+  return 1;
+}
+
+template <typename T, int KS, int STRIDE, int WN, int CPR>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((conv_min_waves<T, KS, STRIDE, WN, CPR>()))))
+void conv_igemm_kernel(const ConvGroup g) {
   using Tile = ConvTile<T, KS, STRIDE, WN, CPR>;
   using frag_t = typename Mma<T>::frag_t;
   constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB;
@@ -197,24 +211,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGroup g) {
     GTX_COMMIT()
     __syncthreads();
     if (chunk + 1 < nchunks) GTX_PREFETCH(chunk + 1)
+    if constexpr (KS == 3 && STRIDE == 1) {
+      // Fragment reads run one (tap, k-step) ahead of the MFMAs that consume them: a wave's MFMAs then issue
+      // back to back instead of each waiting for its own ds_read (the compiler's default schedule).
+      constexpr int NSTEP = KS * KS * (CPR / 2);
+      frag_t bq[2], aq[2][WN];
+#define GTX_LOAD_FRAGS(STEP, SLOT)                                                             \
+      {                                                                                          \
+        const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
+        const int p__ = p0 + (tap__ / KS) * PW + (tap__ % KS);                                   \
+        const int c__ = 2 * ks__ + h;                                                            \
+        bq[SLOT] = *reinterpret_cast<const frag_t*>(lds_patch + p__ * RB + ((c__ ^ Tile::swz(p__)) << 4)); \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                         \
+          const int nrow__ = 32 * j + prow;                                                      \
+          aq[SLOT][j] = *reinterpret_cast<const frag_t*>(                                        \
+              lds_w + (tap__ * BN + nrow__) * RB + ((c__ ^ Tile::swz(nrow__)) << 4));            \
+        }                                                                                        \
+      }
+      GTX_LOAD_FRAGS(0, 0)
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky) {
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) {
+          if (st & 1) GTX_LOAD_FRAGS(st + 1, 0) else GTX_LOAD_FRAGS(st + 1, 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the reads of step st+1 ahead of the MFMAs of step st
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const int p = p0 + ky * PW + kx;
-        const int tap = ky * KS + kx;
-        const char* prow_ptr = lds_patch + p * RB;
-        const int pswz = Tile::swz(p);
+        for (int j = 0; j < WN; ++j) Mma<T>::run(acc[j], aq[st & 1][j], bq[st & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef GTX_LOAD_FRAGS
+    } else {
 #pragma unroll
-        for (int ks = 0; ks < CPR / 2; ++ks) {
-          const int c = 2 * ks + h;
-          const frag_t bfrag = *reinterpret_cast<const frag_t*>(prow_ptr + ((c ^ pswz) << 4));
+      for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            const int nrow = 32 * j + prow;
-            const frag_t afrag = *reinterpret_cast<const frag_t*>(
-                lds_w + (tap * BN + nrow) * RB + ((c ^ Tile::swz(nrow)) << 4));
-            Mma<T>::run(acc[j], afrag, bfrag);
+        for (int kx = 0; kx < KS; ++kx) {
+          const int p = p0 + ky * PW + kx;
+          const int tap = ky * KS + kx;
+          const char* prow_ptr = lds_patch + p * RB;
+          const int pswz = Tile::swz(p);
+#pragma unroll
+          for (int ks = 0; ks < CPR / 2; ++ks) {
+            const int c = 2 * ks + h;
+            const frag_t bfrag = *reinterpret_cast<const frag_t*>(prow_ptr + ((c ^ pswz) << 4));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int nrow = 32 * j + prow;
+              const frag_t afrag = *reinterpret_cast<const frag_t*>(
+                  lds_w + (tap * BN + nrow) * RB + ((c ^ Tile::swz(nrow)) << 4));
+              Mma<T>::run(acc[j], afrag, bfrag);
+            }
           }
         }
       }
