@@ -494,7 +494,7 @@ void Detector::run_post(int nb, hipStream_t s) {
 
 // Asynchronous half: enqueue preprocess -> forward -> decode/NMS -> D2H of the result rows on the
 // context's stream and return. Results are picked up by collect(). The gray image of this batch
-// goes to the next slot of a 6-deep ring so that consumers on other streams (stabilizers) can
+// goes to the next slot of a 16-deep ring so that consumers on other streams (stabilizers) can
 // still read the images of the four batches before the newest collected one.
 void Detector::submit_dev(const void* frames, int nb, int h, int w) {
   GTX_CHECK(finalized_, "detector not finalized");

@@ -119,7 +119,7 @@ class Detector {
   DevBuf gray_;              // [N][gh][gw] u8
   int gray_h_ = 0, gray_w_ = 0;
   const void* cur_frames_ = nullptr;
-  static constexpr int kGrayRing = 6;
+  static constexpr int kGrayRing = 16;
   int gray_slot_ = 0, collected_gray_slot_ = 0;
   bool in_flight_ = false;
   int flight_nb_ = 0;

@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import collections
 import os
+import queue
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -162,10 +164,20 @@ class ExtractEngine:
 
     def run(self, batches):
         """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM) or of lists of <= B host frames.
-        Yields one FrameResult per frame, in feeding order."""
+        Yields one FrameResult per frame, in feeding order.
+
+        With a tracker or stabilizers the loop runs as three host stages on their own threads, joined by bounded
+        queues (the C-ABI calls release the GIL): detector submit/collect -> GMC + tracker (clip order) ->
+        stabilizer submit/collect + box warp (this thread, which yields). Per-frame results are the same as
+        frame at a time; only the host work overlaps. GTX_ENGINE_THREADS=0 keeps everything on the calling thread."""
+        threaded = (self.tracker is not None or bool(self.stabs)) and os.environ.get("GTX_ENGINE_THREADS", "1") != "0"
+        frames = self._tracked_frames_threaded(batches) if threaded else self._tracked_frames(batches)
+        return self._stabilized(frames)
+
+    # ---- stage 1: detector batches (submit keeps every detector stream busy; collect blocks on the oldest pass)
+    def _detected_batches(self, batches):
         it = iter(batches)
         inflight = collections.deque()                          # (detector, frames in the batch)
-        pending = collections.deque()                           # (stabilizer, partial FrameResult) awaiting collect
         k = 0
 
         def submit_next():
@@ -177,14 +189,7 @@ class ExtractEngine:
             k += 1
             inflight.append((det, self._submit(det, b)))
 
-        def finish():
-            st, r = pending.popleft()
-            st.collect()
-            r.H = st.get_cur_trans_matrix()
-            if r.xywh is not None:
-                r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
-            return r
-
+        host_gray = bool(self.stabs) and not self.use_dev_gray
         for _ in range(len(self.dets)):
             submit_next()
         while inflight:
@@ -193,51 +198,134 @@ class ExtractEngine:
             grays = [det.gray_dptr(b) for b in range(nb)]
             hosts = self._host_frames.pop(id(det), None)
             det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
-            if not (self.stabs and not self.use_dev_gray):
+            if not host_gray:
                 submit_next()                                   # keep this detector busy while the host works on the batch
-            if self.gmc is not None:                            # whole batch queues on the GMC stream, results in order
-                for d, g in zip(dets, grays):
-                    if len(d):
-                        self.gmc.submit_gray_dev(*g)
-            for b, (d, g) in enumerate(zip(dets, grays)):
-                ids = None
-                xyxy, conf, cls = d.xyxy, d.conf, d.cls
-                if len(d) and self.tracker is not None:
-                    warp = self.gmc.collect() if self.gmc is not None else None
-                    t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
-                    if len(t_ids):
-                        xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
-                elif len(d) and self.gmc is not None:
-                    self.gmc.collect()
-                r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms)
-                self._index += 1
-                if not self.stabs:
-                    yield r
-                    continue
-                if not self._have_ref:                          # reference frame: boxes pass through, no transform row
-                    det.ctx.synchronize()
-                    for st in self.stabs:
-                        if self.use_dev_gray:
-                            st.set_ref_gray_dev(g[0], g[1], g[2], r.xywh)
-                        else:
-                            st.set_ref_frame(hosts[b], r.xywh)
-                    self._have_ref = True
-                    r.xywh_stab = None if r.xywh is None else r.xywh.copy()
-                    yield r
-                    continue
-                if len(pending) == len(self.stabs):             # results are taken in frame order
-                    yield finish()
-                st = self.stabs[r.index % len(self.stabs)]
-                if self.use_dev_gray:
-                    st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
-                    pending.append((st, r))
-                else:                                           # other downsample ratios: the stabilizer makes its own gray
-                    st.stabilize(hosts[b], r.xywh)
-                    r.H = st.get_cur_trans_matrix()
-                    if r.xywh is not None:
-                        r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
-                    yield r
-            if self.stabs and not self.use_dev_gray:
+            yield det, dets, grays, hosts, det_ms
+            if host_gray:
                 submit_next()
+
+    # ---- stage 2: camera-motion compensation + tracker, strictly in clip order
+    def _track_batch(self, det, dets, grays, hosts, det_ms):
+        if self.gmc is not None:                                # whole batch queues on the GMC stream, results in order
+            for d, g in zip(dets, grays):
+                if len(d):
+                    self.gmc.submit_gray_dev(*g)
+        out = []
+        for b, (d, g) in enumerate(zip(dets, grays)):
+            ids = None
+            xyxy, conf, cls = d.xyxy, d.conf, d.cls
+            if len(d) and self.tracker is not None:
+                warp = self.gmc.collect() if self.gmc is not None else None
+                t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
+                if len(t_ids):
+                    xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
+            elif len(d) and self.gmc is not None:
+                self.gmc.collect()
+            r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms)
+            self._index += 1
+            out.append((r, det, g, hosts[b] if hosts is not None else None))
+        return out
+
+    def _tracked_frames(self, batches):
+        for item in self._detected_batches(batches):
+            yield from self._track_batch(*item)
+
+    def _tracked_frames_threaded(self, batches):
+        # Queue depths. A frame's gray image lives in its detector's 16-deep ring (detector.hpp kGrayRing) until that
+        # detector has started 15 more passes; by then stage 1 has handed on at least 14 * n_dets * B later frames, so
+        # the frames between stage 1 and the stabilizer's collect must stay below that.
+        n_batches = 2
+        n_frames = 2 * self.B * len(self.dets)
+        in_flight = (n_batches + 1) * self.B + n_frames + len(self.stabs) + 1
+        assert in_flight <= 14 * len(self.dets) * self.B, "engine queues outlive the detector's gray ring"
+        q_det = queue.Queue(maxsize=n_batches)                  # detected batches
+        q_trk = queue.Queue(maxsize=n_frames)                   # tracked frames
+        stop = threading.Event()
+        END = object()
+
+        def put(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def stage(src, q, work):
+            try:
+                for item in src:
+                    for out in work(item):
+                        if not put(q, out):
+                            return
+                put(q, END)
+            except BaseException as e:                          # handed to the consumer, which re-raises it
+                put(q, e)
+
+        def drain(q):
+            while True:
+                item = q.get()
+                if item is END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+
+        t1 = threading.Thread(target=stage, args=(self._detected_batches(batches), q_det, lambda item: (item,)), daemon=True)
+        t2 = threading.Thread(target=stage, args=(drain(q_det), q_trk, lambda item: self._track_batch(*item)), daemon=True)
+        t1.start()
+        t2.start()
+        try:
+            yield from drain(q_trk)
+        finally:
+            stop.set()
+            for q in (q_det, q_trk):                            # unblock producers stuck in put()
+                try:
+                    while True:
+                        q.get_nowait()
+                except queue.Empty:
+                    pass
+            t1.join()
+            t2.join()
+
+    # ---- stage 3: stabilizer submit/collect + box warp; results leave in frame order
+    def _stabilized(self, frames):
+        pending = collections.deque()                           # (stabilizer, partial FrameResult) awaiting collect
+
+        def finish():
+            st, r = pending.popleft()
+            st.collect()
+            r.H = st.get_cur_trans_matrix()
+            if r.xywh is not None:
+                r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
+            return r
+
+        for r, det, g, host in frames:
+            if not self.stabs:
+                yield r
+                continue
+            if not self._have_ref:                              # reference frame: boxes pass through, no transform row
+                det.ctx.synchronize()
+                for st in self.stabs:
+                    if self.use_dev_gray:
+                        st.set_ref_gray_dev(g[0], g[1], g[2], r.xywh)
+                    else:
+                        st.set_ref_frame(host, r.xywh)
+                self._have_ref = True
+                r.xywh_stab = None if r.xywh is None else r.xywh.copy()
+                yield r
+                continue
+            if len(pending) == len(self.stabs):                 # results are taken in frame order
+                yield finish()
+            st = self.stabs[r.index % len(self.stabs)]
+            if self.use_dev_gray:
+                st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
+                pending.append((st, r))
+            else:                                               # other downsample ratios: the stabilizer makes its own gray
+                st.stabilize(host, r.xywh)
+                r.H = st.get_cur_trans_matrix()
+                if r.xywh is not None:
+                    r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
+                yield r
         while pending:
             yield finish()

@@ -177,8 +177,8 @@ int gtx_detector_submit_dev(gtx_detector* det, const void* frames_dptr, int nb, 
 int gtx_detector_collect(gtx_detector* det, int* n_out, float* xyxy, float* conf, int* cls,
                          float speed_ms[3]);
 /* Device pointer of the half-resolution gray image the preprocess pass wrote for batch slot b of
- * the most recently *collected* batch (the images live in a 6-deep ring: an image stays valid until
- * four more batches have been submitted after the one that follows it), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
+ * the most recently *collected* batch (the images live in a 16-deep ring: an image stays valid until
+ * fourteen more batches have been submitted after the one that follows it), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
 const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w);
 /* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
  * pixels + sigmoid class scores), like the tensor ultralytics' Detect returns. */
