@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -490,12 +491,14 @@ struct Gmc::Impl {
   bool have_prev = false;
   // results of up to kRing submitted frames wait in pinned memory, one event each (stream order
   // makes the device-side buffers reusable from one frame to the next)
-  static constexpr int kRing = 16;
+  static constexpr int kRing = 64;
   GmcResult* h_res = nullptr;  // pinned [kRing]
   float4* h_pairs = nullptr;   // pinned [kRing][1024]
   hipEvent_t done[kRing] = {};
   bool first[kRing] = {};
-  int head = 0, pending = 0;   // oldest pending slot, number pending
+  // result ring, single producer (submit) / single consumer (collect): the two may run on different host threads
+  std::atomic<unsigned> submitted{0}, collected{0};
+  int pending() const { return (int)(submitted.load(std::memory_order_acquire) - collected.load(std::memory_order_acquire)); }
   int cand_cap = 0;
   int stats[3] = {0, 0, 0};
 };
@@ -540,15 +543,15 @@ Gmc::~Gmc() {
 }
 
 void Gmc::reset() {
-  GTX_CHECK(impl_->pending == 0, "gmc: reset while a frame is in flight");
+  GTX_CHECK(impl_->pending() == 0, "gmc: reset while a frame is in flight");
   impl_->have_prev = false;
 }
 
 void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
   Impl& S = *impl_;
   GTX_CHECK(gray && gh == S.h && gw == S.w, "gmc: gray image is %dx%d, expected %dx%d", gw, gh, S.w, S.h);
-  GTX_CHECK(S.pending < Impl::kRing, "gmc: %d frames already in flight, collect first", S.pending);
-  const int slot = (S.head + S.pending) % Impl::kRing;
+  GTX_CHECK(S.pending() < Impl::kRing, "gmc: %d frames already in flight, collect first", S.pending());
+  const int slot = (int)(S.submitted.load(std::memory_order_relaxed) % Impl::kRing);
   GTX_HIP(hipSetDevice(S.device));
   hipStream_t s = S.s;
   const int c = S.cur, p = c ^ 1;
@@ -582,7 +585,7 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
   }
   GTX_HIP(hipGetLastError());
   GTX_HIP(hipEventRecord(S.done[slot], s));
-  S.pending += 1;
+  S.submitted.fetch_add(1, std::memory_order_release);
   S.have_prev = true;
   S.cur = p;       // the next frame overwrites what is now "previous"
 }
@@ -590,7 +593,7 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
 void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
   Impl& S = *impl_;
   GTX_CHECK(frame_bgr && h / 2 == S.h && w / 2 == S.w, "gmc: frame is %dx%d, created for %dx%d", w, h, 2 * S.w, 2 * S.h);
-  GTX_CHECK(S.pending == 0, "gmc: the host-frame path keeps one frame in flight");
+  GTX_CHECK(S.pending() == 0, "gmc: the host-frame path keeps one frame in flight");
   GTX_HIP(hipSetDevice(S.device));
   const size_t bytes = (size_t)h * w * 3;
   if (S.frame.bytes < bytes) S.frame.alloc(bytes);
@@ -602,12 +605,10 @@ void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
 
 void Gmc::collect(double A[6], int* valid, int stats[3]) {
   Impl& S = *impl_;
-  GTX_CHECK(S.pending > 0, "gmc: collect without a submitted frame");
+  GTX_CHECK(S.pending() > 0, "gmc: collect without a submitted frame");
   GTX_HIP(hipSetDevice(S.device));
-  const int slot = S.head;
+  const int slot = (int)(S.collected.load(std::memory_order_relaxed) % Impl::kRing);
   GTX_HIP(hipEventSynchronize(S.done[slot]));
-  S.head = (S.head + 1) % Impl::kRing;
-  S.pending -= 1;
   const double I6[6] = {1, 0, 0, 0, 1, 0};
   std::memcpy(A, I6, sizeof I6);
   if (valid) *valid = 0;
@@ -640,11 +641,12 @@ void Gmc::collect(double A[6], int* valid, int stats[3]) {
     }
   }
   if (stats) std::memcpy(stats, S.stats, sizeof S.stats);
+  S.collected.fetch_add(1, std::memory_order_release);   // the slot's pinned records are free for the producer again
 }
 
 void Gmc::debug_points(int which, int cap, int* n, float* xy, int* status) const {
   const Impl& S = *impl_;
-  GTX_CHECK(S.pending == 0, "gmc: debug read while a frame is in flight");
+  GTX_CHECK(S.pending() == 0, "gmc: debug read while a frame is in flight");
   GTX_HIP(hipSetDevice(S.device));
   GTX_HIP(hipStreamSynchronize(S.s));
   // which 0: corners of the last submitted frame; 1: corners of the frame before; 2: their LK positions in the last frame

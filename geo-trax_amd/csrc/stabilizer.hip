@@ -600,7 +600,11 @@ __global__ __launch_bounds__(256) void describe_kernel(const Levels L,
 __global__ __launch_bounds__(256) void compact_kernel(const Levels L, const int* __restrict__ kp_n, const KeyPoint* __restrict__ kps,
                                                       const unsigned long long* __restrict__ desc, const float2* __restrict__ xy,
                                                       KeyPoint* __restrict__ okp, unsigned long long* __restrict__ odesc,
-                                                      float2* __restrict__ oxy, int* __restrict__ total) {
+                                                      float2* __restrict__ oxy, int* __restrict__ total,
+                                                      int* __restrict__ counters, int n_counters) {
+  // last kernel of a frame's feature pass: nobody reads the candidate counters / score histograms any more, so
+  // they are cleared here for the next frame (saves a memset launch per frame; they start out zero)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_counters; i += gridDim.x * blockDim.x) counters[i] = 0;
   int base = 0;
   for (int li = 0; li < L.n; ++li) {
     const int n = kp_n[li];
@@ -1000,6 +1004,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_elig.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_counters.alloc(sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels));
+  GTX_HIP(hipMemset(S.d_counters.p, 0, sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels)));
   S.d_kp_n.alloc(sizeof(int) * kPyrLevels);
   S.d_kps.alloc(sizeof(KeyPoint) * slots);
   S.d_desc.alloc(32 * (size_t)slots);
@@ -1101,11 +1106,10 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
       mask = d_mask.as<uint8_t>();
     }
   }
-  // counters: [cand_n 8][elig_n 8][score histogram 8 x 256], cleared with one memset
+  // counters: [cand_n 8][elig_n 8][score histogram 8 x 256]; zero here: compact_kernel clears them at the end of every pass
   int* cand_n = d_counters.as<int>();
   int* elig_n = cand_n + kPyrLevels;
   int* hist = elig_n + kPyrLevels;
-  GTX_HIP(hipMemsetAsync(d_counters.p, 0, sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels), s));
   hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, mask, gw, gh, L, cfg.fast_threshold, d_cand.as<Cand>(),
                      cand_n, hist);
   hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
@@ -1117,7 +1121,7 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
                      d_pattern.as<int8_t>(), d_desc.as<unsigned long long>(), d_xy.as<float2>(), 1.0f / cfg.downsample_ratio, slots);
   hipLaunchKernelGGL(compact_kernel, dim3(8), dim3(256), 0, s, L, d_kp_n.as<int>(), d_kps.as<KeyPoint>(),
                      d_desc.as<unsigned long long>(), d_xy.as<float2>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(),
-                     out.xy.as<float2>(), out.n.as<int>());
+                     out.xy.as<float2>(), out.n.as<int>(), d_counters.as<int>(), 2 * kPyrLevels + 256 * kPyrLevels);
   GTX_HIP(hipGetLastError());
 }
 

@@ -200,16 +200,16 @@ class ExtractEngine:
             det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
             if not host_gray:
                 submit_next()                                   # keep this detector busy while the host works on the batch
+            if self.gmc is not None:                            # the batch queues on the GMC stream now, results in order
+                for d, g in zip(dets, grays):                   # (frames without detections never reach the tracker)
+                    if len(d):
+                        self.gmc.submit_gray_dev(*g)
             yield det, dets, grays, hosts, det_ms
             if host_gray:
                 submit_next()
 
     # ---- stage 2: camera-motion compensation + tracker, strictly in clip order
     def _track_batch(self, det, dets, grays, hosts, det_ms):
-        if self.gmc is not None:                                # whole batch queues on the GMC stream, results in order
-            for d, g in zip(dets, grays):
-                if len(d):
-                    self.gmc.submit_gray_dev(*g)
         out = []
         for b, (d, g) in enumerate(zip(dets, grays)):
             ids = None
@@ -238,6 +238,7 @@ class ExtractEngine:
         n_frames = 2 * self.B * len(self.dets)
         in_flight = (n_batches + 1) * self.B + n_frames + len(self.stabs) + 1
         assert in_flight <= 14 * len(self.dets) * self.B, "engine queues outlive the detector's gray ring"
+        assert self.gmc is None or (n_batches + 2) * self.B <= 63, "engine queues outrun the GMC's 64-deep result ring"
         q_det = queue.Queue(maxsize=n_batches)                  # detected batches
         q_trk = queue.Queue(maxsize=n_frames)                   # tracked frames
         stop = threading.Event()
