@@ -104,6 +104,7 @@ class ExtractEngine:
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
         self._index, self._have_ref = 0, False
+        self._gmc_sub = self._gmc_col = 0   # frames queued on the GMC stream / warps taken (one writer thread each)
 
     # ---- lifecycle
     def set_reference(self, frame: np.ndarray) -> None:
@@ -127,6 +128,8 @@ class ExtractEngine:
         if self.tracker is not None:
             self.tracker.reset()
         if self.gmc is not None:
+            while self._gmc_sub > self._gmc_col:                # a run that was abandoned half way
+                self._gmc_collect()
             self.gmc.reset_params()
 
     def close(self) -> None:
@@ -190,23 +193,32 @@ class ExtractEngine:
             inflight.append((det, self._submit(det, b)))
 
         host_gray = bool(self.stabs) and not self.use_dev_gray
-        for _ in range(len(self.dets)):
-            submit_next()
-        while inflight:
-            det, nb = inflight.popleft()
-            dets = det.collect()
-            grays = [det.gray_dptr(b) for b in range(nb)]
-            hosts = self._host_frames.pop(id(det), None)
-            det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
-            if not host_gray:
-                submit_next()                                   # keep this detector busy while the host works on the batch
-            if self.gmc is not None:                            # the batch queues on the GMC stream now, results in order
-                for d, g in zip(dets, grays):                   # (frames without detections never reach the tracker)
-                    if len(d):
-                        self.gmc.submit_gray_dev(*g)
-            yield det, dets, grays, hosts, det_ms
-            if host_gray:
+        try:
+            for _ in range(len(self.dets)):
                 submit_next()
+            while inflight:
+                det, nb = inflight.popleft()
+                dets = det.collect()
+                grays = [det.gray_dptr(b) for b in range(nb)]
+                hosts = self._host_frames.pop(id(det), None)
+                det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
+                if not host_gray:
+                    submit_next()                               # keep this detector busy while the host works on the batch
+                if self.gmc is not None:                        # the batch queues on the GMC stream now, results in order
+                    for d, g in zip(dets, grays):               # (frames without detections never reach the tracker)
+                        if len(d):
+                            self.gmc.submit_gray_dev(*g)
+                            self._gmc_sub += 1
+                yield det, dets, grays, hosts, det_ms
+                if host_gray:
+                    submit_next()
+        finally:                                                # consumer stopped early or a stage failed: leave no pass in flight
+            for det, _ in inflight:
+                try:
+                    det.collect()
+                except Exception:
+                    pass
+            self._host_frames.clear()
 
     # ---- stage 2: camera-motion compensation + tracker, strictly in clip order
     def _track_batch(self, det, dets, grays, hosts, det_ms):
@@ -215,16 +227,21 @@ class ExtractEngine:
             ids = None
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
             if len(d) and self.tracker is not None:
-                warp = self.gmc.collect() if self.gmc is not None else None
+                warp = self._gmc_collect() if self.gmc is not None else None
                 t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
             elif len(d) and self.gmc is not None:
-                self.gmc.collect()
+                self._gmc_collect()
             r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms)
             self._index += 1
             out.append((r, det, g, hosts[b] if hosts is not None else None))
         return out
+
+    def _gmc_collect(self):
+        warp = self.gmc.collect()
+        self._gmc_col += 1
+        return warp
 
     def _tracked_frames(self, batches):
         for item in self._detected_batches(batches):
@@ -262,6 +279,8 @@ class ExtractEngine:
                 put(q, END)
             except BaseException as e:                          # handed to the consumer, which re-raises it
                 put(q, e)
+            finally:
+                src.close()                                     # runs the source's cleanup on this thread
 
         def drain(q):
             while True:
@@ -301,32 +320,40 @@ class ExtractEngine:
                 r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
             return r
 
-        for r, det, g, host in frames:
-            if not self.stabs:
-                yield r
-                continue
-            if not self._have_ref:                              # reference frame: boxes pass through, no transform row
-                det.ctx.synchronize()
-                for st in self.stabs:
-                    if self.use_dev_gray:
-                        st.set_ref_gray_dev(g[0], g[1], g[2], r.xywh)
-                    else:
-                        st.set_ref_frame(host, r.xywh)
-                self._have_ref = True
-                r.xywh_stab = None if r.xywh is None else r.xywh.copy()
-                yield r
-                continue
-            if len(pending) == len(self.stabs):                 # results are taken in frame order
+        try:
+            for r, det, g, host in frames:
+                if not self.stabs:
+                    yield r
+                    continue
+                if not self._have_ref:                              # reference frame: boxes pass through, no transform row
+                    det.ctx.synchronize()
+                    for st in self.stabs:
+                        if self.use_dev_gray:
+                            st.set_ref_gray_dev(g[0], g[1], g[2], r.xywh)
+                        else:
+                            st.set_ref_frame(host, r.xywh)
+                    self._have_ref = True
+                    r.xywh_stab = None if r.xywh is None else r.xywh.copy()
+                    yield r
+                    continue
+                if len(pending) == len(self.stabs):                 # results are taken in frame order
+                    yield finish()
+                st = self.stabs[r.index % len(self.stabs)]
+                if self.use_dev_gray:
+                    st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
+                    pending.append((st, r))
+                else:                                               # other downsample ratios: the stabilizer makes its own gray
+                    st.stabilize(host, r.xywh)
+                    r.H = st.get_cur_trans_matrix()
+                    if r.xywh is not None:
+                        r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
+                    yield r
+            while pending:
                 yield finish()
-            st = self.stabs[r.index % len(self.stabs)]
-            if self.use_dev_gray:
-                st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
-                pending.append((st, r))
-            else:                                               # other downsample ratios: the stabilizer makes its own gray
-                st.stabilize(host, r.xywh)
-                r.H = st.get_cur_trans_matrix()
-                if r.xywh is not None:
-                    r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
-                yield r
-        while pending:
-            yield finish()
+        finally:                                                # abandoned run: take what the stabilizers still owe
+            while pending:
+                try:
+                    pending.popleft()[0].collect()
+                except Exception:
+                    pass
+            frames.close()

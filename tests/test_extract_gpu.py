@@ -381,3 +381,66 @@ def test_engine_host_frames_equal_blocking_calls(gtx_ctx, ratio):
             list(eng.run([frames[:3]]))                                            # more frames than the batch size
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+def test_engine_threaded_equals_single_thread_and_survives_an_abandoned_run(gtx_ctx, monkeypatch, tracker):
+    """The three-thread host pipeline (detector / tracker / stabilizer stages) returns exactly what the
+    single-thread loop returns; a run abandoned half way leaves no pass in flight, so the engine can be
+    reset and used again; an error raised in a worker stage reaches the caller."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    scene = make_scene(seed=8, h=H, w=W)
+    frames = [scene.render(6 * k, 150) for k in range(9)]
+    kw = dict(imgsz=IMGSZ, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=2, nc=4)
+    det = Detector(w, (H, W), ctx=gtx_ctx, **kw)
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 50)
+    det.close()
+    batches = [frames[i:i + 2] for i in range(0, len(frames), 2)]
+
+    def run(threads):
+        monkeypatch.setenv("GTX_ENGINE_THREADS", threads)
+        eng = ExtractEngine(w, (H, W), kw, Tracker(tracker), dict(max_features=500), batch=2, det_streams=2, stab_streams=3,
+                            gmc=tracker == "botsort")
+        try:
+            first = list(eng.run(batches))
+            # abandon a run after three frames, then go again from a clean state
+            eng.reset()
+            it = eng.run(batches)
+            for _ in range(3):
+                next(it)
+            it.close()
+            eng.reset()
+            again = list(eng.run(batches))
+            return first, again
+        finally:
+            eng.close()
+
+    (a1, a2), (b1, _) = run("1"), run("0")
+    for got, want in ((a1, b1), (a2, a1)):
+        assert [r.index for r in got] == list(range(len(frames)))
+        for r, q in zip(got, want):
+            for x, y in ((r.ids, q.ids), (r.xywh, q.xywh), (r.H, q.H), (r.xywh_stab, q.xywh_stab)):
+                assert (x is None) == (y is None)
+                if x is not None:
+                    np.testing.assert_array_equal(x, y)
+    assert any(r.ids is not None and len(r.ids) for r in a1) and sum(r.H is not None for r in a1) == len(frames) - 1
+
+    monkeypatch.setenv("GTX_ENGINE_THREADS", "1")
+    trk = Tracker(tracker)
+    eng = ExtractEngine(w, (H, W), kw, trk, dict(max_features=500), batch=2, gmc=tracker == "botsort")
+    try:
+        def boom(*a, **k):
+            raise RuntimeError("tracker stage failed")
+        monkeypatch.setattr(trk, "update", boom)
+        with pytest.raises(RuntimeError, match="tracker stage failed"):
+            list(eng.run(batches))
+    finally:
+        eng.close()
