@@ -3,6 +3,7 @@
 #include <cstdint>
 
 struct gtx_ctx;
+struct gtx_georef_chain;
 
 namespace gtx {
 
@@ -13,6 +14,11 @@ void warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_out)
 
 // cv2.perspectiveTransform on f64 points (geotrax/georeference.py:599-605).
 void perspective_points(const double H[9], const double* x, const double* y, int n, double* ox, double* oy);
+
+// The georeference stage's per-row chain pixel -> orthophoto pixel -> lat/lon -> projected metres
+// (geotrax/georeference.py:173-177, 599-628). Device kernel in georef.hip.
+void georef_points(gtx_ctx* ctx, const gtx_georef_chain& chain, const double* x, const double* y, int n, double* ox, double* oy,
+                   double* lat, double* lon, double* east, double* north);
 
 // cv2.warpPerspective(frame, H, (w, h)): dst(x,y) = bilinear src(H^-1 (x,y)), constant 0 border
 // (geotrax/visualize.py:289). Device kernel in warp.hip.

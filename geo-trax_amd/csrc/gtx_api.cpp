@@ -583,6 +583,14 @@ int gtx_perspective_points(const double H[9], const double* x, const double* y, 
     gtx::perspective_points(H, x, y, n, ox, oy);
   });
 }
+int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const double* x, const double* y, int n,
+                         double* ortho_x, double* ortho_y, double* lat, double* lon, double* east, double* north) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(chain, "chain");
+    if (n > 0) { need(x, "x"); need(y, "y"); }
+    gtx::georef_points(ctx, *chain, x, y, n, ortho_x, ortho_y, lat, lon, east, north);
+  });
+}
 int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr) {
   return guarded([&] {
     need(ctx, "ctx"); need(src_bgr, "src"); need(H, "H"); need(dst_bgr, "dst");

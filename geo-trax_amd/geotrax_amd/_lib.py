@@ -50,6 +50,13 @@ class RegConfig(C.Structure):
                 ("ransac_confidence", C.c_float), ("rsift_eps", C.c_float), ("seed", C.c_int)]
 
 
+class GeorefChain(C.Structure):
+    """gtx_georef_chain (include/gtx.h)."""
+    _fields_ = [("H", C.c_double * 9), ("ortho", C.c_double * 6), ("projected", C.c_int), ("semi_major", C.c_double),
+                ("flattening", C.c_double), ("lon0_deg", C.c_double), ("k0", C.c_double), ("false_easting", C.c_double),
+                ("false_northing", C.c_double)]
+
+
 class StabConfig(C.Structure):
     _fields_ = [
         ("downsample_ratio", C.c_float), ("max_features", C.c_int), ("ref_multiplier", C.c_float),
@@ -126,6 +133,7 @@ _SIGNATURES = {
     "gtx_stabilizer_pattern": (C.c_int, [_P, _P]),
     "gtx_warp_boxes": (C.c_int, [_P, _P, C.c_int, _P]),
     "gtx_perspective_points": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "gtx_op_georef_points": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
 }
 

@@ -93,10 +93,65 @@ def ortho2local(ortho_x, ortho_y, ortho_params, source_crs, target_crs) -> tuple
     return geo2local(lat, lon, source_crs, target_crs)
 
 
-def frame2local(points_px: np.ndarray, homography: np.ndarray, ortho_params, source_crs, target_crs) -> np.ndarray:
+def frame2local(points_px: np.ndarray, homography: np.ndarray, ortho_params, source_crs, target_crs, ctx=None) -> np.ndarray:
+    """Frame pixels -> local metres (georeference.py:173-177). With a `_lib.Context` the whole chain is one HIP pass
+    (`transform_points`); without, the host functions above, as in the reference."""
+    if ctx is not None:
+        out = transform_points(points_px[:, 0], points_px[:, 1], homography, ortho_params, source_crs, target_crs, ctx=ctx)
+        return np.array([out["x_local"], out["y_local"]]).T
     x, y = apply_homography(points_px[:, 0], points_px[:, 1], homography)
     xl, yl = ortho2local(x, y, ortho_params, source_crs, target_crs)
     return np.array([xl, yl]).T
+
+
+def georef_chain(homography, ortho_params, source_crs: str | None = None, target_crs: str | None = None):
+    """The parameter block of gtx_op_georef_points for a homography, an orthophoto geotransform and (optionally) a
+    projected target CRS -- the same CRS rules as geo2local."""
+    from ._lib import GeorefChain
+
+    ch = GeorefChain()
+    ch.H[:] = [float(v) for v in np.asarray(homography, np.float64).reshape(9)]
+    ch.ortho[:] = [float(v) for v in ortho_params]
+    ch.projected = 0
+    if target_crs is None:
+        return ch
+    src, dst = _parse_epsg(source_crs), _parse_epsg(target_crs)
+    if src not in (4326, 4737, 4019):
+        raise NotImplementedError(f"source_crs EPSG:{src}: only geographic WGS 84 / GRS 80 sources are implemented")
+    ch.projected, ch.semi_major = 1, _A
+    if 32601 <= dst <= 32660 or 32701 <= dst <= 32760:
+        ch.flattening, ch.lon0_deg, ch.k0 = _F_WGS84, (dst % 100) * 6 - 183, 0.9996
+        ch.false_easting, ch.false_northing = 500000.0, 0.0 if dst < 32700 else 10000000.0
+    elif dst in (5185, 5186, 5187, 5188):
+        lon0 = {5185: 125.0, 5186: 127.0, 5187: 129.0, 5188: 131.0}[dst]
+        north0, _ = _tm_forward(38.0, lon0, lon0, _F_GRS80)
+        ch.flattening, ch.lon0_deg, ch.k0 = _F_GRS80, lon0, 1.0
+        ch.false_easting, ch.false_northing = 200000.0, 600000.0 - float(north0)
+    else:
+        raise NotImplementedError(f"target_crs EPSG:{dst}: implemented targets are UTM (326xx/327xx) and Korea 2000 belts (5185-5188)")
+    return ch
+
+
+def transform_points(x_px, y_px, homography, ortho_params, source_crs: str | None = None, target_crs: str | None = None, ctx=None) -> dict:
+    """The per-row chain of the georeference stage on the GPU (gtx_op_georef_points, include/gtx.h): frame pixel ->
+    orthophoto pixel -> latitude/longitude -> local metres, f64, one pass over the track table.
+    -> dict(ortho_x, ortho_y, latitude, longitude[, x_local, y_local])."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    ctx = ctx or _lib.default_context()
+    ch = georef_chain(homography, ortho_params, source_crs, target_crs)
+    x = np.ascontiguousarray(x_px, dtype=np.float64).reshape(-1)
+    y = np.ascontiguousarray(y_px, dtype=np.float64).reshape(-1)
+    if len(x) != len(y):
+        raise ValueError("x and y differ in length")
+    names = ["ortho_x", "ortho_y", "latitude", "longitude"] + (["x_local", "y_local"] if ch.projected else [])
+    out = {k: np.empty_like(x) for k in names}
+    ptrs = [_lib.ptr(out[k]) for k in names] + [None] * (6 - len(names))
+    _lib.check(lib.gtx_op_georef_points(ctx.handle, C.byref(ch), _lib.ptr(x), _lib.ptr(y), len(x), *ptrs))
+    return out
 
 
 # --------------------------------------------------------------------------- per-track quantities

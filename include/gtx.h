@@ -348,6 +348,21 @@ int gtx_warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_o
 int gtx_perspective_points(const double H[9], const double* x, const double* y, int n,
                            double* ox, double* oy);
 
+/* The georeference stage's per-row transform chain in one HIP pass (replaces
+ * geotrax/georeference.py:173-177 = apply_homography :599-605 -> ortho2geo :608-615 -> geo2local :618-628, where the
+ * reference reprojects through pyproj): frame pixel -H-> orthophoto pixel -affine-> lat/lon (deg)
+ * -transverse Mercator (Krueger series, 6th order)-> metres. f64. x, y and every non-NULL output are host arrays of n. */
+typedef struct gtx_georef_chain {
+  double H[9];            /* frame (stabilized) pixel -> orthophoto pixel */
+  double ortho[6];        /* lng0, lat0, dlng, dlat, skew_x, skew_y (georeference.py:608-615) */
+  int projected;          /* 0: stop at lat/lon; east/north are not written */
+  double semi_major, flattening;            /* ellipsoid of the target CRS */
+  double lon0_deg, k0;                      /* central meridian, scale on it */
+  double false_easting, false_northing;     /* false_northing includes -k0 * (meridian arc to the latitude of origin) */
+} gtx_georef_chain;
+int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const double* x, const double* y, int n,
+                         double* ortho_x, double* ortho_y, double* lat, double* lon, double* east, double* north);
+
 /* cv2.warpPerspective(frame, H, (w,h)) with bilinear sampling and constant-0 border
  * (visualize.py:289). BGR u8 in/out, host buffers. */
 int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9],
