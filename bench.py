@@ -25,6 +25,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")   # torch is only plumbing here; 256 idle OpenMP spinners starve the host stages under a CPU quota
 import queue
 import sys
 import threading
@@ -219,7 +221,7 @@ def main():
 
     cdev = f"cuda:{local}" if args.backend == "nccl" else "cpu"     # where the collectives' tensors live
     from geotrax_amd import _lib
-    from geotrax_amd.distributed import pack_frame_record, unpack_frame_record
+    from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
     from geotrax_amd.geometry import warp_boxes
     from geotrax_amd.stabilizer import Stabilizer
     from geotrax_amd.synth import make_scene
@@ -276,6 +278,14 @@ def main():
         g = k * world + rank
         return pool + ((g * B) % len(order)) * fbytes
 
+    def batch_item(k):
+        """What the engine is fed for local step k. Frame-sharded BoT-SORT run: the batch does not continue the rank's
+        previous one, so the GMC is primed with the frame that precedes it in the clip (every rank holds the clip)."""
+        if not shard_gmc:
+            return batch_ptr(k)
+        g = k * world + rank
+        return batch_ptr(k), (None if g == 0 else pool + ((g * B - 1) % len(order)) * fbytes)
+
     extract = args.workload == "extract"
     sharded = world > 1 or force_dist
     tracker = Tracker(args.tracker)                              # N > 1: used by rank 0's replay thread only
@@ -283,15 +293,17 @@ def main():
     # The product's own engine (geotrax_amd/engine.py, what `geotrax_amd.extract` runs): detector streams take the
     # batches round-robin, the tracker works in clip order, stabilizers (and BoT-SORT's GMC) run on their own streams.
     # N > 1: a shard rank's engine has no tracker (mask from the raw detections); rank 0 tracks the
-    # gathered records. The frame-sharded run skips the GMC: a rank does not hold the frame before its batches.
+    # gathered records. BoT-SORT there: each rank runs the GMC over [frame before its batch, its batch] and ships the
+    # warps in the records; rank 0's tracker applies them in clip order.
     from geotrax_amd.engine import ExtractEngine
 
     det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
                   rect=bool(args.rect))
     stab_kw = {} if extract else None
+    shard_gmc = sharded and extract and args.tracker == "botsort"
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
                            det_streams=args.det_streams, stab_streams=args.stab_streams,
-                           gmc=extract and args.tracker == "botsort" and not sharded, detectors=[det])
+                           gmc=extract and args.tracker == "botsort", detectors=[det])
     n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
     if extract:
         engine.set_reference(ref_frame)                          # every rank registers against frame 0 of the clip
@@ -300,10 +312,10 @@ def main():
     def run(k0, n_steps, sharded):
         """n_steps batches through the engine; per-frame results are identical to the frame-at-a-time order."""
         n_rows = 0
-        for r in engine.run(batch_ptr(k0 + k) for k in range(n_steps)):
+        for r in engine.run(batch_item(k0 + k) for k in range(n_steps)):
             n_rows = len(r.xyxy)
             if sharded and extract:
-                records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H))
+                records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H, r.gmc, with_gmc=shard_gmc))
                 if live[0]:
                     gather_ready()
         return n_rows
@@ -354,7 +366,7 @@ def main():
             xyxy, conf, cls, Hm = unpack_frame_record(rec, max_det)
             if len(conf) == 0:
                 continue
-            bx, ids = tracker.update(xyxy, conf, cls)[:2]
+            bx, ids = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if shard_gmc else None)[:2]
             if len(ids) and Hm is not None:
                 warp_boxes(Hm, xywh_of(bx))
             n_last = len(ids)
@@ -416,7 +428,7 @@ def main():
                              f"{B} frame(s) per step (BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
                              f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
-                "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
+                "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s, class bias calibrated on one frame (no checkpoint reachable)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),

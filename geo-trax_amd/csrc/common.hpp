@@ -12,6 +12,15 @@
 
 namespace gtx {
 
+// Flags for the events host threads wait on (detector / stabilizer / GMC results). Blocking waits let a waiting
+// thread sleep instead of spinning: one process per GPU with three host stages each would otherwise burn 3 cores
+// per rank just waiting (the GPU boxes give a job a CPU quota). GTX_SPIN_WAIT=1 keeps the default spinning waits.
+inline unsigned wait_event_flags(bool timing) {
+  static const bool spin = [] { const char* e = getenv("GTX_SPIN_WAIT"); return e && e[0] == '1'; }();
+  return (spin ? 0u : (unsigned)hipEventBlockingSync) | (timing ? 0u : (unsigned)hipEventDisableTiming);
+}
+
+
 // Error transport: C++ exceptions never cross the C ABI; gtx_api.cpp catches
 // them, stores the text in a thread-local buffer and returns a negative code.
 struct Error : std::runtime_error {

@@ -18,7 +18,7 @@ Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cf
   lb_ = letterbox_geometry(cfg.frame_h, cfg.frame_w, cfg.imgsz, cfg.rect != 0, 32);
   GTX_CHECK(lb_.net_h % 32 == 0 && lb_.net_w % 32 == 0, "network input %dx%d is not stride aligned", lb_.net_h, lb_.net_w);
   GTX_HIP(hipSetDevice(ctx->device));
-  for (auto& e : ev_) GTX_HIP(hipEventCreate(&e));
+  for (auto& e : ev_) GTX_HIP(hipEventCreateWithFlags(&e, wait_event_flags(true)));
   for (auto& e : ev_up_) GTX_HIP(hipEventCreate(&e));
 }
 

@@ -529,7 +529,7 @@ Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : imp
   S.res.alloc(sizeof(GmcResult)); S.model.alloc(sizeof(double4) * kHyp); S.count.alloc(sizeof(int) * kHyp);
   GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(GmcResult) * Impl::kRing));
   GTX_HIP(hipHostMalloc((void**)&S.h_pairs, sizeof(float4) * 1024 * Impl::kRing));
-  for (auto& e : S.done) GTX_HIP(hipEventCreate(&e));
+  for (auto& e : S.done) GTX_HIP(hipEventCreateWithFlags(&e, wait_event_flags(false)));
   GTX_HIP(hipDeviceSynchronize());
 }
 
@@ -546,6 +546,8 @@ void Gmc::reset() {
   GTX_CHECK(impl_->pending() == 0, "gmc: reset while a frame is in flight");
   impl_->have_prev = false;
 }
+
+void Gmc::restart() { impl_->have_prev = false; }   // submit-side state only
 
 void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
   Impl& S = *impl_;
@@ -601,6 +603,18 @@ void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
   GTX_HIP(hipMemcpyAsync(S.frame.p, frame_bgr, bytes, hipMemcpyHostToDevice, S.s));
   hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, S.s, S.frame.as<uint8_t>(), w, S.gray.as<uint8_t>(), S.h, S.w);
   submit_gray_dev(S.gray.p, S.h, S.w);
+}
+
+void Gmc::submit_frame_dev(const void* frame_bgr_dptr, int h, int w, bool restart) {
+  Impl& S = *impl_;
+  GTX_CHECK(frame_bgr_dptr && h / 2 == S.h && w / 2 == S.w, "gmc: frame is %dx%d, created for %dx%d", w, h, 2 * S.w, 2 * S.h);
+  GTX_HIP(hipSetDevice(S.device));
+  // one gray buffer is enough: conversion, the copy into the pyramid and the next conversion are ordered by the stream
+  if (S.gray.bytes < (size_t)S.w * S.h) S.gray.alloc((size_t)S.w * S.h);
+  uint8_t* gray = S.gray.as<uint8_t>();
+  hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, S.s, static_cast<const uint8_t*>(frame_bgr_dptr), w, gray, S.h, S.w);
+  if (restart) S.have_prev = false;
+  submit_gray_dev(gray, S.h, S.w);
 }
 
 void Gmc::collect(double A[6], int* valid, int stats[3]) {

@@ -283,6 +283,12 @@ int gtx_gmc_apply(gtx_gmc* g, const uint8_t* frame_bgr, int h, int w, double A[6
 int gtx_gmc_submit_gray_dev(gtx_gmc* g, const void* gray_dptr, int gh, int gw) {
   return guarded([&] { need(g, "gmc"); need(gray_dptr, "gray"); g->impl->submit_gray_dev(gray_dptr, gh, gw); });
 }
+int gtx_gmc_restart(gtx_gmc* g) {
+  return guarded([&] { need(g, "gmc"); g->impl->restart(); });
+}
+int gtx_gmc_submit_frame_dev(gtx_gmc* g, const void* frame_bgr_dptr, int h, int w, int restart) {
+  return guarded([&] { need(g, "gmc"); need(frame_bgr_dptr, "frame"); g->impl->submit_frame_dev(frame_bgr_dptr, h, w, restart != 0); });
+}
 int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]) {
   return guarded([&] { need(g, "gmc"); need(A, "A"); g->impl->collect(A, valid, stats); });
 }

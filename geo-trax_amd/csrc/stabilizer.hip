@@ -1027,7 +1027,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_res.alloc(sizeof(StabResult));
   GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(StabResult)));
   GTX_HIP(hipHostMalloc((void**)&S.h_pts, sizeof(float4) * slots));
-  GTX_HIP(hipEventCreate(&S.done_ev));
+  GTX_HIP(hipEventCreateWithFlags(&S.done_ev, wait_event_flags(false)));
   S.d_hok.alloc(sizeof(int) * S.n_hyp);
   {
     const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;

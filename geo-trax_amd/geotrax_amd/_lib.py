@@ -91,6 +91,8 @@ _SIGNATURES = {
     "gtx_gmc_reset": (C.c_int, [_P]),
     "gtx_gmc_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P]),
     "gtx_gmc_submit_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gtx_gmc_restart": (C.c_int, [_P]),
+    "gtx_gmc_submit_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "gtx_gmc_collect": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "gtx_gmc_points": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P]),
     "gtx_register_images": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P, _P]),

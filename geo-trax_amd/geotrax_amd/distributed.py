@@ -27,17 +27,27 @@ def shard_range(n_frames: int, rank: int, world: int, first: int = 0) -> tuple[i
     return start, start + per + (1 if rank < rem else 0)
 
 
-def pack_frame_record(max_det: int, xyxy, conf, cls, H) -> np.ndarray:
-    """Fixed-stride float64 record: n, max_det x (x1,y1,x2,y2,conf,cls), valid, h11..h33."""
-    rec = np.zeros(1 + max_det * 6 + 10, dtype=np.float64)
+def pack_frame_record(max_det: int, xyxy, conf, cls, H, gmc=None, with_gmc: bool = False) -> np.ndarray:
+    """Fixed-stride float64 record: n, max_det x (x1,y1,x2,y2,conf,cls), [gmc valid, 2x3 camera-motion warp,]
+    valid, h11..h33. The GMC block is present when with_gmc (BoT-SORT runs: the shard rank computes the warp, rank 0's
+    tracker applies it)."""
+    rec = np.zeros(1 + max_det * 6 + (7 if with_gmc else 0) + 10, dtype=np.float64)
     n = min(len(conf), max_det)
     rec[0] = n
     body = rec[1:1 + max_det * 6].reshape(max_det, 6)
     body[:n, :4], body[:n, 4], body[:n, 5] = xyxy[:n], conf[:n], cls[:n]
+    if with_gmc and gmc is not None:
+        rec[-17] = 1.0
+        rec[-16:-10] = np.asarray(gmc, dtype=np.float64).reshape(6)
     if H is not None:
         rec[-10] = 1.0
         rec[-9:] = np.asarray(H, dtype=np.float64).reshape(9)
     return rec
+
+
+def unpack_frame_gmc(rec: np.ndarray):
+    """The 2x3 warp of a record packed with_gmc, or None when the rank had none for the frame."""
+    return rec[-16:-10].reshape(2, 3).copy() if rec[-17] > 0 else None
 
 
 def unpack_frame_record(rec: np.ndarray, max_det: int):

@@ -46,6 +46,7 @@ class FrameResult:
     H: np.ndarray | None             # 3x3 f64 current -> reference, None for the reference frame / when no model was found
     n_det: int = 0                   # raw detections of the frame
     det_ms: float = 0.0              # detector GPU time of the frame's batch divided by its size
+    gmc: np.ndarray | None = None    # 2x3 camera-motion warp the GMC found for the frame (engines built with gmc=True)
 
 
 def xyxy_to_xywh(b: np.ndarray) -> np.ndarray | None:
@@ -167,7 +168,9 @@ class ExtractEngine:
 
     def run(self, batches):
         """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM) or of lists of <= B host frames.
-        Yields one FrameResult per frame, in feeding order.
+        Yields one FrameResult per frame, in feeding order. An item may also be a pair (batch, prev): the batch does not
+        continue the previous one (a shard rank of the frame-sharded run) and the GMC is primed with `prev`, the
+        device pointer of the frame that precedes the batch in the clip (None: the batch opens the clip).
 
         With a tracker or stabilizers the loop runs as three host stages on their own threads, joined by bounded
         queues (the C-ABI calls release the GIL): detector submit/collect -> GMC + tracker (clip order) ->
@@ -188,32 +191,45 @@ class ExtractEngine:
             b = next(it, None)
             if b is None:
                 return
+            prev = None
+            if isinstance(b, tuple):                            # (batch, device pointer of the frame before it | None | False)
+                b, prev = b
+                prev = False if prev is None else prev          # None: the batch opens the clip -> restart without a frame
             det = self.dets[k % len(self.dets)]
             k += 1
-            inflight.append((det, self._submit(det, b)))
+            inflight.append((det, self._submit(det, b), prev))
 
         host_gray = bool(self.stabs) and not self.use_dev_gray
         try:
             for _ in range(len(self.dets)):
                 submit_next()
             while inflight:
-                det, nb = inflight.popleft()
+                det, nb, prev = inflight.popleft()
                 dets = det.collect()
                 grays = [det.gray_dptr(b) for b in range(nb)]
                 hosts = self._host_frames.pop(id(det), None)
                 det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
                 if not host_gray:
                     submit_next()                               # keep this detector busy while the host works on the batch
+                n_skip = 0
                 if self.gmc is not None:                        # the batch queues on the GMC stream now, results in order
+                    restart = prev is not None                  # a shard rank's batch: it does not continue the previous one
+                    if restart and prev is not False:           # the frame that precedes the batch in the clip, from HBM
+                        self.gmc.submit_frame_dev(int(prev), self.frame_hw[0], self.frame_hw[1], restart=True)
+                        self._gmc_sub += 1
+                        n_skip, restart = 1, False
                     for d, g in zip(dets, grays):               # (frames without detections never reach the tracker)
                         if len(d):
+                            if restart:                         # no frame before it: the batch's first frame opens the sequence
+                                self.gmc.reset_sequence()
+                                restart = False
                             self.gmc.submit_gray_dev(*g)
                             self._gmc_sub += 1
-                yield det, dets, grays, hosts, det_ms
+                yield det, dets, grays, hosts, det_ms, n_skip
                 if host_gray:
                     submit_next()
         finally:                                                # consumer stopped early or a stage failed: leave no pass in flight
-            for det, _ in inflight:
+            for det, *_ in inflight:
                 try:
                     det.collect()
                 except Exception:
@@ -221,19 +237,19 @@ class ExtractEngine:
             self._host_frames.clear()
 
     # ---- stage 2: camera-motion compensation + tracker, strictly in clip order
-    def _track_batch(self, det, dets, grays, hosts, det_ms):
+    def _track_batch(self, det, dets, grays, hosts, det_ms, n_skip=0):
+        for _ in range(n_skip):                                 # warp of the frame that only primed the GMC (identity)
+            self._gmc_collect()
         out = []
         for b, (d, g) in enumerate(zip(dets, grays)):
             ids = None
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
+            warp = self._gmc_collect() if (len(d) and self.gmc is not None) else None
             if len(d) and self.tracker is not None:
-                warp = self._gmc_collect() if self.gmc is not None else None
                 t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
-            elif len(d) and self.gmc is not None:
-                self._gmc_collect()
-            r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms)
+            r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms, warp)
             self._index += 1
             out.append((r, det, g, hosts[b] if hosts is not None else None))
         return out

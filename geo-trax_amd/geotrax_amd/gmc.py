@@ -56,6 +56,15 @@ class GMC:
     def submit_gray_dev(self, gray_dptr: int, gh: int, gw: int) -> None:
         check(self.ctx.lib.gtx_gmc_submit_gray_dev(self.handle, C.c_void_p(gray_dptr), gh, gw))
 
+    def submit_frame_dev(self, frame_dptr: int, h: int, w: int, restart: bool = False) -> None:
+        """A BGR frame in HBM; restart=True opens a new sequence with it (identity warp, next frame is compared with it)."""
+        check(self.ctx.lib.gtx_gmc_submit_frame_dev(self.handle, C.c_void_p(frame_dptr), h, w, int(restart)))
+
+    def reset_sequence(self) -> None:
+        """The next submitted frame opens a new sequence (identity warp), with frames still in flight: only the
+        submitting side's state changes. reset_params() is the blocking variant used between clips."""
+        check(self.ctx.lib.gtx_gmc_restart(self.handle))
+
     def collect(self) -> np.ndarray:
         A, valid = np.zeros(6, np.float64), C.c_int()
         check(self.ctx.lib.gtx_gmc_collect(self.handle, ptr(A), C.byref(valid), ptr(self.stats)))

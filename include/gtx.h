@@ -297,9 +297,15 @@ void gtx_gmc_destroy(gtx_gmc* g);
 int gtx_gmc_reset(gtx_gmc* g);
 int gtx_gmc_apply(gtx_gmc* g, const uint8_t* frame_bgr, int h, int w, double A[6], int* valid, int stats[3]);
 /* Asynchronous pair on the half-resolution gray image the detector left in HBM (gtx_detector_gray).
- * Up to 16 frames may be submitted ahead (the image is copied at submit); _collect returns their warps
+ * Up to 64 frames may be submitted ahead (the image is copied at submit); _collect returns their warps
  * in submission order. */
 int gtx_gmc_submit_gray_dev(gtx_gmc* g, const void* gray_dptr, int gray_h, int gray_w);
+/* The next submitted frame opens a new sequence (identity warp); unlike _reset, frames may still be in flight. */
+int gtx_gmc_restart(gtx_gmc* g);
+/* The same for a full BGR u8 frame [h][w][3] in HBM (gray + 2x2 mean first). restart != 0: the frame opens a new
+ * sequence -- its own warp is the identity and the next submitted frame is compensated against it. A rank of the
+ * frame-sharded run hands the GMC the frame that precedes its batch in the clip this way. */
+int gtx_gmc_submit_frame_dev(gtx_gmc* g, const void* frame_bgr_dptr, int h, int w, int restart);
 int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]);
 /* Parity hook: which 0 = corners of the last frame, 1 = corners of the frame before, 2 = where LK put
  * those in the last frame (+ status). xy in half-resolution pixels. */

@@ -444,3 +444,62 @@ def test_engine_threaded_equals_single_thread_and_survives_an_abandoned_run(gtx_
             list(eng.run(batches))
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_frame_sharded_botsort_gmc_equals_the_unsharded_run(gtx_ctx):
+    """SURVEY.md 8e with BoT-SORT: two 'ranks' take the clip's batches alternately; each primes its GMC with the frame
+    before the batch and ships the warps in its records; the tracker replayed over the records in clip order gives the
+    same tracks as the single engine that sees every frame in order."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    B, n_frames, max_det = 2, 12, 300
+    scene = make_scene(seed=9, h=H, w=W)
+    frames = [scene.render(5 * k, 150) for k in range(n_frames)]
+    kw = dict(imgsz=IMGSZ, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=3, nc=4)
+    det = Detector(w, (H, W), ctx=gtx_ctx, **kw)
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 50)
+    det.close()
+    fbytes = frames[0].nbytes
+    pool = gtx_ctx.dev_alloc(fbytes * n_frames)
+    for i, f in enumerate(frames):
+        gtx_ctx.dev_upload(pool + i * fbytes, f)
+    try:
+        whole = ExtractEngine(w, (H, W), kw, Tracker("botsort"), None, batch=B, det_streams=2, gmc=True)
+        try:
+            want = list(whole.run(pool + g * B * fbytes for g in range(n_frames // B)))
+        finally:
+            whole.close()
+        assert any(r.gmc is not None and not np.array_equal(r.gmc, np.eye(2, 3)) for r in want)        # the camera does move
+        records = {}
+        for rank in range(2):
+            eng = ExtractEngine(w, (H, W), kw, None, None, batch=B, det_streams=2, gmc=True)
+            try:
+                mine = [g for g in range(n_frames // B) if g % 2 == rank]
+                items = [(pool + g * B * fbytes, None if g == 0 else pool + (g * B - 1) * fbytes) for g in mine]
+                got = list(eng.run(items))
+                for j, r in enumerate(got):
+                    frame = mine[j // B] * B + j % B
+                    records[frame] = pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None, r.gmc, with_gmc=True)
+            finally:
+                eng.close()
+        trk = Tracker("botsort")
+        for t in range(n_frames):
+            xyxy, conf, cls, _ = unpack_frame_record(records[t], max_det)
+            warp = unpack_frame_gmc(records[t])
+            np.testing.assert_array_equal(warp, want[t].gmc)                       # same frame pair -> same warp, bit for bit
+            bx, ids = trk.update(xyxy, conf, cls, gmc=warp)[:2]
+            if want[t].ids is None:
+                assert len(ids) == 0
+            else:
+                np.testing.assert_array_equal(ids, want[t].ids)
+                np.testing.assert_array_equal(bx, want[t].xyxy)
+    finally:
+        gtx_ctx.dev_free(pool)
