@@ -33,7 +33,9 @@ namespace {
 #ifdef GTX_TRK_PROF
 struct ProfAcc {
   double t[16] = {0}; const char* n[16] = {nullptr}; int calls = 0;
-  ~ProfAcc() { if (calls) for (int i = 0; i < 16; ++i) if (n[i]) fprintf(stderr, "trk %-10s %8.1f us/call\n", n[i], 1e6 * t[i] / calls); }
+  double cnt[4] = {0};
+  ~ProfAcc() { if (calls) { for (int i = 0; i < 16; ++i) if (n[i]) fprintf(stderr, "trk %-10s %8.1f us/call\n", n[i], 1e6 * t[i] / calls);
+    fprintf(stderr, "trk sizes: pool %.1f dets_hi %.1f pairs %.1f lost %.1f\n", cnt[0] / calls, cnt[1] / calls, cnt[2] / calls, cnt[3] / calls); } }
 };
 static ProfAcc g_prof;
 #define PROF_T0 auto prof_t = std::chrono::steady_clock::now(); int prof_i = 0; g_prof.calls++;
@@ -289,7 +291,10 @@ inline void xyxy_of(const Track& t, bool xywh_state, float out[4]) {
 struct ByteTracker::Impl {
   gtx_tracker_config cfg;
   Kalman kf;
-  std::vector<Track> tracked, lost, removed;
+  std::vector<Track> tracked, lost;
+  // ultralytics' removed_stracks is only ever read for its ids (sub_stracks): keep the ids, in order, plus a set
+  std::vector<int> removed_order;
+  std::unordered_set<int> removed_set;
   int frame_id = 0;
   int next_id = 0;
   int max_time_lost = 30;
@@ -458,7 +463,8 @@ ByteTracker::~ByteTracker() = default;
 void ByteTracker::reset() {
   impl_->tracked.clear();
   impl_->lost.clear();
-  impl_->removed.clear();
+  impl_->removed_order.clear();
+  impl_->removed_set.clear();
   impl_->frame_id = 0;
   impl_->next_id = 0;
 }
@@ -541,6 +547,9 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (Track& d : det_hi) dh.push_back(&d);
   {
     const SparseCost c1 = S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh);
+#ifdef GTX_TRK_PROF
+    g_prof.cnt[0] += pool.size(); g_prof.cnt[1] += dh.size(); g_prof.cnt[2] += c1.adj.size(); g_prof.cnt[3] += S.lost.size();
+#endif
     PROF_MARK(cost1)
     linear_assignment_sparse(c1, x, y);
   }
@@ -613,11 +622,8 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (Track* t : refind)
     if (!ids.count(t->id)) { ids.insert(t->id); new_tracked.push_back(*t); }
   // lost = sub(lost, tracked) + lost_now, then minus removed
-  std::vector<Track> removed_all = S.removed;
-  for (Track* t : removed_now) removed_all.push_back(*t);
-  std::unordered_set<int> removed_ids;
   // ultralytics subtracts self.removed_stracks *before* extending it with this frame's removals
-  for (const Track& t : S.removed) removed_ids.insert(t.id);
+  const std::unordered_set<int>& removed_ids = S.removed_set;
   for (Track& t : S.lost)
     if (!ids.count(t.id) && !has_ptr(lost_now, &t)) new_lost.push_back(t);
   for (Track* t : lost_now) new_lost.push_back(*t);
@@ -655,8 +661,13 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   PROF_MARK(dups)
   S.tracked.swap(new_tracked);
   S.lost.swap(new_lost);
-  S.removed.swap(removed_all);
-  if (S.removed.size() > 1000) S.removed.erase(S.removed.begin(), S.removed.end() - 999);
+  for (Track* t : removed_now)
+    if (S.removed_set.insert(t->id).second) S.removed_order.push_back(t->id);
+  if (S.removed_order.size() > 1000) {                      // upstream keeps the 999 most recent
+    const size_t drop = S.removed_order.size() - 999;
+    for (size_t i = 0; i < drop; ++i) S.removed_set.erase(S.removed_order[i]);
+    S.removed_order.erase(S.removed_order.begin(), S.removed_order.begin() + drop);
+  }
 
   int k = 0;
   for (const Track& t : S.tracked) {

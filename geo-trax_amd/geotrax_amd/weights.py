@@ -112,7 +112,8 @@ def yolov8_layer_specs(scale: str = "s", nc: int = 4) -> list[tuple[str, tuple[i
 
 
 def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: float = -4.0,
-                     gain: float = 1.7, box_decay: float = 0.3) -> dict[str, np.ndarray]:
+                     gain: float = 1.7, box_decay: float = 0.3, level_bias: tuple = (0.0, 0.0, 0.0),
+                     box_weight_scale: float = 0.3) -> dict[str, np.ndarray]:
     """Seeded random fused weights of the YOLOv8 architecture (no checkpoint is reachable here).
 
     Conv weights ~ N(0, gain^2 / fan_in) so activations keep O(1) scale through the SiLU stack;
@@ -120,8 +121,14 @@ def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: flo
     anchors clear the confidence threshold, which is the load the decode/NMS stage sees on real
     footage. The box branch's final bias decays over the 16 DFL bins
     (-box_decay * bin) and its weights are damped, so decoded boxes span about six strides per
-    side -- vehicle-sized, localised boxes instead of the frame-filling ones uniform DFL logits
-    give -- which keeps NMS, the tracker and the stabilizer mask in a realistic regime."""
+    side -- localised boxes instead of the frame-filling ones uniform DFL logits give. In practice the random
+    stack's activations grow with depth (class logits of O(200) at the coarse heads, DFL logits that swamp the
+    decaying bias), so with the defaults the strongest anchors sit on the stride-32 head and the boxes come out
+    400-700 px wide in a 4K frame, each overlapping ~30 others. The two knobs below put the post-processing in
+    the regime of drone footage: ``level_bias`` is added to the class logits of the stride-8/16/32 heads
+    ((0, -1e4, -1e4): only stride-8 anchors can fire) and ``box_weight_scale`` scales the last box conv's weights
+    (0.002: the decaying bias decides, every side is ~2.9 bins -> boxes of ~46 network pixels, ~90 px in 4K, few
+    of which overlap)."""
     rng = np.random.default_rng(seed)
     t: dict[str, np.ndarray] = {}
     for name, shape, has_act in yolov8_layer_specs(scale, nc):
@@ -130,9 +137,9 @@ def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: flo
         t[name + ".weight"] = (rng.standard_normal(shape) * (g / np.sqrt(fan_in))).astype(np.float32)
         b = rng.standard_normal(shape[0]) * 0.05
         if name.endswith("cv3.0.2") or name.endswith("cv3.1.2") or name.endswith("cv3.2.2"):
-            b = b + cls_bias
+            b = b + cls_bias + float(level_bias[int(name.split(".")[3])])
         if ".cv2." in name and name.endswith(".2"):
-            t[name + ".weight"] *= np.float32(0.3)
+            t[name + ".weight"] *= np.float32(box_weight_scale)
             b = b - box_decay * np.tile(np.arange(16), 4)
         t[name + ".bias"] = b.astype(np.float32)
     return t
