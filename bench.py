@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--stab-streams", type=int, default=4, help="stabilizer instances (own HIP stream each) working on consecutive frames")
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM per rank (played ping-pong)")
     ap.add_argument("--detections", type=int, default=132, help="boxes per frame the seeded weights are calibrated to (golden clip: 132)")
-    ap.add_argument("--trace-every", type=int, default=4, help="HIP-event timing of every launch on every n-th detector pass inside the timed region (roofline); 0 = off")
+    ap.add_argument("--trace-every", type=int, default=8, help="HIP-event timing of every launch on every n-th detector pass inside the timed region (roofline); 0 = off")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps between two gathers of per-frame records to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU to test the sharded path)")
@@ -125,6 +125,16 @@ def cpu_baseline(weights, ref_frame, frame, args, pattern):
     are prepared outside the timed region, as in steady state."""
     import torch
     from oracle.bytetrack_ref import ByteTrackRef
+
+    # host cores this job may use: the cgroup quota when there is one (the GPU boxes give 16 of 256), else the affinity mask
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
     from oracle.stabilo_ref import StabilizerRef
     from oracle.yolov8_ref import YoloV8Ref, detect
 
