@@ -503,3 +503,34 @@ def test_frame_sharded_botsort_gmc_equals_the_unsharded_run(gtx_ctx):
                 np.testing.assert_array_equal(bx, want[t].xyxy)
     finally:
         gtx_ctx.dev_free(pool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+def test_engine_frames_without_detections(gtx_ctx, tracker):
+    """extract.py:156-165: a frame without detections never reaches the tracker (ids None -> written as -1 and dropped),
+    has no boxes to warp, but is still registered against the reference frame (no foreground mask). Here every
+    frame is empty (confidence threshold above every score) except that the tracker must stay untouched."""
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import synthetic_yolov8
+
+    scene = make_scene(seed=4, h=H, w=W)
+    frames = [scene.render(8 * k, 150) for k in range(5)]
+    kw = dict(imgsz=IMGSZ, conf=0.999999, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=1, nc=4, cls_bias=-30.0)
+    trk = Tracker(tracker)
+    calls = []
+    orig = trk.update
+    trk.update = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    eng = ExtractEngine(w, (H, W), kw, trk, dict(max_features=500), batch=2, det_streams=2, stab_streams=2, gmc=tracker == "botsort")
+    try:
+        got = list(eng.run([frames[0:2], frames[2:4], frames[4:5]]))
+    finally:
+        eng.close()
+    assert [r.index for r in got] == list(range(5)) and not calls
+    for i, r in enumerate(got):
+        assert r.n_det == 0 and r.ids is None and r.xywh is None and r.xywh_stab is None and len(r.xyxy) == 0 and r.gmc is None
+        assert (r.H is None) == (i == 0)                     # the reference frame has no transform row; the others register
+    assert all(np.isfinite(r.H).all() and abs(np.linalg.det(r.H) - 1.0) < 0.05 for r in got[1:])
