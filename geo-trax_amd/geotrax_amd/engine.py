@@ -300,7 +300,12 @@ class ExtractEngine:
 
         def drain(q):
             while True:
-                item = q.get()
+                try:
+                    item = q.get(timeout=0.05)
+                except queue.Empty:
+                    if stop.is_set():                           # the consumer is gone and so may be the producer
+                        return
+                    continue
                 if item is END:
                     return
                 if isinstance(item, BaseException):
