@@ -114,3 +114,25 @@ def test_frame_record_round_trip():
     np.testing.assert_array_equal(d, H)
     a, b, c, d = unpack_frame_record(pack_frame_record(8, xyxy[:0], conf[:0], cls[:0], None), 8)
     assert len(a) == 0 and d is None
+
+
+def test_frame_record_with_gmc_block_round_trips():
+    """Records of the frame-sharded BoT-SORT run carry the rank's camera-motion warp next to the detections and H."""
+    from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
+
+    rng = np.random.default_rng(0)
+    xyxy = rng.uniform(0, 3000, (5, 4)).astype(np.float32)
+    conf, cls = rng.uniform(0.3, 1, 5).astype(np.float32), rng.integers(0, 4, 5).astype(np.int32)
+    Hm, warp = rng.normal(size=(3, 3)), rng.normal(size=(2, 3))
+    plain = pack_frame_record(8, xyxy, conf, cls, Hm)
+    with_gmc = pack_frame_record(8, xyxy, conf, cls, Hm, warp, with_gmc=True)
+    assert len(with_gmc) == len(plain) + 7
+    for rec in (plain, with_gmc):
+        b, c, k, H2 = unpack_frame_record(rec, 8)
+        np.testing.assert_array_equal(b, xyxy)
+        np.testing.assert_array_equal(c, conf)
+        np.testing.assert_array_equal(k, cls)
+        np.testing.assert_array_equal(H2, Hm)
+    np.testing.assert_array_equal(unpack_frame_gmc(with_gmc), warp)
+    none = pack_frame_record(8, xyxy[:0], conf[:0], cls[:0], None, None, with_gmc=True)
+    assert unpack_frame_gmc(none) is None and unpack_frame_record(none, 8)[3] is None and len(unpack_frame_record(none, 8)[1]) == 0
