@@ -482,10 +482,17 @@ bool similarity_from(const std::vector<float4>& pr, const std::vector<char>& inl
 
 struct Gmc::Impl {
   int device;
-  hipStream_t s;
+  // Two streams: frame t works on st[t & 1]. Pyramid + corner detection of a frame need nothing from other
+  // frames, so consecutive frames overlap; only the flow step waits (events) for the previous frame's corners,
+  // and a frame's buffers are reused two frames later, after the flow step that read them as "previous".
+  hipStream_t st[2] = {nullptr, nullptr};
+  bool own_st1 = false;
+  hipEvent_t front_ev[2] = {nullptr, nullptr};   // pyramid + corners of the last frame of that parity are ready
+  hipEvent_t back_ev[2] = {nullptr, nullptr};    // flow step of the last frame of that parity is done
   int w, h;                    // half-resolution gray size
   unsigned seed;
-  DevBuf frame, gray, pyr[2], lam, cand, counters, hist16, pts[2], npts[2], next, status, pairs, res, model, count;
+  DevBuf frame, gray[2], pyr[2], lam[2], cand[2], counters[2], hist16[2], pts[2], npts[2], next[2], status[2], pairs[2], res[2], model[2],
+      count[2];
   Pyr P[2]{};
   int cur = 0;                 // index of the buffers the next frame is written to
   bool have_prev = false;
@@ -506,8 +513,14 @@ struct Gmc::Impl {
 Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : impl_(new Impl) {
   Impl& S = *impl_;
   GTX_CHECK(gray_h >= 64 && gray_w >= 64, "gmc: gray image %dx%d too small", gray_w, gray_h);
-  S.device = device; S.s = stream; S.w = gray_w; S.h = gray_h; S.seed = (unsigned)seed;
+  S.device = device; S.st[0] = stream; S.w = gray_w; S.h = gray_h; S.seed = (unsigned)seed;
   GTX_HIP(hipSetDevice(device));
+  GTX_HIP(hipStreamCreateWithFlags(&S.st[1], hipStreamNonBlocking));   // default priority: a high-priority pair measured 830 vs 1060 frames/s
+  S.own_st1 = true;
+  for (int k = 0; k < 2; ++k) {
+    GTX_HIP(hipEventCreateWithFlags(&S.front_ev[k], hipEventDisableTiming));
+    GTX_HIP(hipEventCreateWithFlags(&S.back_ev[k], hipEventDisableTiming));
+  }
   size_t total = 0;
   int w = gray_w, h = gray_h;
   for (int l = 0; l <= kMaxLevel; ++l) { total += (size_t)w * h; w = (w + 1) / 2; h = (h + 1) / 2; }
@@ -520,13 +533,15 @@ Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : imp
     S.npts[k].alloc(sizeof(int));
     GTX_HIP(hipMemset(S.npts[k].p, 0, sizeof(int)));
   }
-  S.lam.alloc(sizeof(double) * gray_w * gray_h);
   S.cand_cap = gray_w * gray_h / 4;
-  S.cand.alloc(sizeof(Cand) * S.cand_cap);
-  S.counters.alloc(16);
-  S.hist16.alloc(sizeof(int) * 256);
-  S.next.alloc(sizeof(float2) * 1024); S.status.alloc(sizeof(int) * 1024); S.pairs.alloc(sizeof(float4) * 1024);
-  S.res.alloc(sizeof(GmcResult)); S.model.alloc(sizeof(double4) * kHyp); S.count.alloc(sizeof(int) * kHyp);
+  for (int k = 0; k < 2; ++k) {
+    S.lam[k].alloc(sizeof(double) * gray_w * gray_h);
+    S.cand[k].alloc(sizeof(Cand) * S.cand_cap);
+    S.counters[k].alloc(16);
+    S.hist16[k].alloc(sizeof(int) * 256);
+    S.next[k].alloc(sizeof(float2) * 1024); S.status[k].alloc(sizeof(int) * 1024); S.pairs[k].alloc(sizeof(float4) * 1024);
+    S.res[k].alloc(sizeof(GmcResult)); S.model[k].alloc(sizeof(double4) * kHyp); S.count[k].alloc(sizeof(int) * kHyp);
+  }
   GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(GmcResult) * Impl::kRing));
   GTX_HIP(hipHostMalloc((void**)&S.h_pairs, sizeof(float4) * 1024 * Impl::kRing));
   for (auto& e : S.done) GTX_HIP(hipEventCreateWithFlags(&e, wait_event_flags(false)));
@@ -539,6 +554,11 @@ Gmc::~Gmc() {
     if (impl_->h_pairs) (void)hipHostFree(impl_->h_pairs);
     for (auto& e : impl_->done)
       if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+      if (impl_->front_ev[k]) (void)hipEventDestroy(impl_->front_ev[k]);
+      if (impl_->back_ev[k]) (void)hipEventDestroy(impl_->back_ev[k]);
+    }
+    if (impl_->own_st1 && impl_->st[1]) { (void)hipStreamSynchronize(impl_->st[1]); (void)hipStreamDestroy(impl_->st[1]); }
   }
 }
 
@@ -555,36 +575,41 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
   GTX_CHECK(S.pending() < Impl::kRing, "gmc: %d frames already in flight, collect first", S.pending());
   const int slot = (int)(S.submitted.load(std::memory_order_relaxed) % Impl::kRing);
   GTX_HIP(hipSetDevice(S.device));
-  hipStream_t s = S.s;
   const int c = S.cur, p = c ^ 1;
+  hipStream_t s = S.st[c];
   const Pyr& Pc = S.P[c];
+  // this parity's pyramid and corners were last read, as "previous", by the flow step of the frame before this one
+  GTX_HIP(hipStreamWaitEvent(s, S.back_ev[p], 0));
   // pyramid of the current frame (level 0 is a copy: the caller's buffer may be recycled)
   GTX_HIP(hipMemcpyAsync(const_cast<uint8_t*>(Pc.img[0]), gray, (size_t)S.w * S.h, hipMemcpyDeviceToDevice, s));
   for (int l = 1; l <= kMaxLevel; ++l)
     hipLaunchKernelGGL(pyrdown_kernel, dim3(cdiv(Pc.w[l], 256), Pc.h[l]), dim3(256), 0, s, Pc.img[l - 1], Pc.w[l - 1], Pc.h[l - 1],
                        const_cast<uint8_t*>(Pc.img[l]), Pc.w[l], Pc.h[l]);
   // corners of the current frame
-  GTX_HIP(hipMemsetAsync(S.counters.p, 0, 16, s));
-  GTX_HIP(hipMemsetAsync(S.hist16.p, 0, sizeof(int) * 256, s));
-  unsigned long long* max_bits = S.counters.as<unsigned long long>();
+  GTX_HIP(hipMemsetAsync(S.counters[c].p, 0, 16, s));
+  GTX_HIP(hipMemsetAsync(S.hist16[c].p, 0, sizeof(int) * 256, s));
+  unsigned long long* max_bits = S.counters[c].as<unsigned long long>();
   int* n_cand = reinterpret_cast<int*>(max_bits + 1);
-  hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, kRT_W), cdiv(S.h, kRT_H)), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam.as<double>(), max_bits);
-  hipLaunchKernelGGL(nms_kernel, dim3(cdiv(S.w - 2, 256), S.h - 2), dim3(256), 0, s, S.lam.as<double>(), S.w, S.h, max_bits, S.cand.as<Cand>(),
-                     n_cand, S.cand_cap, S.hist16.as<int>());
-  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand.as<Cand>(), n_cand, S.cand_cap, S.w, S.hist16.as<int>(), max_bits, S.pts[c].as<float2>(),
-                     S.npts[c].as<int>());
+  hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, kRT_W), cdiv(S.h, kRT_H)), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam[c].as<double>(), max_bits);
+  hipLaunchKernelGGL(nms_kernel, dim3(cdiv(S.w - 2, 256), S.h - 2), dim3(256), 0, s, S.lam[c].as<double>(), S.w, S.h, max_bits, S.cand[c].as<Cand>(),
+                     n_cand, S.cand_cap, S.hist16[c].as<int>());
+  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, s, S.cand[c].as<Cand>(), n_cand, S.cand_cap, S.w, S.hist16[c].as<int>(), max_bits,
+                     S.pts[c].as<float2>(), S.npts[c].as<int>());
+  GTX_HIP(hipEventRecord(S.front_ev[c], s));
   S.first[slot] = !S.have_prev;
   if (S.have_prev) {
+    GTX_HIP(hipStreamWaitEvent(s, S.front_ev[p], 0));          // the previous frame's pyramid and corners (other stream)
     hipLaunchKernelGGL(lk_kernel, dim3(cdiv(kMaxCorners, 4)), dim3(256), 0, s, S.P[p], Pc, S.pts[p].as<float2>(), S.npts[p].as<int>(),
-                       S.next.as<float2>(), S.status.as<int>());
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, S.pts[p].as<float2>(), S.next.as<float2>(), S.status.as<int>(),
-                       S.npts[p].as<int>(), S.pairs.as<float4>(), S.res.as<GmcResult>());
-    hipLaunchKernelGGL(ransac_kernel, dim3(kHyp / 4), dim3(256), 0, s, S.pairs.as<float4>(), S.res.as<GmcResult>(), S.seed, S.model.as<double4>(),
-                       S.count.as<int>());
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(kHyp), 0, s, S.model.as<double4>(), S.count.as<int>(), S.res.as<GmcResult>());
-    GTX_HIP(hipMemcpyAsync(S.h_res + slot, S.res.p, sizeof(GmcResult), hipMemcpyDeviceToHost, s));
-    GTX_HIP(hipMemcpyAsync(S.h_pairs + (size_t)slot * 1024, S.pairs.p, sizeof(float4) * 1024, hipMemcpyDeviceToHost, s));
+                       S.next[c].as<float2>(), S.status[c].as<int>());
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, S.pts[p].as<float2>(), S.next[c].as<float2>(), S.status[c].as<int>(),
+                       S.npts[p].as<int>(), S.pairs[c].as<float4>(), S.res[c].as<GmcResult>());
+    hipLaunchKernelGGL(ransac_kernel, dim3(kHyp / 4), dim3(256), 0, s, S.pairs[c].as<float4>(), S.res[c].as<GmcResult>(), S.seed,
+                       S.model[c].as<double4>(), S.count[c].as<int>());
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(kHyp), 0, s, S.model[c].as<double4>(), S.count[c].as<int>(), S.res[c].as<GmcResult>());
+    GTX_HIP(hipMemcpyAsync(S.h_res + slot, S.res[c].p, sizeof(GmcResult), hipMemcpyDeviceToHost, s));
+    GTX_HIP(hipMemcpyAsync(S.h_pairs + (size_t)slot * 1024, S.pairs[c].p, sizeof(float4) * 1024, hipMemcpyDeviceToHost, s));
   }
+  GTX_HIP(hipEventRecord(S.back_ev[c], s));                    // whatever read the other parity's buffers has been queued
   GTX_HIP(hipGetLastError());
   GTX_HIP(hipEventRecord(S.done[slot], s));
   S.submitted.fetch_add(1, std::memory_order_release);
@@ -599,20 +624,24 @@ void Gmc::submit_frame(const uint8_t* frame_bgr, int h, int w) {
   GTX_HIP(hipSetDevice(S.device));
   const size_t bytes = (size_t)h * w * 3;
   if (S.frame.bytes < bytes) S.frame.alloc(bytes);
-  if (S.gray.bytes < (size_t)S.w * S.h) S.gray.alloc((size_t)S.w * S.h);
-  GTX_HIP(hipMemcpyAsync(S.frame.p, frame_bgr, bytes, hipMemcpyHostToDevice, S.s));
-  hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, S.s, S.frame.as<uint8_t>(), w, S.gray.as<uint8_t>(), S.h, S.w);
-  submit_gray_dev(S.gray.p, S.h, S.w);
+  DevBuf& gray = S.gray[S.cur];
+  hipStream_t s = S.st[S.cur];
+  if (gray.bytes < (size_t)S.w * S.h) gray.alloc((size_t)S.w * S.h);
+  GTX_HIP(hipMemcpyAsync(S.frame.p, frame_bgr, bytes, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, s, S.frame.as<uint8_t>(), w, gray.as<uint8_t>(), S.h, S.w);
+  submit_gray_dev(gray.p, S.h, S.w);
 }
 
 void Gmc::submit_frame_dev(const void* frame_bgr_dptr, int h, int w, bool restart) {
   Impl& S = *impl_;
   GTX_CHECK(frame_bgr_dptr && h / 2 == S.h && w / 2 == S.w, "gmc: frame is %dx%d, created for %dx%d", w, h, 2 * S.w, 2 * S.h);
   GTX_HIP(hipSetDevice(S.device));
-  // one gray buffer is enough: conversion, the copy into the pyramid and the next conversion are ordered by the stream
-  if (S.gray.bytes < (size_t)S.w * S.h) S.gray.alloc((size_t)S.w * S.h);
-  uint8_t* gray = S.gray.as<uint8_t>();
-  hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, S.s, static_cast<const uint8_t*>(frame_bgr_dptr), w, gray, S.h, S.w);
+  // one gray buffer per parity (= per stream): conversion, the copy into the pyramid and the next conversion on
+  // that stream are ordered. Allocated on first use, before anything is queued on it.
+  DevBuf& gbuf = S.gray[S.cur];
+  if (gbuf.bytes < (size_t)S.w * S.h) gbuf.alloc((size_t)S.w * S.h);
+  uint8_t* gray = gbuf.as<uint8_t>();
+  hipLaunchKernelGGL(gray_half_kernel, dim3(cdiv(S.w, 256), S.h), dim3(256), 0, S.st[S.cur], static_cast<const uint8_t*>(frame_bgr_dptr), w, gray, S.h, S.w);
   if (restart) S.have_prev = false;
   submit_gray_dev(gray, S.h, S.w);
 }
@@ -662,7 +691,8 @@ void Gmc::debug_points(int which, int cap, int* n, float* xy, int* status) const
   const Impl& S = *impl_;
   GTX_CHECK(S.pending() == 0, "gmc: debug read while a frame is in flight");
   GTX_HIP(hipSetDevice(S.device));
-  GTX_HIP(hipStreamSynchronize(S.s));
+  GTX_HIP(hipStreamSynchronize(S.st[0]));
+  GTX_HIP(hipStreamSynchronize(S.st[1]));
   // which 0: corners of the last submitted frame; 1: corners of the frame before; 2: their LK positions in the last frame
   const int last = S.cur ^ 1, before = S.cur;
   const DevBuf& np = which == 0 ? S.npts[last] : S.npts[before];
@@ -671,9 +701,9 @@ void Gmc::debug_points(int which, int cap, int* n, float* xy, int* status) const
   *n = cnt;
   const int m = std::min(cnt, cap);
   if (m <= 0) return;
-  const void* src = which == 0 ? S.pts[last].p : which == 1 ? S.pts[before].p : S.next.p;
+  const void* src = which == 0 ? S.pts[last].p : which == 1 ? S.pts[before].p : S.next[last].p;
   if (xy) GTX_HIP(hipMemcpy(xy, src, sizeof(float2) * m, hipMemcpyDeviceToHost));
-  if (status && which == 2) GTX_HIP(hipMemcpy(status, S.status.p, sizeof(int) * m, hipMemcpyDeviceToHost));
+  if (status && which == 2) GTX_HIP(hipMemcpy(status, S.status[last].p, sizeof(int) * m, hipMemcpyDeviceToHost));
 }
 
 }  // namespace gtx
