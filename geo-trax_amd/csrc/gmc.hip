@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void nms_kernel(const double* __restrict__ lam
 // (a 6 %-wide value range: a few hundred candidates) into LDS, where a bitonic sort of (key, pix)
 // finishes the job. A bucket too full for LDS is narrowed by further 8-bit radix passes first.
 constexpr int kSelCap = 4096;
-__global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ cand, const int* __restrict__ n_cand, int cap, int w,
-                                                      const int* __restrict__ hist16, const unsigned long long* __restrict__ max_bits_p,
+__global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ cand, int* __restrict__ n_cand, int cap, int w,
+                                                      int* __restrict__ hist16, unsigned long long* __restrict__ max_bits_p,
                                                       float2* __restrict__ pts, int* __restrict__ n_pts) {
   __shared__ unsigned long long s_key[kSelCap];
   __shared__ int s_pix[kSelCap];
@@ -261,6 +261,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ c
     }
   if (tid < want) pts[tid] = make_float2((float)(s_pix[tid] % w), (float)(s_pix[tid] / w));
   if (tid == 0) *n_pts = want;
+  // last reader of the frame's counters: clear them for the next frame of this parity (two memset launches less per
+  // frame on the tracker's critical path; they start out zero)
+  if (tid < 256) hist16[tid] = 0;
+  if (tid == 0) { *max_bits_p = 0ull; *n_cand = 0; }
 }
 
 // ---- pyramid
@@ -539,6 +543,8 @@ Gmc::Gmc(int device, hipStream_t stream, int gray_h, int gray_w, int seed) : imp
     S.cand[k].alloc(sizeof(Cand) * S.cand_cap);
     S.counters[k].alloc(16);
     S.hist16[k].alloc(sizeof(int) * 256);
+    GTX_HIP(hipMemset(S.counters[k].p, 0, 16));
+    GTX_HIP(hipMemset(S.hist16[k].p, 0, sizeof(int) * 256));
     S.next[k].alloc(sizeof(float2) * 1024); S.status[k].alloc(sizeof(int) * 1024); S.pairs[k].alloc(sizeof(float4) * 1024);
     S.res[k].alloc(sizeof(GmcResult)); S.model[k].alloc(sizeof(double4) * kHyp); S.count[k].alloc(sizeof(int) * kHyp);
   }
@@ -586,8 +592,6 @@ void Gmc::submit_gray_dev(const void* gray, int gh, int gw) {
     hipLaunchKernelGGL(pyrdown_kernel, dim3(cdiv(Pc.w[l], 256), Pc.h[l]), dim3(256), 0, s, Pc.img[l - 1], Pc.w[l - 1], Pc.h[l - 1],
                        const_cast<uint8_t*>(Pc.img[l]), Pc.w[l], Pc.h[l]);
   // corners of the current frame
-  GTX_HIP(hipMemsetAsync(S.counters[c].p, 0, 16, s));
-  GTX_HIP(hipMemsetAsync(S.hist16[c].p, 0, sizeof(int) * 256, s));
   unsigned long long* max_bits = S.counters[c].as<unsigned long long>();
   int* n_cand = reinterpret_cast<int*>(max_bits + 1);
   hipLaunchKernelGGL(response_kernel, dim3(cdiv(S.w, kRT_W), cdiv(S.h, kRT_H)), dim3(256), 0, s, Pc.img[0], S.w, S.h, S.lam[c].as<double>(), max_bits);
