@@ -66,8 +66,8 @@ class ExtractEngine:
         self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
         self.B = max(int(batch), 1)
         # HIP spreads streams over a few hardware queues (4 by default) in creation order, and streams that share
-        # a queue run in order. The creation order below -- first detector, GMC, stabilizers, remaining detectors --
-        # is the measured best on MI355X (BoT-SORT run: 979 vs 820 frames/s for detectors-first); GPU_MAX_HW_QUEUES=8
+        # a queue run in order. The creation orders below are the measured best on MI355X (ByteTrack: first detector,
+        # stabilizers, remaining detectors: 1390 vs 1300-1340 frames/s for detectors-first); GPU_MAX_HW_QUEUES=8
         # (no sharing at all) is slower for the default run (1040 vs 1230): the stabilizers then crowd the detector.
         self.dets = list(detectors or [])
         n_dets = max(int(det_streams), len(self.dets), 1)
@@ -77,7 +77,11 @@ class ExtractEngine:
         self.stabs = []
         self._spare = []                 # contexts created only to steer the stream -> hardware-queue mapping
         # order of stream creation: d = detector, g = GMC, s = stabilizer, x = unused stream (takes a queue slot)
-        order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(["d"] + (["g"] if gmc else []) + ["s"] * n_stab + ["d"] * (n_dets - 1))
+        if gmc:     # the GMC owns two streams; with them, detector 2 in the middle of the stabilizers measures best (1180 vs 1050)
+            default = ["d", "g"] + ["s"] * (n_stab // 2) + ["d"] * (n_dets - 1) + ["s"] * (n_stab - n_stab // 2)
+        else:
+            default = ["d"] + ["s"] * n_stab + ["d"] * (n_dets - 1)
+        order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(default)
         have_d = len(self.dets)          # adopted detectors already own their streams
         made_d = 0
         for tok in order.split(","):
