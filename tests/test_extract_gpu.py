@@ -534,3 +534,4 @@ def test_engine_frames_without_detections(gtx_ctx, tracker):
         assert r.n_det == 0 and r.ids is None and r.xywh is None and r.xywh_stab is None and len(r.xyxy) == 0 and r.gmc is None
         assert (r.H is None) == (i == 0)                     # the reference frame has no transform row; the others register
     assert all(np.isfinite(r.H).all() and abs(np.linalg.det(r.H) - 1.0) < 0.05 for r in got[1:])
+

@@ -167,3 +167,49 @@ def test_matcher_large_self_and_permutation(gtx_ctx):
     i1, i2, d1, d2 = ops.match_2nn(d[perm], d, ctx=gtx_ctx)                     # every query has an exact copy in the train set
     np.testing.assert_array_equal(i1, perm)
     assert d1.max() < 1e-3 and (d2 > 0.05).all() and (i2 != i1).all()
+
+
+def test_shard_mode_mask_moves_the_homography_by_less_than_a_pixel(gtx_ctx):
+    """a shard rank stabilizes before the tracker has run, so its foreground mask is built from the raw
+    detections instead of the tracker's boxes (extract.py:181). At the real size (4K frames, vehicle-sized boxes) the two
+    masks must lead to homographies that agree within the 1 px reprojection bar on a 9 x 16 grid of frame points, and
+    both must stay near the clip's known camera."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    scene = make_scene(seed=0, h=H4, w=W4)
+    frames = [scene.render(6 * k, 150) for k in range(10)]
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=False)
+    w = synthetic_yolov8(seed=0, nc=4, level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002)        # ~85 px boxes, as in bench.py
+    det = Detector(w, (H4, W4), ctx=gtx_ctx, **kw)
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 132)
+    det.close()
+    batches = [frames[i:i + 2] for i in range(0, len(frames), 2)]
+
+    def run(tracker):
+        eng = ExtractEngine(w, (H4, W4), kw, tracker, {}, batch=2, det_streams=2, stab_streams=2)
+        try:
+            return list(eng.run(batches))
+        finally:
+            eng.close()
+
+    exact, shard = run(Tracker("bytetrack")), run(None)
+    assert any(r.ids is not None and len(r.xyxy) != len(s.xyxy) for r, s in zip(exact, shard))        # the masks do differ
+    ys, xs = np.meshgrid(np.linspace(0, H4 - 1, 9), np.linspace(0, W4 - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+
+    def grid_diff(A, B):
+        a, b = A @ P, B @ P
+        return float(np.abs(a[:2] / a[2] - b[:2] / b[2]).max())
+
+    diffs, errs = [], []
+    for k, (r, s) in enumerate(zip(exact[1:], shard[1:]), start=1):
+        truth = np.linalg.inv(scene.camera(6 * k, 150)) @ scene.camera(0, 150)
+        diffs.append(grid_diff(r.H, s.H))
+        errs.append(max(grid_diff(r.H, truth), grid_diff(s.H, truth)))
+    print("exact vs shard mask, max grid difference per frame:", np.round(diffs, 3), "worst error vs the known camera:", np.round(max(errs), 3))
+    assert max(diffs) < 1.0 and max(errs) < 2.0
