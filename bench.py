@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef"],
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
-                         "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU)")
+                         "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
+                         "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres)")
     ap.add_argument("--half", type=int, default=1, help="ultralytics.half: 1 = fp16 MFMA, 0 = fp32 MFMA (reference default)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
@@ -209,10 +210,48 @@ def bench_register(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_georef(args):
+    """--workload georef: one step = gtx_op_georef_points over the rows of a track table (host arrays in and out, as
+    the georeference stage holds them): 2 M rows, i.e. ~100 golden clips' worth (19 817 rows each). The kernel is
+    HBM-bound by construction (16 B in, 48 B out per row); what this line measures includes the PCIe copies."""
+    from geotrax_amd import _lib
+    from geotrax_amd.georeference import apply_homography, geo2local, ortho2geo, transform_points
+
+    ctx = _lib.Context(0)
+    n = 2_000_000
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    Hm = np.array([[1.91, 0.08, 5120.5], [-0.07, 1.88, 3310.25], [1.3e-6, -0.9e-6, 1.0]])
+    ortho = (126.6412, 37.3951, 2.4e-7, -1.9e-7, 1.1e-9, -0.7e-9)
+    steps, warm = min(args.steps, 20), min(args.warmup, 3)
+    for _ in range(max(warm, 1)):
+        out = transform_points(x, y, Hm, ortho, "EPSG:4326", "EPSG:5186", ctx=ctx)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = transform_points(x, y, Hm, ortho, "EPSG:4326", "EPSG:5186", ctx=ctx)
+    elapsed = time.perf_counter() - t0
+    m = 200_000                                                   # CPU baseline: the host chain (reference-like numpy) on a bounded sample
+    t0 = time.perf_counter()
+    ox, oy = apply_homography(x[:m], y[:m], Hm)
+    lat, lon = ortho2geo(ox, oy, ortho)
+    xl, yl = geo2local(lat, lon, "EPSG:4326", "EPSG:5186")
+    cpu_s = time.perf_counter() - t0
+    err = float(max(np.abs(out["x_local"][:m] - xl).max(), np.abs(out["y_local"][:m] - yl).max()))
+    print(json.dumps({"metric": "track rows/sec through the georeference transform chain", "value": n * steps / elapsed, "unit": "rows/s", "n_gpus": 1,
+                      "steps": steps, "warmup": warm, "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"georeference.py:173-177 row chain on {n} rows: homography -> orthophoto geotransform -> Korea 2000 central belt (EPSG:5186), "
+                                             "host arrays in and out (PCIe inclusive)", "max_abs_diff_vs_host_chain_m": err},
+                      "cpu_baseline": {"value": m / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
+                                       "sample": f"{m} rows through the host numpy chain (apply_homography, ortho2geo, geo2local)"}}), flush=True)
+
+
 def main():
     args = parse()
     if args.workload == "register":
         return bench_register(args)
+    if args.workload == "georef":
+        return bench_georef(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
