@@ -209,6 +209,24 @@ void linear_assignment_sparse(const SparseCost& P, std::vector<int>& x, std::vec
   auto push = [&](double d, int j) { heap.emplace_back(d, j); std::push_heap(heap.begin(), heap.end(), std::greater<Item>()); };
   for (int i = 0; i < rows; ++i) {
     if (start[i] == start[i + 1]) continue;           // no feasible pair: stays unmatched
+    {
+      // Fast path: the first column a Dijkstra search from row i would finalise is the row's cheapest reduced
+      // cost (ties: lowest column, as the heap orders pairs); when that column is still free the search ends there
+      // and only u[i] changes. Most rows of a traffic scene end this way; the general search below is unchanged.
+      double best = 0.0 - u[i] - v[cols + i];         // the row's own skip column
+      int bj = cols + i;
+      for (int e = start[i]; e < start[i + 1]; ++e) {
+        const int j = adj[e];
+        const double nd = w[e] - u[i] - v[j];
+        if (nd < best || (nd == best && j < bj)) { best = nd; bj = j; }
+      }
+      if (col_match[bj] < 0) {
+        u[i] += best;
+        col_match[bj] = i;
+        row_match[i] = bj;
+        continue;
+      }
+    }
     heap.clear();
     seen_list.clear();
     auto relax_row = [&](int r, double base, int via_col) {
@@ -361,6 +379,9 @@ struct ByteTracker::Impl {
   // forming the dense matrix: a pair of disjoint boxes costs exactly 1 (see dists) and every limit used is
   // below 1, so only boxes that overlap can qualify. Boxes are swept in x order; the cost of an
   // overlapping pair is the same float32 expression as in dists().
+  mutable std::vector<int> sc_ob;
+  mutable std::vector<float> sc_x1, sc_y1, sc_x2, sc_y2, sc_area, sc_score, sc_cost;
+  mutable std::vector<std::pair<int, float>> sc_rowbuf;
   SparseCost sparse_costs(const std::vector<Track*>& a, const std::vector<Track*>& b, bool fuse, double limit) const {
     SparseCost P;
     const int na = (int)a.size(), nb = (int)b.size();
@@ -386,36 +407,60 @@ struct ByteTracker::Impl {
       }
       return P;
     }
-    std::vector<int> ob(nb);
+    // b sorted by x1, structure of arrays: the candidates of a row are a contiguous band of the sorted list
+    // (x1_a - widest_b < x1_b < x2_a), and the cost of the whole band is computed without branches so that the
+    // compiler vectorises it (same float32 operations in the same order as dists(); a pair that does not
+    // overlap comes out at cost 1 and is dropped by the limit like before).
+    std::vector<int>& ob = sc_ob;
+    ob.resize(nb);
     for (int j = 0; j < nb; ++j) ob[j] = j;
     std::sort(ob.begin(), ob.end(), [&](int p, int q) { return bb[p * 4] < bb[q * 4]; });
-    std::vector<float> bx1(nb);
+    sc_x1.resize(nb); sc_y1.resize(nb); sc_x2.resize(nb); sc_y2.resize(nb); sc_area.resize(nb); sc_score.resize(nb);
     float bw_max = 0.f;                       // widest box of b: x2_b > x1_a implies x1_b > x1_a - bw_max
-    for (int j = 0; j < nb; ++j) { bx1[j] = bb[ob[j] * 4]; bw_max = std::max(bw_max, bb[j * 4 + 2] - bb[j * 4]); }
-    std::vector<std::pair<int, float>> rowbuf;
+    for (int k = 0; k < nb; ++k) {
+      const float* q = &bb[(size_t)ob[k] * 4];
+      sc_x1[k] = q[0]; sc_y1[k] = q[1]; sc_x2[k] = q[2]; sc_y2[k] = q[3];
+      sc_area[k] = (q[2] - q[0]) * (q[3] - q[1]);
+      sc_score[k] = b[ob[k]]->score;
+      bw_max = std::max(bw_max, q[2] - q[0]);
+    }
+    sc_cost.resize(nb);
+    const float* __restrict__ X1 = sc_x1.data(); const float* __restrict__ Y1 = sc_y1.data();
+    const float* __restrict__ X2 = sc_x2.data(); const float* __restrict__ Y2 = sc_y2.data();
+    const float* __restrict__ AR = sc_area.data(); const float* __restrict__ SC = sc_score.data();
+    float* __restrict__ CO = sc_cost.data();
+    std::vector<std::pair<int, float>>& rowbuf = sc_rowbuf;
+    P.adj.reserve((size_t)na * 6); P.w.reserve((size_t)na * 6);
     for (int i = 0; i < na; ++i) {
       const float* p = &ab[(size_t)i * 4];
-      const float a1 = (p[2] - p[0]) * (p[3] - p[1]);
-      rowbuf.clear();
-      // candidates: x1_a - bw_max < x1_b < x2_a (a band of the sorted list), then x2_b > x1_a and y overlap
-      const int hi = (int)(std::lower_bound(bx1.begin(), bx1.end(), p[2]) - bx1.begin());
-      const int lo = (int)(std::lower_bound(bx1.begin(), bx1.begin() + hi, p[0] - bw_max) - bx1.begin());
-      for (int k = lo; k < hi; ++k) {
-        const int j = ob[k];
-        const float* q = &bb[(size_t)j * 4];
-        if (q[2] <= p[0] || q[1] >= p[3] || q[3] <= p[1]) continue;
-        const float iw = std::max(0.f, std::min(p[2], q[2]) - std::max(p[0], q[0]));
-        const float ih = std::max(0.f, std::min(p[3], q[3]) - std::max(p[1], q[1]));
-        const float inter = iw * ih;
-        const float barea = (q[2] - q[0]) * (q[3] - q[1]);
-        const float iou = inter / (barea + a1 - inter + 1e-7f);
-        float cost = 1.f - iou;
-        if (fuse) {
-          const float sim = (1.f - cost) * b[j]->score;
-          cost = 1.f - sim;
+      const float p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+      const float a1 = (p2 - p0) * (p3 - p1);
+      const int hi = (int)(std::lower_bound(sc_x1.begin(), sc_x1.end(), p2) - sc_x1.begin());
+      const int lo = (int)(std::lower_bound(sc_x1.begin(), sc_x1.begin() + hi, p0 - bw_max) - sc_x1.begin());
+      if (fuse) {
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int k = lo; k < hi; ++k) {
+          const float iw = std::max(0.f, std::min(p2, X2[k]) - std::max(p0, X1[k]));
+          const float ih = std::max(0.f, std::min(p3, Y2[k]) - std::max(p1, Y1[k]));
+          const float inter = iw * ih;
+          const float iou = inter / (AR[k] + a1 - inter + 1e-7f);
+          const float cost = 1.f - iou;
+          const float sim = (1.f - cost) * SC[k];
+          CO[k] = 1.f - sim;
         }
-        if ((double)cost < limit) rowbuf.emplace_back(j, cost);
+      } else {
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int k = lo; k < hi; ++k) {
+          const float iw = std::max(0.f, std::min(p2, X2[k]) - std::max(p0, X1[k]));
+          const float ih = std::max(0.f, std::min(p3, Y2[k]) - std::max(p1, Y1[k]));
+          const float inter = iw * ih;
+          const float iou = inter / (AR[k] + a1 - inter + 1e-7f);
+          CO[k] = 1.f - iou;
+        }
       }
+      rowbuf.clear();
+      for (int k = lo; k < hi; ++k)
+        if ((double)CO[k] < limit) rowbuf.emplace_back(ob[k], CO[k]);
       std::sort(rowbuf.begin(), rowbuf.end());
       for (const auto& e : rowbuf) { P.adj.push_back(e.first); P.w.push_back((double)e.second - limit); }
       P.start[i + 1] = (int)P.adj.size();

@@ -36,6 +36,10 @@ class Tracker:
         self._score = np.zeros(max_tracks, np.float32)
         self._cls = np.zeros(max_tracks, np.int32)
         self._idx = np.zeros(max_tracks, np.int32)
+        # addresses of the persistent output buffers, taken once (building ctypes pointers costs ~3 us each per call)
+        self._out_ptrs = tuple(a.ctypes.data for a in (self._xyxy, self._id, self._score, self._cls, self._idx))
+        self._n = C.c_int()
+        self._n_ref = C.byref(self._n)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -57,10 +61,8 @@ class Tracker:
         conf = np.ascontiguousarray(conf, dtype=np.float32)
         cls = np.ascontiguousarray(cls, dtype=np.int32)
         g = None if gmc is None else np.ascontiguousarray(gmc, dtype=np.float64).reshape(6)
-        n = C.c_int()
-        check(self.lib.gtx_tracker_update(self.handle, len(conf), ptr(xyxy), ptr(conf), ptr(cls), ptr(g), self.cap,
-                                          C.byref(n), ptr(self._xyxy), ptr(self._id), ptr(self._score), ptr(self._cls),
-                                          ptr(self._idx)))
-        k = n.value
+        check(self.lib.gtx_tracker_update(self.handle, len(conf), xyxy.ctypes.data, conf.ctypes.data, cls.ctypes.data,
+                                          None if g is None else g.ctypes.data, self.cap, self._n_ref, *self._out_ptrs))
+        k = self._n.value
         return (self._xyxy[:k].copy(), self._id[:k].copy(), self._score[:k].copy(), self._cls[:k].copy(),
                 self._idx[:k].copy())
