@@ -669,15 +669,11 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   // lost = sub(lost, tracked) + lost_now, then minus removed
   // ultralytics subtracts self.removed_stracks *before* extending it with this frame's removals
   const std::unordered_set<int>& removed_ids = S.removed_set;
+  new_lost.reserve(S.lost.size() + lost_now.size());
   for (Track& t : S.lost)
-    if (!ids.count(t.id) && !has_ptr(lost_now, &t)) new_lost.push_back(t);
-  for (Track* t : lost_now) new_lost.push_back(*t);
-  {
-    std::vector<Track> keep;
-    for (Track& t : new_lost)
-      if (!removed_ids.count(t.id)) keep.push_back(t);
-    new_lost.swap(keep);
-  }
+    if (!ids.count(t.id) && !has_ptr(lost_now, &t) && !removed_ids.count(t.id)) new_lost.push_back(t);
+  for (Track* t : lost_now)
+    if (!removed_ids.count(t->id)) new_lost.push_back(*t);
   PROF_MARK(lists)
   // duplicates between tracked and lost (IoU distance < 0.15): keep the older track
   {
