@@ -144,13 +144,13 @@ struct Cand {
 
 // Foreground mask at level-0 resolution: 255 = usable, 0 = inside a (grown) vehicle box. One
 // block per (rectangle, slice of its rows); lanes run along x.
-__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* __restrict__ mask, int w, const int4* __restrict__ rects) {
+__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* __restrict__ mask, int w, const int4* __restrict__ rects, int value) {
   const int4 r = rects[blockIdx.x];
   const int rw = r.z - r.x + 1, rh = r.w - r.y + 1;
   const int rows_per = (rh + gridDim.y - 1) / gridDim.y;
   const int y0 = r.y + blockIdx.y * rows_per, y1 = min(y0 + rows_per, r.w + 1);
   for (int y = y0 + (threadIdx.x >> 6); y < y1; y += 4)
-    for (int x = threadIdx.x & 63; x < rw; x += 64) mask[(size_t)y * w + r.x + x] = 0;
+    for (int x = threadIdx.x & 63; x < rw; x += 64) mask[(size_t)y * w + r.x + x] = (uint8_t)value;
 }
 
 // FAST score + 3x3 non-maximum suppression + foreground test in one pass: a block scores its
@@ -1001,6 +1001,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_pyr.alloc(S.pyr_bytes);
   S.d_rects.alloc(sizeof(int4) * kMaxRects);
   S.d_mask.alloc((size_t)S.gw * S.gh);
+  GTX_HIP(hipMemset(S.d_mask.p, 255, (size_t)S.gw * S.gh));
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_elig.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_counters.alloc(sizeof(int) * (2 * kPyrLevels + 256 * kPyrLevels));
@@ -1096,14 +1097,17 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
                        L.l[i - 1].w, L.l[i - 1].h, pyr + L.l[i].off, L.l[i].w, L.l[i].h);
   }
   const uint8_t* mask = nullptr;
+  int n_rects = 0;
   if (cfg.mask_use && boxes && n > 0) {
     std::vector<int4> rects;
     build_rects(boxes, n, rects);
     if (!rects.empty()) {
-      GTX_HIP(hipMemsetAsync(d_mask.p, 255, (size_t)gw * gh, s));
+      // the mask image stays all-255 between frames: the rectangles are drawn here and erased again right after
+      // the one kernel that reads it (a full 2 MB memset per frame cost several fill launches on this stream)
       GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size(), 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>());
+      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size(), 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>(), 0);
       mask = d_mask.as<uint8_t>();
+      n_rects = (int)rects.size();
     }
   }
   // counters: [cand_n 8][elig_n 8][score histogram 8 x 256]; zero here: compact_kernel clears them at the end of every pass
@@ -1112,6 +1116,8 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
   int* hist = elig_n + kPyrLevels;
   hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, mask, gw, gh, L, cfg.fast_threshold, d_cand.as<Cand>(),
                      cand_n, hist);
+  if (n_rects > 0)      // erase the rectangles again: the mask is all-255 for the next frame
+    hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)n_rects, 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>(), 255);
   hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
   hipLaunchKernelGGL(select_sort_kernel, dim3(L.n), dim3(1024), kSortCap * 12, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
                      d_kp_n.as<int>());
