@@ -14,6 +14,7 @@ python bench.py --half 0 --no-cpu-baseline --steps 60 > $O/bench_fp32.json 2>/de
 python bench.py --workload detect --batch 1 --det-streams 1 --no-cpu-baseline > $O/bench_detect_b1.json 2>/dev/null
 python bench.py --workload detect --no-cpu-baseline > $O/bench_detect_2x2.json 2>/dev/null
 python bench.py --workload register > $O/bench_register.json 2>/dev/null
+python bench.py --workload georef > $O/bench_georef.json 2>/dev/null
 python tools/conv_sweep.py 1920 2 > $O/sweep_b2.txt 2>/dev/null
 python tools/conv_sweep.py 1920 4 > $O/sweep_b4.txt 2>/dev/null
 ls $O
