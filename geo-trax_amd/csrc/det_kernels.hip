@@ -241,6 +241,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restri
                                                         const _Float16* __restrict__ wpk /*[groups][3][64][8]*/,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
                                                         int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
+  constexpr int kStemPitch = 64 + 16;                   // bytes per staged pixel (+16: conflict-free 8-B writes)
+  __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kStemPitch];
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -273,7 +275,27 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restri
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], xf, acc, 0, 0, 0);
       }
-      if (ox < wo) {
+      if (c0 == 32) {
+        // 32 channels = one 64-B line per pixel: the wave transposes its 32 pixels through LDS and stores 16 B per
+        // lane, 1 KB contiguous per instruction (the direct form below writes each line as eight 8-B pieces)
+        char* stg = s_stage + (threadIdx.x >> 6) * (32 * kStemPitch);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 8 * g4 + 4 * hh;
+          half4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (_Float16)silu_f(acc[4 * g4 + i] + bias[cl + i]);
+          *reinterpret_cast<half4*>(stg + r * kStemPitch + cl * 2) = v;
+        }
+        const int ox0 = (int)(t % tiles_per_row) * 32;
+        _Float16* orow = out + (((size_t)n * ho + oy) * wo + ox0) * 32;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int p = it * 16 + (lane >> 2), q = lane & 3;
+          const uint4 val = *reinterpret_cast<const uint4*>(stg + p * kStemPitch + q * 16);
+          if (ox0 + p < wo) *reinterpret_cast<uint4*>(orow + p * 32 + q * 8) = val;
+        }
+      } else if (ox < wo) {
         _Float16* o = out + (((size_t)n * ho + oy) * wo + ox) * c0 + g * 32;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
