@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps between two gathers of per-frame records to rank 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU to test the sharded path)")
+    ap.add_argument("--sharding", default="frames", choices=["frames", "videos"],
+                    help="N > 1: frames = batches of ONE clip dealt to the ranks, tracks gathered to rank 0 (BASELINE north star); "
+                         "videos = every rank runs the whole reference-order pipeline on its own clip, no data-path collective (SURVEY 8e best case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -277,7 +280,7 @@ def main():
     from geotrax_amd.tracker import Tracker
 
     ctx = _lib.Context(local)
-    scene = make_scene(seed=0, h=H, w=W)                       # one clip; ranks take different frames of it
+    scene = make_scene(seed=0 if args.sharding == "frames" else rank, h=H, w=W)   # frames: one clip, ranks take different batches of it; videos: a clip per rank
     n_pool = max(args.frames, 2)
     frames = [scene.render(t, 150) for t in range(n_pool)]    # every rank holds the clip; it processes its own batches of it
     ref_frame = frames[0]
@@ -324,7 +327,7 @@ def main():
         ctx.dev_upload(pool + i * fbytes, frames[t])
 
     def batch_ptr(k):                                            # local step k -> global batch k * world + rank of the playback
-        g = k * world + rank
+        g = k * world + rank if args.sharding == "frames" else k  # videos: every rank plays its own clip from the start
         return pool + ((g * B) % len(order)) * fbytes
 
     def batch_item(k):
@@ -336,7 +339,7 @@ def main():
         return batch_ptr(k), (None if g == 0 else pool + ((g * B - 1) % len(order)) * fbytes)
 
     extract = args.workload == "extract"
-    sharded = world > 1 or force_dist
+    sharded = (world > 1 or force_dist) and args.sharding == "frames"
     tracker = Tracker(args.tracker)                              # N > 1: used by rank 0's replay thread only
     max_det = 1000
     # The product's own engine (geotrax_amd/engine.py, what `geotrax_amd.extract` runs): detector streams take the
@@ -483,6 +486,7 @@ def main():
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),
                 "pipeline": f"{n_det_streams} detector stream(s) take batches round-robin and stay in flight while tracker/stabilizers work through the collected batch; {n_stab} stabilizer streams (submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
+                            "one clip per rank, reference per-frame order on every rank, no data-path collective" if args.sharding == "videos" else
                             f"batches dealt round-robin to ranks; records gathered to rank 0 every {args.gather_every} steps (RCCL), "
                             "tracker replayed there on a second host thread",
             },
