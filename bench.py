@@ -48,8 +48,8 @@ H, W = 2160, 3840
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef"],
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
                          "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
