@@ -1,0 +1,46 @@
+"""bench.py end to end on the GPU box: the single-GPU line carries the contract's fields, and the N > 1 code paths
+(frames of one clip sharded over ranks with the record gather and the tracker replay; one clip per rank) run to
+completion with two ranks sharing the one GPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _last_json(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "24", "--warmup", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 24 and d["value"] > 100 and d["unit"] == "frames/s" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+@pytest.mark.parametrize("mode,tracker", [("frames", "bytetrack"), ("frames", "botsort"), ("videos", "bytetrack")])
+def test_two_ranks_on_one_gpu(mode, tracker):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "18", "--warmup", "2", "--gather-every", "4",
+           "--no-cpu-baseline", "--no-profile", "--backend", "gloo", "--sharding", mode, "--tracker", tracker]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 18 and d["value"] > 50 and d["scaling"] == "weak"
+    assert ("one clip per rank" in d["config"]["sharding"]) == (mode == "videos")
+    if tracker == "botsort":
+        assert "GMC" in d["config"]["tracker"]
