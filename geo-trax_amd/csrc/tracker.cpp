@@ -310,6 +310,7 @@ struct ByteTracker::Impl {
   gtx_tracker_config cfg;
   Kalman kf;
   std::vector<Track> tracked, lost;
+  std::vector<char> id_seen;          // scratch byte map over track ids
   // ultralytics' removed_stracks is only ever read for its ids (sub_stracks): keep the ids, in order, plus a set
   std::vector<int> removed_order;
   std::unordered_set<int> removed_set;
@@ -540,11 +541,13 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   for (Track& t : S.tracked) (t.activated ? confirmed : unconfirmed).push_back(&t);
   // pool = joint(confirmed, lost)
   std::vector<Track*> pool = confirmed;
-  for (Track& t : S.lost) {           // joint_stracks: first occurrence of an id wins
-    bool seen = false;
-    for (Track* q : pool)
-      if (q->id == t.id) { seen = true; break; }
-    if (!seen) pool.push_back(&t);
+  {                                   // joint_stracks: first occurrence of an id wins (ids are small integers: a byte map)
+    std::vector<char>& seen = S.id_seen;
+    if (seen.size() < (size_t)S.next_id + 2) seen.resize((size_t)S.next_id + 1026, 0);   // all zero between uses
+    for (Track* q : pool) seen[q->id] = 1;
+    for (Track& t : S.lost)
+      if (!seen[t.id]) { seen[t.id] = 1; pool.push_back(&t); }
+    for (Track* q : pool) seen[q->id] = 0;
   }
   PROF_MARK(pool)
   // Kalman predict (velocity of the size/aspect state is zeroed for non-tracked tracks)
@@ -654,7 +657,12 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   auto has_ptr = [](const std::vector<Track*>& v, const Track* p) { return std::find(v.begin(), v.end(), p) != v.end(); };
   std::vector<Track> new_tracked, new_lost;
   new_tracked.reserve(S.tracked.size() + 16);
-  std::unordered_set<int> ids;
+  struct IdMap {                       // ids present in new_tracked
+    std::vector<char>& m;
+    bool count(int id) const { return m[id] != 0; }
+    void insert(int id) { m[id] = 1; }
+  } ids{S.id_seen};
+  if (S.id_seen.size() < (size_t)S.next_id + 2) S.id_seen.resize((size_t)S.next_id + 1026, 0);   // activate() may have handed out new ids
   for (Track& t : S.tracked)
     if (t.state == kTracked) { new_tracked.push_back(t); ids.insert(t.id); }
   // joint(tracked, activated): `activated` holds existing tracks (already in tracked if they were
@@ -674,6 +682,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     if (!ids.count(t.id) && !has_ptr(lost_now, &t) && !removed_ids.count(t.id)) new_lost.push_back(t);
   for (Track* t : lost_now)
     if (!removed_ids.count(t->id)) new_lost.push_back(*t);
+  for (const Track& t : new_tracked) S.id_seen[t.id] = 0;     // the byte map is all zero between uses
   PROF_MARK(lists)
   // duplicates between tracked and lost (IoU distance < 0.15): keep the older track
   {
