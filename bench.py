@@ -416,9 +416,7 @@ def main():
         n_last = 0
         for rec in all_records:
             xyxy, conf, cls, Hm = unpack_frame_record(rec, max_det)
-            if len(conf) == 0:
-                continue
-            bx, ids = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if shard_gmc else None)[:2]
+            bx, ids = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if shard_gmc else None)[:2]   # every frame, empty or not
             if len(ids) and Hm is not None:
                 warp_boxes(Hm, xywh_of(bx))
             n_last = len(ids)

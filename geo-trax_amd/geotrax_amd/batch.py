@@ -54,6 +54,9 @@ def handle_existing_results(file: Path, args, logger, exists: bool, action: str,
         logger.warning(f"'{file}' - {action} results already exist and overwrite not allowed.")
         return False
     if exists and args.overwrite and not args.yes:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:           # N ranks cannot all prompt on one terminal
+            logger.warning(f"Skipping '{file}': --overwrite under a multi-rank launcher needs --yes")
+            return False
         return ask(f"Overwrite {action} results for: '{file}'? [y/n]: ").lower() == 'y'
     return True
 
@@ -79,6 +82,12 @@ def process_file(file: Path, args, logger, out_cfg: dict, run=detect_track_stabi
         return 'done'
     except Exception as e:
         logger.error(f"Error with {file}: {e}")
+        return 'failed'
+    except SystemExit as e:
+        # the per-file stage exits on an unreadable video or a missing model (extract.py load_detector /
+        # initialize_streams, like the reference); inside a batch -- and above all under a launcher, where the other
+        # ranks wait in the closing all_reduce -- that is this file's failure, not the batch's
+        logger.error(f"Error with {file}: the extraction stage exited with status {e.code}")
         return 'failed'
 
 

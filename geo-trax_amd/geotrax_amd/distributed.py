@@ -105,11 +105,11 @@ def extract_sharded(n_frames: int, first: int, read_frame: Callable[[int], np.nd
         s, e = shard_range(n_frames, r, world, first)
         for k, f in enumerate(range(s, e)):
             xyxy, conf, cls, H = unpack_frame_record(allrec[r][k], max_det)
+            bx, ids, sc, cl, _ = tracker.update(xyxy, conf, cls)     # every frame, also without detections (ultralytics track.py)
             if len(conf) == 0:
                 if H is not None:
                     transforms.append(np.hstack((np.array([[f]]), H.reshape(1, -1))))
                 continue
-            bx, ids, sc, cl, _ = tracker.update(xyxy, conf, cls)
             if len(ids) == 0:
                 bx, ids, sc, cl = xyxy, np.full(len(conf), -1), conf, cls
             n = len(ids)

@@ -11,8 +11,10 @@ _collect` (include/gtx.h).
 Ordering rules kept from the reference loop:
   * the first frame fed is the reference frame: its boxes pass through unstabilized, no transform row
     (extract.py:176-179);
-  * a frame without detections never reaches the tracker (ultralytics' callback skips it), so neither the
-    tracker state nor the GMC's previous frame advance; the stabilizer still registers it with no mask;
+  * a frame without detections still reaches the tracker (and, with BoT-SORT, the GMC): the pinned
+    ultralytics (>=8.4.80, trackers/track.py on_predict_postprocess_end) calls tracker.update(det, img) on every
+    frame, so the frame counter advances, unmatched tracks go lost / age out and the GMC's previous frame
+    moves on; the frame writes no rows and the stabilizer registers it with no mask (extract.py:159,176-187);
   * when the tracker returns nothing the raw detections are kept with ids None (written as -1 and dropped
     later, extract.py:161-165, 287);
   * the stabilizer's foreground mask is the box set that is written out (tracker boxes, else raw boxes).
@@ -222,13 +224,12 @@ class ExtractEngine:
                         self.gmc.submit_frame_dev(int(prev), self.frame_hw[0], self.frame_hw[1], restart=True)
                         self._gmc_sub += 1
                         n_skip, restart = 1, False
-                    for d, g in zip(dets, grays):               # (frames without detections never reach the tracker)
-                        if len(d):
-                            if restart:                         # no frame before it: the batch's first frame opens the sequence
-                                self.gmc.reset_sequence()
-                                restart = False
-                            self.gmc.submit_gray_dev(*g)
-                            self._gmc_sub += 1
+                    for g in grays:                             # every frame, detections or not (BOTSORT.update -> gmc.apply)
+                        if restart:                             # no frame before it: the batch's first frame opens the sequence
+                            self.gmc.reset_sequence()
+                            restart = False
+                        self.gmc.submit_gray_dev(*g)
+                        self._gmc_sub += 1
                 yield det, dets, grays, hosts, det_ms, n_skip
                 if host_gray:
                     submit_next()
@@ -248,8 +249,8 @@ class ExtractEngine:
         for b, (d, g) in enumerate(zip(dets, grays)):
             ids = None
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
-            warp = self._gmc_collect() if (len(d) and self.gmc is not None) else None
-            if len(d) and self.tracker is not None:
+            warp = self._gmc_collect() if self.gmc is not None else None
+            if self.tracker is not None:                        # also on frames without detections (frame counter, lost/removed ageing)
                 t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids

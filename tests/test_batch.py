@@ -42,13 +42,19 @@ def test_discovery_exclusions_and_skip_rules(tmp_path):
         seen.append(Path(file_args.source).name)
         if file_args.source.name == "two.mp4":
             raise RuntimeError("decoder exploded")
+        if file_args.source.name == "three.mov" and not (file_args.source.parent / "ok").exists():
+            (file_args.source.parent / "ok").write_text("")
+            raise SystemExit(1)                       # extract.py exits on an unreadable video / missing model: this file's failure only
         out = file_args.source.parent / "results"
         out.mkdir(exist_ok=True)
         (out / f"{file_args.source.stem}.txt").write_text("0,1\n")
 
     counts = batch.process_input(_args(tmp_path, exclude_patterns=["skipme"]), logger, run=run)
     assert seen == ["one.npy", "two.mp4", "three.mov", "six.avi"]
-    assert counts == dict(done=3, skipped=0, failed=1, dry=0)                                  # one failure does not stop the batch
+    assert counts == dict(done=2, skipped=0, failed=2, dry=0)                                  # an exception or a sys.exit in one file does not stop the batch
+    seen.clear()
+    counts = batch.process_input(_args(tmp_path, exclude_patterns=["skipme"]), logger, run=run)
+    assert seen == ["two.mp4", "three.mov"] and counts["skipped"] == 2 and counts["done"] == 1
     seen.clear()
     counts = batch.process_input(_args(tmp_path, exclude_patterns=["skipme"]), logger, run=run)
     assert seen == ["two.mp4"] and counts["skipped"] == 3                                      # results exist, no --overwrite
@@ -65,6 +71,11 @@ def test_discovery_exclusions_and_skip_rules(tmp_path):
     a = _args(tmp_path, overwrite=True)
     assert batch.handle_existing_results(f, a, logger, True, "x", ask=lambda _: "Y") is True
     assert batch.handle_existing_results(f, a, logger, True, "x", ask=lambda _: "n") is False
+    os.environ["WORLD_SIZE"] = "2"                    # under a launcher nobody prompts: --overwrite needs --yes
+    try:
+        assert batch.handle_existing_results(f, a, logger, True, "x", ask=lambda _: pytest.fail("prompted")) is False
+    finally:
+        del os.environ["WORLD_SIZE"]
     assert batch.process_input(_args(tmp_path / "nowhere"), logger, run=run) == dict(done=0, skipped=0, failed=0, dry=0)
 
 

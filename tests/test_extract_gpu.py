@@ -508,9 +508,10 @@ def test_frame_sharded_botsort_gmc_equals_the_unsharded_run(gtx_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
 def test_engine_frames_without_detections(gtx_ctx, tracker):
-    """extract.py:156-165: a frame without detections never reaches the tracker (ids None -> written as -1 and dropped),
-    has no boxes to warp, but is still registered against the reference frame (no foreground mask). Here every
-    frame is empty (confidence threshold above every score) except that the tracker must stay untouched."""
+    """extract.py:156-187: a frame without detections writes no rows and has no boxes to warp, but is still
+    registered against the reference frame (no foreground mask). The pinned ultralytics (>=8.4.80, trackers/track.py)
+    calls tracker.update on EVERY frame, so the tracker (frame counter, lost/removed ageing) and BoT-SORT's GMC see
+    the empty frames too. Here every frame is empty (confidence threshold above every score)."""
     from geotrax_amd.engine import ExtractEngine
     from geotrax_amd.synth import make_scene
     from geotrax_amd.tracker import Tracker
@@ -529,9 +530,10 @@ def test_engine_frames_without_detections(gtx_ctx, tracker):
         got = list(eng.run([frames[0:2], frames[2:4], frames[4:5]]))
     finally:
         eng.close()
-    assert [r.index for r in got] == list(range(5)) and not calls
+    assert [r.index for r in got] == list(range(5)) and len(calls) == 5     # one tracker.update per frame, empty or not
     for i, r in enumerate(got):
-        assert r.n_det == 0 and r.ids is None and r.xywh is None and r.xywh_stab is None and len(r.xyxy) == 0 and r.gmc is None
+        assert r.n_det == 0 and r.ids is None and r.xywh is None and r.xywh_stab is None and len(r.xyxy) == 0
+        assert (r.gmc is not None) == (tracker == "botsort")            # the GMC saw the frame (BOTSORT.update -> gmc.apply)
         assert (r.H is None) == (i == 0)                     # the reference frame has no transform row; the others register
     assert all(np.isfinite(r.H).all() and abs(np.linalg.det(r.H) - 1.0) < 0.05 for r in got[1:])
 

@@ -112,6 +112,31 @@ def test_tracker_reset_and_empty_input():
         np.testing.assert_array_equal(x, y)
 
 
+def test_empty_frames_advance_the_tracker_clock():
+    """ultralytics >= 8.4.80 calls tracker.update on frames without detections too: a gap longer than track_buffer
+    removes every track (new ids afterwards), a short gap lets the lost tracks be re-found with their old ids.
+    Same behaviour in the oracle and the C++ tracker."""
+    from geotrax_amd.tracker import Tracker
+    from oracle.bytetrack_ref import ByteTrackRef
+
+    frames = list(_stream(7, n_obj=12, n_frames=8, p_miss=0.0, p_low=0.0))
+    empty = (np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
+    for gap, expect_same in ((5, True), (40, False)):
+        trk, ref = Tracker("bytetrack"), ByteTrackRef()
+        for f in frames[:4]:
+            before = trk.update(*f)[1]
+            ref.update(*f)
+        for _ in range(gap):
+            assert len(trk.update(*empty)[1]) == 0 and len(ref.update(*empty)) == 0
+        after, r = trk.update(*frames[4])[1], ref.update(*frames[4])
+        np.testing.assert_array_equal(after, r[:, 4].astype(np.int32))
+        if expect_same:
+            assert set(after) <= set(before) and len(after) > 0
+        else:                                   # every old track timed out: the frame after the gap opens new, unconfirmed tracks
+            after2 = trk.update(*frames[5])[1]
+            assert len(after) == 0 and len(after2) > 0 and min(after2) > max(before)
+
+
 def test_tracker_rejects_unknown_type():
     from geotrax_amd.tracker import Tracker
 
