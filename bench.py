@@ -123,7 +123,7 @@ def pmc_traffic(kernel, batch):
         return None
 
 
-def cpu_baseline(weights, ref_frame, frame, args, pattern):
+def cpu_baseline(weights, ref_frame, frame, args):
     """The oracle chain (oracle/*_ref.py: torch-CPU YOLOv8s + numpy NMS + numpy ByteTrack + numpy
     ORB/match/RANSAC) on ONE 4K frame, timed on the host cores. The reference frame's keypoints
     are prepared outside the timed region, as in steady state."""
@@ -152,7 +152,7 @@ def cpu_baseline(weights, ref_frame, frame, args, pattern):
     parts = {"detect_s": t_det}
     total = t_det
     if args.workload == "extract":
-        st = StabilizerRef(stab_cfg, (H, W), pattern, n_hyp=256)
+        st = StabilizerRef(stab_cfg, (H, W), n_hyp=256)
         st.set_ref_frame(ref_frame, None)
         t0 = time.perf_counter()
         rows = trk.update(xyxy, conf, cls)
@@ -275,7 +275,6 @@ def main():
     from geotrax_amd import _lib
     from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
     from geotrax_amd.geometry import warp_boxes
-    from geotrax_amd.stabilizer import Stabilizer
     from geotrax_amd.synth import make_scene
     from geotrax_amd.tracker import Tracker
 
@@ -525,8 +524,7 @@ def main():
                                    "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                                   for d in fam]
         if not args.no_cpu_baseline:
-            pattern = (engine.stabs[0] if engine.stabs else Stabilizer((H, W), ctx=ctx)).pattern()
-            out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args, pattern)
+            out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -570,7 +570,13 @@ int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, in
 }
 
 int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out) {
-  return guarded([&] { need(st, "st"); need(out, "out"); st->impl->pattern(out); });
+  return guarded([&] {
+    need(out, "out");
+    if (st) { st->impl->pattern(out); return; }
+    std::vector<int8_t> t;                        // no object: the built-in table (host only, needs no device)
+    gtx::stabilizer_pattern_table(t);
+    std::memcpy(out, t.data(), t.size());
+  });
 }
 
 /* ------------------------------------------------------------------ geometry */

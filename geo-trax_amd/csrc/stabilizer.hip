@@ -918,6 +918,21 @@ void base_pattern(int8_t out[256][4]) {
 
 }  // namespace
 
+void stabilizer_pattern_table(std::vector<int8_t>& out) {
+  int8_t base[256][4];
+  base_pattern(base);
+  out.resize((size_t)kAngleBins * 256 * 4);
+  for (int b = 0; b < kAngleBins; ++b) {
+    const double th = b * (2.0 * M_PI / kAngleBins), cs = std::cos(th), sn = std::sin(th);
+    for (int i = 0; i < 256; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const double x = base[i][2 * k], y = base[i][2 * k + 1];
+        out[((size_t)b * 256 + i) * 4 + 2 * k] = (int8_t)std::lround(x * cs - y * sn);
+        out[((size_t)b * 256 + i) * 4 + 2 * k + 1] = (int8_t)std::lround(x * sn + y * cs);
+      }
+  }
+}
+
 struct Stabilizer::Impl {
   gtx_ctx* ctx;
   gtx_stab_config cfg;
@@ -1048,19 +1063,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
     const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;
     S.d_pidx.alloc(4 * parts); S.d_pd1.alloc(4 * parts); S.d_pd2.alloc(4 * parts);
   }
-  // rotated sampling patterns
-  int8_t base[256][4];
-  base_pattern(base);
-  S.pattern.resize((size_t)kAngleBins * 256 * 4);
-  for (int b = 0; b < kAngleBins; ++b) {
-    const double th = b * (2.0 * M_PI / kAngleBins), cs = std::cos(th), sn = std::sin(th);
-    for (int i = 0; i < 256; ++i)
-      for (int k = 0; k < 2; ++k) {
-        const double x = base[i][2 * k], y = base[i][2 * k + 1];
-        S.pattern[((size_t)b * 256 + i) * 4 + 2 * k] = (int8_t)std::lround(x * cs - y * sn);
-        S.pattern[((size_t)b * 256 + i) * 4 + 2 * k + 1] = (int8_t)std::lround(x * sn + y * cs);
-      }
-  }
+  stabilizer_pattern_table(S.pattern);   // rotated sampling patterns
   S.d_pattern.alloc(S.pattern.size());
   GTX_HIP(hipMemcpy(S.d_pattern.p, S.pattern.data(), S.pattern.size(), hipMemcpyHostToDevice));
   GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 12));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <vector>
 
 #include "../../include/gtx.h"
 #include "common.hpp"
@@ -30,6 +31,9 @@ class Stabilizer {
   struct Impl;
   std::unique_ptr<Impl> impl_;
 };
+
+// The steered-BRIEF sampling table [256 bins][256 tests][ax, ay, bx, by] (host only, no device needed).
+void stabilizer_pattern_table(std::vector<int8_t>& out);
 
 // Robust homography (MSAC hypotheses on the GPU + IRLS refit on the host, f64) from n_match point pairs
 // (x, y) -> (z, w) in HBM; threshold in pixels of the destination. false: no model.

@@ -281,7 +281,9 @@ int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, in
                            int* dist);
 
 /* The steered-BRIEF sampling table the descriptor kernel uses: [256 orientation bins][256
- * tests][ax, ay, bx, by] int8 = 262144 bytes. Data hand-over for the parity tests. */
+ * tests][ax, ay, bx, by] int8 = 262144 bytes. `st` may be NULL (the table does not depend on the
+ * object and needs no device). The oracle generates its own table from the published recipe and
+ * the parity tests compare the two. */
 int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out);
 
 /* ------------------------------------------------------------------ global motion compensation

@@ -14,7 +14,9 @@ scale pyramid, FAST-9/16 with 3x3 non-maximum suppression, FAST-score pre-select
 orientation, steered BRIEF on a Gaussian-smoothed patch; Lowe's ratio test; RANSAC with an
 MSAC score and a robust iteratively re-weighted Gauss-Newton refit) in the integer-exact form the HIP kernels implement
 (geo-trax_amd/csrc/stabilizer.hip), so that every stage can be compared bit for bit. The BRIEF
-sampling table is data handed over by the library (gtx_stabilizer_pattern).
+sampling table is generated HERE (`brief_pattern`: 256 pairs from an isotropic Gaussian, sigma = patch/5,
+BRIEF "G II" of Calonder et al., seeded splitmix64, rotated to 256 orientation bins) and the tests compare
+the library's table (gtx_stabilizer_pattern) with it, not the other way round.
 
 PARITY UNPINNED against stabilo/OpenCV themselves. What pins the stage end to end: synthetic
 sequences with a known camera homography (tests/test_stabilizer_gpu.py) and the envelope of the
@@ -33,6 +35,50 @@ UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
 GAUSS = np.array([18, 34, 49, 54, 49, 34, 18], dtype=np.int64)
 N_BINS = 256
 TAN = [int(np.floor(np.tan((j + 0.5) * 2 * np.pi / N_BINS) * 16777216.0 + 0.5)) for j in range(32)]
+
+
+_M64 = (1 << 64) - 1
+
+
+def brief_pattern(n_bins: int = N_BINS) -> np.ndarray:
+    """Steered-BRIEF sampling table [n_bins][256][ax, ay, bx, by] int8. Base pairs: coordinates drawn from
+    N(0, 6.2^2) (sigma = 31/5, BRIEF 'G II'; the normal is Irwin-Hall(12) - 6 over 24-bit splitmix64 uniforms so
+    that it is exactly reproducible), rounded half away from zero, redrawn outside [-12, 12]; a pair that would
+    compare a pixel with itself is nudged by one. Bin b rotates every point by b * 2 pi / n_bins (ORB steers the
+    pattern by the keypoint orientation; OpenCV uses 30 bins of 12 degrees and a learned pair set)."""
+    state = [0x9E3779B97F4A7C15]
+
+    def nxt():
+        state[0] = (state[0] + 0x9E3779B97F4A7C15) & _M64
+        z = state[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def lround(v):
+        return int(np.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+    base = np.zeros((256, 4), np.int64)
+    for i in range(256):
+        for k in range(4):
+            while True:
+                acc = sum(nxt() >> 40 for _ in range(12))
+                r = lround((acc / 16777216.0 - 6.0) * 6.2)
+                if -12 <= r <= 12:
+                    base[i, k] = r
+                    break
+    for i in range(256):
+        if base[i, 0] == base[i, 2] and base[i, 1] == base[i, 3]:
+            base[i, 2] += -1 if base[i, 2] >= 12 else 1
+    out = np.zeros((n_bins, 256, 4), np.int8)
+    for b in range(n_bins):
+        th = b * (2.0 * np.pi / n_bins)
+        cs, sn = float(np.cos(th)), float(np.sin(th))
+        for k in range(2):
+            x, y = base[:, 2 * k].astype(np.float64), base[:, 2 * k + 1].astype(np.float64)
+            for col, v in ((2 * k, x * cs - y * sn), (2 * k + 1, x * sn + y * cs)):
+                out[b, :, col] = (np.floor(np.abs(v) + 0.5) * np.sign(v)).astype(np.int8)
+    return out
 
 
 def bgr2gray(frame_bgr: np.ndarray, half: bool) -> np.ndarray:
@@ -349,8 +395,9 @@ def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float
 class StabilizerRef:
     """Same call sequence as the product's Stabilizer (set_ref_frame / stabilize)."""
 
-    def __init__(self, cfg: dict, frame_hw, pattern: np.ndarray, n_hyp: int):
-        self.cfg, self.hw, self.pattern, self.n_hyp = cfg, frame_hw, pattern, n_hyp
+    def __init__(self, cfg: dict, frame_hw, pattern: np.ndarray | None = None, n_hyp: int = 2048):
+        self.cfg, self.hw, self.n_hyp = cfg, frame_hw, n_hyp
+        self.pattern = brief_pattern() if pattern is None else pattern      # the oracle's own table unless one is forced
         self.half = cfg["downsample_ratio"] == 0.5
         self.ref = self.cur = None
 

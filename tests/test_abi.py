@@ -53,3 +53,20 @@ def test_no_gpu_means_loud_failure_not_fallback():
         pytest.skip("a GPU is visible")
     with pytest.raises(_lib.GtxError):
         _lib.Context(0)
+
+
+def test_brief_table_equals_the_oracles_own():
+    """The steered-BRIEF sampling table is generated independently by the oracle (published recipe: Gaussian pairs,
+    sigma = patch/5, 256 orientation bins) and by the library; they must be the same bytes. Host only."""
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    from geotrax_amd import _lib
+    from oracle.stabilo_ref import brief_pattern
+
+    lib = _lib.load()
+    out = np.zeros((256, 256, 4), np.int8)
+    _lib.check(lib.gtx_stabilizer_pattern(None, _lib.ptr(out)))
+    want = brief_pattern()
+    np.testing.assert_array_equal(out, want)
+    assert np.abs(want.astype(int)).max() <= 17 and len(np.unique(want[0].reshape(256, 4), axis=0)) > 250

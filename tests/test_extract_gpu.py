@@ -54,7 +54,7 @@ def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False):
     return p, cfg
 
 
-def _oracle_chain(frames, weights, cfg, pattern):
+def _oracle_chain(frames, weights, cfg, pattern=None):
     """detect -> track -> stabilize with the oracle modules, following extract.py:145-197."""
     from oracle.bytetrack_ref import ByteTrackRef
     from oracle.stabilo_ref import StabilizerRef
@@ -76,9 +76,9 @@ def _oracle_chain(frames, weights, cfg, pattern):
     rows, transforms = [], []
     for f, frame in enumerate(frames):
         xyxy, conf, cls = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"])
+        warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
+        t = trk.update(xyxy, conf, cls, gmc=warp)           # every frame, with or without detections (ultralytics track.py)
         if len(conf):
-            warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
-            t = trk.update(xyxy, conf, cls, gmc=warp)
             if len(t):
                 bx, ids, sc, cl = t[:, :4], t[:, 4], t[:, 5], t[:, 6]
             else:
@@ -131,8 +131,7 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     args.cut_frame_left, args.cut_frame_right = 0, None
     tracks, transforms = ex.track_with_model(model, config, logger)
 
-    pattern = Stabilizer((H, W), ctx=gtx_ctx).pattern()
-    ref_tracks, ref_transforms = _oracle_chain(frames, weights, cfg, pattern)
+    ref_tracks, ref_transforms = _oracle_chain(frames, weights, cfg)        # the oracle's own BRIEF table
     assert model.names[0] == "car"
 
     assert tracks.dtype == np.float32 and tracks.shape[1] == 12 and len(tracks) > 20

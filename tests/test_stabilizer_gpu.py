@@ -41,7 +41,8 @@ def test_stages_bit_exact_against_oracle(gtx_ctx, seq):
 
     sc, fr = seq
     st = _make(gtx_ctx)
-    ref = StabilizerRef(CFG, HW, st.pattern(), n_hyp=2048)
+    ref = StabilizerRef(CFG, HW, n_hyp=2048)                 # the oracle's own sampling table (oracle.stabilo_ref.brief_pattern)
+    np.testing.assert_array_equal(st.pattern(), ref.pattern)
     b0, b1 = sc.boxes(0), sc.boxes(40)
     st.set_ref_frame(fr[0], b0)
     ref.set_ref_frame(fr[0], b0)
