@@ -54,7 +54,10 @@ def parse():
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
                          "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
                          "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres)")
-    ap.add_argument("--half", type=int, default=1, help="ultralytics.half: 1 = fp16 MFMA, 0 = fp32 MFMA (reference default)")
+    ap.add_argument("--half", type=int, default=1, help="ultralytics.half: 1 = fp16 activations + fp16 MFMA, 0 = fp32 activations (reference default)")
+    ap.add_argument("--fp32", default=None, choices=["exact", "split"],
+                    help="--half 0 only: exact = v_mfma_f32_32x32x2_f32; split = split-f16x3 (hi+lo fp16 operands, 3 fp16 MFMAs per product, "
+                         "fp32 accumulate). Default: the library's default (geotrax_amd.detector.FP32_SPLIT_DEFAULT)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
     ap.add_argument("--tracker", default="bytetrack", choices=["bytetrack", "botsort"])
@@ -75,6 +78,11 @@ def parse():
     return ap.parse_args()
 
 
+def fp32_split(args):
+    """None = the library default; only meaningful with --half 0."""
+    return None if args.fp32 is None else args.fp32 == "split"
+
+
 def xywh_of(b):
     return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) \
         if len(b) else None
@@ -87,7 +95,7 @@ def calibrated_detector(ctx, frame, args, target):
     from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
 
     kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
-              half=bool(args.half), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
+              half=bool(args.half), fp32_split=fp32_split(args), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
     base = synthetic_yolov8(seed=0, nc=4, scale="s", level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002)   # vehicle-sized boxes from the stride-8 head
     det = Detector(base, (H, W), **kw)
     det.detect(frame)
@@ -314,7 +322,7 @@ def main():
             off += n
         n_det, n_cand = int(meta[0]), int(meta[1])
         det = Detector(weights, (H, W), imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
-                       half=bool(args.half), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
+                       half=bool(args.half), fp32_split=fp32_split(args), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
     # the ping-pong playback (0..n-1, n-2..1: continuous motion) laid out contiguously in HBM, plus the
     # first B-1 frames again, so that every batch of B consecutive frames is one contiguous range
     B = max(args.batch, 1)
@@ -349,7 +357,7 @@ def main():
     from geotrax_amd.engine import ExtractEngine
 
     det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
-                  rect=bool(args.rect))
+                  fp32_split=fp32_split(args), rect=bool(args.rect))
     stab_kw = {} if extract else None
     shard_gmc = sharded and extract and args.tracker == "botsort"
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <mutex>
+
 #include "conv_igemm.hpp"
 
 namespace gtx {
@@ -349,12 +351,6 @@ void conv_igemm_kernel(const ConvGroup g) {
 // ------------------------------------------------------------------------------------------
 
 namespace {
-// GTX_CONV_V2=1 selects the LDS-DMA ring kernel (conv_igemm2.hip) for fp16 layers: measured equal or
-// slower than the register-staged kernel on every YOLOv8s layer, kept for A/B runs.
-bool force_v1() {
-  static const bool v = [] { const char* e = getenv("GTX_CONV_V2"); return !(e && e[0] == '1'); }();
-  return v;
-}
 int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -368,12 +364,15 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
   c.stride = stride;
   GTX_CHECK((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1),
             "conv: unsupported kernel %dx%d stride %d", ks, ks, stride);
-  if (dtype == DT_F16 && !force_v1() && cout % 32 == 0 && cin % (ks == 1 ? 32 : 16) == 0) {
-    c.variant = 1;
+  if (dtype == DT_F32S) {
+    // 3x3: 16-channel chunks (patch 11.5 KB + weight taps 36.9 KB per stage at 64 couts); 1x1: 32-channel chunks
+    c.variant = 2;
+    c.kc = ks == 1 ? (cin % 32 == 0 ? 32 : 16) : 16;
+    if (force_kc > 0) c.kc = force_kc;
     c.bn = (cout % 64 == 0) ? 64 : 32;
-    if (ks == 1) { c.kc = 32; c.th = 1; c.tw = 256; c.ns = env_int("GTX_CONV_NS1", 2); }
-    else if (stride == 1) { c.kc = 16; c.th = 8; c.tw = 32; c.ns = env_int("GTX_CONV_NS3", 3); }
-    else { c.kc = 16; c.th = 4; c.tw = 32; c.ns = env_int("GTX_CONV_NS2", 2); }
+    c.th = 8; c.tw = 16;
+    GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
+    GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -400,28 +399,13 @@ inline uint16_t f32_to_f16_bits(float f) {
 }
 }  // namespace
 
-std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg) {
-  if (cfg.variant == 1) {
-    // stage image of conv_igemm2.hip: [cout tile][cin chunk][row = tap*BN + n][swizzled 16-B chunk]
-    const int cpr = cfg.kc / 8, rb = cpr * 16, rpb = 256 / rb, taps = cfg.ks * cfg.ks;
-    const int n_ct = cout / cfg.bn, nchunks = cin / cfg.kc;
-    std::vector<uint8_t> out((size_t)cout * taps * cin * 2);
-    for (int ct = 0; ct < n_ct; ++ct)
-      for (int ch = 0; ch < nchunks; ++ch)
-        for (int tap = 0; tap < taps; ++tap)
-          for (int n = 0; n < cfg.bn; ++n) {
-            const int row = tap * cfg.bn + n;
-            for (int c = 0; c < cpr; ++c) {
-              const int cs = c ^ ((row / rpb) & (cpr - 1));
-              const size_t dst16 = (((size_t)ct * nchunks + ch) * taps * cfg.bn + row) * cpr + cs;
-              for (int e = 0; e < 8; ++e) {
-                const int ci = ch * cfg.kc + c * 8 + e;
-                const uint16_t hb = f32_to_f16_bits(w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci]);
-                memcpy(&out[dst16 * 16 + e * 2], &hb, 2);
-              }
-            }
-          }
-    return out;
+std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
+  if (acc_scale) *acc_scale = 1.f;
+  if (cfg.variant == 2) {
+    float sc = 1.f;
+    std::vector<uint8_t> r = pack_conv_weights_split(w, cout, cin, cfg, &sc);
+    if (acc_scale) *acc_scale = sc;
+    return r;
   }
   const int es = (int)dtype_size(cfg.dtype);
   const int epc = 16 / es;
@@ -452,39 +436,15 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
   return out;
 }
 
-namespace {
-// One page of zeros per device for the out-of-image lanes of the LDS-DMA kernels (never freed).
-const void* zero_page() {
-  static void* page[16] = {nullptr};
-  int dev = 0;
-  GTX_HIP(hipGetDevice(&dev));
-  GTX_CHECK(dev >= 0 && dev < 16, "conv: device %d out of range", dev);
-  if (!page[dev]) {
-    GTX_HIP(hipMalloc(&page[dev], 4096));
-    GTX_HIP(hipMemset(page[dev], 0, 4096));
-  }
-  return page[dev];
-}
-}  // namespace
-
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
   int total = 0;
-  const void* zp = cfg.variant == 1 ? zero_page() : nullptr;
   for (int i = 0; i < g.count; ++i) {
     ConvProblem& p = g.p[i];
-    p.zero = zp;
-    p.in_blocked = 0;
     p.n_ct = p.Cout / cfg.bn;
     p.block_begin = total;
-    if (cfg.variant == 1 && cfg.ks == 1) {       // linearised pixel index
-      p.tiles_x = cdiv(p.N * p.H * p.W, cfg.tw);
-      p.tiles_y = 1;
-      total += p.tiles_x * p.n_ct;
-    } else {
-      p.tiles_x = cdiv(p.Wo, cfg.tw);
-      p.tiles_y = cdiv(p.Ho, cfg.th);
-      total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
-    }
+    p.tiles_x = cdiv(p.Wo, cfg.tw);
+    p.tiles_y = cdiv(p.Ho, cfg.th);
+    total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
   }
   g.total_blocks = total;
 }
@@ -498,12 +458,11 @@ template <typename T, int KS, int STRIDE, int WN, int CPR>
 void launch_t(const ConvGroup& g, hipStream_t stream) {
   using Tile = ConvTile<T, KS, STRIDE, WN, CPR>;
   auto kern = conv_igemm_kernel<T, KS, STRIDE, WN, CPR>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag once;     // detectors on several host threads launch the same instantiation
+  std::call_once(once, [&] {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
   GTX_HIP(hipGetLastError());
 }
@@ -526,15 +485,15 @@ void launch_dt(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) {
   GTX_CHECK(g.count >= 1 && g.count <= kMaxGroup, "conv: bad group size %d", g.count);
   if (g.total_blocks == 0) return;
-  if (cfg.variant == 1) return conv2_launch(g, cfg, stream);
+  if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);
 }
 
 const char* conv_kernel_name(const ConvConfig& c) {
   static thread_local char buf[96];
-  if (c.variant == 1) {
-    snprintf(buf, sizeof buf, "conv_igemm2_kernel<%d, %d, %d, %d, %d, %d, %d>", c.ks, c.stride, c.th, c.tw / 32, c.bn / 32, c.kc / 8, c.ns);
+  if (c.variant == 2) {
+    snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8);
     return buf;
   }
   snprintf(buf, sizeof buf, "conv_igemm_kernel<%s, %d, %d, %d, %d>", c.dtype == DT_F16 ? "_Float16" : "float",

@@ -18,7 +18,9 @@
 
 namespace gtx {
 
-enum DType : int { DT_F16 = 0, DT_F32 = 1 };
+// DT_F32S: fp32 in HBM like DT_F32, convolutions on the fp16 matrix pipe with every operand split into hi + lo
+// fp16 parts (three MFMAs per product, conv_igemm_split.hip). Only the conv kernels distinguish it from DT_F32.
+enum DType : int { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : 4; }
 
 // One convolution problem. Plain-old-data; copied into kernarg space.
@@ -38,8 +40,7 @@ struct ConvProblem {
   int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8)
   int n_ct;             // cout tiles (Cout / BN)
   int block_begin;      // first logical block of this problem inside a grouped launch
-  int in_blocked;       // EXPERIMENT: read the input as [C/16][H][W][16]
-  const void* zero;     // >= 256 B of zeros in HBM (out-of-image patch pixels of the LDS-DMA kernels)
+  float acc_scale;      // DT_F32S: inverse of the power of two the packed weights were scaled by (else 1)
 };
 
 constexpr int kMaxGroup = 8;
@@ -56,9 +57,8 @@ struct ConvConfig {
   int stride;  // 1 or 2
   int bn;      // cout tile: 32, 64 or 128
   int kc;      // cin elements staged per K chunk
-  int variant; // 0 = register-staged kernel (conv_igemm.hip, fp16 + exact fp32), 1 = LDS-DMA ring (conv_igemm2.hip, fp16)
-  int ns;      // variant 1: ring depth
-  int th, tw;  // variant 1: output pixel tile (rows x cols; 1x1 convs: 1 x 256 of the linearised pixel index)
+  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S)
+  int th, tw;  // output pixel tile (rows x cols)
 };
 
 // Picks the tile configuration used for a layer shape.
@@ -66,8 +66,8 @@ struct ConvConfig {
 ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0);
 
 // Host-side weight packing: w is [Cout][KS][KS][Cin] fp32 (OHWI). Returns the packed
-// byte image for `cfg` (element type per cfg.dtype).
-std::vector<uint8_t> pack_conv_weights(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg);
+// byte image for `cfg` (element type per cfg.dtype). acc_scale (may be null) receives ConvProblem::acc_scale.
+std::vector<uint8_t> pack_conv_weights(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale = nullptr);
 
 // Fills tiles_x/tiles_y/n_ct/block_begin/total_blocks for a group.
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg);
@@ -78,8 +78,9 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 // Algorithmic FLOPs (2*MAC) of a problem.
 double conv_flops(const ConvProblem& p, int ks);
 
-// conv_igemm2.hip
-void conv2_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
+// conv_igemm_split.hip
+void conv_split_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
+std::vector<uint8_t> pack_conv_weights_split(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale);
 
 // Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
 const char* conv_kernel_name(const ConvConfig& cfg);

@@ -1,0 +1,357 @@
+// fp32-grade implicit-GEMM Conv(+bias+SiLU[+residual]) on the fp16 matrix pipe: "split-f16x3".
+// gfx950 only. Activations and outputs stay fp32 in HBM (ultralytics.half: false, the reference default,
+// geotrax/cfg/default.yaml:245); every operand is split into two fp16 values when it enters LDS,
+//     x = hi + lo,   hi = fp16(x),   lo = fp16(x - hi)          (x - hi is exact in fp32)
+// and a product w*x is formed by three fp16 MFMAs with fp32 accumulation,
+//     w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi                   (the lo*lo term is < 2^-22 relative)
+// i.e. 22 significand bits per operand instead of fp32's 24, at 3/16 of the cost of the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32 runs at 1/16 of the fp16 rate, MI355X_MICROARCH.md "Matrix cores").
+// Weights are split on the host (pack_conv_weights_split) after an exact per-layer power-of-two scaling that
+// puts max|w| near 2^13, so that w_lo stays in fp16's normal range; the epilogue multiplies the accumulator by
+// the inverse power of two (exact). Activations are not scaled: x_lo is subnormal for |x| < 2^-3, where the
+// absolute error floor 2^-25 is below fp32's own rounding error for |x| >= 0.5. Values beyond +-65504 are
+// clamped when they are split (an fp32 network never gets there after BN + SiLU; the clamp only keeps an
+// out-of-range value from turning into inf - inf).
+//
+// Work decomposition and LDS staging are those of conv_igemm.hip (8x16 output pixels x 32*WN couts per
+// 4-wave workgroup, per K chunk the input patch and the KS*KS weight taps staged once, taps read shifted
+// fragments); an LDS row holds the CPR hi chunks of its 8*CPR channels followed by the CPR lo chunks.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <mutex>
+
+#include "conv_igemm.hpp"
+
+namespace gtx {
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int KS, int STRIDE, int WN, int CPR>
+struct SplitTile {
+  static constexpr int TH = 8, TW = 16;
+  static constexpr int BN = 32 * WN;
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = (TH - 1) * STRIDE + KS;
+  static constexpr int PW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = PH * PW;
+  static constexpr int NCH = 2 * CPR;                // 16-B chunks per LDS row: hi 0..CPR-1, lo CPR..2CPR-1
+  static constexpr int RB = NCH * 16;                // bytes per LDS row (64 or 128)
+  static constexpr int KC = 8 * CPR;                 // input channels per K chunk
+  static constexpr int PATCH_UNITS = NPIX * CPR;     // one unit = 8 channels of one pixel = 32 B of fp32 in HBM
+  static constexpr int PATCH_SLOTS = (PATCH_UNITS + 255) / 256;
+  static constexpr int W_CHUNKS = KS * KS * BN * NCH;
+  static constexpr int W_SLOTS = (W_CHUNKS + 255) / 256;
+  static constexpr int PATCH_BYTES = NPIX * RB;
+  static constexpr int STAGE_BYTES = PATCH_BYTES + KS * KS * BN * RB;
+  static constexpr int EPI_PITCH = BN * 4 + 16;      // fp32 epilogue transpose: bytes per staged pixel row
+  static constexpr int EPI_BYTES = 4 * 32 * EPI_PITCH;
+  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int ROWS_PER_BANKROW = 256 / RB;  // 4 (RB=64) or 2 (RB=128)
+  static __host__ __device__ constexpr int swz(int row) { return (row / ROWS_PER_BANKROW) & (NCH - 1); }
+};
+
+__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+
+// 8 fp32 values (two 16-B loads) -> 8 hi halves + 8 lo halves
+__device__ __forceinline__ void split8(const uint4& a, const uint4& b, uint4& hi, uint4& lo) {
+  const float f[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                      __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+  half8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = __builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
+    const _Float16 hh = (_Float16)x;
+    h[i] = hh;
+    l[i] = (_Float16)(x - (float)hh);
+  }
+  hi = *reinterpret_cast<const uint4*>(&h);
+  lo = *reinterpret_cast<const uint4*>(&l);
+}
+
+template <int KS, int STRIDE, int WN, int CPR>
+constexpr int split_min_waves() {
+  if (KS == 3) return STRIDE == 1 ? 3 : 2;    // stride 2: the 17x33 patch needs 5 prefetch slots of 8 registers
+  return WN == 1 ? 5 : 4;
+}
+
+template <int KS, int STRIDE, int WN, int CPR>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR>()))))
+void conv_igemm_split_kernel(const ConvGroup g) {
+  using Tile = SplitTile<KS, STRIDE, WN, CPR>;
+  constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB, KC = Tile::KC;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_patch = smem;
+  char* lds_w = smem + Tile::PATCH_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L;   // XCD-aware logical block id (conv_igemm.hip)
+  {
+    const int b = blockIdx.x, nb = g.total_blocks;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < g.count && L >= g.p[i].block_begin) pi = i;
+  const ConvProblem& P = g.p[pi];
+
+  const int lb = L - P.block_begin;
+  const int ct = lb % P.n_ct;
+  const int pt = lb / P.n_ct;
+  const int tx = pt % P.tiles_x;
+  const int t2 = pt / P.tiles_x;
+  const int ty = t2 % P.tiles_y;
+  const int n = t2 / P.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;
+
+  const float* __restrict__ in = static_cast<const float*>(P.in);
+  const int nchunks = P.Cin / KC;
+
+  long goff[Tile::PATCH_SLOTS];   // element offset of the unit's 8 floats, -1 = zero fill
+  int loff[Tile::PATCH_SLOTS];    // LDS byte offset of the unit's hi chunk, -1 = slot unused
+  int lchk[Tile::PATCH_SLOTS];    // ... and of its lo chunk
+#pragma unroll
+  for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {
+    const int qid = tid + 256 * s;
+    const int p = qid / CPR, c = qid % CPR;
+    const int py = p / PW, px = p - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool used = qid < Tile::PATCH_UNITS;
+    const bool inb = used && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    goff[s] = inb ? ((long)(n * P.H + iy) * P.W + ix) * P.in_cstride + P.in_coff + c * 8 : -1;
+    loff[s] = used ? p * RB + ((c ^ Tile::swz(p)) << 4) : -1;
+    lchk[s] = used ? p * RB + (((CPR + c) ^ Tile::swz(p)) << 4) : -1;
+  }
+  const uint4* __restrict__ wsrc =
+      reinterpret_cast<const uint4*>(P.wpack) + (size_t)ct * nchunks * Tile::W_CHUNKS + tid;
+
+  uint4 pre_a[Tile::PATCH_SLOTS], pre_b[Tile::PATCH_SLOTS];
+  uint4 pre_w[Tile::W_SLOTS];
+#define GTXS_PREFETCH(CHUNK)                                                                 \
+  {                                                                                          \
+    const int c0__ = (CHUNK) * KC;                                                           \
+    _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
+      uint4 va__ = make_uint4(0, 0, 0, 0), vb__ = make_uint4(0, 0, 0, 0);                    \
+      if (goff[s] >= 0) {                                                                    \
+        const uint4* src__ = reinterpret_cast<const uint4*>(in + goff[s] + c0__);            \
+        va__ = src__[0];                                                                     \
+        vb__ = src__[1];                                                                     \
+      }                                                                                      \
+      pre_a[s] = va__;                                                                       \
+      pre_b[s] = vb__;                                                                       \
+    }                                                                                        \
+    const uint4* w__ = wsrc + (size_t)(CHUNK) * Tile::W_CHUNKS;                              \
+    _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
+      uint4 v__ = make_uint4(0, 0, 0, 0);                                                    \
+      if (Tile::W_CHUNKS % 256 == 0 || tid + 256 * s < Tile::W_CHUNKS) v__ = w__[256 * s];  \
+      pre_w[s] = v__;                                                                        \
+    }                                                                                        \
+  }
+#define GTXS_COMMIT()                                                                        \
+  {                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
+      if (loff[s] >= 0) {                                                                    \
+        uint4 hi__, lo__;                                                                    \
+        split8(pre_a[s], pre_b[s], hi__, lo__);                                              \
+        *reinterpret_cast<uint4*>(lds_patch + loff[s]) = hi__;                               \
+        *reinterpret_cast<uint4*>(lds_patch + lchk[s]) = lo__;                               \
+      }                                                                                      \
+    }                                                                                        \
+    _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
+      if (Tile::W_CHUNKS % 256 == 0 || tid + 256 * s < Tile::W_CHUNKS)                       \
+        *reinterpret_cast<uint4*>(lds_w + (tid + 256 * s) * 16) = pre_w[s];                  \
+    }                                                                                        \
+  }
+
+  const int prow = lane & 31, h = lane >> 5;
+  const int trow = 2 * wave + (prow >> 4), tcol = prow & 15;
+  const int p0 = trow * STRIDE * PW + tcol * STRIDE;
+
+  floatx16 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  GTXS_PREFETCH(0)
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();   // previous chunk's fragment reads are done
+    GTXS_COMMIT()
+    __syncthreads();
+    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
+    // Fragment reads run one (tap, k-step) ahead of the six MFMAs (WN = 2) that consume them.
+    constexpr int NSTEP = KS * KS * (CPR / 2);
+    half8 bh[2], bl[2], ah[2][WN], al[2][WN];
+#define GTXS_LOAD_FRAGS(STEP, SLOT)                                                            \
+    {                                                                                          \
+      const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
+      const int p__ = p0 + (tap__ / KS) * PW + (tap__ % KS);                                   \
+      const int c__ = 2 * ks__ + h;                                                            \
+      const char* pr__ = lds_patch + p__ * RB;                                                 \
+      bh[SLOT] = *reinterpret_cast<const half8*>(pr__ + ((c__ ^ Tile::swz(p__)) << 4));       \
+      bl[SLOT] = *reinterpret_cast<const half8*>(pr__ + (((CPR + c__) ^ Tile::swz(p__)) << 4)); \
+      _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                         \
+        const int nrow__ = 32 * j + prow;                                                      \
+        const char* wr__ = lds_w + (tap__ * BN + nrow__) * RB;                                 \
+        ah[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + ((c__ ^ Tile::swz(nrow__)) << 4)); \
+        al[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + (((CPR + c__) ^ Tile::swz(nrow__)) << 4)); \
+      }                                                                                        \
+    }
+    GTXS_LOAD_FRAGS(0, 0)
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) {
+        if (st & 1) GTXS_LOAD_FRAGS(st + 1, 0) else GTXS_LOAD_FRAGS(st + 1, 1)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        // small terms first, then the leading one
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1], acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GTXS_LOAD_FRAGS
+  }
+
+  // ---- epilogue: acc * 2^-shift + bias -> SiLU (+ residual) -> fp32 NHWC, whole 128-B lines per store ----
+  // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
+  // BN channels through LDS so that a store instruction writes contiguous runs of BN*4 bytes per pixel.
+  const int oy = oy0 + trow, ox = ox0 + tcol;
+  const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
+  const float sc = P.acc_scale;
+  const bool wide = (P.out_cstride % 4) == 0 && (P.out_coff % 4) == 0;
+  if (wide) {
+    constexpr int PITCH = Tile::EPI_PITCH;
+    __syncthreads();
+    char* stg = smem + wave * (32 * PITCH);
+    const bool inside = oy < P.Ho && ox < P.Wo;
+    const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
+    const float* __restrict__ res =
+        (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = 32 * j + 8 * g4 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = fmaf(acc[j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+          if (P.act) v[i] = silu_f(v[i]);
+        }
+        if (res) {
+          const float4 rv = *reinterpret_cast<const float4*>(res + cl);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    constexpr int LPP = BN / 4;                 // lanes per pixel (16 B each)
+    constexpr int PPI = 64 / LPP;               // pixels per store instruction
+#pragma unroll
+    for (int it = 0; it < 32 / PPI; ++it) {
+      const int p = it * PPI + lane / LPP, q = lane % LPP;
+      const int py = oy0 + 2 * wave + (p >> 4), px = ox0 + (p & 15);
+      const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
+      if (py < P.Ho && px < P.Wo) {
+        float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
+        *reinterpret_cast<uint4*>(dst) = val;
+      }
+    }
+  } else if (oy < P.Ho && ox < P.Wo) {
+    const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
+    float* __restrict__ out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
+    const float* __restrict__ res =
+        P.res ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = 32 * j + 8 * g4 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = fmaf(acc[j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+          if (P.act) v = silu_f(v);
+          if (res) v += res[cl + i];
+          out[cl + i] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, int WN, int CPR>
+void launch_t(const ConvGroup& g, hipStream_t stream) {
+  using Tile = SplitTile<KS, STRIDE, WN, CPR>;
+  auto kern = conv_igemm_split_kernel<KS, STRIDE, WN, CPR>;
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+  });
+  hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
+  GTX_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// [cout tile][cin chunk][tap][n][swizzled 16-B chunk: hi chunks, then lo chunks], fp16; *acc_scale = 2^-shift
+std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
+  const int cpr = cfg.kc / 8, nch = 2 * cpr, rb = nch * 16, rpb = 256 / rb, taps = cfg.ks * cfg.ks;
+  const int n_ct = cout / cfg.bn, nchunks = cin / cfg.kc;
+  float wmax = 0.f;
+  const size_t nw = (size_t)cout * taps * cin;
+  for (size_t i = 0; i < nw; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+  int shift = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int e;
+    std::frexp(wmax, &e);          // wmax = m * 2^e, m in [0.5, 1)
+    shift = 14 - e;                // max |w| * 2^shift in [2^13, 2^14)
+    shift = std::max(-100, std::min(100, shift));
+  }
+  const float up = std::ldexp(1.f, shift);
+  *acc_scale = std::ldexp(1.f, -shift);
+  std::vector<uint8_t> out((size_t)cout * taps * cin * 4);
+  for (int ct = 0; ct < n_ct; ++ct)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int n = 0; n < cfg.bn; ++n) {
+          const int sw = (n / rpb) & (nch - 1);
+          const size_t row16 = ((((size_t)ct * nchunks + ch) * taps + tap) * cfg.bn + n) * nch;
+          for (int c = 0; c < cpr; ++c)
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * cfg.kc + c * 8 + e;
+              const float v = w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] * up;   // exact (power of two)
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              memcpy(&out[(row16 + (size_t)(c ^ sw)) * 16 + e * 2], &hi, 2);
+              memcpy(&out[(row16 + (size_t)((cpr + c) ^ sw)) * 16 + e * 2], &lo, 2);
+            }
+        }
+  return out;
+}
+
+void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
+  const int cpr = c.kc / 8, wn = c.bn / 32;
+#define GTX_CASE(KS, ST, WN, CPR) \
+  if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR) return launch_t<KS, ST, WN, CPR>(g, s);
+  GTX_CASE(3, 1, 1, 2) GTX_CASE(3, 1, 2, 2) GTX_CASE(3, 2, 1, 2) GTX_CASE(3, 2, 2, 2)
+  GTX_CASE(1, 1, 1, 4) GTX_CASE(1, 1, 2, 4) GTX_CASE(1, 1, 1, 2) GTX_CASE(1, 1, 2, 2)
+#undef GTX_CASE
+  fail(-3, "conv (split-f16x3): no kernel for ks=%d stride=%d bn=%d kc=%d", c.ks, c.stride, c.bn, c.kc);
+}
+
+}  // namespace gtx

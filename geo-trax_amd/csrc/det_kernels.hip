@@ -2,6 +2,8 @@
 // oracle/yolov8_ref.py (the checker); the third-party calls they stand in for are listed in
 // SURVEY.md §2b (K2 preprocess, K3 stem/SPPF/upsample, K4 decode + NMS).
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <hip/hip_fp16.h>
 
 #include <cmath>
@@ -648,12 +650,11 @@ void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuf
   GTX_HIP(hipGetLastError());
   dim3 grid2(64, n);
   const size_t lds = (size_t)hp.n_levels * hp.lv[0].cb * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag once;     // detectors run on several host threads (engine stage 1, set_reference)
+  std::call_once(once, [] {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_boxes_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 64 * 4));
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_boxes_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 64 * 4));
-    attr_set = true;
-  }
+  });
   if (dtype == DT_F16) hipLaunchKernelGGL(head_boxes_kernel<_Float16>, grid2, block, lds, s, hp, nb);
   else hipLaunchKernelGGL(head_boxes_kernel<float>, grid2, block, lds, s, hp, nb);
   GTX_HIP(hipGetLastError());

@@ -14,6 +14,7 @@ Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cf
   GTX_CHECK(cfg.frame_h > 0 && cfg.frame_w > 0, "frame size must be given");
   if (cfg_.max_batch < 1) cfg_.max_batch = 1;
   dtype_ = cfg.half ? DT_F16 : DT_F32;
+  conv_dtype_ = (!cfg.half && cfg.fp32_split) ? DT_F32S : dtype_;
   es_ = dtype_size(dtype_);
   lb_ = letterbox_geometry(cfg.frame_h, cfg.frame_w, cfg.imgsz, cfg.rect != 0, 32);
   GTX_CHECK(lb_.net_h % 32 == 0 && lb_.net_w % 32 == 0, "network input %dx%d is not stride aligned", lb_.net_h, lb_.net_w);
@@ -99,9 +100,10 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(dtype_, ks, stride, cin, cout, force_kc_);
+  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_);
   const std::vector<float> ohwi = to_ohwi(w);
-  const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg);
+  float acc_scale = 1.f;
+  const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &acc_scale);
   void* dw = alloc(packed.size());
   GTX_HIP(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
   float* db = nullptr;
@@ -120,6 +122,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   p.res_cstride = residual ? residual->cstride : 0;
   p.res_coff = residual ? residual->coff : 0;
   p.act = act ? 1 : 0;
+  p.acc_scale = acc_scale;
   op.grp.count = 1;
   op.family = conv_kernel_name(op.cfg);
   ops_.push_back(op);
@@ -286,7 +289,7 @@ void Detector::build_graph() {
     bs.data.insert(bs.data.end(), b30.begin(), b30.end());
     tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
     const size_t mark = ops_.size();
-    force_kc_ = dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
+    force_kc_ = conv_dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
     View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
     View h2 = new_view(h1.h, h1.w, cb + cc);
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
@@ -300,7 +303,7 @@ void Detector::build_graph() {
     if (l == 0) { st1.cfg = o1.cfg; st2.cfg = o2.cfg; }
     auto same = [](const ConvConfig& a, const ConvConfig& b) {
       return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc &&
-             a.variant == b.variant && a.ns == b.ns && a.th == b.th && a.tw == b.tw;
+             a.variant == b.variant && a.th == b.th && a.tw == b.tw;
     };
     GTX_CHECK(same(st1.cfg, o1.cfg) && same(st2.cfg, o2.cfg) && same(st2.cfg, o3.cfg),
               "Detect level %d does not share a kernel configuration with level 0", l);
@@ -459,6 +462,8 @@ void Detector::set_trace(int every_n) {
   }
   trace_ms_.assign(ops_.size(), 0.0);
   trace_n_.assign(ops_.size(), 0);
+  trace_flops_.assign(ops_.size(), 0.0);
+  trace_bytes_.assign(ops_.size(), 0.0);
 }
 
 void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
@@ -478,11 +483,13 @@ void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& l
     }
     launches[k] += trace_n_[i];
     ms[k] += (float)trace_ms_[i];
-    flops[k] += ops_[i].flops * trace_n_[i];     // ops_[i].flops is for the current batch size
-    bytes[k] += ops_[i].bytes * trace_n_[i];
+    flops[k] += trace_flops_[i];
+    bytes[k] += trace_bytes_[i];
   }
   trace_ms_.assign(ops_.size(), 0.0);
   trace_n_.assign(ops_.size(), 0);
+  trace_flops_.assign(ops_.size(), 0.0);
+  trace_bytes_.assign(ops_.size(), 0.0);
 }
 
 void Detector::run_post(int nb, hipStream_t s) {
@@ -531,6 +538,8 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
       GTX_HIP(hipEventElapsedTime(&t, trace_ev_[i], trace_ev_[i + 1]));
       trace_ms_[i] += t;
       trace_n_[i] += 1;
+      trace_flops_[i] += ops_[i].flops;          // of THIS pass's batch size (set_batch ran in submit_dev)
+      trace_bytes_[i] += ops_[i].bytes;
     }
     flight_traced_ = false;
   }

@@ -103,7 +103,8 @@ class Detector {
 
   gtx_ctx* ctx_;
   gtx_det_config cfg_;
-  int dtype_;
+  int dtype_;                // activation type in HBM (DT_F16 / DT_F32)
+  int conv_dtype_;           // what the conv kernels compute in (dtype_, or DT_F32S: split-f16x3 on fp32 activations)
   size_t es_;
   Letterbox lb_{};
   std::map<std::string, HostTensor> tensors_;
@@ -137,6 +138,7 @@ class Detector {
   std::vector<hipEvent_t> trace_ev_;      // one per op + 1
   std::vector<double> trace_ms_;          // per op
   std::vector<int> trace_n_;
+  std::vector<double> trace_flops_, trace_bytes_;   // per op, summed over the traced passes (each at its own batch size)
   hipEvent_t ev_up_[2]{};
 };
 

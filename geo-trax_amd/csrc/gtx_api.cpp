@@ -139,7 +139,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   using namespace gtx;
   need(ctx, "ctx"); need(d, "desc");
   GTX_HIP(hipSetDevice(ctx->device));
-  if (d->dtype != GTX_F16 && d->dtype != GTX_F32) fail(GTX_ERR_INVALID, "bad dtype %d", d->dtype);
+  if (d->dtype != GTX_F16 && d->dtype != GTX_F32 && d->dtype != GTX_F32S) fail(GTX_ERR_INVALID, "bad dtype %d", d->dtype);
   const size_t es = dtype_size(d->dtype);
   const int pad = d->ksize / 2;
   st.ho = (d->h + 2 * pad - d->ksize) / d->stride + 1;
@@ -157,8 +157,9 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   else GTX_HIP(hipMemset(st.x.p, 0, xin));
   if (y_init) GTX_HIP(hipMemcpy(st.y.p, y_init, yout, hipMemcpyHostToDevice));
   std::vector<uint8_t> packed;
+  float acc_scale = 1.f;
   if (w) {
-    packed = pack_conv_weights(w, d->cout, d->cin, st.cfg);
+    packed = pack_conv_weights(w, d->cout, d->cin, st.cfg, &acc_scale);
   } else {
     packed.assign((size_t)d->cout * d->cin * d->ksize * d->ksize * es, 0);
   }
@@ -183,6 +184,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.out_cstride = d->out_cstride; p.out_coff = d->out_coff;
   p.res_cstride = d->cout; p.res_coff = 0;
   p.act = d->act;
+  p.acc_scale = acc_scale;
   st.g.count = 1;
   conv_group_finalize(st.g, st.cfg);
 }

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import ConvDesc, check, ptr
 
-GTX_F16, GTX_F32 = 0, 1
+GTX_F16, GTX_F32, GTX_F32S = 0, 1, 2
 
 
 def _dt(a: np.ndarray) -> int:
@@ -25,9 +25,10 @@ def _dt(a: np.ndarray) -> int:
 
 def conv2d(x: np.ndarray, w_ohwi: np.ndarray, bias: np.ndarray | None = None, *, stride: int = 1,
            act: bool = True, residual: np.ndarray | None = None, in_coff: int = 0, cin: int | None = None,
-           out: np.ndarray | None = None, out_coff: int = 0, ctx: _lib.Context | None = None) -> np.ndarray:
+           out: np.ndarray | None = None, out_coff: int = 0, split: bool = False, ctx: _lib.Context | None = None) -> np.ndarray:
     """act(conv2d(x[..., in_coff:in_coff+cin], w) + b) (+ residual), written into
-    out[..., out_coff:out_coff+cout]. x: [n,h,w,cs]; w_ohwi: [cout,k,k,cin] fp32."""
+    out[..., out_coff:out_coff+cout]. x: [n,h,w,cs]; w_ohwi: [cout,k,k,cin] fp32. split=True (float32 arrays only):
+    the split-f16x3 kernel (GTX_F32S) instead of the exact-fp32 MFMA."""
     ctx = ctx or _lib.default_context()
     x = np.ascontiguousarray(x)
     w = np.ascontiguousarray(w_ohwi, dtype=np.float32)
@@ -41,7 +42,9 @@ def conv2d(x: np.ndarray, w_ohwi: np.ndarray, bias: np.ndarray | None = None, *,
         out = np.zeros((n, ho, wo, cout), dtype=x.dtype)
     out = np.ascontiguousarray(out)
     assert out.shape[:3] == (n, ho, wo) and out.dtype == x.dtype
-    d = ConvDesc(dtype=_dt(x), n=n, h=h, w=wd, cin=cin, cout=cout, ksize=k, stride=stride, act=int(act),
+    if split and x.dtype != np.float32:
+        raise TypeError("split=True needs float32 activations")
+    d = ConvDesc(dtype=GTX_F32S if split else _dt(x), n=n, h=h, w=wd, cin=cin, cout=cout, ksize=k, stride=stride, act=int(act),
                  in_cstride=cs, in_coff=in_coff, out_cstride=out.shape[3], out_coff=out_coff,
                  has_residual=int(residual is not None))
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)

@@ -44,7 +44,9 @@ typedef enum gtx_status {
   GTX_ERR_INTERNAL = -5
 } gtx_status;
 
-typedef enum gtx_dtype { GTX_F16 = 0, GTX_F32 = 1 } gtx_dtype;
+/* GTX_F32S (gtx_op_conv2d only): fp32 arrays like GTX_F32, the convolution runs as split-f16x3 (hi + lo fp16
+ * operands, three fp16 MFMAs per product, fp32 accumulate) -- what a detector with fp32_split = 1 uses. */
+typedef enum gtx_dtype { GTX_F16 = 0, GTX_F32 = 1, GTX_F32S = 2 } gtx_dtype;
 
 typedef struct gtx_ctx gtx_ctx;
 typedef struct gtx_detector gtx_detector;
@@ -142,6 +144,10 @@ typedef struct gtx_det_config {
   int classes[80];
   int max_batch;    /* frames per forward pass the buffers are sized for (>=1) */
   int frame_h, frame_w; /* source frame size the buffers are sized for */
+  int fp32_split;   /* half == 0 only. 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). 1: "split-f16x3" -- fp32
+                     * activations in HBM, every conv operand split into hi + lo fp16 parts in LDS, three fp16
+                     * MFMAs per product with fp32 accumulation (22 significand bits per operand; same
+                     * detections as the exact path within the fp32 tolerance, ~3/16 of its matrix cost) */
 } gtx_det_config;
 
 int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out);

@@ -289,17 +289,19 @@ def detect(model: YoloV8Ref, frame_bgr: np.ndarray, imgsz: int, rect: bool, conf
 def conv2d_nhwc(x: np.ndarray, w_ohwi: np.ndarray, bias=None, stride: int = 1, act: bool = True,
                 residual=None) -> np.ndarray:
     """ultralytics Conv.forward_fuse on NHWC data, computed in fp32 with torch (the checker for
-    gtx_op_conv2d). x may be fp16: it is widened exactly, the result is returned as fp32."""
-    xt = torch.from_numpy(np.ascontiguousarray(x.astype(np.float32))).permute(0, 3, 1, 2)
-    wt = torch.from_numpy(np.ascontiguousarray(w_ohwi.astype(np.float32))).permute(0, 3, 1, 2)
-    bt = None if bias is None else torch.from_numpy(np.asarray(bias, dtype=np.float32))
+    gtx_op_conv2d). x may be fp16: it is widened exactly, the result is returned as fp32. float64 inputs are
+    computed and returned in float64 (the yardstick for the fp32-grade kernels' own rounding error)."""
+    dt = np.float64 if x.dtype == np.float64 else np.float32
+    xt = torch.from_numpy(np.ascontiguousarray(x.astype(dt))).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(np.ascontiguousarray(w_ohwi.astype(dt))).permute(0, 3, 1, 2)
+    bt = None if bias is None else torch.from_numpy(np.asarray(bias, dtype=dt))
     with torch.no_grad():
         y = F.conv2d(xt, wt, bt, stride=stride, padding=w_ohwi.shape[1] // 2)
         if act:
             y = F.silu(y)
         y = y.permute(0, 2, 3, 1)
         if residual is not None:
-            y = y + torch.from_numpy(residual.astype(np.float32))
+            y = y + torch.from_numpy(residual.astype(dt))
     return y.contiguous().numpy()
 
 

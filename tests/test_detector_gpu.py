@@ -31,14 +31,18 @@ LAYERS = ["model.0.conv", "model.1.conv", "model.2", "model.3.conv", "model.4", 
           "model.12", "model.15", "model.18", "model.21", "model.22.feat0", "model.22.feat1", "model.22.feat2"]
 
 
-@pytest.mark.parametrize("half,rect,imgsz", [(False, False, 384), (True, False, 384), (False, True, 384), (True, True, 384)])
-def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz):
+@pytest.mark.parametrize("half,rect,imgsz,split", [(False, False, 384, False), (True, False, 384, False), (False, True, 384, False),
+                                                   (True, True, 384, False), (False, False, 384, True), (False, True, 384, True)])
+def test_detector_matches_oracle(gtx_ctx, weights, half, rect, imgsz, split):
+    """split=True: the fp32-grade path on the fp16 matrix pipe (split-f16x3) under the SAME assertions as the
+    exact-fp32 MFMA path: per-layer 2e-4 relative-to-max, identical detections in identical order."""
     from geotrax_amd.detector import Detector
     from oracle.yolov8_ref import YoloV8Ref, detect, letterbox
 
     frame = _frame(0)
     kw = dict(conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True)
-    det = Detector(weights, FRAME_HW, imgsz=imgsz, half=half, rect=rect, ctx=gtx_ctx, **kw)
+    det = Detector(weights, FRAME_HW, imgsz=imgsz, half=half, rect=rect, fp32_split=split, ctx=gtx_ctx, **kw)
+    assert det.fp32_split == split
     got = det.detect(frame)
 
     ref_model = YoloV8Ref(weights, emulate_half=half)
@@ -101,14 +105,14 @@ def test_many_candidates_take_the_general_nms_path(gtx_ctx, weights):
 
     frame = _frame(1, (640, 640))
     ref_model = YoloV8Ref(weights)
-    probe = Detector(weights, (640, 640), imgsz=640, half=False, rect=False, conf=0.5, ctx=gtx_ctx)
+    probe = Detector(weights, (640, 640), imgsz=640, half=False, rect=False, conf=0.5, fp32_split=False, ctx=gtx_ctx)
     probe.detect(frame)
     top = np.sort(probe.raw_output()[:, 4:].max(1))[::-1]
     probe.close()
     conf_small = float(top[600])      # ~600 candidates: non-agnostic NMS on the single-workgroup path
-    for agnostic, conf in ((True, 0.02), (False, 0.02), (False, conf_small)):
+    for agnostic, conf, split in ((True, 0.02, False), (False, 0.02, False), (False, conf_small, False), (True, 0.02, True)):
         det = Detector(weights, (640, 640), imgsz=640, half=False, rect=False, conf=conf, iou=0.6, max_det=300,
-                       classes=[0, 1, 3], agnostic_nms=agnostic, ctx=gtx_ctx)
+                       classes=[0, 1, 3], agnostic_nms=agnostic, fp32_split=split, ctx=gtx_ctx)
         got = det.detect(frame)
         n_cand = int((det.raw_output()[:, 4:].max(1) > conf).sum())
         assert (n_cand > 4096) == (conf < 0.1), n_cand

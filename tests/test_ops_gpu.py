@@ -51,6 +51,57 @@ def test_conv2d_matches_oracle(gtx_ctx, dtype, case):
     np.testing.assert_allclose(got.astype(np.float32), ref, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_split_f16x3_meets_the_fp32_bar(gtx_ctx, case):
+    """The split-f16x3 convolution (fp32 arrays, operands split into hi + lo fp16 parts, three fp16 MFMAs per
+    product) against the float64 oracle: its error must be of the order of the exact-fp32 kernel's own (both
+    far inside BASELINE.md section 5's 1e-4 relative bar for the fp32 path), on wide-range data: activations
+    over five decades including values whose lo part is an fp16 subnormal, weights up to +-8."""
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import conv2d_nhwc
+
+    cin, cout, k, stride, h, w = case
+    rng = np.random.default_rng(hash(case) % 2**32 + 1)
+    x = (rng.standard_normal((2, h, w, cin)) * 10.0 ** rng.uniform(-4, 1, (2, h, w, cin))).astype(np.float32)
+    wt = (rng.standard_normal((cout, k, k, cin)) / np.sqrt(cin * k * k)).astype(np.float32)
+    wt[rng.integers(0, cout), :, :, rng.integers(0, cin)] *= 60.0          # a few large taps set the layer's power-of-two scale
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    ref64 = conv2d_nhwc(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), stride=stride, act=False)
+    exact = ops.conv2d(x, wt, b, stride=stride, act=False, ctx=gtx_ctx)
+    split = ops.conv2d(x, wt, b, stride=stride, act=False, split=True, ctx=gtx_ctx)
+    scale = np.abs(ref64).max()
+    e_exact, e_split = np.abs(exact - ref64).max() / scale, np.abs(split - ref64).max() / scale
+    assert e_split < 2e-6, (e_split, e_exact)                     # 50x inside the 1e-4 bar
+    assert e_split < 8 * e_exact + 1e-7, (e_split, e_exact)       # same order as the exact-fp32 MFMA's summation error
+    got = ops.conv2d(x, wt, b, stride=stride, act=True, split=True, ctx=gtx_ctx)
+    np.testing.assert_allclose(got, conv2d_nhwc(x, wt, b, stride=stride, act=True), rtol=2e-4, atol=2e-4)
+
+
+def test_conv2d_split_slices_residual_and_exact_integers(gtx_ctx):
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import conv2d_nhwc
+
+    rng = np.random.default_rng(7)
+    buf = _rand(rng, (1, 19, 27, 96), np.float32)
+    wt = (rng.standard_normal((32, 3, 3, 32)) / 17).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32) * 0.1
+    res = np.ascontiguousarray(buf[..., 32:64])
+    got = ops.conv2d(buf, wt, b, in_coff=32, cin=32, out=buf.copy(), out_coff=64, residual=res, split=True, ctx=gtx_ctx)
+    np.testing.assert_allclose(got[..., 64:96], conv2d_nhwc(buf[..., 32:64], wt, b, residual=res), rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(got[..., :64], buf[..., :64])
+    # small integers: hi parts carry everything, lo parts are zero, every partial sum is exact
+    for (cin, cout, k, s) in [(32, 64, 3, 1), (64, 32, 3, 2), (128, 64, 1, 1), (48, 32, 1, 1)]:
+        x = rng.integers(-3, 4, (1, 21, 35, cin)).astype(np.float32)
+        wi = rng.integers(-2, 3, (cout, k, k, cin)).astype(np.float32)
+        bi = rng.integers(-4, 5, cout).astype(np.float32)
+        np.testing.assert_array_equal(ops.conv2d(x, wi, bi, stride=s, act=False, split=True, ctx=gtx_ctx),
+                                      conv2d_nhwc(x, wi, bi, stride=s, act=False))
+    # out-of-range activations are clamped when split, never NaN
+    x = np.full((1, 8, 16, 32), 1e6, np.float32)
+    y = ops.conv2d(x, np.ones((32, 1, 1, 32), np.float32), None, act=False, split=True, ctx=gtx_ctx)
+    assert np.isfinite(y).all()
+
+
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
 def test_conv2d_slices_residual_identity(gtx_ctx, dtype):
     """Channel-slice input, channel-slice output (concat buffer untouched elsewhere), residual

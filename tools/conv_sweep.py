@@ -1,6 +1,7 @@
 """Per-layer timing of the YOLOv8s convolution shapes at a given input size and batch, each layer alone on the GPU
-(gtx_op_conv2d_time: HIP events around 20 back-to-back launches). Usage: python tools/conv_sweep.py [imgsz] [batch] [k3s1|k1|k3s2]
-Output committed as profiles/r01_conv_layer_sweep_b<batch>.txt."""
+(gtx_op_conv2d_time: HIP events around 20 back-to-back launches).
+Usage: python tools/conv_sweep.py [imgsz] [batch] [all|k3s1|k1|k3s2] [f16|f32|f32s ...]   (f32s = split-f16x3)
+Output committed as profiles/rNN_conv_layer_sweep_<dtype>_b<batch>.txt."""
 import sys
 import os
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +11,9 @@ from geotrax_amd import _lib, ops
 ctx=_lib.default_context(0)
 S=int(sys.argv[1]) if len(sys.argv)>1 else 1920
 NB=int(sys.argv[2]) if len(sys.argv)>2 else 1
-ONLY=sys.argv[3] if len(sys.argv)>3 else ''
+ONLY=sys.argv[3] if len(sys.argv)>3 and sys.argv[3]!='all' else ''
+DTS=[a for a in sys.argv[4:]] or ['f16']
+DTID={'f16':0,'f32':1,'f32s':2}
 HW={2:S//2,4:S//4,8:S//8,16:S//16,32:S//32}
 # (name, cin, cout, k, stride, input-level-stride)
 L=[("m1",32,64,3,2,2),("m2.cv1",64,64,1,1,4),("m2.m",32,32,3,1,4),("m2.cv2",96,64,1,1,4),("m3",64,128,3,2,4),
@@ -20,7 +23,7 @@ L=[("m1",32,64,3,2,2),("m2.cv1",64,64,1,1,4),("m2.m",32,32,3,1,4),("m2.cv2",96,6
    ("m12.cv1",768,256,1,1,16),("m12.cv2",384,256,1,1,16),("m15.cv1",384,128,1,1,8),("m15.cv2",192,128,1,1,8),
    ("m16",128,128,3,2,8),("m18.cv1",384,256,1,1,16),("m19",256,256,3,2,16),("m21.cv1",768,512,1,1,32),
    ("h0.s1",128,192,3,1,8),("h1.s1",256,192,3,1,16),("h2.s1",512,192,3,1,32),("h0.s2c",128,128,3,1,8),("h0.s2b",64,64,3,1,8)]
-for dt,name in ((0,"f16"),):
+for dt,name in [(DTID[d],d) for d in DTS]:
     tot=0;totf=0
     for (nm,cin,cout,k,s,lv) in L:
         h=HW[lv]
