@@ -41,8 +41,14 @@ import numpy as np  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec; dense MFMA peaks ~2.5 PF fp16/bf16, 157.3 TF fp32
 HBM_PEAK_GBS = 8000.0
-MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}
+# "f32s" = fp32 activations, convolutions as split-f16x3 (three fp16 MFMAs per product): a useful FLOP costs three
+# fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is the dense fp16 peak / 3
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0 / 3.0}
+DTYPE_NAME = {"f16": "f16", "f32": "f32", "f32s": "f32 (split-f16x3 MFMA)"}
 H, W = 2160, 3840
+# seeded weights of the bench: only the stride-8 head fires, DFL biases give ~120 x 60 px boxes in 4K, and the class
+# branch is spatially smooth so that candidates come in clusters and NMS suppresses about half of them
+SYNTH_KW = dict(seed=0, nc=4, scale="s", level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002, smooth_cls=True, box_decay=(0.2, 0.3, 0.2, 0.3))
 
 
 def parse():
@@ -54,13 +60,15 @@ def parse():
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
                          "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
                          "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres)")
-    ap.add_argument("--half", type=int, default=1, help="ultralytics.half: 1 = fp16 activations + fp16 MFMA, 0 = fp32 activations (reference default)")
+    ap.add_argument("--half", type=int, default=0, help="ultralytics.half: 0 = fp32 activations (the reference default, default.yaml:245), 1 = fp16 activations + fp16 MFMA")
+    ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary fp16 measurement (N = 1, --half 0 runs add a shorter --half 1 pass and report it under 'f16')")
     ap.add_argument("--fp32", default=None, choices=["exact", "split"],
                     help="--half 0 only: exact = v_mfma_f32_32x32x2_f32; split = split-f16x3 (hi+lo fp16 operands, 3 fp16 MFMAs per product, "
                          "fp32 accumulate). Default: the library's default (geotrax_amd.detector.FP32_SPLIT_DEFAULT)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
-    ap.add_argument("--tracker", default="bytetrack", choices=["bytetrack", "botsort"])
+    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort"],
+                    help="default: bytetrack at N = 1 (BASELINE configs[2]), botsort at N > 1 (configs[4]; the reference's own default, default.yaml:362)")
     ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
     ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")
     ap.add_argument("--stab-streams", type=int, default=4, help="stabilizer instances (own HIP stream each) working on consecutive frames")
@@ -96,7 +104,7 @@ def calibrated_detector(ctx, frame, args, target):
 
     kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
               half=bool(args.half), fp32_split=fp32_split(args), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
-    base = synthetic_yolov8(seed=0, nc=4, scale="s", level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002)   # vehicle-sized boxes from the stride-8 head
+    base = synthetic_yolov8(**SYNTH_KW)   # vehicle-sized boxes from the stride-8 head, candidates in clusters
     det = Detector(base, (H, W), **kw)
     det.detect(frame)
     logits = det.raw_output(logits=True)[:, 4:]
@@ -121,7 +129,7 @@ def pmc_traffic(kernel, batch):
     written by tools/pmc_summary.py from two rocprofv3 --pmc runs of this command: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950, plus WRITE_SIZE), or None when
     no summary for this batch size is present."""
-    f = ROOT / "profiles" / "r01_pmc_traffic.json"
+    f = ROOT / "profiles" / "r02_pmc_traffic.json"
     try:
         rec = json.loads(f.read_text())
         if rec.get("batch") != batch:
@@ -266,6 +274,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.tracker is None:
+        args.tracker = "botsort" if world > 1 else "bytetrack"
     dist = None
     force_dist = os.environ.get("GTX_BENCH_FORCE_DIST") == "1"   # test hook: the N > 1 code path with one rank
     if world > 1 or force_dist:
@@ -300,7 +310,7 @@ def main():
         from geotrax_amd.detector import Detector
         from geotrax_amd.weights import synthetic_yolov8
 
-        template = synthetic_yolov8(seed=0, nc=4, scale="s", level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002)
+        template = synthetic_yolov8(**SYNTH_KW)
         names = sorted(template)
         meta = torch.zeros(2, dtype=torch.int64)
         if rank == 0:
@@ -475,16 +485,20 @@ def main():
     barrier()
 
     if rank == 0:
-        dt = "f16" if args.half else "f32"
+        dt = "f16" if args.half else ("f32s" if det.fp32_split else "f32")
         out = {
             "metric": "4K frames/sec through detect+stabilize+track", "value": args.steps * B * world / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic",
             "config": {
                 "workload": ("full extract: YOLOv8s + ByteTrack + homography stabilization on 3840x2160 frames, "
                              f"{B} frame(s) per step (BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
                              f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
+                "arithmetic": {"f16": "fp16 activations and weights, fp16 MFMA, fp32 accumulate",
+                               "f32": "fp32 activations, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                               "f32s": "fp32 activations in HBM; conv operands split into hi+lo fp16 parts, three fp16 MFMAs per product, fp32 accumulate "
+                                       "(22 significand bits per operand; passes the fp32 parity assertions of tests/test_detector_gpu.py unchanged)"}[dt],
                 "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
@@ -519,11 +533,15 @@ def main():
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                    "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_PEAK_TFLOPS[dt]),
                                    "traffic": pmc_traffic(top["kernel"], B),
+                                   "traffic_source": "profiles/r02_pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                                     "(tools/collect_profiles.sh), NOT measured in this run; null when no pass for this kernel and batch is committed",
                                    "avg_launch_us": 1000.0 * top["total_ms"] / top["launches"],
                                    "launches_timed": top["launches"],
                                    "flops_per_launch": top["flops"] / top["launches"], "bytes_per_launch": top["bytes"] / top["launches"],
                                    "intensity_flop_per_byte": top["flops"] / max(top["bytes"], 1.0), "machine_balance": balance,
                                    "tflops": tflops, "algo_gbs": gbs,
+                                   "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per useful product" if dt == "f32s" else
+                                                 "MI355X_MICROARCH.md: dense MFMA peak of the arithmetic type; HBM3E 8 TB/s"),
                                    "timing": f"HIP events around every launch of every {args.trace_every}th pass inside the timed region "
                                              "(durations include the time a launch shares the GPU with the other streams)"}
                 out["kernels"] = [{"kernel": d["kernel"], "launches_timed": d["launches"],
@@ -531,6 +549,27 @@ def main():
                                    "tflops": (d["flops"] / (d["total_ms"] * 1e-3) / 1e12) if d["total_ms"] > 0 else 0.0,
                                    "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                                   for d in fam]
+        if world == 1 and dist is None and not args.half and not args.no_f16_line:
+            # secondary key: the same workload with ultralytics.half = true (a legitimate reference knob, not its default)
+            engine.close()
+            kw16 = dict(det_kw, half=True)
+            e16 = ExtractEngine(weights, (H, W), kw16, Tracker(args.tracker) if extract else None, stab_kw, device=local, batch=B,
+                                det_streams=args.det_streams, stab_streams=args.stab_streams, gmc=extract and args.tracker == "botsort")
+            if extract:
+                e16.set_reference(ref_frame)
+            n16 = max(args.steps // 2, 10)
+            for _ in e16.run(batch_ptr(k) for k in range(min(args.warmup, 10))):
+                pass
+            e16.reset(keep_reference=True)
+            ctx.synchronize()
+            t16 = time.perf_counter()
+            for _ in e16.run(batch_ptr(args.warmup + k) for k in range(n16)):
+                pass
+            ctx.synchronize()
+            t16 = time.perf_counter() - t16
+            out["f16"] = {"value": n16 * B / t16, "unit": "frames/s", "steps": n16, "ms_per_step": 1000.0 * t16 / n16, "dtype": "f16",
+                          "note": "same workload, weights and pipeline with ultralytics.half = true (fp16 activations, fp16 MFMA); secondary, not `value`"}
+            e16.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args)
         print(json.dumps(out), flush=True)

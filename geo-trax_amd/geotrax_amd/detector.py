@@ -18,7 +18,7 @@ from ._lib import DetConfig, check, ptr
 
 
 # which fp32-grade convolution a half=False detector uses unless told otherwise (see Detector.__init__)
-FP32_SPLIT_DEFAULT = False
+FP32_SPLIT_DEFAULT = True
 
 
 @dataclass

@@ -112,8 +112,8 @@ def yolov8_layer_specs(scale: str = "s", nc: int = 4) -> list[tuple[str, tuple[i
 
 
 def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: float = -4.0,
-                     gain: float = 1.7, box_decay: float = 0.3, level_bias: tuple = (0.0, 0.0, 0.0),
-                     box_weight_scale: float = 0.3) -> dict[str, np.ndarray]:
+                     gain: float = 1.7, box_decay: float | tuple = 0.3, level_bias: tuple = (0.0, 0.0, 0.0),
+                     box_weight_scale: float = 0.3, smooth_cls: bool = False) -> dict[str, np.ndarray]:
     """Seeded random fused weights of the YOLOv8 architecture (no checkpoint is reachable here).
 
     Conv weights ~ N(0, gain^2 / fan_in) so activations keep O(1) scale through the SiLU stack;
@@ -128,19 +128,28 @@ def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: flo
     the regime of drone footage: ``level_bias`` is added to the class logits of the stride-8/16/32 heads
     ((0, -1e4, -1e4): only stride-8 anchors can fire) and ``box_weight_scale`` scales the last box conv's weights
     (0.002: the decaying bias decides, every side is ~2.9 bins -> boxes of ~46 network pixels, ~90 px in 4K, few
-    of which overlap)."""
+    of which overlap). ``box_decay`` may be a 4-tuple (left, top, right, bottom) for non-square boxes.
+    ``smooth_cls`` makes the two 3x3 convs of every class branch and those of the stride-8 neck stage (model.15)
+    tap-uniform (each output channel applies one random channel mix to the 3x3 box mean of its input): class logits
+    then vary smoothly over neighbouring anchors, so the
+    anchors that clear the confidence threshold come in clusters of several per object and NMS has boxes to
+    suppress -- the load SURVEY.md 8d.2 asks for (1-3 k candidates in ~132 clusters) instead of isolated ones."""
     rng = np.random.default_rng(seed)
+    decay = np.broadcast_to(np.asarray(box_decay, dtype=np.float64), (4,))
     t: dict[str, np.ndarray] = {}
     for name, shape, has_act in yolov8_layer_specs(scale, nc):
         fan_in = shape[1] * shape[2] * shape[3]
         g = gain if has_act else 1.0
         t[name + ".weight"] = (rng.standard_normal(shape) * (g / np.sqrt(fan_in))).astype(np.float32)
+        if smooth_cls and shape[2] == 3 and (".cv3." in name or name.startswith("model.15.m.")):
+            mix = t[name + ".weight"][:, :, 1:2, 1:2] * np.float32(np.sqrt(shape[2] * shape[3]))   # keeps the output variance for smooth inputs
+            t[name + ".weight"] = np.broadcast_to(mix / np.float32(shape[2] * shape[3]), shape).astype(np.float32).copy()
         b = rng.standard_normal(shape[0]) * 0.05
         if name.endswith("cv3.0.2") or name.endswith("cv3.1.2") or name.endswith("cv3.2.2"):
             b = b + cls_bias + float(level_bias[int(name.split(".")[3])])
         if ".cv2." in name and name.endswith(".2"):
             t[name + ".weight"] *= np.float32(box_weight_scale)
-            b = b - box_decay * np.tile(np.arange(16), 4)
+            b = b - np.repeat(decay, 16) * np.tile(np.arange(16), 4)
         t[name + ".bias"] = b.astype(np.float32)
     return t
 

@@ -29,6 +29,11 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["value"] > 100 and d["unit"] == "frames/s" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the default line is the reference's own precision (ultralytics.half: false, default.yaml:245); fp16 rides along
+    assert d["dtype"].startswith("f32") and d["config"]["half"] is False
+    assert d["f16"]["dtype"] == "f16" and d["f16"]["value"] > d["value"]
+    # NMS sees clustered candidates: more candidates than detections in the calibration frame
+    assert d["config"]["candidates_per_frame"] > 1.3 * d["config"]["detections_per_frame"]
 
 
 @pytest.mark.parametrize("mode,tracker", [("frames", "bytetrack"), ("frames", "botsort"), ("videos", "bytetrack")])

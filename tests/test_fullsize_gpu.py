@@ -1,4 +1,5 @@
-"""Parity at BASELINE.json's full sizes (3840x2160 frames, 1920x1920 network input, fp16) through
+"""Parity at BASELINE.json's full sizes (3840x2160 frames, 1920x1920 network input; fp32 -- the reference's own
+precision, as split-f16x3 and as exact-fp32 MFMA -- and fp16) through
 size-independent properties: the oracle cannot finish these sizes in seconds, so each check is an
 invariant of the operation itself (bit-identity between equivalent schedules, linearity and shift
 equivariance of a convolution on exact data, NMS postconditions, round trips, a known camera)."""
@@ -19,13 +20,17 @@ def scene4k():
     return sc, {t: sc.render(t, 150) for t in (0, 1, 40)}
 
 
-@pytest.fixture(scope="module")
-def detector4k(gtx_ctx, scene4k):
+PRECISIONS = {"f16": dict(half=True), "f32-split": dict(half=False, fp32_split=True), "f32-exact": dict(half=False, fp32_split=False)}
+
+
+@pytest.fixture(scope="module", params=list(PRECISIONS))
+def detector4k(request, gtx_ctx, scene4k):
     from geotrax_amd.detector import Detector
     from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
 
     sc, fr = scene4k
-    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=False, max_batch=2, ctx=gtx_ctx)
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, rect=False, max_batch=2, ctx=gtx_ctx,
+              **PRECISIONS[request.param])
     w = synthetic_yolov8(seed=0, nc=4)
     det = Detector(w, (H4, W4), **kw)
     det.detect(fr[0])
@@ -80,8 +85,49 @@ def test_detector_full_size_schedules_agree_and_nms_postconditions_hold(gtx_ctx,
     assert set(np.unique(a.cls)) <= {0, 1, 2, 3}
 
 
+def test_fp32_paths_agree_at_full_size(gtx_ctx, scene4k):
+    """4K frame, 1920x1920 input: the split-f16x3 detector and the exact-fp32 MFMA detector (same weights) return the
+    same detections in the same order, scores within 1e-4 and boxes within 0.05 px (BASELINE.md section 5's fp32 bar);
+    their raw class scores agree to 1e-4 over all 75 600 anchors."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    sc, fr = scene4k
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, rect=False, half=False, ctx=gtx_ctx)
+    w = synthetic_yolov8(seed=0, nc=4, level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002, smooth_cls=True, box_decay=(0.2, 0.3, 0.2, 0.3))
+    det = Detector(w, (H4, W4), fp32_split=False, **kw)
+    det.detect(fr[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 400)
+    det.close()
+    exact = Detector(w, (H4, W4), fp32_split=False, **kw)
+    split = Detector(w, (H4, W4), fp32_split=True, **kw)
+    try:
+        a, b = exact.detect(fr[0]), split.detect(fr[0])
+        ra, rb = exact.raw_output(), split.raw_output()
+    finally:
+        exact.close()
+        split.close()
+    n_cand = int((ra[:, 4:].max(1) > 0.25).sum())
+    assert len(a) > 50 and n_cand > len(a) * 1.3                            # NMS had clustered candidates to suppress
+    np.testing.assert_allclose(rb[:, 4:], ra[:, 4:], atol=1e-4)
+    np.testing.assert_allclose(rb[:, :4], ra[:, :4], rtol=2e-5, atol=5e-3)
+    assert len(a) == len(b)
+    # same detections; the order may differ only between neighbours whose scores tie to 1e-5 (the smooth class branch
+    # of these seeded weights gives neighbouring anchors nearly equal scores; ~200 detections at 4K hold a few such ties)
+    np.testing.assert_allclose(a.conf, b.conf, atol=1e-4)
+    order = np.lexsort((np.round(b.xyxy[:, 0], 0), np.round(b.xyxy[:, 1], 0)))
+    order_a = np.lexsort((np.round(a.xyxy[:, 0], 0), np.round(a.xyxy[:, 1], 0)))
+    np.testing.assert_allclose(a.xyxy[order_a], b.xyxy[order], atol=5e-2)
+    np.testing.assert_array_equal(a.cls[order_a], b.cls[order])
+    moved = np.nonzero(order_a != order)[0]
+    assert len(moved) <= 0.1 * len(a)
+    for i, j in zip(order_a[moved], order[moved]):
+        assert abs(int(i) - int(j)) <= 2 and abs(a.conf[i] - a.conf[j]) < 1e-5, (i, j, a.conf[i], a.conf[j])
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32-split", "f32-exact"])
 @pytest.mark.parametrize("cin,cout,k,s,hw", [(64, 64, 3, 1, 480), (128, 256, 3, 2, 240), (256, 128, 1, 1, 240)])
-def test_conv_full_layer_sizes_linearity_and_shift_equivariance(gtx_ctx, cin, cout, k, s, hw):
+def test_conv_full_layer_sizes_linearity_and_shift_equivariance(gtx_ctx, cin, cout, k, s, hw, prec):
     """Real YOLOv8s layer shapes at the 1920x1920 input. Small-integer data makes every fp32 partial sum
     exact, so conv(x1 + x2) == conv(x1) + conv(x2) and a shift of the input by one tile must hold bit for
     bit, whatever the tiling; a checksum ties the interior to numpy on a strip the oracle can afford."""
@@ -89,18 +135,20 @@ def test_conv_full_layer_sizes_linearity_and_shift_equivariance(gtx_ctx, cin, co
     from oracle.yolov8_ref import conv2d_nhwc
 
     rng = np.random.default_rng(cin + cout + k)
-    x1 = rng.integers(-2, 3, (1, hw, hw, cin)).astype(np.float16)
-    x2 = rng.integers(-2, 3, (1, hw, hw, cin)).astype(np.float16)
+    adt = np.float16 if prec == "f16" else np.float32
+    ckw = dict(stride=s, act=False, ctx=gtx_ctx, **({"split": True} if prec == "f32-split" else {}))
+    x1 = rng.integers(-2, 3, (1, hw, hw, cin)).astype(adt)
+    x2 = rng.integers(-2, 3, (1, hw, hw, cin)).astype(adt)
     wt = rng.integers(-1, 2, (cout, k, k, cin)).astype(np.float32)
-    y1 = ops.conv2d(x1, wt, None, stride=s, act=False, ctx=gtx_ctx).astype(np.float32)
-    y2 = ops.conv2d(x2, wt, None, stride=s, act=False, ctx=gtx_ctx).astype(np.float32)
-    y12 = ops.conv2d((x1 + x2).astype(np.float16), wt, None, stride=s, act=False, ctx=gtx_ctx).astype(np.float32)
+    y1 = ops.conv2d(x1, wt, None, **ckw).astype(np.float32)
+    y2 = ops.conv2d(x2, wt, None, **ckw).astype(np.float32)
+    y12 = ops.conv2d((x1 + x2).astype(adt), wt, None, **ckw).astype(np.float32)
     assert np.abs(y12).max() < 2048                                          # exactly representable in fp16
     np.testing.assert_array_equal(y12, y1 + y2)
     sh = 16 * s                                                              # one output tile
     xs = np.zeros_like(x1)
     xs[:, sh:, sh:] = x1[:, :-sh, :-sh]
-    ys = ops.conv2d(xs, wt, None, stride=s, act=False, ctx=gtx_ctx).astype(np.float32)
+    ys = ops.conv2d(xs, wt, None, **ckw).astype(np.float32)
     o = sh // s
     np.testing.assert_array_equal(ys[:, o + 1:-1, o + 1:-1], y1[:, 1:-o - 1, 1:-o - 1])  # away from the seam and the far zero padding
     strip = conv2d_nhwc(x1[:, :3 * 8 * s + k], wt, None, stride=s, act=False)    # a few output rows on the CPU
