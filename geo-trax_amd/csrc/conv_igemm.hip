@@ -370,7 +370,7 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     c.kc = ks == 1 ? (cin % 32 == 0 ? 32 : 16) : 16;
     if (force_kc > 0) c.kc = force_kc;
     c.bn = (cout % 64 == 0) ? 64 : 32;
-    c.th = 8; c.tw = 16;
+    c.th = 8; c.tw = 16;                           // conv_pick_tile() may raise th to 16 once the problem size is known
     GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
     GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
     return c;
@@ -436,6 +436,22 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
   return out;
 }
 
+// 16x16-pixel tiles (two 32-pixel sub-tiles per wave) halve the weight re-staging and the LDS fragment reads per MFMA,
+// but make 4x fewer, 2x larger workgroups at 2 per CU: worth it only when the launch still fills the chip.
+void conv_pick_tile(const ConvGroup& g, ConvConfig& cfg) {
+  if (cfg.variant != 2 || cfg.stride != 1) return;
+  static const int mode = env_int("GTX_CONV_TH16", -1);   // -1 = by size, 0 = never, 1 = always
+  static const int k1 = env_int("GTX_CONV_TH16_K1", 0);   // 1x1 convs are HBM-bound either way
+  if (cfg.ks == 1 && !k1) { cfg.th = 8; return; }
+  long wgs = 0;
+  for (int i = 0; i < g.count; ++i) {
+    const ConvProblem& p = g.p[i];
+    wgs += (long)p.N * cdiv(p.Wo, 16) * cdiv(p.Ho, 16) * (p.Cout / cfg.bn);
+  }
+  const bool big = mode == 1 || (mode == -1 && wgs >= env_int("GTX_CONV_TH16_MIN", 400));
+  cfg.th = big ? 16 : 8;
+}
+
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
   int total = 0;
   for (int i = 0; i < g.count; ++i) {
@@ -493,7 +509,7 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
 const char* conv_kernel_name(const ConvConfig& c) {
   static thread_local char buf[96];
   if (c.variant == 2) {
-    snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8);
+    snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8, c.th / 8);
     return buf;
   }
   snprintf(buf, sizeof buf, "conv_igemm_kernel<%s, %d, %d, %d, %d>", c.dtype == DT_F16 ? "_Float16" : "float",

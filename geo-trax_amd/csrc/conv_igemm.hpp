@@ -69,6 +69,9 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
 // byte image for `cfg` (element type per cfg.dtype). acc_scale (may be null) receives ConvProblem::acc_scale.
 std::vector<uint8_t> pack_conv_weights(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale = nullptr);
 
+// Chooses the pixel tile (cfg.th) for the group's current problem sizes (batch included); call before finalize.
+void conv_pick_tile(const ConvGroup& g, ConvConfig& cfg);
+
 // Fills tiles_x/tiles_y/n_ct/block_begin/total_blocks for a group.
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg);
 

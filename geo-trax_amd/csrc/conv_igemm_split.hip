@@ -31,9 +31,9 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int KS, int STRIDE, int WN, int CPR>
+template <int KS, int STRIDE, int WN, int CPR, int WM>
 struct SplitTile {
-  static constexpr int TH = 8, TW = 16;
+  static constexpr int TH = 8 * WM, TW = 16;         // WM sub-tiles of 2 rows x 16 pixels per wave
   static constexpr int BN = 32 * WN;
   static constexpr int PAD = KS / 2;
   static constexpr int PH = (TH - 1) * STRIDE + KS;
@@ -49,7 +49,7 @@ struct SplitTile {
   static constexpr int PATCH_BYTES = NPIX * RB;
   static constexpr int STAGE_BYTES = PATCH_BYTES + KS * KS * BN * RB;
   static constexpr int EPI_PITCH = BN * 4 + 16;      // fp32 epilogue transpose: bytes per staged pixel row
-  static constexpr int EPI_BYTES = 4 * 32 * EPI_PITCH;
+  static constexpr int EPI_BYTES = 4 * 32 * EPI_PITCH;   // one 32-pixel sub-tile per wave at a time
   static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   static constexpr int ROWS_PER_BANKROW = 256 / RB;  // 4 (RB=64) or 2 (RB=128)
   static __host__ __device__ constexpr int swz(int row) { return (row / ROWS_PER_BANKROW) & (NCH - 1); }
@@ -73,16 +73,17 @@ __device__ __forceinline__ void split8(const uint4& a, const uint4& b, uint4& hi
   lo = *reinterpret_cast<const uint4*>(&l);
 }
 
-template <int KS, int STRIDE, int WN, int CPR>
+template <int KS, int STRIDE, int WN, int CPR, int WM>
 constexpr int split_min_waves() {
+  if (WM == 2) return 2;                      // 64 accumulator + 64 fragment registers
   if (KS == 3) return STRIDE == 1 ? 3 : 2;    // stride 2: the 17x33 patch needs 5 prefetch slots of 8 registers
   return WN == 1 ? 5 : 4;
 }
 
-template <int KS, int STRIDE, int WN, int CPR>
-__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR>()))))
+template <int KS, int STRIDE, int WN, int CPR, int WM>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR, WM>()))))
 void conv_igemm_split_kernel(const ConvGroup g) {
-  using Tile = SplitTile<KS, STRIDE, WN, CPR>;
+  using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
   constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB, KC = Tile::KC;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,14 +176,19 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   }
 
   const int prow = lane & 31, h = lane >> 5;
-  const int trow = 2 * wave + (prow >> 4), tcol = prow & 15;
-  const int p0 = trow * STRIDE * PW + tcol * STRIDE;
+  const int tcol = prow & 15;
+  // sub-tile m of this wave: tile rows 2*(WM*wave + m) and +1
+  const int trow0 = 2 * WM * wave + (prow >> 4);
+  const int p0 = trow0 * STRIDE * PW + tcol * STRIDE;
+  constexpr int PSUB = 2 * STRIDE * PW;              // patch rows between two sub-tiles
 
-  floatx16 acc[WN];
+  floatx16 acc[WM][WN];
 #pragma unroll
-  for (int j = 0; j < WN; ++j)
+  for (int m = 0; m < WM; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
 
   GTXS_PREFETCH(0)
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -192,15 +198,17 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
     // Fragment reads run one (tap, k-step) ahead of the six MFMAs (WN = 2) that consume them.
     constexpr int NSTEP = KS * KS * (CPR / 2);
-    half8 bh[2], bl[2], ah[2][WN], al[2][WN];
+    half8 bh[2][WM], bl[2][WM], ah[2][WN], al[2][WN];
 #define GTXS_LOAD_FRAGS(STEP, SLOT)                                                            \
     {                                                                                          \
       const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
-      const int p__ = p0 + (tap__ / KS) * PW + (tap__ % KS);                                   \
       const int c__ = 2 * ks__ + h;                                                            \
-      const char* pr__ = lds_patch + p__ * RB;                                                 \
-      bh[SLOT] = *reinterpret_cast<const half8*>(pr__ + ((c__ ^ Tile::swz(p__)) << 4));       \
-      bl[SLOT] = *reinterpret_cast<const half8*>(pr__ + (((CPR + c__) ^ Tile::swz(p__)) << 4)); \
+      _Pragma("unroll") for (int m = 0; m < WM; ++m) {                                         \
+        const int p__ = p0 + m * PSUB + (tap__ / KS) * PW + (tap__ % KS);                      \
+        const char* pr__ = lds_patch + p__ * RB;                                               \
+        bh[SLOT][m] = *reinterpret_cast<const half8*>(pr__ + ((c__ ^ Tile::swz(p__)) << 4));   \
+        bl[SLOT][m] = *reinterpret_cast<const half8*>(pr__ + (((CPR + c__) ^ Tile::swz(p__)) << 4)); \
+      }                                                                                        \
       _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                         \
         const int nrow__ = 32 * j + prow;                                                      \
         const char* wr__ = lds_w + (tap__ * BN + nrow__) * RB;                                 \
@@ -216,12 +224,14 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        // small terms first, then the leading one
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1], acc[j], 0, 0, 0);
-      }
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          // small terms first, then the leading one
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1][m], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef GTXS_LOAD_FRAGS
@@ -230,74 +240,78 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   // ---- epilogue: acc * 2^-shift + bias -> SiLU (+ residual) -> fp32 NHWC, whole 128-B lines per store ----
   // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
   // BN channels through LDS so that a store instruction writes contiguous runs of BN*4 bytes per pixel.
-  const int oy = oy0 + trow, ox = ox0 + tcol;
   const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
   const float sc = P.acc_scale;
   const bool wide = (P.out_cstride % 4) == 0 && (P.out_coff % 4) == 0;
-  if (wide) {
-    constexpr int PITCH = Tile::EPI_PITCH;
-    __syncthreads();
-    char* stg = smem + wave * (32 * PITCH);
-    const bool inside = oy < P.Ho && ox < P.Wo;
-    const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
-    const float* __restrict__ res =
-        (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+  if (wide) __syncthreads();                    // every wave is done with the staging buffers
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
+  for (int m = 0; m < WM; ++m) {
+    const int trow = trow0 + 2 * m;
+    const int oy = oy0 + trow, ox = ox0 + tcol;
+    if (wide) {
+      constexpr int PITCH = Tile::EPI_PITCH;
+      char* stg = smem + wave * (32 * PITCH);   // wave-private: its own LDS writes are ordered before its reads
+      const bool inside = oy < P.Ho && ox < P.Wo;
+      const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
+      const float* __restrict__ res =
+          (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int cl = 32 * j + 8 * g4 + 4 * h;
-        float v[4];
+      for (int j = 0; j < WN; ++j) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = fmaf(acc[j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
-          if (P.act) v[i] = silu_f(v[i]);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 32 * j + 8 * g4 + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = fmaf(acc[m][j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+            if (P.act) v[i] = silu_f(v[i]);
+          }
+          if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + cl);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (res) {
-          const float4 rv = *reinterpret_cast<const float4*>(res + cl);
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+      }
+      constexpr int LPP = BN / 4;                 // lanes per pixel (16 B each)
+      constexpr int PPI = 64 / LPP;               // pixels per store instruction
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int p = it * PPI + lane / LPP, q = lane % LPP;
+        const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
+        const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
+        if (py < P.Ho && px < P.Wo) {
+          float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
+          *reinterpret_cast<uint4*>(dst) = val;
         }
-        *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
-    }
-    constexpr int LPP = BN / 4;                 // lanes per pixel (16 B each)
-    constexpr int PPI = 64 / LPP;               // pixels per store instruction
+    } else if (oy < P.Ho && ox < P.Wo) {
+      const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
+      float* __restrict__ out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
+      const float* __restrict__ res =
+          P.res ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
 #pragma unroll
-    for (int it = 0; it < 32 / PPI; ++it) {
-      const int p = it * PPI + lane / LPP, q = lane % LPP;
-      const int py = oy0 + 2 * wave + (p >> 4), px = ox0 + (p & 15);
-      const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
-      if (py < P.Ho && px < P.Wo) {
-        float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
-        *reinterpret_cast<uint4*>(dst) = val;
-      }
-    }
-  } else if (oy < P.Ho && ox < P.Wo) {
-    const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
-    float* __restrict__ out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
-    const float* __restrict__ res =
-        P.res ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+      for (int j = 0; j < WN; ++j) {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 32 * j + 8 * g4 + 4 * h;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int cl = 32 * j + 8 * g4 + 4 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = fmaf(acc[j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
-          if (P.act) v = silu_f(v);
-          if (res) v += res[cl + i];
-          out[cl + i] = v;
+          for (int i = 0; i < 4; ++i) {
+            float v = fmaf(acc[m][j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+            if (P.act) v = silu_f(v);
+            if (res) v += res[cl + i];
+            out[cl + i] = v;
+          }
         }
       }
     }
   }
 }
 
-template <int KS, int STRIDE, int WN, int CPR>
+template <int KS, int STRIDE, int WN, int CPR, int WM>
 void launch_t(const ConvGroup& g, hipStream_t stream) {
-  using Tile = SplitTile<KS, STRIDE, WN, CPR>;
-  auto kern = conv_igemm_split_kernel<KS, STRIDE, WN, CPR>;
+  using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
+  auto kern = conv_igemm_split_kernel<KS, STRIDE, WN, CPR, WM>;
   static std::once_flag once;
   std::call_once(once, [&] {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
@@ -345,13 +359,15 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
 }
 
 void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
-  const int cpr = c.kc / 8, wn = c.bn / 32;
-#define GTX_CASE(KS, ST, WN, CPR) \
-  if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR) return launch_t<KS, ST, WN, CPR>(g, s);
-  GTX_CASE(3, 1, 1, 2) GTX_CASE(3, 1, 2, 2) GTX_CASE(3, 2, 1, 2) GTX_CASE(3, 2, 2, 2)
-  GTX_CASE(1, 1, 1, 4) GTX_CASE(1, 1, 2, 4) GTX_CASE(1, 1, 1, 2) GTX_CASE(1, 1, 2, 2)
+  const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;
+#define GTX_CASE(KS, ST, WN, CPR, WM) \
+  if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR && wm == WM) return launch_t<KS, ST, WN, CPR, WM>(g, s);
+  GTX_CASE(3, 1, 1, 2, 1) GTX_CASE(3, 1, 2, 2, 1) GTX_CASE(3, 2, 1, 2, 1) GTX_CASE(3, 2, 2, 2, 1)
+  GTX_CASE(3, 1, 1, 2, 2) GTX_CASE(3, 1, 2, 2, 2)
+  GTX_CASE(1, 1, 1, 4, 1) GTX_CASE(1, 1, 2, 4, 1) GTX_CASE(1, 1, 1, 2, 1) GTX_CASE(1, 1, 2, 2, 1)
+  GTX_CASE(1, 1, 1, 4, 2) GTX_CASE(1, 1, 2, 4, 2)
 #undef GTX_CASE
-  fail(-3, "conv (split-f16x3): no kernel for ks=%d stride=%d bn=%d kc=%d", c.ks, c.stride, c.bn, c.kc);
+  fail(-3, "conv (split-f16x3): no kernel for ks=%d stride=%d bn=%d kc=%d th=%d", c.ks, c.stride, c.bn, c.kc, c.th);
 }
 
 }  // namespace gtx

@@ -348,6 +348,8 @@ void Detector::set_batch(int nb) {
   for (Op& op : ops_) {
     if (op.kind != Op::CONV) continue;
     for (int i = 0; i < op.grp.count; ++i) op.grp.p[i].N = nb;
+    conv_pick_tile(op.grp, op.cfg);
+    op.family = conv_kernel_name(op.cfg);
     conv_group_finalize(op.grp, op.cfg);
     op.flops = 0;
     op.bytes = 0;

@@ -186,6 +186,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.act = d->act;
   p.acc_scale = acc_scale;
   st.g.count = 1;
+  conv_pick_tile(st.g, st.cfg);
   conv_group_finalize(st.g, st.cfg);
 }
 }  // namespace
@@ -569,6 +570,10 @@ int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which, int cap, int* n, flo
 }
 int gtx_stabilizer_matches(gtx_stabilizer* st, int cap, int* n, int* cur_idx, int* ref_idx, int* dist) {
   return guarded([&] { need(st, "st"); need(n, "n"); st->impl->matches(cap, n, cur_idx, ref_idx, dist); });
+}
+
+int gtx_stabilizer_last_ms(gtx_stabilizer* st, float* ms) {
+  return guarded([&] { need(st, "st"); need(ms, "ms"); *ms = st->impl->last_ms(); });
 }
 
 int gtx_stabilizer_pattern(gtx_stabilizer* st, int8_t* out) {

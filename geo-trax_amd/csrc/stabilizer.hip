@@ -954,6 +954,8 @@ struct Stabilizer::Impl {
   StabResult* h_res = nullptr;   // pinned
   float4* h_pts = nullptr;       // pinned
   hipEvent_t done_ev = nullptr;
+  hipEvent_t t0_ev = nullptr, t1_ev = nullptr;   // GPU time of the last submitted pass (timing events)
+  float last_ms = 0.f;
   bool pending = false;
   bool have_ref = false;
   // last results
@@ -1058,6 +1060,8 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(StabResult)));
   GTX_HIP(hipHostMalloc((void**)&S.h_pts, sizeof(float4) * slots));
   GTX_HIP(hipEventCreateWithFlags(&S.done_ev, wait_event_flags(false)));
+  GTX_HIP(hipEventCreate(&S.t0_ev));
+  GTX_HIP(hipEventCreate(&S.t1_ev));
   S.d_hok.alloc(sizeof(int) * S.n_hyp);
   {
     const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;
@@ -1077,6 +1081,8 @@ Stabilizer::~Stabilizer() {
     if (impl_->h_res) (void)hipHostFree(impl_->h_res);
     if (impl_->h_pts) (void)hipHostFree(impl_->h_pts);
     if (impl_->done_ev) (void)hipEventDestroy(impl_->done_ev);
+    if (impl_->t0_ev) (void)hipEventDestroy(impl_->t0_ev);
+    if (impl_->t1_ev) (void)hipEventDestroy(impl_->t1_ev);
   }
 }
 
@@ -1309,6 +1315,7 @@ void Stabilizer::Impl::submit_match() {
   GTX_HIP(hipGetLastError());
   GTX_HIP(hipMemcpyAsync(h_res, d_res.p, sizeof(StabResult), hipMemcpyDeviceToHost, s));
   GTX_HIP(hipMemcpyAsync(h_pts, d_mpts.p, sizeof(float4) * slots_cur, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipEventRecord(t1_ev, s));
   GTX_HIP(hipEventRecord(done_ev, s));
   pending = true;
 }
@@ -1318,6 +1325,7 @@ void Stabilizer::Impl::collect(double Hout[9], int* valid_out, int st[4]) {
   GTX_CHECK(pending, "stabilizer: collect without a submitted frame");
   GTX_HIP(hipEventSynchronize(done_ev));
   pending = false;
+  if (hipEventElapsedTime(&last_ms, t0_ev, t1_ev) != hipSuccess) last_ms = 0.f;
   const StabResult& R = *h_res;
   const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
   cur.host_n = R.n_cur;
@@ -1377,9 +1385,12 @@ void Stabilizer::submit_gray_dev(const void* gray, int gh, int gw, const float* 
   GTX_CHECK(!S.pending, "stabilizer: a frame is already in flight");
   GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
   GTX_HIP(hipSetDevice(S.ctx->device));
+  GTX_HIP(hipEventRecord(S.t0_ev, S.ctx->stream));
   S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
   S.submit_match();
 }
+
+float Stabilizer::last_ms() const { return impl_->last_ms; }
 
 void Stabilizer::collect(double H[9], int* valid, int stats[4]) {
   GTX_HIP(hipSetDevice(impl_->ctx->device));

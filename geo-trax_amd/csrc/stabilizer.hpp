@@ -26,6 +26,8 @@ class Stabilizer {
   void matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist);
   // rotated sampling pattern table [256 bins][256 tests][ax, ay, bx, by] int8 (data, for the oracle)
   void pattern(int8_t* out) const;
+  // GPU time (ms, stream-ordered events) of the last collected submit_gray_dev pass: keypoints -> matching -> RANSAC
+  float last_ms() const;
 
  private:
   struct Impl;

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "gtx_stabilizer_keypoints": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "gtx_stabilizer_matches": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
     "gtx_stabilizer_pattern": (C.c_int, [_P, _P]),
+    "gtx_stabilizer_last_ms": (C.c_int, [_P, _P]),
     "gtx_warp_boxes": (C.c_int, [_P, _P, C.c_int, _P]),
     "gtx_perspective_points": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "gtx_op_georef_points": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),

@@ -16,17 +16,49 @@ from pathlib import Path
 
 import yaml
 
-DEFAULT_CFG = Path(__file__).resolve().parent / "cfg" / "default.yaml"
+CFG_DIR = Path(__file__).resolve().parent / "cfg"
+DEFAULT_CFG = CFG_DIR / "default.yaml"
+PRESETS = ("default", "confident", "lenient", "stable")
+
+
+def resolve_config_path(cfg_filepath) -> Path:
+    """config_utils.resolve_config_path (:38-63): the path as given, else inside the bundled cfg directory; a
+    missing '.yaml' suffix and a leading 'cfg/' (or the reference's 'geotrax/cfg/') are tolerated, so 'confident',
+    'cfg/default.yaml' and 'geotrax/cfg/lenient.yaml' all resolve to the bundled presets."""
+    path = Path(cfg_filepath)
+    if not path.suffix:
+        path = path.with_suffix(".yaml")
+    candidates = [path]
+    if not path.is_absolute():
+        candidates.append(CFG_DIR / path.name if path.parent.name in ("", "cfg") or path.parts[-2:-1] == ("cfg",) else CFG_DIR / path)
+    for c in candidates:
+        if c.is_file():
+            return c
+    return Path(cfg_filepath)
+
+
+def _merge(base: dict, over: dict) -> dict:
+    out = dict(base)
+    for k, v in over.items():
+        out[k] = _merge(base[k], v) if isinstance(v, dict) and isinstance(base.get(k), dict) else v
+    return out
 
 
 def load_config(cfg_filepath, logger: logging.Logger) -> dict:
-    path = Path(cfg_filepath) if cfg_filepath else DEFAULT_CFG
+    """One YAML -> dict. A file may carry `_base: <preset or path>`: it then only lists the keys that differ from that
+    file (how the bundled confident / lenient / stable presets are written here; a full file such as the reference's
+    own geotrax/cfg/*.yaml has no `_base` and loads unchanged)."""
+    path = resolve_config_path(cfg_filepath) if cfg_filepath else DEFAULT_CFG
     try:
         with open(path, "r") as f:
-            return yaml.safe_load(f)
+            cfg = yaml.safe_load(f) or {}
     except FileNotFoundError:
         logger.critical(f"Configuration file '{cfg_filepath}' not found.")
         sys.exit(1)
+    base = cfg.pop("_base", None)
+    if base is not None:
+        cfg = _merge(load_config(base, logger), cfg)
+    return cfg
 
 
 def backfill_args_from_config(args: argparse.Namespace, mapping: dict) -> None:

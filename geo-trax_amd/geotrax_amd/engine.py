@@ -49,6 +49,8 @@ class FrameResult:
     n_det: int = 0                   # raw detections of the frame
     det_ms: float = 0.0              # detector GPU time of the frame's batch divided by its size
     gmc: np.ndarray | None = None    # 2x3 camera-motion warp the GMC found for the frame (engines built with gmc=True)
+    stab_ms: float = 0.0             # GPU time of the frame's stabilizer pass (0 for the reference frame / no stabilizer)
+    H_fallback: bool = False         # True when registration failed and H is the last known transform
 
 
 def xyxy_to_xywh(b: np.ndarray) -> np.ndarray | None:
@@ -111,6 +113,7 @@ class ExtractEngine:
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
         self._index, self._have_ref = 0, False
+        self._last_H = None              # last valid current->reference transform, in frame order
         self._gmc_sub = self._gmc_col = 0   # frames queued on the GMC stream / warps taken (one writer thread each)
 
     # ---- lifecycle
@@ -130,6 +133,7 @@ class ExtractEngine:
     def reset(self, keep_reference: bool = False) -> None:
         """Forget the tracks and the camera-motion state (and, unless told otherwise, the reference frame)."""
         self._index = 0
+        self._last_H = None
         if not keep_reference:
             self._have_ref = False
         if self.tracker is not None:
@@ -338,10 +342,22 @@ class ExtractEngine:
     def _stabilized(self, frames):
         pending = collections.deque()                           # (stabilizer, partial FrameResult) awaiting collect
 
+        def last_known(r):
+            # stabilo keeps `trans_matrix_last_known`: when a frame cannot be registered (too few matches, no model)
+            # the previous valid transform is used for its boxes and reported as its matrix. Results leave here in
+            # frame order, so "last" is the previous frame's, whichever stabilizer object produced it.
+            if r.H is None:
+                if self._last_H is not None:
+                    r.H, r.H_fallback = self._last_H.copy(), True
+            else:
+                self._last_H = r.H.copy()
+
         def finish():
             st, r = pending.popleft()
             st.collect()
             r.H = st.get_cur_trans_matrix()
+            r.stab_ms = st.last_ms()
+            last_known(r)
             if r.xywh is not None:
                 r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
             return r
@@ -371,6 +387,7 @@ class ExtractEngine:
                 else:                                               # other downsample ratios: the stabilizer makes its own gray
                     st.stabilize(host, r.xywh)
                     r.H = st.get_cur_trans_matrix()
+                    last_known(r)
                     if r.xywh is not None:
                         r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()
                     yield r

@@ -125,7 +125,7 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
     stab_kw = {k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')} if do_stab else None
     eng_cfg = config['main'].get('engine') or {}
     first, last = args.cut_frame_left, args.cut_frame_right
-    out, frame_nums, det_ms, n_frames = _Collector(), [], [], 0
+    out, frame_nums, det_ms, stab_ms, n_frames = _Collector(), [], [], [], 0
     t_wall = time.time()
     engine = None
     try:
@@ -150,15 +150,19 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
                     out.stab.append(r.xywh_stab)
             if do_stab and r.index > 0:
                 out.add_transform(frame_num, r.H)
+                stab_ms.append(r.stab_ms)
     except Exception as e:
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return np.empty((0, 12), dtype=np.float32), np.empty((0, 10))
     else:
         if n_frames:
-            # the reference logs per-stage averages of its blocking loop (extract.py:205-207); here detection,
-            # tracking and stabilization overlap, so the detector average and the wall clock are what exists
+            # the reference's three averages (extract.py:205-207), same wording. Its loop is blocking, so its pipeline
+            # figure is 1000 n / (sum yolo + sum stab); here the stages overlap on the GPU: the first two lines are the
+            # per-frame GPU times of the detector pass and of the stabilizer pass, the third is the wall clock
             wall = time.time() - t_wall
             logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(det_ms) / len(det_ms):5.1f}ms.")
+            if stab_ms:
+                logger.info(f"Average stabilization time: {sum(stab_ms) / len(stab_ms):5.1f}ms")
             logger.info(f"Average pipeline time: {n_frames / wall:4.1f}fps.")
     finally:
         reader.release()
@@ -284,14 +288,22 @@ def _build_run_metadata(config: dict, save_dir: Path) -> dict:
         'tracker': {'active': main.get('tracker_active'), 'params': main.get('tracker_params', {})},
         'stabilo': config['stabilo'],
         'georef': config['georef'],
+        'paths': {'ortho_folder': getattr(args, 'ortho_folder', None), 'master_folder': getattr(args, 'master_folder', None),
+                  'segmentation_folder': getattr(args, 'segmentation_folder', None)},
+        'visualization': main.get('visualization', {}),
+        'plotting': main.get('plotting', {}),
+        'batch': main.get('batch', {}),
     }
 
 
 def add_common_args(group) -> None:
     """The shared flags of every geotrax stage (cli_utils.add_common_args :16-32)."""
-    group.add_argument('--cfg', '-c', type=Path, default=None, help='Path to a custom pipeline config file.')
+    group.add_argument('--cfg', '-c', type=Path, default=None,
+                       help='Pipeline config: a bundled preset name (default, confident, lenient, stable) or a path to a config file.')
     group.add_argument('--output-folder', '-of', type=str, default=None, help='Root folder for outputs.')
-    group.add_argument('--log-path', '-lp', type=str, default=None, help='Where to write logs.')
+    group.add_argument('--log-path', '-lp', type=Path, default=None,
+                       help='Where to write detailed logs: a directory (<stage>.log inside it) or a full file path. '
+                            'Defaults to $XDG_STATE_HOME/geo-trax/logs (~/.local/state/geo-trax/logs).')
     group.add_argument('--verbose', '-v', action='store_true', help='Set print verbosity level to INFO.')
 
 
@@ -314,10 +326,51 @@ def parse_cli_args(argv=None) -> argparse.Namespace:
     return parser.parse_args(argv)
 
 
+def default_log_dir() -> Path:
+    """logging_utils.default_log_dir (:63-72), Linux branch."""
+    import os
+
+    return Path(os.environ.get('XDG_STATE_HOME') or (Path.home() / '.local' / 'state')) / 'geo-trax' / 'logs'
+
+
+def setup_logger(name: str, verbose: bool = False, log_path=None, dry_run: bool = False) -> logging.Logger:
+    """logging_utils.setup_logger (:75-110): console at WARNING (INFO with --verbose), plus a file handler at INFO.
+    `log_path` may be a directory (<stage>.log inside it) or a full file path; default: default_log_dir()."""
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+    for h in list(logger.handlers):
+        logger.removeHandler(h)
+        h.close()
+    fmt = logging.Formatter('%(asctime)s - %(levelname)s - %(name)s:%(module)s:%(funcName)s - %(message)s')
+    console = logging.StreamHandler()
+    console.setFormatter(fmt)
+    console.setLevel(logging.INFO if verbose else logging.WARNING)
+    logger.addHandler(console)
+    if not dry_run:
+        stage = f"{name.split('.')[-1]}.log"
+        if log_path is None:
+            file = default_log_dir() / stage
+        else:
+            log_path = Path(log_path)
+            file = log_path / stage if log_path.is_dir() else log_path
+        try:
+            file.parent.mkdir(parents=True, exist_ok=True)
+            fh = logging.FileHandler(file)
+        except OSError as e:                                # a read-only home must not stop the run
+            logger.warning(f"Cannot write the log file '{file}': {e}")
+        else:
+            fh.setFormatter(fmt)
+            fh.setLevel(logging.INFO)
+            logger.addHandler(fh)
+            print(f"Saving logs to: {file}")
+    return logger
+
+
 def main(argv=None) -> None:
     args = parse_cli_args(argv)
-    logging.basicConfig(level=logging.INFO if args.verbose else logging.WARNING, format='%(levelname)s: %(message)s')
-    detect_track_stabilize(args, logging.getLogger('geotrax_amd.extract'))
+    logger = setup_logger('geotrax_amd.extract', args.verbose, args.log_path)
+    detect_track_stabilize(args, logger)
 
 
 if __name__ == '__main__':

@@ -123,6 +123,12 @@ class Stabilizer:
         check(self.ctx.lib.gtx_stabilizer_collect(self.handle, ptr(H), C.byref(valid), ptr(self._stats)))
         self._finish(H, valid, self._pending_boxes)
 
+    def last_ms(self) -> float:
+        """GPU time (ms) of the last collected asynchronous pass."""
+        ms = C.c_float()
+        check(self.ctx.lib.gtx_stabilizer_last_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
     def get_cur_trans_matrix(self) -> np.ndarray | None:
         """3x3 float64 mapping current-frame pixels to reference-frame pixels, or None."""
         return None if self._H is None else self._H.copy()

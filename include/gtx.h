@@ -278,6 +278,10 @@ int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr,
 int gtx_stabilizer_submit_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
                                    const float* boxes_xywh, int n);
 int gtx_stabilizer_collect(gtx_stabilizer* st, double H[9], int* valid, int stats[4]);
+/* GPU time (ms) of the last collected asynchronous pass: what the reference logs as "Average stabilization
+ * time" (geotrax/extract.py:175,188,206) is the wall time of the blocking stabilo calls; here the pass runs on
+ * its own stream beside the detector, so its stream-ordered duration is reported instead. */
+int gtx_stabilizer_last_ms(gtx_stabilizer* st, float* ms);
 /* Keypoints / descriptors of the last processed image (for parity tests): xy in full-res
  * pixels, level, angle bin, 32-byte descriptors. */
 int gtx_stabilizer_keypoints(gtx_stabilizer* st, int which /*0 ref, 1 cur*/, int cap, int* n,

@@ -150,6 +150,39 @@ def make_postprocess_vectors(ex):
     print("postprocess_vectors.npz:", len(out), "arrays")
 
 
+def make_class_vote_ties(ex):
+    """class_vote_ties.npz: track tables on which the winner of the confidence-weighted class vote depends on HOW the
+    scores are summed (row by row in float32, as the reference does on its float32 table, vs. any other order or
+    precision): two classes per track whose vote totals differ by less than a float32 ulp of the sum. Found by seeded
+    search; inputs plus the reference's own output."""
+    rng = np.random.default_rng(7)
+    found_in, found_out = [], []
+    while len(found_in) < 12:
+        n = int(rng.integers(40, 400))
+        conf = rng.uniform(0.25, 0.95, n).astype(np.float32)
+        cls = rng.integers(0, 2, n)
+        # nudge one score so that the exact (float64) totals of the two classes almost coincide
+        d = conf[cls == 0].astype(np.float64).sum() - conf[cls == 1].astype(np.float64).sum()
+        k = int(np.nonzero(cls == (0 if d > 0 else 1))[0][-1])
+        c = float(conf[k]) - abs(d) + rng.uniform(-2e-6, 2e-6)
+        if not 0.05 < c < 0.99:
+            continue
+        conf[k] = np.float32(c)
+        t = np.zeros((n, 12), np.float32)
+        t[:, 0], t[:, 1], t[:, -2], t[:, -1] = np.arange(n), 1, cls, conf
+        seq32 = [np.float32(0), np.float32(0)]
+        for c_, s_ in zip(cls, conf):
+            seq32[c_] = np.float32(seq32[c_] + s_)
+        exact = [conf[cls == 0].astype(np.float64).sum(), conf[cls == 1].astype(np.float64).sum()]
+        if int(np.argmax(seq32)) == int(np.argmax(exact)) and seq32[0] != seq32[1]:
+            continue                                  # keep only tables where the summation order decides (or ties exactly)
+        found_in.append(t)
+        found_out.append(ex.calculate_unique_classes(t.copy())[:, -2].copy())
+    np.savez_compressed(OUT / "class_vote_ties.npz", **{f"in{i}": a for i, a in enumerate(found_in)},
+                        **{f"out{i}": a for i, a in enumerate(found_out)})
+    print("class_vote_ties.npz:", len(found_in), "tables")
+
+
 def copy_reference_goldens():
     src = REF / "data" / "results-full"
     with open(src / "U_video_cut.txt", "rb") as f, gzip.GzipFile(OUT / "U_video_cut.txt.gz", "wb", mtime=0) as g:
@@ -231,6 +264,10 @@ def make_georeference_vectors(gr):
 
 if __name__ == "__main__":
     ex = import_reference_extract()
+    if "--ties-only" in sys.argv:
+        make_class_vote_ties(ex)
+        sys.exit(0)
     make_postprocess_vectors(ex)
+    make_class_vote_ties(ex)
     copy_reference_goldens()
     make_georeference_vectors(import_reference_georeference())

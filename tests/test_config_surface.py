@@ -1,0 +1,85 @@
+"""The CLI / config surface of the extract stage:
+preset names for --cfg (cli_utils.py:16-32, config_utils.py:38-63), --log-path (logging_utils.py:75-110),
+the run-metadata sections (extract.py:526-568) and the flag spelling (extract.py:571-603). CPU only."""
+import argparse
+import logging
+from pathlib import Path
+
+import pytest
+import yaml
+
+logger = logging.getLogger("cfg-test")
+
+
+def test_preset_names_resolve_and_differ_as_the_reference_presets_do():
+    from geotrax_amd.config_utils import CFG_DIR, PRESETS, load_config, resolve_config_path
+
+    for name in PRESETS:
+        for spelling in (name, f"{name}.yaml", f"cfg/{name}.yaml", f"geotrax/cfg/{name}.yaml"):
+            assert resolve_config_path(spelling) == CFG_DIR / f"{name}.yaml", spelling
+    d, c, l, s = (load_config(n, logger) for n in PRESETS)
+    # the differences the reference's preset headers list (geotrax/cfg/{confident,lenient,stable}.yaml)
+    assert (d["ultralytics"]["conf"], d["ultralytics"]["iou"], d["extraction"]["min_track_length"]) == (0.25, 0.7, 3)
+    assert (c["ultralytics"]["conf"], c["ultralytics"]["iou"], c["extraction"]["min_track_length"]) == (0.4, 0.6, 8)
+    assert (l["ultralytics"]["conf"], l["ultralytics"]["iou"], l["ultralytics"]["max_det"]) == (0.15, 0.8, 1500)
+    b = l["tracker"]["botsort"]
+    assert (b["track_high_thresh"], b["new_track_thresh"], b["track_buffer"], b["match_thresh"]) == (0.2, 0.1, 45, 0.9)
+    assert l["tracker"]["bytetrack"]["track_buffer"] == 30 and b["gmc_method"] == "sparseOptFlow"     # untouched keys come from the base
+    assert (s["stabilo"]["clahe"], s["stabilo"]["downsample_ratio"], s["stabilo"]["max_features"], s["stabilo"]["filter_ratio"]) == (True, 1.0, 4000, 0.8)
+    assert c["stabilo"] == d["stabilo"] and "_base" not in c
+
+
+def test_a_full_config_file_and_an_overlay_file_load(tmp_path):
+    from geotrax_amd.config_utils import DEFAULT_CFG, load_config, load_config_all
+
+    full = yaml.safe_load(DEFAULT_CFG.read_text())
+    full["ultralytics"]["conf"] = 0.33
+    full["visualization"] = {"mode": 1}
+    p = tmp_path / "mine.yaml"
+    p.write_text(yaml.safe_dump(full))
+    assert load_config(p, logger)["ultralytics"]["conf"] == 0.33
+    q = tmp_path / "overlay.yaml"
+    q.write_text(f"_base: {p}\nultralytics:\n  iou: 0.5\n")
+    cfg = load_config(q, logger)
+    assert (cfg["ultralytics"]["conf"], cfg["ultralytics"]["iou"]) == (0.33, 0.5)
+    args = argparse.Namespace(cfg=p, model=["synthetic:0"], class_names=None, classes=None, conf=0.5, show=None)
+    allc = load_config_all(args, logger, model_names={0: "car"})
+    assert allc["ultralytics"]["conf"] == 0.5 and allc["main"]["tracker_active"] == "botsort"       # CLI over config
+    with pytest.raises(SystemExit):
+        load_config(tmp_path / "missing.yaml", logger)
+
+
+def test_cli_flags_log_path_and_metadata_sections(tmp_path):
+    from geotrax_amd import extract as ex
+
+    a = ex.parse_cli_args(["clip.npy", "-c", "confident", "-of", "out", "-lp", str(tmp_path), "-v", "-m", "w.safetensors", "-cn", "0=car",
+                           "-co", "0.3", "-cls", "0", "2", "-cfl", "5", "-cfr", "50", "--interpolate"])
+    assert (str(a.cfg), a.output_folder, a.log_path, a.verbose, a.model, a.class_names, a.conf, a.classes, a.cut_frame_left, a.cut_frame_right,
+            a.interpolate) == ("confident", "out", tmp_path, True, ["w.safetensors"], ["0=car"], 0.3, [0, 2], 5, 50, True)
+    d = ex.parse_cli_args(["clip.npy"])                        # every processing flag defaults to None and is back-filled from the YAML
+    assert all(getattr(d, k) is None for k in ("model", "class_names", "conf", "classes", "cut_frame_left", "cut_frame_right", "interpolate", "log_path"))
+    # --log-path: a directory gets <stage>.log, a file path is used as is
+    lg = ex.setup_logger("geotrax_amd.extract", verbose=False, log_path=tmp_path)
+    lg.info("to the file only")
+    lg.warning("to both")
+    for h in lg.handlers:
+        h.flush()
+    text = (tmp_path / "extract.log").read_text()
+    assert "to the file only" in text and "to both" in text
+    f = tmp_path / "sub" / "custom.log"
+    lg = ex.setup_logger("geotrax_amd.extract", log_path=f)
+    lg.info("hello")
+    for h in lg.handlers:
+        h.flush()
+    assert "hello" in f.read_text()
+    ex.setup_logger("geotrax_amd.extract", dry_run=True)       # drops the file handlers again
+    # run metadata: the reference's fourteen sections, in its order (extract.py:534-567)
+    from geotrax_amd.config_utils import load_config_all
+
+    args = argparse.Namespace(source="x.npy", cfg=None, model=["synthetic:0"], class_names=None, classes=None, conf=None, show=None,
+                              ortho_folder="ORTHO", master_folder=None)
+    meta = ex._build_run_metadata(load_config_all(args, logger, model_names={0: "car", 1: "bus", 2: "truck", 3: "motorcycle"}), Path("results"))
+    assert list(meta) == ["run", "model", "class_names", "extraction", "processing", "output", "detection", "tracker", "stabilo", "georef",
+                          "paths", "visualization", "plotting", "batch"]
+    assert meta["paths"] == {"ortho_folder": "ORTHO", "master_folder": None, "segmentation_folder": None}
+    assert meta["class_names"]["mapping"] == {0: "car", 1: "bus", 2: "truck", 3: "motorcycle"} and meta["tracker"]["active"] == "botsort"

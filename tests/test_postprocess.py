@@ -107,6 +107,22 @@ def test_unique_classes_cases():
     np.testing.assert_array_equal(pp.calculate_unique_classes(t)[:, -2], [2, 2])
 
 
+def test_class_vote_near_ties_follow_the_reference_summation():
+    """tests/golden/class_vote_ties.npz (made by the reference's calculate_unique_classes, extract.py:380-401): tables on
+    which the winning class depends on the summation order / precision of the votes. The reference sums row by row in
+    the table's float32; so must this build."""
+    vec = np.load(G / "class_vote_ties.npz")
+    n = len([k for k in vec.files if k.startswith("in")])
+    assert n >= 10
+    flips = 0
+    for i in range(n):
+        t = vec[f"in{i}"]
+        np.testing.assert_array_equal(pp.calculate_unique_classes(t.copy())[:, -2], vec[f"out{i}"], err_msg=f"table {i}")
+        exact = [t[t[:, -2] == c, -1].astype(np.float64).sum() for c in (0, 1)]
+        flips += int(np.argmax(exact)) != int(vec[f"out{i}"][0])
+    assert flips >= 3            # the fixture really contains cases where float64 accumulation picks the other class
+
+
 def test_dimension_cases():
     cfg = DIM_CFGS[1]
     assert pp.estimate_vehicle_dimensions(np.empty((0, 12), dtype=np.float32), cfg, (1920, 1080)).shape == (0, 14)
