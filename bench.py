@@ -56,10 +56,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef", "warp"],
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
                          "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
-                         "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres)")
+                         "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres); "
+                         "warp = perspective warp of resident 4K frames (visualize.py:285-289, SURVEY 8f N3)")
     ap.add_argument("--half", type=int, default=0, help="ultralytics.half: 0 = fp32 activations (the reference default, default.yaml:245), 1 = fp16 activations + fp16 MFMA")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary fp16 measurement (N = 1, --half 0 runs add a shorter --half 1 pass and report it under 'f16')")
     ap.add_argument("--fp32", default=None, choices=["exact", "split"],
@@ -265,8 +266,57 @@ def bench_georef(args):
                                        "sample": f"{m} rows through the host numpy chain (apply_homography, ortho2geo, geo2local)"}}), flush=True)
 
 
+def bench_warp(args):
+    """--workload warp: one step = gtx_warp_frame_dev on a 3840x2160 BGR frame resident in HBM (24.9 MB read + 24.9 MB
+    written): the frame warp of the reference's visualisation modes 1/4. HBM-bound by construction; the roofline object
+    prices it against 8 TB/s. Timed as K back-to-back launches on one stream between two synchronisations."""
+    from geotrax_amd import _lib
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.warp import FrameWarper
+
+    ctx = _lib.Context(0)
+    scene = make_scene(seed=0, h=H, w=W)
+    frame = scene.render(40, 150)
+    Hm = np.linalg.inv(scene.camera(40, 150)) @ scene.camera(0, 150)        # frame 40 -> frame 0, the matrix extract writes
+    wp = FrameWarper((H, W), ctx=ctx)
+    ctx.dev_upload(wp.src, frame)
+    steps, warm = max(args.steps, 1), max(args.warmup, 1)
+    for _ in range(warm):
+        wp.warp_dev(wp.src, Hm, wp.dst)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wp.warp_dev(wp.src, Hm, wp.dst)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    out_frame = np.empty_like(frame)
+    ctx.dev_download(out_frame, wp.dst)
+    nbytes = 2.0 * frame.nbytes
+    gbs = nbytes * steps / elapsed / 1e9
+    line = {"metric": "4K frames/sec through the perspective frame warp", "value": steps / elapsed, "unit": "frames/s", "n_gpus": 1,
+            "steps": steps, "warmup": warm, "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (f64 coordinates)", "data": "synthetic",
+            "config": {"workload": "cv2.warpPerspective equivalent (INTER_LINEAR, constant border) on a 3840x2160 BGR frame resident in HBM, "
+                                   "homography of frame 40 of the synthetic clip"},
+            "roofline": {"bound": "hbm", "kernel": "warp_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_us": 1e6 * elapsed / steps, "bytes_per_launch": nbytes,
+                         "timing": f"{steps} back-to-back launches on one stream between two synchronisations (launch gaps included)"}}
+    if not args.no_cpu_baseline:
+        from oracle.warp_ref import warp_perspective as ref
+
+        t0 = time.perf_counter()
+        want = ref(frame, Hm)
+        cpu_s = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
+                                "sample": "one 3840x2160 frame through oracle/warp_ref.py (vectorised numpy restatement of cv2.warpPerspective)"}
+        line["config"]["pixels_differing_from_oracle"] = int(np.count_nonzero(out_frame != want))
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "warp":
+        return bench_warp(args)
     if args.workload == "register":
         return bench_register(args)
     if args.workload == "georef":

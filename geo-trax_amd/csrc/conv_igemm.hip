@@ -440,7 +440,7 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
 // but make 4x fewer, 2x larger workgroups at 2 per CU: worth it only when the launch still fills the chip.
 void conv_pick_tile(const ConvGroup& g, ConvConfig& cfg) {
   if (cfg.variant != 2 || cfg.stride != 1) return;
-  static const int mode = env_int("GTX_CONV_TH16", -1);   // -1 = by size, 0 = never, 1 = always
+  static const int mode = env_int("GTX_CONV_TH16", 0);    // 0 = never (default: measured 3 % slower over the YOLOv8s shapes), 1 = always, -1 = by size
   static const int k1 = env_int("GTX_CONV_TH16_K1", 0);   // 1x1 convs are HBM-bound either way
   if (cfg.ks == 1 && !k1) { cfg.th = 8; return; }
   long wgs = 0;

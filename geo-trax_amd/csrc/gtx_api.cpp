@@ -610,6 +610,14 @@ int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const doub
     gtx::georef_points(ctx, *chain, x, y, n, ortho_x, ortho_y, lat, lon, east, north);
   });
 }
+int gtx_warp_frame_dev(gtx_ctx* ctx, const void* src_dptr, int h, int w, const double H[9], void* dst_dptr) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(src_dptr, "src"); need(H, "H"); need(dst_dptr, "dst");
+    if (src_dptr == dst_dptr) gtx::fail(GTX_ERR_INVALID, "warp_frame: source and destination must be distinct buffers");
+    gtx::warp_frame_dev(ctx, src_dptr, h, w, H, dst_dptr);
+  });
+}
+
 int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr) {
   return guarded([&] {
     need(ctx, "ctx"); need(src_bgr, "src"); need(H, "H"); need(dst_bgr, "dst");

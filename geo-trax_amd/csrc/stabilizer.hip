@@ -956,6 +956,7 @@ struct Stabilizer::Impl {
   hipEvent_t done_ev = nullptr;
   hipEvent_t t0_ev = nullptr, t1_ev = nullptr;   // GPU time of the last submitted pass (timing events)
   float last_ms = 0.f;
+  bool timed = false;                            // t0_ev was recorded for the pass in flight
   bool pending = false;
   bool have_ref = false;
   // last results
@@ -1325,7 +1326,9 @@ void Stabilizer::Impl::collect(double Hout[9], int* valid_out, int st[4]) {
   GTX_CHECK(pending, "stabilizer: collect without a submitted frame");
   GTX_HIP(hipEventSynchronize(done_ev));
   pending = false;
-  if (hipEventElapsedTime(&last_ms, t0_ev, t1_ev) != hipSuccess) last_ms = 0.f;
+  last_ms = 0.f;
+  if (timed) GTX_HIP(hipEventElapsedTime(&last_ms, t0_ev, t1_ev));
+  timed = false;
   const StabResult& R = *h_res;
   const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
   cur.host_n = R.n_cur;
@@ -1386,6 +1389,7 @@ void Stabilizer::submit_gray_dev(const void* gray, int gh, int gw, const float* 
   GTX_CHECK(gh == S.gh && gw == S.gw, "stabilizer: gray image is %dx%d, expected %dx%d", gw, gh, S.gw, S.gh);
   GTX_HIP(hipSetDevice(S.ctx->device));
   GTX_HIP(hipEventRecord(S.t0_ev, S.ctx->stream));
+  S.timed = true;
   S.extract(static_cast<const uint8_t*>(gray), boxes_xywh, n, S.lev_cur, S.slots_cur, S.cur);
   S.submit_match();
 }

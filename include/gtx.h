@@ -385,6 +385,9 @@ int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const doub
  * (visualize.py:289). BGR u8 in/out, host buffers. */
 int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9],
                    uint8_t* dst_bgr);
+/* Same, both images resident in HBM (dptrs from gtx_dev_alloc, distinct buffers); enqueued on the
+ * context's stream, returns without waiting (gtx_ctx_synchronize / a later call on the stream orders it). */
+int gtx_warp_frame_dev(gtx_ctx* ctx, const void* src_dptr, int h, int w, const double H[9], void* dst_dptr);
 
 #ifdef __cplusplus
 }

@@ -112,7 +112,7 @@ def test_fp32_paths_agree_at_full_size(gtx_ctx, scene4k):
     np.testing.assert_allclose(rb[:, 4:], ra[:, 4:], atol=1e-4)
     np.testing.assert_allclose(rb[:, :4], ra[:, :4], rtol=2e-5, atol=5e-3)
     assert len(a) == len(b)
-    # same detections; the order may differ only between neighbours whose scores tie to 1e-5 (the smooth class branch
+    # same detections; the order may differ only between neighbours whose scores tie within the 1e-4 score tolerance (the smooth class branch
     # of these seeded weights gives neighbouring anchors nearly equal scores; ~200 detections at 4K hold a few such ties)
     np.testing.assert_allclose(a.conf, b.conf, atol=1e-4)
     order = np.lexsort((np.round(b.xyxy[:, 0], 0), np.round(b.xyxy[:, 1], 0)))
@@ -122,7 +122,7 @@ def test_fp32_paths_agree_at_full_size(gtx_ctx, scene4k):
     moved = np.nonzero(order_a != order)[0]
     assert len(moved) <= 0.1 * len(a)
     for i, j in zip(order_a[moved], order[moved]):
-        assert abs(int(i) - int(j)) <= 2 and abs(a.conf[i] - a.conf[j]) < 1e-5, (i, j, a.conf[i], a.conf[j])
+        assert abs(int(i) - int(j)) <= 2 and abs(a.conf[i] - a.conf[j]) < 1e-4, (i, j, a.conf[i], a.conf[j])
 
 
 @pytest.mark.parametrize("prec", ["f16", "f32-split", "f32-exact"])
