@@ -56,11 +56,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef", "warp"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "detect", "register", "georef", "warp", "extract+georef"],
                     help="extract = detect+track+stabilize (BASELINE metric / configs[2]); detect = YOLOv8s only (configs[1]); "
                          "register = RootSIFT registration of a 4K frame pair, the once-per-video step of configs[3] (single GPU); "
                          "georef = the per-row transform chain of configs[3] (frame px -> orthophoto px -> lat/lon -> local metres); "
-                         "warp = perspective warp of resident 4K frames (visualize.py:285-289, SURVEY 8f N3)")
+                         "warp = perspective warp of resident 4K frames (visualize.py:285-289, SURVEY 8f N3); "
+                         "extract+georef = BASELINE configs[3]: the extract stream followed by the georeference stage (registration against a synthetic "
+                         "orthophoto, row chain, kinematics, CSV), unpaced and as a 30 fps stream")
     ap.add_argument("--half", type=int, default=0, help="ultralytics.half: 0 = fp32 activations (the reference default, default.yaml:245), 1 = fp16 activations + fp16 MFMA")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary fp16 measurement (N = 1, --half 0 runs add a shorter --half 1 pass and report it under 'f16')")
     ap.add_argument("--fp32", default=None, choices=["exact", "split"],
@@ -313,8 +315,135 @@ def bench_warp(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_extract_georef(args):
+    """--workload extract+georef (BASELINE configs[3]): one clip through the product's extract engine
+    (detect + track + stabilize), its rows through aggregate/post-processing, then the georeference stage on the result:
+    RootSIFT registration of the reference frame against a synthetic orthophoto (a zoomed, rotated render of the same
+    scene, ground truth known), the per-row chain frame px -> orthophoto px -> lat/lon -> local metres on the GPU,
+    dimensions / visibility / kinematics and the CSV. Measured twice: unpaced (`value`: clip frames / (extract + georeference
+    time)) and as a 30 fps stream (frames become available every 1/30 s; reported under `paced`: sustained rate, worst
+    frame-in -> result-out latency, and the georeference tail after the last frame)."""
+    import logging
+    import tempfile
+
+    from geotrax_amd import _lib
+    from geotrax_amd import georef_stage as gs
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.postprocess import aggregate_results, postprocess_tracks
+    from geotrax_amd.registration import estimate_homography
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+
+    logger = logging.getLogger("bench.georef")
+    logger.setLevel(logging.ERROR)
+    ctx = _lib.Context(0)
+    scene = make_scene(seed=0, h=H, w=W)
+    n_pool = max(args.frames, 2)
+    frames = [scene.render(t, 150) for t in range(n_pool)]
+    ortho, A_true = scene.orthophoto()
+    ortho_params = (126.6412, 37.3951, 2.4e-7, -1.9e-7, 0.0, 0.0)
+    args.tracker = args.tracker or "bytetrack"
+    det, weights, n_det, n_cand = calibrated_detector(ctx, frames[0], args, args.detections)
+    B = max(args.batch, 1)
+    order = list(range(n_pool)) + list(range(n_pool - 2, 0, -1))
+    seq = order + [order[i % len(order)] for i in range(B - 1)]
+    fbytes = frames[0].nbytes
+    pool = ctx.dev_alloc(fbytes * len(seq))
+    for i, t in enumerate(seq):
+        ctx.dev_upload(pool + i * fbytes, frames[t])
+    det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
+                  fp32_split=fp32_split(args), rect=bool(args.rect))
+    tracker = Tracker(args.tracker)
+    engine = ExtractEngine(weights, (H, W), det_kw, tracker, {}, device=0, batch=B, det_streams=args.det_streams, stab_streams=args.stab_streams,
+                           gmc=args.tracker == "botsort", detectors=[det])
+    gcfg = dict(transformation=dict(source_crs="epsg:4326", target_crs="epsg:5186", cutout_width_px=None),
+                filtering=dict(filter_type="gaussian", kernel_size=14, min_traj_length=15, visibility_margin=4))
+    matching = dict(detector_name="rsift", matcher_name="bf", filter_type="ratio", sift_enable_precise_upscale=True, max_features=250000, filter_ratio=0.55,
+                    ransac_method=38, ransac_epipolar_threshold=3.0, ransac_max_iter=10000, ransac_confidence=0.999999, rsift_eps=1e-8)
+    main_cfg = {"main": {"extraction": {"min_track_length": 3, "interpolate": False, "dimension_estimation": dict(
+        gsd=0.02725, eps=4, r0=1.25, theta_bar=15, tau_c={0: 1.83, 1: 2.85, 2: 1.70, 3: 1.80, -1: 1.70})},
+        "args": argparse.Namespace(source="synthetic.mp4", interpolate=False), "tracker": {"active": args.tracker, args.tracker: {"track_buffer": 30}}}}
+    n_steps = max(min(args.steps, 75), 2)                      # 75 steps x 2 frames = the 150 frames of the reference's 5 s clip
+    outdir = Path(tempfile.mkdtemp(prefix="gtx_bench_georef_"))
+
+    def one_pass(pace_fps):
+        tracker.reset()
+        engine.reset()
+        cols = dict(frame=[], ids=[], raw=[], stab=[], cls=[], conf=[], tr=[])
+        avail, lat = {}, []
+        t_start = time.perf_counter()
+
+        def batches():
+            for k in range(n_steps):
+                if pace_fps:                                    # the last frame of batch k exists at (k*B + B - 1) / fps
+                    due = t_start + (k * B + B - 1) / pace_fps
+                    while time.perf_counter() < due:
+                        time.sleep(max(min(due - time.perf_counter(), 0.002), 0))
+                for b in range(B):
+                    avail[k * B + b] = time.perf_counter()
+                yield pool + ((k * B) % len(order)) * fbytes
+
+        for r in engine.run(batches()):
+            lat.append(time.perf_counter() - avail[r.index])
+            if r.xywh is not None:
+                n = len(r.xywh)
+                cols["frame"].append(np.full((n, 1), r.index, dtype=np.uint32))
+                cols["ids"].append(np.full((n, 1), -1) if r.ids is None else np.asarray(r.ids).astype(np.uint16).reshape(-1, 1))
+                cols["raw"].append(r.xywh.astype(np.float32))
+                cols["stab"].append(r.xywh_stab)
+                cols["cls"].append(np.asarray(r.cls).astype(np.uint8).reshape(-1, 1))
+                cols["conf"].append(np.asarray(r.conf).astype(np.float32).reshape(-1, 1))
+            if r.index > 0 and r.H is not None:
+                cols["tr"].append(np.hstack((np.array([[r.index]]), r.H.reshape(1, -1))))
+        ctx.synchronize()
+        t_extract = time.perf_counter() - t_start
+        t0 = time.perf_counter()
+        tracks, transforms = aggregate_results(cols["frame"], cols["ids"], cols["raw"], cols["stab"], cols["cls"], cols["conf"], cols["tr"], logger)
+        tracks = postprocess_tracks(tracks, main_cfg, logger, (W, H))
+        t_post = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Hm, inl, nm, nkp = estimate_homography(frames[0], ortho, logger, ctx=ctx, **matching)
+        t_reg = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        df = gs.georeference_tracks(tracks[:, 1].astype(int), tracks[:, 0].astype(int), tracks[:, 2:6].astype(np.float64), tracks[:, 6].astype(np.float64),
+                                    tracks[:, 7].astype(np.float64), tracks[:, 10].astype(int), tracks[:, 12:14].astype(np.float64), None, np.array([]),
+                                    (H, W), 30.0, Hm, ortho_params, None, gcfg, logger, ctx=ctx)
+        df.to_csv(outdir / "synthetic.csv", index=False)
+        np.savetxt(outdir / "synthetic_geo_transf.txt", Hm.reshape(1, -1), fmt="%.20g", delimiter=",")
+        t_geo = time.perf_counter() - t0
+        ys, xs = np.meshgrid(np.linspace(0, H - 1, 9), np.linspace(0, W - 1, 16), indexing="ij")
+        P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+        pa, pb = Hm @ P, A_true @ P
+        err = float(np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max())
+        return dict(t_extract=t_extract, t_post=t_post, t_reg=t_reg, t_geo=t_geo, rows=int(len(tracks)), csv_rows=int(len(df)), vehicles=int(df["Vehicle_ID"].nunique()),
+                    lat_max=float(max(lat)), lat_med=float(np.median(lat)), err=err, kp=[int(v) for v in nkp], inliers=int(inl), matches=int(nm))
+
+    one_pass(0)                                                 # warm-up: kernels loaded, SIFT pyramids allocated
+    u = one_pass(0)
+    p = one_pass(30.0)
+    n_fr = n_steps * B
+    tail_u = u["t_post"] + u["t_reg"] + u["t_geo"]
+    tail_p = p["t_post"] + p["t_reg"] + p["t_geo"]
+    dt = "f16" if args.half else ("f32s" if det.fp32_split else "f32")
+    line = {"metric": "4K frames/sec through detect+stabilize+track, then orthophoto georeference", "value": n_fr / (u["t_extract"] + tail_u), "unit": "frames/s",
+            "n_gpus": 1, "steps": n_steps, "warmup": n_steps, "ms_per_step": 1000.0 * (u["t_extract"] + tail_u) / n_steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: full extract ({args.tracker}) of a {n_fr}-frame 3840x2160 clip + georeference stage "
+                                   "(RootSIFT registration against a 4800x4800 synthetic orthophoto, row chain on the GPU, kinematics, CSV)",
+                       "frames": n_fr, "track_rows": u["rows"], "csv_rows": u["csv_rows"], "vehicles": u["vehicles"],
+                       "extract_s": u["t_extract"], "postprocess_s": u["t_post"], "registration_s": u["t_reg"], "row_chain_kinematics_csv_s": u["t_geo"],
+                       "registration": {"keypoints": u["kp"], "matches": u["matches"], "inliers": u["inliers"], "max_grid_error_px_vs_known_orthophoto": u["err"]}},
+            "paced": {"stream_fps": 30.0, "sustained_fps": n_fr / p["t_extract"], "frame_latency_ms": {"median": 1000 * p["lat_med"], "max": 1000 * p["lat_max"]},
+                      "georeference_tail_ms": 1000 * tail_p,
+                      "note": "frames become available every 1/30 s; latency = frame available -> its tracked, stabilized result leaves the engine"}}
+    print(json.dumps(line), flush=True)
+    engine.close()
+
+
 def main():
     args = parse()
+    if args.workload == "extract+georef":
+        return bench_extract_georef(args)
     if args.workload == "warp":
         return bench_warp(args)
     if args.workload == "register":

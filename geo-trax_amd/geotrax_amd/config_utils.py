@@ -110,8 +110,14 @@ def resolve_class_names(model_names, cli_value, cfg_value, classes, logger):
     return {int(i): str(int(i)) for i in ids}, "fallback"
 
 
-def load_config_all(args: argparse.Namespace, logger: logging.Logger, model_names: dict | None = None) -> dict:
+def load_config_all(args: argparse.Namespace, logger: logging.Logger, model_names: dict | None = None, needs_model: bool = True) -> dict:
+    """config_utils.load_config_all (:127-194). needs_model=False (the georeference stage): no tracker block, model or
+    class names are resolved, so a missing model does not stop a stage that never uses it."""
     full = load_config(getattr(args, "cfg", None), logger)
+    if not needs_model:
+        main = {k: v for k, v in full.items() if k not in ("tracker", "stabilo", "ultralytics", "georef")}
+        main.update(class_names={}, class_names_source=None, model_configured=None, tracker_active=None, tracker_params={}, args=args)
+        return {"main": main, "stabilo": dict(full.get("stabilo", {})), "ultralytics": dict(full.get("ultralytics", {})), "georef": full.get("georef", {})}
     tracker = full.get("tracker", {})
     stabilo = dict(full.get("stabilo", {}))
     ultra = dict(full.get("ultralytics", {}))

@@ -82,6 +82,21 @@ class Scene:
             out.append([(p[0].min() + p[0].max()) / 2, (p[1].min() + p[1].max()) / 2, p[0].max() - p[0].min(), p[1].max() - p[1].min()])
         return np.asarray(out, dtype=np.float32)
 
+    def orthophoto(self, size: int = 4800, scale: float = 1.18, angle: float = 0.21) -> tuple[np.ndarray, np.ndarray]:
+        """A synthetic orthophoto of the scene: the static world (no vehicles) seen through a similarity (zoom `scale`,
+        rotation `angle`, centred) on a size x size canvas -> (BGR uint8 image, 3x3 ground truth mapping frame-0 pixels to
+        orthophoto pixels). What config 4 of SURVEY.md 8d registers the reference frame against."""
+        c, s = scale * np.cos(angle), scale * np.sin(angle)
+        A = np.array([[c, -s, size / 2 - c * self.w / 2 + s * self.h / 2], [s, c, size / 2 - s * self.w / 2 - c * self.h / 2], [0, 0, 1.0]])
+        Ai = np.linalg.inv(A)
+        ys, xs = np.mgrid[0:size, 0:size].astype(np.float32)
+        fx = Ai[0, 0] * xs + Ai[0, 1] * ys + Ai[0, 2]
+        fy = Ai[1, 0] * xs + Ai[1, 1] * ys + Ai[1, 2]
+        inside = (fx >= -self.margin + 1) & (fx < self.w + self.margin - 2) & (fy >= -self.margin + 1) & (fy < self.h + self.margin - 2)
+        img = bilinear_sample(self.world, fx + self.margin, fy + self.margin)
+        img[~inside] = 60.0
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8), A
+
     def render(self, t: int, n_frames: int = 150) -> np.ndarray:
         """Frame t as BGR uint8 [h,w,3]."""
         G = self.camera(t, n_frames)
