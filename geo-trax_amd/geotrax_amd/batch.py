@@ -116,6 +116,7 @@ def process_input(args, logger: logging.Logger, run=detect_track_stabilize) -> d
     mine = shard(files, rank, world) if world > 1 else files
     if world > 1:
         os.environ.setdefault("GTX_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        os.environ["GTX_FRAME_SHARDING"] = "0"                    # whole videos per rank here, not frames of one video (extract.py)
         logger.info(f"rank {rank}/{world}: {len(mine)} of {len(files)} videos")
     for f in mine:
         counts[process_file(f, args, logger, out_cfg, run)] += 1

@@ -57,58 +57,76 @@ def unpack_frame_record(rec: np.ndarray, max_det: int):
     return body[:, :4].astype(np.float32), body[:, 4].astype(np.float32), body[:, 5].astype(np.int32), H
 
 
-def extract_sharded(n_frames: int, first: int, read_frame: Callable[[int], np.ndarray],
-                    detect: Callable[[np.ndarray], tuple], set_ref: Callable[[np.ndarray, np.ndarray | None], None],
-                    stabilize: Callable[[np.ndarray, np.ndarray | None], np.ndarray | None], tracker, warp_boxes,
-                    max_det: int, dist=None, device=None):
-    """Runs this rank's shard and, on rank 0, returns the per-frame lists the aggregation step
-    expects: (frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms). Other ranks return None.
+def init_process_group(local_device_count: int | None = None):
+    """torch.distributed for a launcher-started run (RANK / WORLD_SIZE / MASTER_* in the environment). One process per
+    GPU -> backend "nccl" (RCCL over xGMI) with collectives on device tensors; ranks that must share a GPU (tests on a
+    one-GPU box), or GTX_DIST_BACKEND=gloo -> gloo with host tensors. Returns (dist, device for the collectives' tensors,
+    local GPU index)."""
+    import os
 
-    detect(frame) -> (xyxy [n,4], conf [n], cls [n]);  set_ref(frame, xywh|None);
-    stabilize(frame, xywh|None) -> 3x3 or None;  tracker.update(xyxy, conf, cls) -> (xyxy, id, score, cls, idx);
-    warp_boxes(H, xywh) -> xywh.  `dist` is torch.distributed (initialised) or None for one process."""
-    rank = dist.get_rank() if dist is not None else 0
-    world = dist.get_world_size() if dist is not None else 1
+    import torch
+    import torch.distributed as dist
 
+    world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count() if local_device_count is None else local_device_count
+    backend = os.environ.get("GTX_DIST_BACKEND") or ("nccl" if n_dev >= min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))) and n_dev > 0 else "gloo")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    return dist, dev, (local % max(n_dev, 1))
+
+
+def gather_records(local: np.ndarray, failed: bool, dist=None, device=None):
+    """The one data-path collective of a frame-sharded video: every rank contributes its [per, stride] float64 block
+    (padded to the same `per`) and a failure flag; rank 0 gets (list of blocks by rank, any_failed), the others
+    (None, any_failed). A rank that failed on its shard still takes part (with zeros), so nobody waits for a
+    timeout; rank 0 then voids the whole video like the reference does for any exception (extract.py:198-200)."""
+    if dist is None or dist.get_world_size() == 1:
+        return [local], bool(failed)
+    import torch
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    flag = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64)
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    if device is not None:
+        flag, t = flag.to(device), t.to(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)                  # every rank learns whether the video is void
+    any_failed = bool(flag.item() > 0)
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, bufs, dst=0)
+    if rank != 0:
+        return None, any_failed
+    return [b.cpu().numpy() for b in bufs], any_failed
+
+
+def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_boxes, max_det: int, with_gmc: bool = False):
+    """Rank 0: the sequential half of the loop over the gathered records, in clip order (extract.py:153-187 with the
+    detector and stabilizer results taken from the records): tracker.update on every frame (with the rank's
+    camera-motion warp for BoT-SORT), ids -1 when the tracker returns nothing, boxes warped by the frame's H, the first
+    frame passes through as the reference frame. -> (frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms)."""
     def xywh_of(b):
-        return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) \
-            if len(b) else None
+        return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32)
 
-    ref = read_frame(first)
-    rx, _, _ = detect(ref)
-    set_ref(ref, xywh_of(rx))
-    start, stop = shard_range(n_frames, rank, world, first)
-    per = -(-max(n_frames - first, 0) // world)                  # records per rank, padded
-    stride = 1 + max_det * 6 + 10
-    local = np.zeros((per, stride), dtype=np.float64)
-    for k, f in enumerate(range(start, stop)):
-        frame = ref if f == first else read_frame(f)
-        xyxy, conf, cls = detect(frame)
-        H = None if f == first else stabilize(frame, xywh_of(xyxy))
-        local[k] = pack_frame_record(max_det, xyxy, conf, cls, H)
-    if dist is not None and world > 1:
-        import torch
-
-        t = torch.from_numpy(local)
-        if device is not None:
-            t = t.to(device)
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-        dist.gather(t, bufs, dst=0)
-        if rank != 0:
-            return None
-        allrec = [b.cpu().numpy() for b in bufs]
-    else:
-        allrec = [local]
-    # ---- rank 0: sequential tracker over the frames in order
     frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms = [], [], [], [], [], [], []
+    last_H = None
     for r in range(world):
         s, e = shard_range(n_frames, r, world, first)
         for k, f in enumerate(range(s, e)):
-            xyxy, conf, cls, H = unpack_frame_record(allrec[r][k], max_det)
-            bx, ids, sc, cl, _ = tracker.update(xyxy, conf, cls)     # every frame, also without detections (ultralytics track.py)
-            if len(conf) == 0:
+            rec = blocks[r][k]
+            xyxy, conf, cls, H = unpack_frame_record(rec, max_det)
+            bx, ids, sc, cl, _ = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if with_gmc else None)   # every frame, empty or not
+            if f != first:
+                if H is None:
+                    H = last_H                                   # stabilo's last known transform (see engine._stabilized)
+                else:
+                    last_H = H
                 if H is not None:
                     transforms.append(np.hstack((np.array([[f]]), H.reshape(1, -1))))
+            if len(conf) == 0:
                 continue
             if len(ids) == 0:
                 bx, ids, sc, cl = xyxy, np.full(len(conf), -1), conf, cls
@@ -119,10 +137,30 @@ def extract_sharded(n_frames: int, first: int, read_frame: Callable[[int], np.nd
             bbox.append(xywh)
             class_id.append(np.asarray(cl).astype(np.uint8).reshape(-1, 1))
             confs.append(np.asarray(sc, dtype=np.float32).reshape(-1, 1))
-            if f == first:
-                bbox_stab.append(xywh)
-            else:
-                bbox_stab.append(warp_boxes(H, xywh) if H is not None else xywh.copy())
-                if H is not None:
-                    transforms.append(np.hstack((np.array([[f]]), H.reshape(1, -1))))
+            bbox_stab.append(xywh if f == first or H is None else warp_boxes(H, xywh))
     return frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms
+
+
+def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max_det: int, dist=None, device=None, with_gmc: bool = False):
+    """One video, frames [first, n_frames) sharded in contiguous ranges over the ranks of `dist` (None: one process).
+    `produce(start, stop)` yields this rank's packed records in frame order (geotrax_amd.extract drives the HIP engine
+    there; the CPU tests a deterministic stand-in). Rank 0 returns the per-frame lists aggregate_results() expects, the
+    other ranks None. If any rank fails, every rank raises RuntimeError after the (still completed) collective."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    start, stop = shard_range(n_frames, rank, world, first)
+    per = -(-max(n_frames - first, 0) // world)                  # records per rank, padded
+    stride = 1 + max_det * 6 + (7 if with_gmc else 0) + 10
+    local = np.zeros((per, stride), dtype=np.float64)
+    failed, err = False, None
+    try:
+        for k, rec in enumerate(produce(start, stop)):
+            local[k] = rec
+    except Exception as e:                                       # this rank's shard is lost: tell the others through the collective
+        failed, err = True, e
+    blocks, any_failed = gather_records(local, failed, dist, device)
+    if any_failed:
+        raise RuntimeError(f"frame-sharded extraction failed on {'this rank: ' + repr(err) if failed else 'another rank'}")
+    if rank != 0:
+        return None
+    return replay_records(blocks, n_frames, first, world, tracker, warp_boxes, max_det, with_gmc)

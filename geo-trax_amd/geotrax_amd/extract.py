@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import datetime
 import logging
+import os
 import sys
 import time
 from pathlib import Path
@@ -53,7 +54,13 @@ def detect_track_stabilize(args: argparse.Namespace, logger: logging.Logger) -> 
         'output_folder': out_cfg_raw.get('folder', 'results'),
     })
     out_cfg = {**out_cfg_raw, 'folder': args.output_folder}
-    tracks, transforms = track_with_model(model, config, logger)
+    if frame_sharding_active():
+        res = track_with_model_sharded(model, config, logger)
+        if res is None:                                     # ranks other than 0 have handed their records over
+            return
+        tracks, transforms = res
+    else:
+        tracks, transforms = track_with_model(model, config, logger)
     w_h = get_video_dimensions(config['main']['args'].source)
     tracks = postprocess_tracks(tracks, config, logger, w_h)
     save_results(tracks, transforms, config, logger, out_cfg)
@@ -107,6 +114,121 @@ def _frame_batches(reader, first: int, last, batch: int, frame_nums: list):
         yield group
 
 
+def _engine_kwargs(config: dict) -> tuple[dict, dict | None, dict]:
+    ul = config['ultralytics']
+    imgsz = ul.get('imgsz', 640)
+    det_kw = dict(imgsz=int(max(imgsz) if isinstance(imgsz, (list, tuple)) else imgsz), conf=float(ul.get('conf') or 0.1),
+                  iou=float(ul.get('iou', 0.7)), max_det=int(ul.get('max_det', 300)), classes=ul.get('classes'),
+                  agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', True)))
+    do_stab = config['main']['extraction']['stabilize']
+    stab_kw = {k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')} if do_stab else None
+    return det_kw, stab_kw, (config['main'].get('engine') or {})
+
+
+def frame_sharding_active() -> bool:
+    """Under a launcher (WORLD_SIZE > 1) `geotrax_amd.extract` shards the frames of its one video over the ranks
+    (SURVEY.md 8e / BASELINE north star); `geotrax_amd.batch` deals whole videos to the ranks instead and switches
+    this off (GTX_FRAME_SHARDING=0)."""
+    import os
+
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("GTX_FRAME_SHARDING", "1") != "0"
+
+
+def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray] | None:
+    """The hot loop with the frames of the video sharded over the ranks of the launcher (one process per GPU):
+    contiguous frame ranges, every rank registers against the same reference frame and detects + stabilizes its range
+    (foreground mask from the raw detections; BoT-SORT: the rank's GMC is primed with the frame before its range),
+    fixed-stride records go to rank 0 in ONE gather (RCCL when every rank has its own GPU), and rank 0 replays the
+    tracker in clip order. Rank 0 returns (tracks, transforms); the other ranks None. A failure on any rank voids the
+    video on all of them (geotrax_amd.distributed.extract_sharded)."""
+    from . import distributed as D
+    from .engine import ExtractEngine
+    from .geometry import warp_boxes
+
+    args = config['main']['args']
+    det_kw, stab_kw, eng_cfg = _engine_kwargs(config)
+    do_stab = stab_kw is not None
+    dist, dev, local = D.init_process_group()
+    rank = dist.get_rank()
+    first, last = args.cut_frame_left or 0, args.cut_frame_right
+    tracker = model._make_tracker(config['ultralytics'].get('tracker', {'tracker_type': 'botsort'}))   # also decides whether a GMC runs
+    with_gmc = model._gmc_method is not None
+    max_det = det_kw['max_det']
+    state = {}
+
+    def produce(start, stop):
+        reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
+        state['reader'] = reader
+        n_total = reader.frame_count if last is None else min(reader.frame_count, last + 1)
+        assert n_total == state['n_frames']
+        engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, None, stab_kw, device=local, batch=int(eng_cfg.get('batch', 2)),
+                               det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)), gmc=with_gmc)
+        state['engine'] = engine
+        ref, prev, f = None, None, 0
+        while f < start:                                    # sequential source: skip to the range, keeping the two frames needed
+            ok, frame = reader.read()
+            if not ok:
+                raise RuntimeError(f"frame {f} could not be read")
+            if f == first:
+                ref = frame
+            if f == start - 1:
+                prev = frame
+            f += 1
+
+        def batches():
+            nonlocal ref
+            group, opened = [], False
+            prev_ptr = None
+            if with_gmc and prev is not None and start > first:
+                ctx0 = engine.dets[0].ctx
+                prev_ptr = ctx0.dev_alloc(prev.nbytes)
+                state['prev_ptr'] = (ctx0, prev_ptr)
+                ctx0.dev_upload(prev_ptr, np.ascontiguousarray(prev, np.uint8))
+            fail_at = os.environ.get("GTX_TEST_FAIL_AT_FRAME")          # fault injection for the failure-path test
+            for f in range(start, stop):
+                ok, frame = reader.read()
+                if not ok or (fail_at is not None and f == int(fail_at)):
+                    raise RuntimeError(f"frame {f} could not be read")
+                if f == first:
+                    ref = frame
+                if ref is not None and not state.get('have_ref') and do_stab:
+                    engine.set_reference(ref)               # every rank registers against the clip's reference frame
+                    state['have_ref'] = True
+                group.append(frame)
+                if len(group) == engine.B or f == stop - 1:
+                    yield group if opened else (group, prev_ptr)    # the range does not continue another batch: (re)start the GMC
+                    opened, group = True, []
+
+        if start < stop:
+            if do_stab and ref is not None and start > first:
+                engine.set_reference(ref)
+                state['have_ref'] = True
+            for r in engine.run(batches()):
+                yield D.pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None if r.H_fallback else r.H, r.gmc, with_gmc=with_gmc)
+
+    try:
+        probe = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
+        state['n_frames'] = probe.frame_count if last is None else min(probe.frame_count, last + 1)
+        probe.release()
+        lists = D.extract_sharded(state['n_frames'], first, produce, tracker, warp_boxes, max_det, dist=dist, device=dev, with_gmc=with_gmc)
+    except Exception as e:
+        logger.error(f"Error processing: '{args.source}' due to: {e}")
+        return (np.empty((0, 12), dtype=np.float32), np.empty((0, 10))) if rank == 0 else None
+    finally:
+        if 'prev_ptr' in state:
+            state['prev_ptr'][0].dev_free(state['prev_ptr'][1])
+        if 'reader' in state:
+            state['reader'].release()
+        if 'engine' in state:
+            state['engine'].close()
+    if rank != 0:
+        return None
+    frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms = lists
+    if not do_stab:
+        bbox_stab, transforms = [], []
+    return aggregate_results(frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms, logger)
+
+
 def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray]:
     """The hot loop (extract.py:134-214): read -> detect+track -> stabilize, through the pipelined engine
     (geotrax_amd.engine: batches on the detector streams, tracker in clip order, stabilizers on their own
@@ -118,12 +240,7 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
     reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
     do_stab = config['main']['extraction']['stabilize']
     ul = config['ultralytics']
-    imgsz = ul.get('imgsz', 640)
-    det_kw = dict(imgsz=int(max(imgsz) if isinstance(imgsz, (list, tuple)) else imgsz), conf=float(ul.get('conf') or 0.1),
-                  iou=float(ul.get('iou', 0.7)), max_det=int(ul.get('max_det', 300)), classes=ul.get('classes'),
-                  agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', True)))
-    stab_kw = {k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')} if do_stab else None
-    eng_cfg = config['main'].get('engine') or {}
+    det_kw, stab_kw, eng_cfg = _engine_kwargs(config)
     first, last = args.cut_frame_left, args.cut_frame_right
     out, frame_nums, det_ms, stab_ms, n_frames = _Collector(), [], [], [], 0
     t_wall = time.time()

@@ -44,19 +44,44 @@ class _FakeStab:
         return np.array([[1, 0, -0.1 * (i - self.ref)], [0, 1, 0.2 * (i - self.ref)], [0, 0, 1.0]])
 
 
-def _run(dist_mod):
+def _xywh(b):
+    return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) if len(b) else None
+
+
+def _producer(first, fail_at=None):
+    """What geotrax_amd.extract does with the HIP engine, with the stand-ins: this rank's frames -> packed records."""
+    stab = _FakeStab()
+    stab.set_ref(_frame(first), None)
+
+    def produce(start, stop):
+        for f in range(start, stop):
+            if f == fail_at:
+                raise RuntimeError("decoder exploded")
+            xyxy, conf, cls = _fake_detect(_frame(f))
+            H = None if f == first else stab.stabilize(_frame(f), _xywh(xyxy))
+            yield pack_frame_record(MAX_DET, xyxy, conf, cls, H)
+    return produce
+
+
+def _run(dist_mod, fail_at=None):
     from geotrax_amd.geometry import warp_boxes
     from geotrax_amd.tracker import Tracker
 
-    stab = _FakeStab()
-    return extract_sharded(N_FRAMES, 2, _frame, _fake_detect, stab.set_ref, stab.stabilize, Tracker("bytetrack"), warp_boxes,
-                           MAX_DET, dist=dist_mod)
+    return extract_sharded(N_FRAMES, 2, _producer(2, fail_at), Tracker("bytetrack"), warp_boxes, MAX_DET, dist=dist_mod)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fail_at=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if fail_at is not None:
+            try:
+                _run(dist, fail_at)
+            except RuntimeError as e:                   # EVERY rank learns of the failure through the collective and returns
+                q.put((rank, str(e)))
+            else:
+                q.put((rank, "no error"))
+            return
         out = _run(dist)
         if rank == 0:
             q.put([[np.asarray(a) for a in lst] for lst in out])
@@ -66,16 +91,35 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_equals_single_process():
-    single = _run(None)
+def _spawn(world, fail_at=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fail_at)) for r in range(world)]
     for p in procs:
         p.start()
+    return q, procs
+
+
+def test_a_failing_rank_voids_the_video_on_every_rank_without_a_hang():
+    """SURVEY.md section 5 (failure detection): a rank whose shard raises still joins the gather; all ranks then raise, so
+    rank 0 writes no partial output (extract.py:198-200) and nobody sits in a collective until the timeout."""
+    q, procs = _spawn(2, fail_at=N_FRAMES - 3)          # a frame of rank 1's range
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == 0 and "another rank" in got[0][1]
+    assert got[1][0] == 1 and "decoder exploded" in got[1][1]
+    with pytest.raises(RuntimeError):
+        _run(None, fail_at=5)                            # single process: same rule
+
+
+def test_world2_gloo_equals_single_process():
+    single = _run(None)
+    q, procs = _spawn(2)
     multi = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
@@ -87,7 +131,8 @@ def test_world2_gloo_equals_single_process():
             np.testing.assert_array_equal(np.asarray(x), y)
     frames = np.concatenate(single[0])[:, 0]
     assert frames.min() == 2 and frames.max() == N_FRAMES - 1
-    assert len(single[6]) == sum(1 for i in range(3, N_FRAMES) if i % 7 != 3)
+    assert len(single[6]) == N_FRAMES - 4                # frames 4.. all carry a transform: frame 3 (no model) has none yet,
+    #                                                       later failures (10, 17) fall back to the last known one
 
 
 def test_shard_ranges_partition_the_frames():

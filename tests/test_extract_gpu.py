@@ -9,6 +9,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+ROOT = Path(__file__).resolve().parent.parent
+
 pytestmark = pytest.mark.gpu
 logger = logging.getLogger("test_extract")
 
@@ -536,3 +538,77 @@ def test_engine_frames_without_detections(gtx_ctx, tracker):
         assert (r.H is None) == (i == 0)                     # the reference frame has no transform row; the others register
     assert all(np.isfinite(r.H).all() and abs(np.linalg.det(r.H) - 1.0) < 0.05 for r in got[1:])
 
+
+
+def _run_sharded_cli(tmp_path, cfg_path, clip, out, n_ranks, backend, port, extra_env=None):
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GTX_DIST_BACKEND=backend, OMP_NUM_THREADS="1",
+               PYTHONPATH=str(ROOT / "geo-trax_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""), **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "geotrax_amd.extract", str(clip), "--cfg", str(cfg_path), "--output-folder", str(out)]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
+
+
+@pytest.mark.parametrize("tracker", ["botsort", "bytetrack"])
+def test_cli_under_a_launcher_shards_the_frames_of_one_video(gtx_ctx, tmp_path, tracker):
+    """`torchrun ... -m geotrax_amd.extract <video>`: contiguous frame ranges per rank, one gather, tracker replay on rank 0
+    (the product path of geotrax_amd.distributed). Two ranks share the one GPU here over gloo. Against the
+    single-process run: same rows, ids, raw boxes, classes, scores (the tracker sees the same detections and, with
+    BoT-SORT, the same camera-motion warps: each rank primes its GMC with the frame before its range); the stabilized
+    boxes agree within the 1 px bar (shard ranks mask with the raw detections, extract.py:181 with the tracker's boxes)."""
+    from geotrax_amd import extract as ex
+    from geotrax_amd.synth import make_scene
+
+    sc = make_scene(seed=4, h=H, w=W)
+    frames = np.stack([sc.render(3 * t, 150) for t in range(9)])
+    clip = tmp_path / "U_clip.npy"
+    np.save(clip, frames)
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, frames[0])
+    cfg_path, _ = _cfg_file(tmp_path, wpath, tracker=tracker)
+    ex.main([str(clip), "--cfg", str(cfg_path), "--output-folder", str(tmp_path / "single")])
+    p = _run_sharded_cli(tmp_path, cfg_path, clip, tmp_path / "sharded", 2, "gloo", 29547)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    a = np.loadtxt(tmp_path / "single" / "U_clip.txt", delimiter=",", ndmin=2)
+    b = np.loadtxt(tmp_path / "sharded" / "U_clip.txt", delimiter=",", ndmin=2)
+    assert a.shape == b.shape and len(a) > 50 and set(np.unique(a[:, 0])) == set(range(9))
+    np.testing.assert_array_equal(a[:, [0, 1, 10, 11]], b[:, [0, 1, 10, 11]])         # frames, ids, classes, scores
+    np.testing.assert_allclose(a[:, 2:6], b[:, 2:6], rtol=0, atol=1e-3)               # tracker boxes (%g text)
+    # stabilized boxes differ by the mask choice only. On this 768x432 clip (500 keypoints, seeded weights whose boxes cover a
+    # large part of the frame) that moves them by up to ~1.5 px; at 4K with vehicle-sized boxes the two masks agree to 0.4 px
+    # (tests/test_fullsize_gpu.py::test_shard_mode_mask_moves_the_homography_by_less_than_a_pixel)
+    assert np.abs(a[:, 6:10] - b[:, 6:10]).max() < 3.0
+    ta = np.loadtxt(tmp_path / "single" / "U_clip_vid_transf.txt", delimiter=",", ndmin=2)
+    tb = np.loadtxt(tmp_path / "sharded" / "U_clip_vid_transf.txt", delimiter=",", ndmin=2)
+    assert list(ta[:, 0]) == list(tb[:, 0]) == list(range(1, 9))
+    # a rank that fails voids the video for everybody: no output, no hang (rank 1's range holds frame 7)
+    p = _run_sharded_cli(tmp_path, cfg_path, clip, tmp_path / "void", 2, "gloo", 29548, {"GTX_TEST_FAIL_AT_FRAME": "7"})
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert not (tmp_path / "void" / "U_clip.txt").exists()
+    assert "Error processing" in p.stderr + p.stdout
+
+
+def test_cli_frame_sharding_over_rccl_with_two_gpus(gtx_ctx, tmp_path):
+    """The same run with one GPU per rank and the records gathered over RCCL (backend nccl). Needs two visible GPUs: the
+    builder's and the driver's single-GPU boxes skip it, an 8-GPU node runs it."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL gather between ranks)")
+    from geotrax_amd import extract as ex
+    from geotrax_amd.synth import make_scene
+
+    sc = make_scene(seed=4, h=H, w=W)
+    frames = np.stack([sc.render(3 * t, 150) for t in range(9)])
+    clip = tmp_path / "U_clip.npy"
+    np.save(clip, frames)
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, frames[0])
+    cfg_path, _ = _cfg_file(tmp_path, wpath, tracker="botsort")
+    ex.main([str(clip), "--cfg", str(cfg_path), "--output-folder", str(tmp_path / "single")])
+    p = _run_sharded_cli(tmp_path, cfg_path, clip, tmp_path / "sharded", 2, "nccl", 29549)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    a = np.loadtxt(tmp_path / "single" / "U_clip.txt", delimiter=",", ndmin=2)
+    b = np.loadtxt(tmp_path / "sharded" / "U_clip.txt", delimiter=",", ndmin=2)
+    np.testing.assert_array_equal(a[:, [0, 1, 10, 11]], b[:, [0, 1, 10, 11]])
