@@ -646,8 +646,16 @@ def main():
             worker.start()
     barrier()
     t0 = time.perf_counter()
-    n_tracks = run(args.warmup, args.steps, sharded)
-    ctx.synchronize()
+    failure = None
+    try:
+        n_tracks = run(args.warmup, args.steps, sharded)
+        ctx.synchronize()
+    except Exception as e:                                       # this rank's shard is lost; it still joins every collective below
+        failure = f"rank {rank}: {type(e).__name__}: {e}"
+        if sharded and extract:                                  # empty records for the steps it did not finish (same gather count on every rank)
+            empty = pack_frame_record(max_det, np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32), None, None, with_gmc=shard_gmc)
+            while len(records) < args.steps * B:
+                records.append(empty)
     if sharded and extract:
         gather_ready(final=True)                                 # the steps since the last full chunk
         if worker is not None:
@@ -658,15 +666,19 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device=cdev)
+        t = torch.tensor([elapsed, 1.0 if failure else 0.0], device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if float(t[1].item()) > 0 and failure is None:
+            failure = "another rank failed (see its stderr)"
+    if failure is not None:
+        print(f"bench: {failure}", file=sys.stderr, flush=True)
     barrier()
 
     if rank == 0:
         dt = "f16" if args.half else ("f32s" if det.fp32_split else "f32")
         out = {
-            "metric": "4K frames/sec through detect+stabilize+track", "value": args.steps * B * world / elapsed, "unit": "frames/s",
+            "metric": "4K frames/sec through detect+stabilize+track", "value": (args.steps * B * world / elapsed) if failure is None else 0.0, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic",
             "config": {
@@ -689,6 +701,8 @@ def main():
                             "tracker replayed there on a second host thread",
             },
         }
+        if failure is not None:
+            out["error"] = failure + " -- the measurement is void (a rank that fails still joins the gathers, so nobody hangs)"
         if not args.no_profile:
             # kernel durations as they were inside the timed region: HIP events in front of every launch of
             # every --trace-every-th pass, on the stream the kernels were launched on (gtx_detector_trace)

@@ -357,7 +357,7 @@ int env_int(const char* name, int dflt) {
 }
 }  // namespace
 
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc) {
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc, long est_pixels) {
   ConvConfig c{};
   c.dtype = dtype;
   c.ks = ks;
@@ -370,6 +370,11 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     c.kc = ks == 1 ? (cin % 32 == 0 ? 32 : 16) : 16;
     if (force_kc > 0) c.kc = force_kc;
     c.bn = (cout % 64 == 0) ? 64 : 32;
+    // few output pixels (the 120x120 / 60x60 stages at small batch): with 64-cout tiles the launch has fewer workgroups
+    // than the chip has slots and each one is a long serial chain of K chunks; 32-cout tiles double the workgroups and
+    // halve the matrix work per chunk (GTX_SPLIT_BN32_BELOW = workgroup count below which that is done; 0 = never)
+    static const int bn32_below = env_int("GTX_SPLIT_BN32_BELOW", 0);
+    if (c.bn == 64 && est_pixels > 0 && bn32_below > 0 && (est_pixels / 128) * (cout / 64) < bn32_below) c.bn = 32;
     c.th = 8; c.tw = 16;                           // conv_pick_tile() may raise th to 16 once the problem size is known
     GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
     GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);

@@ -63,7 +63,9 @@ struct ConvConfig {
 
 // Picks the tile configuration used for a layer shape.
 // force_kc > 0 pins the K chunk (grouped launches: every member must use the same kernel instantiation).
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0);
+// est_pixels: N*Ho*Wo of the launch when known (0 = unknown): layers with few output pixels take 32-cout tiles so that
+// the launch still has enough workgroups to fill the chip.
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0, long est_pixels = 0);
 
 // Host-side weight packing: w is [Cout][KS][KS][Cin] fp32 (OHWI). Returns the packed
 // byte image for `cfg` (element type per cfg.dtype). acc_scale (may be null) receives ConvProblem::acc_scale.

@@ -314,8 +314,107 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restri
   }
 }
 
+// fp32 stem on the fp16 matrix pipe ("split-f16x3", see conv_igemm_split.hip): the same implicit GEMM as
+// stem_mfma_kernel on fp32 NHWC4 pixels and fp32 outputs. Every lane splits the pixels it gathers into hi + lo fp16
+// parts, the weights arrive pre-split (scaled by an exact power of two, undone by `acc_scale`), a product costs three
+// MFMAs (w_lo x_hi + w_hi x_lo + w_hi x_hi). The 32-channel fp32 output row of a pixel is 128 B: the wave transposes
+// its 32 pixels through LDS and stores whole lines.
+__global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ img, int h, int w,
+                                                         const _Float16* __restrict__ wpk /*[groups][3][hi|lo][64][8]*/,
+                                                         const float* __restrict__ bias, float acc_scale, float* __restrict__ out,
+                                                         int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
+  constexpr int kPitch = 128 + 16;                      // bytes per staged pixel (32 fp32 channels + pad)
+  __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kPitch];
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int n = blockIdx.y;
+  const float* base = img + (size_t)n * h * w * 4;
+  for (int g = 0; g < groups; ++g) {
+    half8 wh[3], wl[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      wh[s] = *reinterpret_cast<const half8*>(wpk + ((((size_t)g * 3 + s) * 2 + 0) * 64 + lane) * 8);
+      wl[s] = *reinterpret_cast<const half8*>(wpk + ((((size_t)g * 3 + s) * 2 + 1) * 64 + lane) * 8);
+    }
+    for (long t = wave; t < n_tiles; t += nwaves) {
+      const int oy = (int)(t / tiles_per_row), ox = (int)(t % tiles_per_row) * 32 + r;
+      floatx16_t acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        half8 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[e] = (_Float16)0.f; xl[e] = (_Float16)0.f; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tap = 2 * (2 * s + hh) + q;
+          if (tap < 9) {
+            const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+            if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
+              const float4 px = *reinterpret_cast<const float4*>(base + ((size_t)iy * w + ix) * 4);
+              const float v[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const _Float16 hi = (_Float16)v[e];       // image values are in [0, 1]
+                xh[4 * q + e] = hi;
+                xl[4 * q + e] = (_Float16)(v[e] - (float)hi);
+              }
+            }
+          }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc, 0, 0, 0);
+      }
+      if (c0 == 32) {
+        char* stg = s_stage + (threadIdx.x >> 6) * (32 * kPitch);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 8 * g4 + 4 * hh;
+          float4 v;
+          v.x = silu_f(fmaf(acc[4 * g4 + 0], acc_scale, bias[cl + 0]));
+          v.y = silu_f(fmaf(acc[4 * g4 + 1], acc_scale, bias[cl + 1]));
+          v.z = silu_f(fmaf(acc[4 * g4 + 2], acc_scale, bias[cl + 2]));
+          v.w = silu_f(fmaf(acc[4 * g4 + 3], acc_scale, bias[cl + 3]));
+          *reinterpret_cast<float4*>(stg + r * kPitch + cl * 4) = v;
+        }
+        const int ox0 = (int)(t % tiles_per_row) * 32;
+        float* orow = out + (((size_t)n * ho + oy) * wo + ox0) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                  // 8 pixels x 128 B per store instruction
+          const int p = it * 8 + (lane >> 3), q = lane & 7;
+          const uint4 val = *reinterpret_cast<const uint4*>(stg + p * kPitch + q * 16);
+          if (ox0 + p < wo) *reinterpret_cast<uint4*>(orow + p * 32 + q * 4) = val;
+        }
+      } else if (ox < wo) {
+        float* o = out + (((size_t)n * ho + oy) * wo + ox) * c0 + g * 32;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 8 * g4 + 4 * hh;
+          if (g * 32 + cl < c0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[cl + i] = silu_f(fmaf(acc[4 * g4 + i], acc_scale, bias[g * 32 + cl + i]));
+          }
+        }
+      }
+    }
+  }
+}
+
 void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
-                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s) {
+                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s, float acc_scale) {
+  if (dtype == DT_F32S) {
+    GTX_CHECK(wpk_f16 != nullptr, "stem: split weights missing");
+    const int tiles_per_row = cdiv(wo, 32);
+    const long n_tiles = (long)tiles_per_row * ho;
+    const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
+    hipLaunchKernelGGL(stem_split_kernel, dim3(blocks, n), dim3(256), 0, s, (const float*)img, h, w, (const _Float16*)wpk_f16,
+                       bias, acc_scale, (float*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
+    GTX_HIP(hipGetLastError());
+    return;
+  }
   if (dtype == DT_F16 && wpk_f16) {
     const int tiles_per_row = cdiv(wo, 32);
     const long n_tiles = (long)tiles_per_row * ho;
@@ -360,6 +459,42 @@ std::vector<uint16_t> pack_stem_weights_f16(const float* w27 /*[27][c0], (tap*3+
             uint16_t bits;
             memcpy(&bits, &hv, 2);
             out[(((size_t)g * 3 + s) * 64 + lane) * 8 + 4 * q + ch] = bits;
+          }
+        }
+      }
+  return out;
+}
+
+// Split (hi + lo) packing for stem_split_kernel: [group][k-step 3][hi | lo][lane 64][8 halves], weights scaled by the
+// power of two that puts max |w| in [2^13, 2^14); *acc_scale receives its inverse.
+std::vector<uint16_t> pack_stem_weights_split(const float* w27, int c0, float* acc_scale) {
+  const int groups = cdiv(c0, 32);
+  float wmax = 0.f;
+  for (int i = 0; i < 27 * c0; ++i) wmax = std::max(wmax, std::fabs(w27[i]));
+  int shift = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int e;
+    std::frexp(wmax, &e);
+    shift = std::max(-100, std::min(100, 14 - e));
+  }
+  const float up = std::ldexp(1.f, shift);
+  *acc_scale = std::ldexp(1.f, -shift);
+  std::vector<uint16_t> out((size_t)groups * 3 * 2 * 64 * 8, 0);
+  for (int g = 0; g < groups; ++g)
+    for (int s = 0; s < 3; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, hh = lane >> 5, co = g * 32 + r;
+        for (int q = 0; q < 2; ++q) {
+          const int tap = 2 * (2 * s + hh) + q;
+          for (int ch = 0; ch < 4; ++ch) {
+            float v = 0.f;
+            if (tap < 9 && ch < 3 && co < c0) v = w27[(size_t)(tap * 3 + ch) * c0 + co] * up;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            uint16_t bh, bl;
+            memcpy(&bh, &hi, 2);
+            memcpy(&bl, &lo, 2);
+            out[((((size_t)g * 3 + s) * 2 + 0) * 64 + lane) * 8 + 4 * q + ch] = bh;
+            out[((((size_t)g * 3 + s) * 2 + 1) * 64 + lane) * 8 + 4 * q + ch] = bl;
           }
         }
       }

@@ -28,8 +28,10 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
 // (ky*3+kx)*3 + c), bias [c0]. c0 must be a multiple of 16 and <= 64.
 // wpk_f16: weights packed by pack_stem_weights_f16 (fp16 MFMA path) or null (VALU path).
 void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w27, const float* bias,
-                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s);
+                 const void* wpk_f16, int c0, void* out, int ho, int wo, hipStream_t s, float acc_scale = 1.f);
 std::vector<uint16_t> pack_stem_weights_f16(const float* w27, int c0);
+// dtype DT_F32S (fp32 image and output, split-f16x3 MFMA): hi + lo packed weights, *acc_scale = inverse of their power-of-two scaling
+std::vector<uint16_t> pack_stem_weights_split(const float* w27, int c0, float* acc_scale);
 
 // SPPF pools: channels [0,c) -> 5x5 / 9x9 / 13x13 clipped-window maxima at [c,2c) [2c,3c) [3c,4c).
 void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s);

@@ -100,7 +100,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_);
+  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, grouped_ ? 0 : (long)x.n * ho * wo);
   const std::vector<float> ohwi = to_ohwi(w);
   float acc_scale = 1.f;
   const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &acc_scale);
@@ -176,13 +176,18 @@ void Detector::build_graph() {
     Op op;
     op.kind = Op::STEM;
     op.name = "model.0.conv";
-    op.family = dtype_ == DT_F16 ? "stem_mfma_kernel" : "stem_kernel";
+    op.family = dtype_ == DT_F16 ? "stem_mfma_kernel" : (conv_dtype_ == DT_F32S ? "stem_split_kernel" : "stem_kernel");
     op.in = img_;
     op.out = a0;
     op.w27 = dw;
     op.bias = db;
     if (dtype_ == DT_F16) {
       const std::vector<uint16_t> pk = pack_stem_weights_f16(w27.data(), c0);
+      void* dp = alloc(pk.size() * 2);
+      GTX_HIP(hipMemcpy(dp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+      op.wpk = dp;
+    } else if (conv_dtype_ == DT_F32S) {
+      const std::vector<uint16_t> pk = pack_stem_weights_split(w27.data(), c0, &op.stem_scale);
       void* dp = alloc(pk.size() * 2);
       GTX_HIP(hipMemcpy(dp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
       op.wpk = dp;
@@ -290,12 +295,14 @@ void Detector::build_graph() {
     tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
     const size_t mark = ops_.size();
     force_kc_ = conv_dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
+    grouped_ = true;                               // ... and one cout tile: no per-problem size hints
     View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
     View h2 = new_view(h1.h, h1.w, cb + cc);
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
     conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
     conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
     force_kc_ = 0;
+    grouped_ = false;
     // move the three freshly built single-problem ops into the two grouped stage ops
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
@@ -412,7 +419,8 @@ void Detector::run_op(const Op& op, int nb, hipStream_t s) {
   switch (op.kind) {
     case Op::CONV: conv_launch(op.grp, op.cfg, s); break;
     case Op::STEM:
-      launch_stem(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.wpk, op.out.c, op.out.ptr, op.out.h, op.out.w, s);
+      launch_stem(dtype_ == DT_F32 ? conv_dtype_ : dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.wpk, op.out.c, op.out.ptr, op.out.h,
+                  op.out.w, s, op.stem_scale);
       break;
     case Op::POOL: launch_sppf_pool(dtype_, op.out.ptr, nb, op.in.h, op.in.w, op.in.c, s); break;
     case Op::UPSAMPLE:

@@ -52,7 +52,8 @@ struct Op {
   View in, out;
   const float* w27 = nullptr;
   const float* bias = nullptr;
-  const void* wpk = nullptr;   // fp16 MFMA stem weights
+  const void* wpk = nullptr;   // fp16 MFMA / split-f16x3 stem weights
+  float stem_scale = 1.f;      // split-f16x3 stem: inverse of the weights' power-of-two scaling
   double flops = 0;      // algorithmic 2*MAC
   double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
 };
@@ -113,6 +114,7 @@ class Detector {
   std::map<std::string, View> layer_views_;
   bool finalized_ = false;
   int force_kc_ = 0;         // K chunk forced on the convs being built (grouped head stages)
+  bool grouped_ = false;     // the convs being built will share one grouped launch (one kernel configuration)
   int cur_nb_ = 0;
 
   View img_;                 // [N][net_h][net_w][4]
