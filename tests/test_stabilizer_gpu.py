@@ -108,6 +108,33 @@ def test_recovers_ground_truth_homography(gtx_ctx, seq, t):
         np.testing.assert_allclose(warped[static, :2], sc.boxes(0)[static, :2], atol=1.0)
 
 
+def test_homographies_of_the_synthetic_clip_stay_inside_the_golden_envelope(gtx_ctx, seq):
+    """The reference's golden `_vid_transf` table (tests/golden, 149 frames of hovering-drone footage) has a shape every
+    sane stabilization of such footage shares: det ~ 1, h33 = 1, rotation and scale within a few 1e-3, a perspective part
+    that moves no pixel by more than a pixel or two, translations of a few pixels that drift smoothly. The synthetic clip
+    is built to that envelope; what this build estimates on it must stay inside it (with the estimator's own noise)."""
+    from pathlib import Path
+
+    from geotrax_amd import agreement as A
+
+    gold = A.homography_envelope(np.loadtxt(Path(__file__).parent / "golden" / "U_video_cut_vid_transf.txt", delimiter=","))
+    sc, fr = seq
+    st = _make(gtx_ctx)
+    st.set_ref_frame(fr[0], sc.boxes(0))
+    rows = []
+    for t in sorted(k for k in fr if k > 0):
+        st.stabilize(fr[t], sc.boxes(t))
+        Hm = st.get_cur_trans_matrix()
+        assert Hm is not None
+        rows.append(np.r_[t, Hm.ravel()])
+    e = A.homography_envelope(np.asarray(rows))
+    w = HW[1]
+    assert e["det_min"] > 0.98 and e["h33_dev_max"] < 1e-9
+    assert e["rotation_abs_max"] < max(3 * gold["rotation_abs_max"], 5e-3) and e["scale_dev_max"] < max(3 * gold["scale_dev_max"], 5e-3)
+    assert e["perspective_abs_max"] * w * w < 3.0                       # the projective part moves no pixel by more than ~3 px
+    assert e["translation_abs_max"][0] < gold["translation_abs_max"][0] + 1.5 and e["translation_abs_max"][1] < gold["translation_abs_max"][1] + 1.5
+
+
 def test_identical_frame_gives_identity_and_state_errors(gtx_ctx, seq):
     from geotrax_amd._lib import GtxError
     from geotrax_amd.stabilizer import Stabilizer
