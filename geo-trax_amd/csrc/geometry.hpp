@@ -23,6 +23,8 @@ void georef_points(gtx_ctx* ctx, const gtx_georef_chain& chain, const double* x,
 // cv2.warpPerspective(frame, H, (w, h)): dst(x,y) = bilinear src(H^-1 (x,y)), constant 0 border
 // (geotrax/visualize.py:289). Device kernel in warp.hip.
 void warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr);
+// yuv.hip: I420 frame in HBM -> BGR frame in HBM (BT.601 limited range, OpenCV's fixed point), asynchronous
+void yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv, int h, int w, void* bgr);
 void warp_frame_dev(gtx_ctx* ctx, const void* src_bgr, int h, int w, const double H[9], void* dst_bgr);   // both in HBM, asynchronous
 
 // 3x3 inverse (adjugate / det). Returns false if singular.

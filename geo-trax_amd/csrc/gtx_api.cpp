@@ -610,6 +610,13 @@ int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const doub
     gtx::georef_points(ctx, *chain, x, y, n, ortho_x, ortho_y, lat, lon, east, north);
   });
 }
+int gtx_yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv_dptr, int h, int w, void* bgr_dptr) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(yuv_dptr, "yuv"); need(bgr_dptr, "bgr");
+    gtx::yuv420_to_bgr_dev(ctx, yuv_dptr, h, w, bgr_dptr);
+  });
+}
+
 int gtx_warp_frame_dev(gtx_ctx* ctx, const void* src_dptr, int h, int w, const double H[9], void* dst_dptr) {
   return guarded([&] {
     need(ctx, "ctx"); need(src_dptr, "src"); need(H, "H"); need(dst_dptr, "dst");

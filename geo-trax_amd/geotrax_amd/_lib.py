@@ -139,6 +139,7 @@ _SIGNATURES = {
     "gtx_op_georef_points": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gtx_warp_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "gtx_yuv420_to_bgr_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
 }
 
 _lib = None

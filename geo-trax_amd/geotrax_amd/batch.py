@@ -23,7 +23,7 @@ from . import __version__
 from .config_utils import backfill_args_from_config, load_config
 from .extract import add_common_args, add_processing_args, detect_track_stabilize, get_output_dir
 
-VIDEO_FORMATS = {'.mp4', '.mov', '.avi', '.mkv', '.npy'}          # constants.py:10 plus this build's array clips
+VIDEO_FORMATS = {'.mp4', '.mov', '.avi', '.mkv', '.npy', '.y4m'}  # constants.py:10 plus this build's array / uncompressed clips
 ACTION_EXTRACT = "Detecting, tracking, and stabilizing"
 
 

@@ -22,6 +22,7 @@ Ordering rules kept from the reference loop:
 from __future__ import annotations
 
 import collections
+import ctypes as C
 import os
 import queue
 import threading
@@ -120,6 +121,8 @@ class ExtractEngine:
     def set_reference(self, frame: np.ndarray) -> None:
         """Registers every stabilizer against `frame` (host BGR) ahead of run(): the frames fed afterwards are all
         registered against it. The foreground mask is the frame's raw detections."""
+        if hasattr(frame, "bgr"):                               # a Yuv420Frame of a .y4m source
+            frame = frame.bgr()
         d = self.dets[0].detect(np.ascontiguousarray(frame, np.uint8))
         g = self.dets[0].gray_dptr(0)
         boxes = d.xywh if len(d) else None
@@ -145,7 +148,7 @@ class ExtractEngine:
 
     def close(self) -> None:
         for d in self.dets:
-            for p in [self._stage.pop(id(d), None)]:
+            for p in [self._stage.pop(id(d), None), self._stage.pop(("yuv", id(d)), None)]:
                 if p:
                     d.ctx.dev_free(p)
             d.close()
@@ -160,20 +163,30 @@ class ExtractEngine:
         if isinstance(batch, (int, np.integer)):                # device pointer to B contiguous frames
             det.submit_dev(int(batch), self.B)
             return self.B
-        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
+        from .frames import Yuv420Frame
+
+        frames = [f if isinstance(f, Yuv420Frame) else np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
         if not 1 <= len(frames) <= self.B:
             raise ValueError(f"a batch holds 1..{self.B} frames, got {len(frames)}")
-        nbytes = frames[0].nbytes
+        nbytes = self.frame_hw[0] * self.frame_hw[1] * 3
         key = id(det)
         if key not in self._stage:
             self._stage[key] = det.ctx.dev_alloc(nbytes * self.B)
         for i, f in enumerate(frames):
-            if f.shape[:2] != self.frame_hw:
+            if tuple(f.shape[:2]) != self.frame_hw:
                 raise ValueError(f"frame is {f.shape[1]}x{f.shape[0]}, engine was built for {self.frame_hw[1]}x{self.frame_hw[0]}")
-            det.ctx.dev_upload(self._stage[key] + i * nbytes, f)
+            if isinstance(f, Yuv420Frame):                      # I420 planes cross PCIe (half the bytes), BGR is made on the GPU
+                ykey = ("yuv", key)
+                if ykey not in self._stage:
+                    self._stage[ykey] = det.ctx.dev_alloc(len(f.data))
+                det.ctx.dev_upload(self._stage[ykey], f.data)
+                _lib.check(det.ctx.lib.gtx_yuv420_to_bgr_dev(det.ctx.handle, C.c_void_p(self._stage[ykey]), f.h, f.w,
+                                                             C.c_void_p(self._stage[key] + i * nbytes)))
+            else:
+                det.ctx.dev_upload(self._stage[key] + i * nbytes, f)
         det.submit_dev(self._stage[key], len(frames))
         if self.stabs and not self.use_dev_gray:
-            self._host_frames[key] = frames
+            self._host_frames[key] = [f.bgr() if isinstance(f, Yuv420Frame) else f for f in frames]
         return len(frames)
 
     def run(self, batches):

@@ -165,6 +165,14 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
                                det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)), gmc=with_gmc)
         state['engine'] = engine
         ref, prev, f = None, None, 0
+        if hasattr(reader, 'seek') and start > first:       # seekable source (.y4m): jump, reading only the two frames needed
+            reader.seek(first)
+            ok, ref = reader.read()
+            reader.seek(start - 1)
+            ok2, prev = reader.read()
+            if not (ok and ok2):
+                raise RuntimeError(f"frames {first} / {start - 1} could not be read")
+            f = start
         while f < start:                                    # sequential source: skip to the range, keeping the two frames needed
             ok, frame = reader.read()
             if not ok:
@@ -181,9 +189,9 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
             prev_ptr = None
             if with_gmc and prev is not None and start > first:
                 ctx0 = engine.dets[0].ctx
-                prev_ptr = ctx0.dev_alloc(prev.nbytes)
+                prev_ptr = ctx0.dev_alloc(prev.nbytes)          # (.nbytes of a Yuv420Frame is that of its BGR frame)
                 state['prev_ptr'] = (ctx0, prev_ptr)
-                ctx0.dev_upload(prev_ptr, np.ascontiguousarray(prev, np.uint8))
+                ctx0.dev_upload(prev_ptr, np.ascontiguousarray(prev.bgr() if hasattr(prev, "bgr") else prev, np.uint8))
             fail_at = os.environ.get("GTX_TEST_FAIL_AT_FRAME")          # fault injection for the failure-path test
             for f in range(start, stop):
                 ok, frame = reader.read()

@@ -7,6 +7,9 @@ with the same three calls the loop uses (``isOpened`` / ``read`` / ``release``) 
   * ``*.npy``                    one array [F,H,W,3] uint8 BGR (memory-mapped)
   * a directory                  of per-frame ``*.npy`` / ``*.png`` / ``*.jpg`` files (sorted)
   * ``synthetic://?seed=0&frames=150&h=2160&w=3840``   the seeded scene of geotrax_amd.synth
+  * ``*.y4m``                    YUV4MPEG2, 8-bit 4:2:0 (``ffmpeg -i clip.mp4 -pix_fmt yuv420p clip.y4m``): the uncompressed
+                                 video container; frames travel to the GPU as I420 planes (half the bytes of BGR) and are
+                                 converted there (csrc/yuv.hip) -- the route for real footage on a box without a decoder
   * any other file (``.mp4`` ...) through cv2 when it is importable
 """
 from __future__ import annotations
@@ -70,6 +73,116 @@ class DirReader(FrameReader):
         return True, np.ascontiguousarray(f, dtype=np.uint8)
 
 
+class Yuv420Frame:
+    """One I420 frame as it sits in the file: `data` = Y plane (h*w) + U + V planes (((h+1)//2)*((w+1)//2) each), uint8.
+    The engine uploads `data` and converts on the GPU; `bgr()` is the host conversion (same arithmetic) for callers that
+    need an ndarray (reference-frame consumers, tests)."""
+
+    def __init__(self, data: np.ndarray, h: int, w: int):
+        self.data, self.h, self.w = data, h, w
+
+    @property
+    def shape(self):
+        return (self.h, self.w, 3)
+
+    @property
+    def nbytes(self) -> int:                               # of the BGR frame it stands for (the engine sizes its staging by it)
+        return self.h * self.w * 3
+
+    def bgr(self) -> np.ndarray:
+        return yuv420_to_bgr_host(self.data, self.h, self.w)
+
+
+def yuv420_to_bgr_host(data: np.ndarray, h: int, w: int) -> np.ndarray:
+    """Host twin of csrc/yuv.hip (BT.601 limited range, OpenCV's 20-bit fixed point, nearest chroma)."""
+    ch, cw = (h + 1) // 2, (w + 1) // 2
+    d = np.asarray(data, dtype=np.uint8).reshape(-1)
+    y = d[:h * w].reshape(h, w).astype(np.int64)
+    u = d[h * w:h * w + ch * cw].reshape(ch, cw).astype(np.int64) - 128
+    v = d[h * w + ch * cw:h * w + 2 * ch * cw].reshape(ch, cw).astype(np.int64) - 128
+    u, v = np.repeat(np.repeat(u, 2, 0), 2, 1)[:h, :w], np.repeat(np.repeat(v, 2, 0), 2, 1)[:h, :w]
+    yl = np.maximum(y - 16, 0) * 1220542
+    half = 1 << 19
+    b = (yl + half + 2116026 * u) >> 20
+    g = (yl + half - 852492 * v - 409993 * u) >> 20
+    r = (yl + half + 1673527 * v) >> 20
+    return np.clip(np.stack([b, g, r], -1), 0, 255).astype(np.uint8)
+
+
+class Y4mReader(FrameReader):
+    """YUV4MPEG2 (.y4m), 8-bit 4:2:0. Header: 'YUV4MPEG2 W<w> H<h> F<num>:<den> [I..] [A..] [C420*]'; every frame is the line
+    'FRAME[ params]' followed by the three planes. read() returns Yuv420Frame objects; seek(i) makes frame i the next one
+    (frame-sharded ranks jump to their range without reading what precedes it)."""
+
+    def __init__(self, path: Path):
+        self.path = Path(path)
+        self.f = open(self.path, "rb")
+        head = self.f.readline()
+        tok = head.split()
+        if not tok or tok[0] != b"YUV4MPEG2":
+            raise ValueError(f"'{path}' is not a YUV4MPEG2 file")
+        par = {t[:1]: t[1:].decode() for t in tok[1:]}
+        self.w, self.h = int(par[b"W"]), int(par[b"H"])
+        cs = par.get(b"C", "420jpeg")
+        if not cs.startswith("420") or "p1" in cs or "p12" in cs or "p16" in cs:
+            raise NotImplementedError(f"'{path}': colour space C{cs} -- only 8-bit 4:2:0 is implemented (ffmpeg -pix_fmt yuv420p)")
+        num, den = (int(v) for v in par.get(b"F", "30:1").split(":"))
+        self.fps = num / den if den else 0.0
+        self.frame_hw = (self.h, self.w)
+        self.frame_bytes = self.h * self.w + 2 * ((self.h + 1) // 2) * ((self.w + 1) // 2)
+        self.data_start = self.f.tell()
+        first = self.f.readline()                          # 'FRAME...\n' lines normally have no parameters: fixed stride then
+        self.frame_head = len(first)
+        size = self.path.stat().st_size
+        self.frame_count = (size - self.data_start) // (self.frame_head + self.frame_bytes) if first.startswith(b"FRAME") else 0
+        self.i, self._open = 0, self.frame_count > 0
+        self.f.seek(self.data_start)
+
+    def seek(self, i: int) -> None:
+        self.i = int(i)
+        self.f.seek(self.data_start + self.i * (self.frame_head + self.frame_bytes))
+
+    def read(self):
+        if self.i >= self.frame_count:
+            return False, None
+        line = self.f.readline()
+        if not line.startswith(b"FRAME"):
+            return False, None
+        if len(line) != self.frame_head:                   # a frame with parameters: the fixed stride no longer holds
+            self.frame_count = self.i + 1
+        buf = np.frombuffer(self.f.read(self.frame_bytes), dtype=np.uint8)
+        if len(buf) != self.frame_bytes:
+            return False, None
+        self.i += 1
+        return True, Yuv420Frame(buf, self.h, self.w)
+
+    def release(self):
+        self._open = False
+        self.f.close()
+
+
+def write_y4m(path, frames_bgr, fps=(30000, 1001)) -> None:
+    """Writes BGR frames as a .y4m file (BT.601 limited range, 2x2 chroma averaging) -- for tests and for exporting the
+    synthetic clips; real footage comes from `ffmpeg -pix_fmt yuv420p`."""
+    frames_bgr = list(frames_bgr)
+    h, w = frames_bgr[0].shape[:2]
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F{fps[0]}:{fps[1]} Ip A1:1 C420jpeg\n".encode())
+        for fr in frames_bgr:
+            b, g, r = (fr[..., k].astype(np.float64) for k in range(3))
+            y = 16 + (65.481 * r + 128.553 * g + 24.966 * b) / 255
+            cb = 128 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255
+            cr = 128 + (112.0 * r - 93.786 * g - 18.214 * b) / 255
+
+            def sub(c):
+                c = np.pad(c, ((0, h % 2), (0, w % 2)), mode="edge")
+                return (c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2]) / 4
+
+            f.write(b"FRAME\n")
+            for plane in (y, sub(cb), sub(cr)):
+                f.write(np.clip(np.rint(plane), 0, 255).astype(np.uint8).tobytes())
+
+
 class SyntheticReader(FrameReader):
     def __init__(self, seed=0, frames=150, h=2160, w=3840):
         from .synth import make_scene
@@ -112,6 +225,8 @@ def open_source(source) -> FrameReader:
         return DirReader(p)
     if p.suffix == ".npy":
         return ArrayReader(np.load(p, mmap_mode="r"))
+    if p.suffix.lower() == ".y4m":
+        return Y4mReader(p)
     try:
         return Cv2Reader(p)
     except ImportError as e:

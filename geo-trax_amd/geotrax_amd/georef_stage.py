@@ -186,7 +186,7 @@ def get_video_data(source: Path, ref_frame_num: int, logger: logging.Logger) -> 
     if fps == 0:
         side = Path(source).with_suffix(".fps")             # a one-number sidecar for frame sources that carry no rate (.npy, image folders)
         fps = float(side.read_text().split()[0]) if side.exists() else DEFAULT_FPS
-    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    frame = np.ascontiguousarray(frame.bgr() if hasattr(frame, "bgr") else frame, dtype=np.uint8)
     logger.info(f"Loaded reference frame {ref_frame_num} from: '{source}' with dimensions {frame.shape[:2]} and FPS {fps}.")
     return frame, frame.shape[:2], fps
 

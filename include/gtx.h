@@ -75,6 +75,12 @@ int gtx_dev_free(gtx_ctx* ctx, void* dptr);
 int gtx_dev_upload(gtx_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int gtx_dev_download(gtx_ctx* ctx, void* host, const void* dptr, size_t bytes);
 
+/* One planar YUV 4:2:0 (I420) frame in HBM -> packed BGR u8 in HBM: the colour conversion a video decoder applies
+ * before extract.py:146 sees the frame (cv2.VideoCapture.read() returns BGR). BT.601 limited range, the fixed-point
+ * constants of cv2.cvtColor(COLOR_YUV2BGR_I420), one chroma sample per 2x2 luma block. yuv_dptr: h*w luma bytes, then
+ * the U and V planes of ((h+1)/2)*((w+1)/2) bytes each; bgr_dptr: h*w*3 bytes. Enqueued on the context's stream. */
+int gtx_yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv_dptr, int h, int w, void* bgr_dptr);
+
 /* ------------------------------------------------------------------ operator level
  * Single operators of the detector, exposed so the parity tests can check every kernel
  * against oracle/ on the exact layer shapes. Host buffers in, host buffers out. */

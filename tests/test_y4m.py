@@ -1,0 +1,58 @@
+"""The uncompressed video source: YUV4MPEG2 reader, its host colour conversion against
+oracle/yuv_ref.py (the published cvtColor(COLOR_YUV2BGR_I420) arithmetic), seeking, and the file written by write_y4m
+coming back within the quantisation of 8-bit 4:2:0. CPU only; tests/test_y4m_gpu.py checks the HIP kernel and the engine."""
+import numpy as np
+import pytest
+
+
+def _clip(n=4, h=37, w=50, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 120 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    return [np.clip(np.stack([base + 30 * np.sin(k + c) + 5 * rng.standard_normal((h, w)) for c in range(3)], -1), 0, 255).astype(np.uint8) for k in range(n)]
+
+
+def test_y4m_round_trip_reader_and_seek(tmp_path):
+    from geotrax_amd.frames import Y4mReader, open_source, write_y4m, yuv420_to_bgr_host
+    from oracle.yuv_ref import i420_to_bgr
+
+    frames = _clip()
+    p = tmp_path / "clip.y4m"
+    write_y4m(p, frames, fps=(30000, 1001))
+    r = open_source(p)
+    assert isinstance(r, Y4mReader) and r.frame_count == 4 and r.frame_hw == (37, 50) and abs(r.fps - 29.97) < 0.01 and r.isOpened()
+    got = []
+    for k in range(4):
+        ok, f = r.read()
+        assert ok and f.shape == (37, 50, 3) and f.nbytes == 37 * 50 * 3
+        bgr = f.bgr()
+        np.testing.assert_array_equal(bgr, i420_to_bgr(f.data, 37, 50))          # host conversion == the oracle, odd sizes included
+        np.testing.assert_array_equal(bgr, yuv420_to_bgr_host(f.data, 37, 50))
+        # smooth content survives 8-bit limited-range 4:2:0 within a few grey levels
+        assert np.abs(bgr.astype(int) - frames[k].astype(int)).mean() < 4.0
+        got.append(bgr)
+    assert r.read() == (False, None)
+    r.seek(2)
+    ok, f = r.read()
+    np.testing.assert_array_equal(f.bgr(), got[2])
+    r.release()
+    assert not r.isOpened()
+    (tmp_path / "bad.y4m").write_bytes(b"RIFF....")
+    with pytest.raises(ValueError):
+        open_source(tmp_path / "bad.y4m")
+    (tmp_path / "deep.y4m").write_bytes(b"YUV4MPEG2 W8 H8 F30:1 C420p10\nFRAME\n" + bytes(8 * 8 * 3))
+    with pytest.raises(NotImplementedError):
+        open_source(tmp_path / "deep.y4m")
+
+
+def test_conversion_known_answers():
+    """Limited-range BT.601: (Y,U,V) = (16,128,128) is black, (235,128,128) white, (81,90,240) pure red within a level."""
+    from oracle.yuv_ref import i420_to_bgr
+
+    def px(y, u, v):
+        return i420_to_bgr(np.array([y] * 4 + [u] + [v], np.uint8), 2, 2)[0, 0]
+
+    np.testing.assert_array_equal(px(16, 128, 128), [0, 0, 0])
+    np.testing.assert_array_equal(px(235, 128, 128), [255, 255, 255])
+    assert np.abs(px(81, 90, 240).astype(int) - [0, 0, 255]).max() <= 1
+    np.testing.assert_array_equal(px(0, 128, 128), [0, 0, 0])                         # below black clamps
