@@ -1,6 +1,8 @@
 """gtx_op_georef_points (K12): the frame-pixel -> orthophoto -> lat/lon -> local-metres chain as one
-HIP pass, against the host restatement of the same chain (geotrax_amd.georeference, itself pinned on the
-reference's known answers in tests/test_georeference.py) and against those known answers directly.
+HIP pass, against oracle/georef_ref.py (independent restatement: OpenCV's perspectiveTransform rule, the reference's
+affine, and Snyder's transverse-Mercator series -- a different formula from the Krueger series the kernel uses),
+against the reference tests' known answers, and (tighter, as an internal consistency check) against the package's
+own host functions.
 
 Tolerances (f64 both sides; the device libm differs from numpy's in the last ulps of sin/sinh/atanh):
 orthophoto pixels and degrees 1e-12 relative, metres 1e-6 absolute (a micrometre at 5e6 m is 2e-13 relative)."""
@@ -34,6 +36,29 @@ def test_chain_matches_host_functions(gtx_ctx, target, n):
     xl, yl = geo2local(lat, lon, "EPSG:4326", target)
     np.testing.assert_allclose(got["x_local"], xl, atol=1e-6, rtol=0)
     np.testing.assert_allclose(got["y_local"], yl, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("target,ortho", [("EPSG:5186", ORTHO), ("EPSG:32652", (128.6, 36.0, 2.4e-7, -1.9e-7, 0.0, 0.0)),
+                                          ("EPSG:32734", (20.9, -33.1, 2.4e-7, -1.9e-7, 0.0, 0.0))])
+def test_chain_matches_the_independent_oracle(gtx_ctx, target, ortho):
+    """HIP chain vs oracle/georef_ref.py. The oracle's transverse Mercator is Snyder's longitude-difference series (USGS PP
+    1395), the kernel's is the Krueger n-series: no shared formula. Pixels / degrees agree to rounding; metres to 0.1 mm
+    (the oracle series' own truncation: 0.01-0.3 mm within a degree of the central meridian)."""
+    from geotrax_amd.georeference import transform_points
+    from oracle import georef_ref as R
+
+    rng = np.random.default_rng(11)
+    x, y = rng.uniform(0, 3840, 50_000), rng.uniform(0, 2160, 50_000)
+    got = transform_points(x, y, HOM, ortho, "EPSG:4326", target, ctx=gtx_ctx)
+    ox, oy = R.apply_homography(x, y, HOM)
+    lat, lon = R.ortho2geo(ox, oy, ortho)
+    np.testing.assert_allclose(got["ortho_x"], ox, rtol=1e-13)
+    np.testing.assert_allclose(got["ortho_y"], oy, rtol=1e-13)
+    np.testing.assert_allclose(got["latitude"], lat, rtol=1e-14)
+    np.testing.assert_allclose(got["longitude"], lon, rtol=1e-14)
+    xl, yl = R.geo2local(lat, lon, "EPSG:4326", target)
+    np.testing.assert_allclose(got["x_local"], xl, atol=4e-4, rtol=0)
+    np.testing.assert_allclose(got["y_local"], yl, atol=4e-4, rtol=0)
 
 
 def test_chain_reference_known_answers(gtx_ctx):

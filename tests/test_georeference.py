@@ -151,3 +151,23 @@ def test_save_homography_format(tmp_path):
     # same layout as the reference's committed golden file
     ref = (GOLD / "U_video_cut_geo_transf.txt").read_text().strip()
     assert ref.count(",") == 8 and "\n" not in ref
+
+
+def test_independent_oracle_meets_the_reference_known_answers():
+    """oracle/georef_ref.py (Snyder's series, cv2.perspectiveTransform's rule) on the reference tests' own pins
+    (tests/test_georeference.py:31-63 of the reference) and against the package's Krueger-series projection."""
+    from geotrax_amd import georeference as G
+    from oracle import georef_ref as R
+
+    x, y = R.apply_homography([1.0, 2.0], [3.0, 4.0], np.eye(3))
+    np.testing.assert_array_equal([x, y], [[1.0, 2.0], [3.0, 4.0]])
+    x, y = R.apply_homography([1.0, 2.0], [3.0, 4.0], np.array([[1, 0, 10.0], [0, 1, -5.0], [0, 0, 1]]))
+    np.testing.assert_array_equal([x, y], [[11.0, 12.0], [-2.0, -1.0]])
+    lat, lon = R.ortho2geo(np.array([10.0]), np.array([20.0]), (1.0, 2.0, 0.1, -0.2, 0.0, 0.0))
+    np.testing.assert_allclose([lat[0], lon[0]], [2.0 - 4.0, 1.0 + 1.0])
+    e, n = R.geo2local(np.array([46.5]), np.array([6.6]), "epsg:4326", "epsg:32631")
+    assert abs(e[0] - 776225.4478) < 1e-2 and abs(n[0] - 5155902.1301) < 1e-2           # pyproj's value, the reference's own tolerance
+    rng = np.random.default_rng(0)
+    lat, lon = rng.uniform(37.2, 37.6, 2000), rng.uniform(126.4, 127.6, 2000)
+    a, b = R.geo2local(lat, lon, "EPSG:4326", "EPSG:5186"), G.geo2local(lat, lon, "EPSG:4326", "EPSG:5186")
+    assert np.abs(a[0] - b[0]).max() < 1e-4 and np.abs(a[1] - b[1]).max() < 1e-4             # two different series, 0.1 mm
