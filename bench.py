@@ -12,8 +12,8 @@ on the batch size (tests/test_detector_gpu.py::test_detector_batch_equals_single
 
   N = 1   the reference's per-frame order (geotrax/extract.py:145-197): HIP detector -> host C++
           tracker -> HIP stabilizer (mask from the tracker's boxes) -> box warp.
-  N > 1   the clip's batches are dealt round-robin to the ranks (global batch g goes to
-          rank g % N): every rank detects and stabilizes its K batches (mask from the raw detections);
+  N > 1   the clip is dealt to the ranks in runs of --gather-every consecutive batches (contiguous
+          ranges per rank): every rank detects and stabilizes its K batches (mask from the raw detections);
           every --gather-every steps the fixed-stride per-frame records of those steps are gathered to
           rank 0 over RCCL, where a second host thread runs the tracker over them in clip order and
           warps the boxes while the GPUs carry on -- all inside the timed region. No other collective.
@@ -522,16 +522,32 @@ def main():
     for i, t in enumerate(seq):
         ctx.dev_upload(pool + i * fbytes, frames[t])
 
-    def batch_ptr(k):                                            # local step k -> global batch k * world + rank of the playback
-        g = k * world + rank if args.sharding == "frames" else k  # videos: every rank plays its own clip from the start
-        return pool + ((g * B) % len(order)) * fbytes
+    CH = max(args.gather_every, 1)                               # steps per contiguous run of a rank = steps per gather
+
+    def global_batch(k):
+        """Local step k -> global batch of the playback. Frame sharding deals the clip in runs of CH consecutive batches:
+        within a gather interval rank r holds batches [r*CH, (r+1)*CH) of that interval, so its frames continue each other
+        (BoT-SORT's GMC needs the previous frame: one priming frame per run instead of one per batch) and the gathered
+        records are in clip order rank by rank. Warm-up and timed region are separate epochs."""
+        if args.sharding != "frames" or world == 1:
+            return k                                             # videos: every rank plays its own clip from the start
+        base, kk, total = (0, k, args.warmup) if k < args.warmup else (args.warmup * world, k - args.warmup, args.steps)
+        c, j = divmod(kk, CH)
+        n_c = min(CH, total - c * CH)                            # the last run of an epoch may be shorter
+        return base + c * CH * world + rank * n_c + j
+
+    def batch_ptr(k):
+        return pool + ((global_batch(k) * B) % len(order)) * fbytes
 
     def batch_item(k):
-        """What the engine is fed for local step k. Frame-sharded BoT-SORT run: the batch does not continue the rank's
-        previous one, so the GMC is primed with the frame that precedes it in the clip (every rank holds the clip)."""
+        """What the engine is fed for local step k. Frame-sharded BoT-SORT run: the first batch of a run does not continue
+        the rank's previous one, so the GMC is primed with the frame that precedes it in the clip (every rank holds the clip)."""
         if not shard_gmc:
             return batch_ptr(k)
-        g = k * world + rank
+        kk = k if k < args.warmup else k - args.warmup
+        if kk % CH != 0 and world > 1:
+            return batch_ptr(k)                                  # continues the run
+        g = global_batch(k)
         return batch_ptr(k), (None if g == 0 else pool + ((g * B - 1) % len(order)) * fbytes)
 
     extract = args.workload == "extract"
@@ -598,8 +614,8 @@ def main():
                 dist.gather(t, bufs, dst=0)
                 if rank == 0:
                     host = np.stack([b.cpu().numpy() for b in bufs])            # [world, n*B, stride]
-                    # clip order: step-major, then rank, then frame within the batch
-                    replay_q.put(host.reshape(world, n, B, -1).transpose(1, 0, 2, 3).reshape(world * n * B, -1))
+                    # clip order: every rank holds one contiguous run of the interval -> rank-major is clip order
+                    replay_q.put(host.reshape(world * n * B, -1))
 
     def replay_worker():
         while True:
@@ -697,8 +713,8 @@ def main():
                 "pipeline": f"{n_det_streams} detector stream(s) take batches round-robin and stay in flight while tracker/stabilizers work through the collected batch; {n_stab} stabilizer streams (submit/collect C ABI)",
                 "sharding": "none (reference per-frame order)" if world == 1 else
                             "one clip per rank, reference per-frame order on every rank, no data-path collective" if args.sharding == "videos" else
-                            f"batches dealt round-robin to ranks; records gathered to rank 0 every {args.gather_every} steps (RCCL), "
-                            "tracker replayed there on a second host thread",
+                            f"runs of {args.gather_every} consecutive batches dealt round-robin to the ranks; their records gathered to rank 0 once "
+                            "per run (RCCL), tracker replayed there in clip order on a second host thread",
             },
         }
         if failure is not None:
