@@ -357,7 +357,7 @@ int env_int(const char* name, int dflt) {
 }
 }  // namespace
 
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc, long est_pixels) {
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc) {
   ConvConfig c{};
   c.dtype = dtype;
   c.ks = ks;
@@ -370,12 +370,7 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     c.kc = ks == 1 ? (cin % 32 == 0 ? 32 : 16) : 16;
     if (force_kc > 0) c.kc = force_kc;
     c.bn = (cout % 64 == 0) ? 64 : 32;
-    // few output pixels (the 120x120 / 60x60 stages at small batch): with 64-cout tiles the launch has fewer workgroups
-    // than the chip has slots and each one is a long serial chain of K chunks; 32-cout tiles double the workgroups and
-    // halve the matrix work per chunk (GTX_SPLIT_BN32_BELOW = workgroup count below which that is done; 0 = never)
-    static const int bn32_below = env_int("GTX_SPLIT_BN32_BELOW", 0);
-    if (c.bn == 64 && est_pixels > 0 && bn32_below > 0 && (est_pixels / 128) * (cout / 64) < bn32_below) c.bn = 32;
-    c.th = 8; c.tw = 16;                           // conv_pick_tile() may raise th to 16 once the problem size is known
+    c.th = 8; c.tw = 16;
     GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
     GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
     return c;
@@ -439,22 +434,6 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
             }
           }
   return out;
-}
-
-// 16x16-pixel tiles (two 32-pixel sub-tiles per wave) halve the weight re-staging and the LDS fragment reads per MFMA,
-// but make 4x fewer, 2x larger workgroups at 2 per CU: worth it only when the launch still fills the chip.
-void conv_pick_tile(const ConvGroup& g, ConvConfig& cfg) {
-  if (cfg.variant != 2 || cfg.stride != 1) return;
-  static const int mode = env_int("GTX_CONV_TH16", 0);    // 0 = never (default: measured 3 % slower over the YOLOv8s shapes), 1 = always, -1 = by size
-  static const int k1 = env_int("GTX_CONV_TH16_K1", 0);   // 1x1 convs are HBM-bound either way
-  if (cfg.ks == 1 && !k1) { cfg.th = 8; return; }
-  long wgs = 0;
-  for (int i = 0; i < g.count; ++i) {
-    const ConvProblem& p = g.p[i];
-    wgs += (long)p.N * cdiv(p.Wo, 16) * cdiv(p.Ho, 16) * (p.Cout / cfg.bn);
-  }
-  const bool big = mode == 1 || (mode == -1 && wgs >= env_int("GTX_CONV_TH16_MIN", 400));
-  cfg.th = big ? 16 : 8;
 }
 
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {

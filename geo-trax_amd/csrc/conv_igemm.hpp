@@ -63,16 +63,11 @@ struct ConvConfig {
 
 // Picks the tile configuration used for a layer shape.
 // force_kc > 0 pins the K chunk (grouped launches: every member must use the same kernel instantiation).
-// est_pixels: N*Ho*Wo of the launch when known (0 = unknown): layers with few output pixels take 32-cout tiles so that
-// the launch still has enough workgroups to fill the chip.
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0, long est_pixels = 0);
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0);
 
 // Host-side weight packing: w is [Cout][KS][KS][Cin] fp32 (OHWI). Returns the packed
 // byte image for `cfg` (element type per cfg.dtype). acc_scale (may be null) receives ConvProblem::acc_scale.
 std::vector<uint8_t> pack_conv_weights(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale = nullptr);
-
-// Chooses the pixel tile (cfg.th) for the group's current problem sizes (batch included); call before finalize.
-void conv_pick_tile(const ConvGroup& g, ConvConfig& cfg);
 
 // Fills tiles_x/tiles_y/n_ct/block_begin/total_blocks for a group.
 void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg);

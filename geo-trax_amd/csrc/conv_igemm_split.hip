@@ -363,9 +363,8 @@ void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 #define GTX_CASE(KS, ST, WN, CPR, WM) \
   if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR && wm == WM) return launch_t<KS, ST, WN, CPR, WM>(g, s);
   GTX_CASE(3, 1, 1, 2, 1) GTX_CASE(3, 1, 2, 2, 1) GTX_CASE(3, 2, 1, 2, 1) GTX_CASE(3, 2, 2, 2, 1)
-  GTX_CASE(3, 1, 1, 2, 2) GTX_CASE(3, 1, 2, 2, 2)
   GTX_CASE(1, 1, 1, 4, 1) GTX_CASE(1, 1, 2, 4, 1) GTX_CASE(1, 1, 1, 2, 1) GTX_CASE(1, 1, 2, 2, 1)
-  GTX_CASE(1, 1, 1, 4, 2) GTX_CASE(1, 1, 2, 4, 2)
+
 #undef GTX_CASE
   fail(-3, "conv (split-f16x3): no kernel for ks=%d stride=%d bn=%d kc=%d th=%d", c.ks, c.stride, c.bn, c.kc, c.th);
 }

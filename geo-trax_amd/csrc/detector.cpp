@@ -100,7 +100,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, grouped_ ? 0 : (long)x.n * ho * wo);
+  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_);
   const std::vector<float> ohwi = to_ohwi(w);
   float acc_scale = 1.f;
   const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &acc_scale);
@@ -295,14 +295,12 @@ void Detector::build_graph() {
     tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
     const size_t mark = ops_.size();
     force_kc_ = conv_dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
-    grouped_ = true;                               // ... and one cout tile: no per-problem size hints
     View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
     View h2 = new_view(h1.h, h1.w, cb + cc);
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
     conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
     conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
     force_kc_ = 0;
-    grouped_ = false;
     // move the three freshly built single-problem ops into the two grouped stage ops
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
@@ -355,8 +353,6 @@ void Detector::set_batch(int nb) {
   for (Op& op : ops_) {
     if (op.kind != Op::CONV) continue;
     for (int i = 0; i < op.grp.count; ++i) op.grp.p[i].N = nb;
-    conv_pick_tile(op.grp, op.cfg);
-    op.family = conv_kernel_name(op.cfg);
     conv_group_finalize(op.grp, op.cfg);
     op.flops = 0;
     op.bytes = 0;

@@ -114,7 +114,6 @@ class Detector {
   std::map<std::string, View> layer_views_;
   bool finalized_ = false;
   int force_kc_ = 0;         // K chunk forced on the convs being built (grouped head stages)
-  bool grouped_ = false;     // the convs being built will share one grouped launch (one kernel configuration)
   int cur_nb_ = 0;
 
   View img_;                 // [N][net_h][net_w][4]

@@ -144,7 +144,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   const int pad = d->ksize / 2;
   st.ho = (d->h + 2 * pad - d->ksize) / d->stride + 1;
   st.wo = (d->w + 2 * pad - d->ksize) / d->stride + 1;
-  st.cfg = conv_pick_config(d->dtype, d->ksize, d->stride, d->cin, d->cout, 0, (long)d->n * st.ho * st.wo);
+  st.cfg = conv_pick_config(d->dtype, d->ksize, d->stride, d->cin, d->cout);
   const int vn = 16 / (int)es;
   GTX_CHECK(d->in_cstride % vn == 0 && d->in_coff % vn == 0 && d->out_cstride % 4 == 0 && d->out_coff % 4 == 0,
             "conv: channel strides/offsets must keep 16-byte (input) / 4-element (output) alignment");
@@ -186,7 +186,6 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.act = d->act;
   p.acc_scale = acc_scale;
   st.g.count = 1;
-  conv_pick_tile(st.g, st.cfg);
   conv_group_finalize(st.g, st.cfg);
 }
 }  // namespace
