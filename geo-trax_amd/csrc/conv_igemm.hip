@@ -71,7 +71,8 @@ struct ConvTile {
   }
 };
 
-__device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 template <typename T> __device__ __forceinline__ void store4(T* dst, const float (&v)[4]);
 template <> __device__ __forceinline__ void store4<_Float16>(_Float16* dst, const float (&v)[4]) {

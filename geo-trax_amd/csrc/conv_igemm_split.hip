@@ -55,7 +55,8 @@ struct SplitTile {
   static __host__ __device__ constexpr int swz(int row) { return (row / ROWS_PER_BANKROW) & (NCH - 1); }
 };
 
-__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 // 8 fp32 values (two 16-B loads) -> 8 hi halves + 8 lo halves
 __device__ __forceinline__ void split8(const uint4& a, const uint4& b, uint4& hi, uint4& lo) {

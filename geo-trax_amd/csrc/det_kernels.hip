@@ -169,7 +169,8 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
 }
 
 // ============================================================================ stem conv
-__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 template <typename T> __device__ __forceinline__ void load_px4(const T* p, float (&v)[4]);
 template <> __device__ __forceinline__ void load_px4<_Float16>(const _Float16* p, float (&v)[4]) {

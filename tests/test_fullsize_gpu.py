@@ -109,7 +109,11 @@ def test_fp32_paths_agree_at_full_size(gtx_ctx, scene4k):
         split.close()
     n_cand = int((ra[:, 4:].max(1) > 0.25).sum())
     assert len(a) > 50 and n_cand > len(a) * 1.3                            # NMS had clustered candidates to suppress
-    np.testing.assert_allclose(rb[:, 4:], ra[:, 4:], atol=1e-4)
+    # class scores over all 302 400 (anchor, class) pairs. The seeded weights' class logits reach O(100) at 4K, so a relative
+    # logit difference of 4e-6 (22-bit operands through ~60 layers) shows as up to ~1e-4 in a score near 0.5: 2e-4 bar on the
+    # extreme element, 2e-5 on the 99.9th percentile
+    d = np.abs(rb[:, 4:] - ra[:, 4:])
+    assert d.max() < 2e-4 and np.percentile(d, 99.9) < 2e-5, (d.max(), np.percentile(d, 99.9))
     np.testing.assert_allclose(rb[:, :4], ra[:, :4], rtol=2e-5, atol=5e-3)
     assert len(a) == len(b)
     # same detections; the order may differ only between neighbours whose scores tie within the 1e-4 score tolerance (the smooth class branch

@@ -9,7 +9,8 @@
   reports half of the bytes of wide (16 B per lane) reads (MI355X_MICROARCH.md, HBM section), so HBM bytes per
   launch = 2 * FETCH_SIZE + WRITE_SIZE. Written to profiles/<tag>_pmc_traffic.json, which bench.py reads for
   roofline.traffic.
-* --sq: optional SQ pass (SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES, ...) -> MFMA busy fraction per kernel.
+* --sq DIR[,DIR]: SQ / GRBM passes of tools/op_profile.py (launches alone on their stream) -> profiles/<tag>_pmc_sq.json:
+  normalised matrix-pipe utilisation, LDS activity and bank conflicts, wave stall shares, occupancy per kernel family.
 """
 import argparse
 import collections
@@ -25,6 +26,12 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def family(name: str) -> str:
     """rocprof kernel name -> the family name bench.py / gtx_detector_profile use."""
+    m = re.search(r"conv_igemm_split_kernel<([^>]*)>", name)             # demangled (anonymous namespace) form
+    if m:
+        return f"conv_igemm_split_kernel<{m.group(1)}>"
+    m = re.match(r"_ZN3gtx12_GLOBAL__N_123conv_igemm_split_kernelI(.*?)EEvNS_9ConvGroupE", name)
+    if m:
+        return "conv_igemm_split_kernel<" + ", ".join(re.findall(r"Li(\d+)E", m.group(1))) + ">"
     m = re.match(r"_ZN3gtx\d+(conv_igemm2?_kernel)I(.*?)EEvNS_9ConvGroupE", name)
     if m:
         args = m.group(2)
@@ -64,7 +71,8 @@ def main():
     ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--sq")
     ap.add_argument("--batch", type=int, required=True)
     ap.add_argument("--tag", default="r01")
-    ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-profile")
+    ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-profile --no-f16-line")
+    ap.add_argument("--sq-command", default="python3 tools/op_profile.py 2 f32s 3")
     a = ap.parse_args()
     out = ROOT / "profiles"
     out.mkdir(exist_ok=True)
@@ -86,15 +94,49 @@ def main():
                           "KB per dispatch averaged over all dispatches of the kernel; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                           "(gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
                    kernels=kernels)
-        if a.sq:
-            s = counters(a.sq, {"SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16"})
-            for k, c in s.items():
-                if k in kernels and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"][1] > 0:
-                    busy = c["SQ_BUSY_CYCLES"][1]
-                    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-                        kernels[k]["mfma_busy_over_sq_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / busy, 4)
         (out / f"{a.tag}_pmc_traffic.json").write_text(json.dumps(rec, indent=1) + "\n")
         print(json.dumps({k: v for k, v in list(kernels.items())[:6]}, indent=1))
+    if a.sq:
+        sq_summary(a.sq.split(","), out / f"{a.tag}_pmc_sq.json", a.sq_command)
+
+
+N_SIMD, N_CU, N_XCD = 1024, 256, 8
+
+
+def sq_summary(dirs, dst, command):
+    """Normalised SQ / GRBM counters per kernel family from one or more `rocprofv3 --pmc ... --kernel-trace` passes of
+    tools/op_profile.py (every launch alone on its stream). Per launch averages; units per MI355X_MICROARCH.md:
+    SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_f16), SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_*
+    count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+      mfma_busy_pct      = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles * 1024 SIMDs)      the matrix-pipe utilisation
+      lds_active_pct     = SQ_LDS_IDX_ACTIVE / (kernel cycles * 256 CUs)
+      lds_conflict_pct   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+      wave_*_pct         = shares of SQ_WAVE_CYCLES (waiting in s_waitcnt/barrier, issue-stalled, issuing)
+      occupancy_waves_per_simd = SQ_WAVE_CYCLES * 4 / (kernel cycles * 1024)"""
+    want = {"SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT",
+            "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM_RD"}
+    acc = collections.defaultdict(dict)
+    for d in dirs:
+        for k, c in counters(d, want).items():
+            for name, (n, v) in c.items():
+                acc[k][name] = v / n
+    out = {}
+    for k, c in acc.items():
+        if "GRBM_GUI_ACTIVE" not in c or "SQ_WAVE_CYCLES" not in c:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"] / N_XCD
+        w = c["SQ_WAVE_CYCLES"]
+        r = {"kernel_cycles": round(cyc), "mfma_instructions": round(c.get("SQ_INSTS_MFMA", 0)),
+             "mfma_busy_pct": round(100 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * N_SIMD), 1),
+             "lds_active_pct": round(100 * c.get("SQ_LDS_IDX_ACTIVE", 0) / (cyc * N_CU), 1),
+             "lds_conflict_pct": round(100 * c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0), 1), 1),
+             "wave_waiting_pct": round(100 * c.get("SQ_WAIT_ANY", 0) / w, 1), "wave_issue_stalled_pct": round(100 * c.get("SQ_WAIT_INST_ANY", 0) / w, 1),
+             "wave_issuing_pct": round(100 * c.get("SQ_ACTIVE_INST_ANY", 0) / w, 1), "wave_lds_issue_stall_pct": round(100 * c.get("SQ_WAIT_INST_LDS", 0) / w, 1),
+             "occupancy_waves_per_simd": round(4 * w / (cyc * N_SIMD), 2), "valu_per_mfma": round(c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_INSTS_MFMA", 0), 1), 1)}
+        out[k] = r
+    dst.write_text(json.dumps({"command": command, "method": sq_summary.__doc__, "kernels": out}, indent=1) + "\n")
+    for k in list(out)[:6]:
+        print(k, out[k])
 
 
 if __name__ == "__main__":
