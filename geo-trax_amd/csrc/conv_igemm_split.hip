@@ -95,17 +95,22 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  // launch header first, as one burst of scalar loads: block count, group size and every member's first block
+  const int nb = g.total_blocks, cnt = g.count;
+  int bb[kMaxGroup];
+#pragma unroll
+  for (int i = 0; i < kMaxGroup; ++i) bb[i] = g.p[i].block_begin;
   int L;   // XCD-aware logical block id (conv_igemm.hip)
   {
-    const int b = blockIdx.x, nb = g.total_blocks;
+    const int b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = b & 7;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
-    if (i < g.count && L >= g.p[i].block_begin) pi = i;
-  const ConvProblem& P = g.p[pi];
+    if (i < cnt && L >= bb[i]) pi = i;
+  const ConvProblem P = g.p[pi];            // by value: one burst of wide scalar loads instead of a load (and a wait) per field
 
   const int lb = L - P.block_begin;
   const int ct = lb % P.n_ct;
@@ -183,23 +188,36 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const int p0 = trow0 * STRIDE * PW + tcol * STRIDE;
   constexpr int PSUB = 2 * STRIDE * PW;              // patch rows between two sub-tiles
 
+  // The accumulators start at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue is one multiply and
+  // has no loads of its own: the bias fetch overlaps the first global -> LDS round trip instead of opening the epilogue.
   floatx16 acc[WM][WN];
-#pragma unroll
-  for (int m = 0; m < WM; ++m)
+  {
+    float4 b4[WN][4];
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {                             // one uniform branch, eight independent loads
+      const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);
+    }
+    const float inv_sc = __builtin_amdgcn_rcpf(P.acc_scale);     // exact: acc_scale is a power of two
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          acc[m][j][4 * g4 + 0] = b4[j][g4].x * inv_sc; acc[m][j][4 * g4 + 1] = b4[j][g4].y * inv_sc;
+          acc[m][j][4 * g4 + 2] = b4[j][g4].z * inv_sc; acc[m][j][4 * g4 + 3] = b4[j][g4].w * inv_sc;
+        }
+  }
 
-  GTXS_PREFETCH(0)
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();   // previous chunk's fragment reads are done
-    GTXS_COMMIT()
-    __syncthreads();
-    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
-    // Fragment reads run one (tap, k-step) ahead of the six MFMAs (WN = 2) that consume them.
-    constexpr int NSTEP = KS * KS * (CPR / 2);
-    half8 bh[2][WM], bl[2][WM], ah[2][WN], al[2][WN];
+  constexpr int NSTEP = KS * KS * (CPR / 2);
+  half8 bh[2][WM], bl[2][WM], ah[2][WN], al[2][WN];
 #define GTXS_LOAD_FRAGS(STEP, SLOT)                                                            \
     {                                                                                          \
       const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
@@ -217,31 +235,37 @@ void conv_igemm_split_kernel(const ConvGroup g) {
         al[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + (((CPR + c__) ^ Tile::swz(nrow__)) << 4)); \
       }                                                                                        \
     }
-    GTXS_LOAD_FRAGS(0, 0)
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-      if (st + 1 < NSTEP) {
-        if (st & 1) GTXS_LOAD_FRAGS(st + 1, 0) else GTXS_LOAD_FRAGS(st + 1, 1)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          // small terms first, then the leading one
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1][m], acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
+  // The matrix phase of one K chunk: fragment reads run one (tap, k-step) ahead of the 3 * WM * WN MFMAs that consume them.
+#define GTXS_MATRIX_PHASE()                                                                    \
+    GTXS_LOAD_FRAGS(0, 0)                                                                      \
+    _Pragma("unroll") for (int st = 0; st < NSTEP; ++st) {                                     \
+      if (st + 1 < NSTEP) {                                                                    \
+        if (st & 1) GTXS_LOAD_FRAGS(st + 1, 0) else GTXS_LOAD_FRAGS(st + 1, 1)                 \
+      }                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      _Pragma("unroll") for (int m = 0; m < WM; ++m)                                           \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                       \
+          /* small terms first, then the leading one */                                       \
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0); \
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1][m], acc[m][j], 0, 0, 0); \
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0); \
+        }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-#undef GTXS_LOAD_FRAGS
+  GTXS_PREFETCH(0)
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();   // previous chunk's fragment reads are done
+    GTXS_COMMIT()
+    __syncthreads();
+    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
+    GTXS_MATRIX_PHASE()
   }
+#undef GTXS_MATRIX_PHASE
+#undef GTXS_LOAD_FRAGS
 
   // ---- epilogue: acc * 2^-shift + bias -> SiLU (+ residual) -> fp32 NHWC, whole 128-B lines per store ----
   // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
   // BN channels through LDS so that a store instruction writes contiguous runs of BN*4 bytes per pixel.
-  const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
   const float sc = P.acc_scale;
   const bool wide = (P.out_cstride % 4) == 0 && (P.out_coff % 4) == 0;
   if (wide) __syncthreads();                    // every wave is done with the staging buffers
@@ -264,7 +288,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = fmaf(acc[m][j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+            v[i] = acc[m][j][4 * g4 + i] * sc;
             if (P.act) v[i] = silu_f(v[i]);
           }
           if (res) {
@@ -298,7 +322,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           const int cl = 32 * j + 8 * g4 + 4 * h;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float v = fmaf(acc[m][j][4 * g4 + i], sc, bias ? bias[cl + i] : 0.f);
+            float v = acc[m][j][4 * g4 + i] * sc;
             if (P.act) v = silu_f(v);
             if (res) v += res[cl + i];
             out[cl + i] = v;
