@@ -125,17 +125,22 @@ void conv_igemm_kernel(const ConvGroup g) {
   // XCD-aware logical block id: blocks b and b+8 share an XCD (speed only, never correctness);
   // give each XCD a contiguous run of logical blocks so that the cout tiles of one pixel tile
   // (same input patch) and neighbouring pixel tiles (shared halo) meet in one L2.
+  // launch header first, as one burst of scalar loads: block count, group size and every member's first block
+  const int nb = g.total_blocks, cnt = g.count;
+  int bb[kMaxGroup];
+#pragma unroll
+  for (int i = 0; i < kMaxGroup; ++i) bb[i] = g.p[i].block_begin;
   int L;
   {
-    const int b = blockIdx.x, nb = g.total_blocks;
+    const int b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = b & 7;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
-    if (i < g.count && L >= g.p[i].block_begin) pi = i;
-  const ConvProblem& P = g.p[pi];
+    if (i < cnt && L >= bb[i]) pi = i;
+  const ConvProblem P = g.p[pi];            // by value: one burst of wide scalar loads instead of a load (and a wait) per field
 
   const int lb = L - P.block_begin;
   const int ct = lb % P.n_ct;
@@ -202,11 +207,30 @@ void conv_igemm_kernel(const ConvGroup g) {
   const int trow = 2 * wave + (prow >> 4), tcol = prow & 15;
   const int p0 = trow * STRIDE * PW + tcol * STRIDE;
 
+  // The accumulators start at the bias, so the epilogue has no loads of its own: the bias fetch overlaps the first
+  // global -> LDS round trip instead of opening the epilogue.
   floatx16 acc[WN];
+  {
+    float4 b4[WN][4];
 #pragma unroll
-  for (int j = 0; j < WN; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {
+      const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        acc[j][4 * g4 + 0] = b4[j][g4].x; acc[j][4 * g4 + 1] = b4[j][g4].y;
+        acc[j][4 * g4 + 2] = b4[j][g4].z; acc[j][4 * g4 + 3] = b4[j][g4].w;
+      }
+  }
 
   GTX_PREFETCH(0)
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -277,7 +301,6 @@ void conv_igemm_kernel(const ConvGroup g) {
   // lines per pixel. The values are the same bits either way (rounded to fp16 before staging).
   const int oy = oy0 + trow, ox = ox0 + tcol;
   const bool wide = sizeof(T) == 2 && (P.out_cstride % 8) == 0 && (P.out_coff % 8) == 0;
-  const float* __restrict__ bias = P.bias ? P.bias + ct * BN : nullptr;
   if (wide) {
     constexpr int PITCH = BN * 2 + 16;          // bytes per staged pixel row; +16 keeps ds_write_b64 conflict free
     __syncthreads();                            // every wave is done with the staging buffers
@@ -294,7 +317,7 @@ void conv_igemm_kernel(const ConvGroup g) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = acc[j][4 * g4 + i] + (bias ? bias[cl + i] : 0.f);
+          v[i] = acc[j][4 * g4 + i];
           if (P.act) v[i] = silu(v[i]);
         }
         if (res) {
@@ -332,7 +355,7 @@ void conv_igemm_kernel(const ConvGroup g) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = acc[j][4 * g4 + i] + (bias ? bias[cl + i] : 0.f);
+          v[i] = acc[j][4 * g4 + i];
           if (P.act) v[i] = silu(v[i]);
         }
         if (res) {
