@@ -1,0 +1,90 @@
+// Host-only driver for the sanitizer builds (make -C geo-trax_amd asan | tsan): the tracker and the projective-geometry
+// helpers are the parts of libgtx that run on the host inside the hot loop (the reference has no
+// sanitizer story; a multi-threaded, multi-stream build should own one). GPU AddressSanitizer is not available on this
+// pool, so the HIP kernels are out of reach of this target; the C++ that manages tracks, lists and the LAP is not.
+//   asan: one long seeded detection stream through ByteTrack and BoT-SORT (births, deaths, empty frames, dense overlaps,
+//         >1000 removed tracks so that the ring of removed ids wraps), box warps and point transforms on edge inputs.
+//   tsan: the same streams on several tracker objects from several threads at once (objects are independent; the library
+//         promises nothing shared between them).
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../geometry.hpp"
+#include "../tracker.hpp"
+
+namespace {
+struct Frame { std::vector<float> xyxy, conf; std::vector<int> cls; };
+
+std::vector<Frame> stream(unsigned seed, int n_obj, int n_frames, float w, float h) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> U(0.f, 1.f);
+  std::vector<float> px(n_obj), py(n_obj), vx(n_obj), vy(n_obj), sw(n_obj), sh(n_obj), cf(n_obj);
+  for (int k = 0; k < n_obj; ++k) {
+    px[k] = 50 + U(rng) * (w - 100); py[k] = 50 + U(rng) * (h - 100); vx[k] = (U(rng) - 0.5f) * 12; vy[k] = (U(rng) - 0.5f) * 12;
+    sw[k] = 40 + U(rng) * 120; sh[k] = 25 + U(rng) * 45; cf[k] = 0.3f + U(rng) * 0.65f;
+  }
+  std::vector<Frame> out(n_frames);
+  for (int t = 0; t < n_frames; ++t) {
+    if (t % 37 == 17) continue;                       // an empty frame now and then
+    for (int k = 0; k < n_obj; ++k) {
+      if (U(rng) < 0.1f) continue;
+      if ((t + k) % 61 == 0) { px[k] = 50 + U(rng) * (w - 100); py[k] = 50 + U(rng) * (h - 100); }   // teleport: old track dies, new one is born
+      const float cx = px[k] + vx[k] * (t % 40), cy = py[k] + vy[k] * (t % 40);
+      out[t].xyxy.insert(out[t].xyxy.end(), {cx - sw[k] / 2, cy - sh[k] / 2, cx + sw[k] / 2, cy + sh[k] / 2});
+      out[t].conf.push_back(U(rng) < 0.1f ? 0.12f + 0.1f * U(rng) : cf[k]);
+      out[t].cls.push_back(k % 4);
+    }
+  }
+  return out;
+}
+
+long run_tracker(int type, unsigned seed) {
+  gtx_tracker_config cfg{};
+  cfg.type = type; cfg.track_high_thresh = 0.25f; cfg.track_low_thresh = 0.1f; cfg.new_track_thresh = 0.25f; cfg.track_buffer = 30;
+  cfg.match_thresh = 0.8f; cfg.fuse_score = 1; cfg.frame_rate = 30;
+  gtx::ByteTracker trk(cfg);
+  const int cap = 512;
+  std::vector<float> ob(cap * 4), os(cap);
+  std::vector<int> oi(cap), oc(cap), od(cap);
+  long rows = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    for (const Frame& f : stream(seed, rep ? 150 : 60, 400, rep ? 900.f : 3840.f, rep ? 600.f : 2160.f)) {   // second pass: dense overlaps
+      const double warp[6] = {1.0, 1e-4, 0.3, -1e-4, 1.0, -0.2};
+      int n = 0;
+      trk.update((int)f.conf.size(), f.xyxy.data(), f.conf.data(), f.cls.data(), type == 1 ? warp : nullptr, cap, &n, ob.data(), oi.data(),
+                 os.data(), oc.data(), od.data());
+      rows += n;
+    }
+    if (rep == 0) trk.reset();
+  }
+  return rows;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  const bool threads = argc > 1 && argv[1][0] == 't';
+  long rows = 0;
+  if (threads) {
+    std::vector<long> r(6);
+    std::vector<std::thread> th;
+    for (int i = 0; i < 6; ++i) th.emplace_back([&r, i] { r[i] = run_tracker(i & 1, 100 + i); });
+    for (auto& t : th) t.join();
+    for (long v : r) rows += v;
+  } else {
+    rows = run_tracker(0, 1) + run_tracker(1, 2);
+    // geometry helpers on edge inputs: zero boxes, a point on the line at infinity, a degenerate matrix
+    const double H[9] = {1.01, 0.002, 3.0, -0.001, 0.99, -6.0, 1e-7, -1e-7, 1.0};
+    std::vector<float> in = {100, 200, 50, 20, 3800, 2100, 90, 40}, outb(8);
+    gtx::warp_boxes(H, in.data(), 2, outb.data());
+    gtx::warp_boxes(H, in.data(), 0, outb.data());
+    const double Hinf[9] = {1, 0, 0, 0, 1, 0, 1, 0, -5};
+    double x[2] = {5.0, 1.0}, y[2] = {7.0, 2.0}, ox[2], oy[2];
+    gtx::perspective_points(Hinf, x, y, 2, ox, oy);
+    if (!(ox[0] == 0.0 && oy[0] == 0.0) || !std::isfinite(outb[0])) { std::fprintf(stderr, "geometry edge cases wrong\n"); return 2; }
+  }
+  std::printf("sanitize_host ok: %ld track rows\n", rows);
+  return rows > 10000 ? 0 : 1;
+}
