@@ -31,6 +31,13 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifdef GTX_CLOCK_STAMP
+// Diagnostic build only (`make stamp`, tools/clock_probe.py): shader-clock and 100 MHz wall-clock ticks spent inside the K loop,
+// summed over workgroups, to read the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
+// The sums live in a buffer of their own; no output value depends on them.
+__device__ unsigned long long g_clock_stamp[8];   // [0..2] loop cycles, 100 MHz ticks, workgroups; [3..7] per-phase cycles of wave 0
+#endif
+
 template <int KS, int STRIDE, int WN, int CPR, int WM>
 struct SplitTile {
   static constexpr int TH = 8 * WM, TW = 16;         // WM sub-tiles of 2 rows x 16 pixels per wave
@@ -253,6 +260,35 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
   GTXS_PREFETCH(0)
+#ifdef GTX_CLOCK_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef GTX_CLOCK_STAMP
+#define GTXS_STAMP(T)                                                                            \
+  unsigned long long T;                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory");                      \
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long st_prev = st_c0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();
+    GTXS_STAMP(ta)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GTXS_STAMP(tb)
+    GTXS_COMMIT()
+    GTXS_STAMP(tc)
+    __syncthreads();
+    GTXS_STAMP(td)
+    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
+    GTXS_MATRIX_PHASE()
+    GTXS_STAMP(te)
+    ph[0] += ta - st_prev; ph[1] += tb - ta; ph[2] += tc - tb; ph[3] += td - tc; ph[4] += te - td;
+    st_prev = te;
+  }
+  if (tid == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_clock_stamp[3 + i], ph[i]);
+#else
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
     GTXS_COMMIT()
@@ -260,8 +296,19 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
     GTXS_MATRIX_PHASE()
   }
+#endif
 #undef GTXS_MATRIX_PHASE
 #undef GTXS_LOAD_FRAGS
+#ifdef GTX_CLOCK_STAMP
+  {
+    const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      atomicAdd(&g_clock_stamp[0], st_c1 - st_c0);
+      atomicAdd(&g_clock_stamp[1], st_r1 - st_r0);
+      atomicAdd(&g_clock_stamp[2], 1ull);
+    }
+  }
+#endif
 
   // ---- epilogue: acc * 2^-shift + bias -> SiLU (+ residual) -> fp32 NHWC, whole 128-B lines per store ----
   // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
@@ -395,3 +442,14 @@ void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 }
 
 }  // namespace gtx
+
+#ifdef GTX_CLOCK_STAMP
+// out = {shader-clock ticks, 100 MHz ticks, workgroups, then wave 0's cycles in: first barrier, load wait, commit, second
+// barrier, prefetch issue + matrix phase} summed since the last call; clears the sums.
+extern "C" int gtx_debug_conv_clock(unsigned long long out[8]) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtx::g_clock_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(gtx::g_clock_stamp), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif

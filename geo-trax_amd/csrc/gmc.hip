@@ -296,7 +296,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const float2* __restrict__ pts, const int* __restrict__ n_pts,
                                                  float2* __restrict__ out, int* __restrict__ status) {
-  __shared__ double s_I[4][kPatch * kPatch], s_Ix[4][kPatch * kPatch], s_Iy[4][kPatch * kPatch], s_J[4][kPatch * kPatch];
+  // Patches are kept in LDS in the narrowest exact form -- pixels as bytes, the Scharr sums as their integer numerators
+  // (|3(c-a) + 10(f-d) + 3(m-g)| <= 4080) -- and widened to double when read: the same doubles as before, bit for bit, in
+  // 11.6 KB per workgroup instead of 62 KB (at 62 KB the 250 workgroups of a frame took a third of every CU's LDS away from
+  // the convolutions that share the GPU).
+  __shared__ uint8_t s_I[4][kPatch * kPatch], s_J[4][kPatch * kPatch];
+  __shared__ short s_Ix[4][kPatch * kPatch], s_Iy[4][kPatch * kPatch];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + wave;
   if (n >= *n_pts) return;
@@ -322,12 +327,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
     for (int k = lane; k < kPatch * kPatch; k += 64) {
       const int yy = y0 + k / kPatch, xx = x0 + k % kPatch;
       const int ym = refl101(yy - 1, h), yp = refl101(yy + 1, h), xm = refl101(xx - 1, w), xp = refl101(xx + 1, w);
-      const double a = I[(size_t)ym * w + xm], b = I[(size_t)ym * w + xx], c = I[(size_t)ym * w + xp];
-      const double d = I[(size_t)yy * w + xm], f = I[(size_t)yy * w + xp];
-      const double g = I[(size_t)yp * w + xm], hh = I[(size_t)yp * w + xx], m = I[(size_t)yp * w + xp];
+      const int a = I[(size_t)ym * w + xm], b = I[(size_t)ym * w + xx], c = I[(size_t)ym * w + xp];
+      const int d = I[(size_t)yy * w + xm], f = I[(size_t)yy * w + xp];
+      const int g = I[(size_t)yp * w + xm], hh = I[(size_t)yp * w + xx], m = I[(size_t)yp * w + xp];
       s_I[wave][k] = I[(size_t)yy * w + xx];
-      s_Ix[wave][k] = (3.0 * (c - a) + 10.0 * (f - d) + 3.0 * (m - g)) / 32.0;
-      s_Iy[wave][k] = (3.0 * (g - a) + 10.0 * (hh - b) + 3.0 * (m - c)) / 32.0;
+      s_Ix[wave][k] = (short)(3 * (c - a) + 10 * (f - d) + 3 * (m - g));      // x 1/32 when read
+      s_Iy[wave][k] = (short)(3 * (g - a) + 10 * (hh - b) + 3 * (m - c));
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -340,9 +345,11 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
       Iw[t] = 0; Ixw[t] = 0; Iyw[t] = 0;
       if (k < kWinSamples) {
         const int r = k / kWin, c = k % kWin, q = r * kPatch + c;
-        Iw[t] = s_I[wave][q] * w00 + s_I[wave][q + 1] * w01 + s_I[wave][q + kPatch] * w10 + s_I[wave][q + kPatch + 1] * w11;
-        Ixw[t] = s_Ix[wave][q] * w00 + s_Ix[wave][q + 1] * w01 + s_Ix[wave][q + kPatch] * w10 + s_Ix[wave][q + kPatch + 1] * w11;
-        Iyw[t] = s_Iy[wave][q] * w00 + s_Iy[wave][q + 1] * w01 + s_Iy[wave][q + kPatch] * w10 + s_Iy[wave][q + kPatch + 1] * w11;
+        auto dx_ = [&](int i) { return (double)s_Ix[wave][i] / 32.0; };
+        auto dy_ = [&](int i) { return (double)s_Iy[wave][i] / 32.0; };
+        Iw[t] = (double)s_I[wave][q] * w00 + (double)s_I[wave][q + 1] * w01 + (double)s_I[wave][q + kPatch] * w10 + (double)s_I[wave][q + kPatch + 1] * w11;
+        Ixw[t] = dx_(q) * w00 + dx_(q + 1) * w01 + dx_(q + kPatch) * w10 + dx_(q + kPatch + 1) * w11;
+        Iyw[t] = dy_(q) * w00 + dy_(q + 1) * w01 + dy_(q + kPatch) * w10 + dy_(q + kPatch + 1) * w11;
         a11 += Ixw[t] * Ixw[t]; a12 += Ixw[t] * Iyw[t]; a22 += Iyw[t] * Iyw[t];
       }
     }
@@ -374,7 +381,8 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
         const int k = lane + 64 * t;
         if (k < kWinSamples) {
           const int r = k / kWin, c = k % kWin, q = r * kPatch + c;
-          const double Jw = s_J[wave][q] * v00 + s_J[wave][q + 1] * v01 + s_J[wave][q + kPatch] * v10 + s_J[wave][q + kPatch + 1] * v11;
+          const double Jw = (double)s_J[wave][q] * v00 + (double)s_J[wave][q + 1] * v01 + (double)s_J[wave][q + kPatch] * v10 +
+                            (double)s_J[wave][q + kPatch + 1] * v11;
           const double diff = Jw - Iw[t];
           b1 += diff * Ixw[t]; b2 += diff * Iyw[t];
         }
