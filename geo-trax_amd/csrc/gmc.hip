@@ -309,6 +309,10 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
   const double half = (kWin - 1) * 0.5;
   double nx = 0.0, ny = 0.0;
   bool ok = true;
+  constexpr int kPatchSlots = (kPatch * kPatch + 63) / 64;
+  int prow[kPatchSlots], pcol[kPatchSlots];        // this lane's patch positions (the same at every level and iteration)
+#pragma unroll
+  for (int t = 0; t < kPatchSlots; ++t) { prow[t] = (lane + 64 * t) / kPatch; pcol[t] = (lane + 64 * t) % kPatch; }
   for (int L = kMaxLevel; L >= 0; --L) {
     const double sc = 1.0 / (double)(1 << L);
     const double qx = px * sc, qy = py * sc;
@@ -324,8 +328,11 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
     }
     const double fx = tx - x0, fy = ty - y0;
     // previous image patch and its Scharr derivatives at the 22x22 integer positions
-    for (int k = lane; k < kPatch * kPatch; k += 64) {
-      const int yy = y0 + k / kPatch, xx = x0 + k % kPatch;
+#pragma unroll
+    for (int t = 0; t < kPatchSlots; ++t) {
+      const int k = lane + 64 * t;
+      if (k >= kPatch * kPatch) break;
+      const int yy = y0 + prow[t], xx = x0 + pcol[t];
       const int ym = refl101(yy - 1, h), yp = refl101(yy + 1, h), xm = refl101(xx - 1, w), xp = refl101(xx + 1, w);
       const int a = I[(size_t)ym * w + xm], b = I[(size_t)ym * w + xx], c = I[(size_t)ym * w + xp];
       const int d = I[(size_t)yy * w + xm], f = I[(size_t)yy * w + xp];
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
     }
     D = 1.0 / D;
     double pdx = 0.0, pdy = 0.0;
+    int last_jx0 = -(1 << 30), last_jy0 = 0;
     for (int j = 0; j < kMaxIters; ++j) {
       const double ux = nx - half, uy = ny - half;
       const int jx0 = (int)floor(ux), jy0 = (int)floor(uy);
@@ -370,10 +378,17 @@ __global__ __launch_bounds__(256) void lk_kernel(const Pyr P, const Pyr C, const
         break;
       }
       const double gx = ux - jx0, gy = uy - jy0;
-      __builtin_amdgcn_wave_barrier();
-      for (int k = lane; k < kPatch * kPatch; k += 64) s_J[wave][k] = J[(size_t)(jy0 + k / kPatch) * w + jx0 + k % kPatch];
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
+      if (jx0 != last_jx0 || jy0 != last_jy0) {     // sub-pixel steps mostly stay inside the same integer window: the staged patch is still it
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < kPatchSlots; ++t) {
+          const int k = lane + 64 * t;
+          if (k < kPatch * kPatch) s_J[wave][k] = J[(size_t)(jy0 + prow[t]) * w + jx0 + pcol[t]];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        last_jx0 = jx0; last_jy0 = jy0;
+      }
       const double v00 = (1 - gx) * (1 - gy), v01 = gx * (1 - gy), v10 = (1 - gx) * gy, v11 = gx * gy;
       double b1 = 0, b2 = 0;
 #pragma unroll
