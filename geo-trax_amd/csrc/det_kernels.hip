@@ -51,16 +51,6 @@ __device__ __forceinline__ int bgr2gray(int b, int g, int r) {
   return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;
 }
 
-template <typename T> __device__ __forceinline__ void store_rgb0(T* dst, float r, float g, float b);
-template <> __device__ __forceinline__ void store_rgb0<_Float16>(_Float16* dst, float r, float g, float b) {
-  half4 v;
-  v[0] = (_Float16)r; v[1] = (_Float16)g; v[2] = (_Float16)b; v[3] = (_Float16)0.f;
-  *reinterpret_cast<half4*>(dst) = v;
-}
-template <> __device__ __forceinline__ void store_rgb0<float>(float* dst, float r, float g, float b) {
-  *reinterpret_cast<float4*>(dst) = make_float4(r, g, b, 0.f);
-}
-
 struct PreParams {
   const uint8_t* frames;
   void* img;
@@ -70,22 +60,24 @@ struct PreParams {
   float scale_x, scale_y;  // src/new for the general bilinear path
 };
 
+// The network input is kept as RGB0 bytes: the /255 of ultralytics' preprocess maps 256 possible values, so the stem
+// kernels apply it through a 256-entry table as they read (the same correctly rounded fp32 division, per table entry
+// instead of per pixel), and this pass writes 4 bytes per pixel instead of 16 (fp32) or 8 (fp16): 29.5 MB instead of
+// 118 MB per two 1920x1920 frames, and as much less for the stem to read back.
 // One thread per network-input pixel. Exact-2x path: out = (a+b+c+d+2)>>2 per channel, which is
 // what cv2.resize(INTER_LINEAR) yields for an exact 0.5 scale (OpenCV switches to its 2x2 area
 // kernel; the fixed-point bilinear gives the same integers). General path: OpenCV's 11-bit
 // fixed-point bilinear [restated from memory of resize.cpp -- unverified against cv2 here].
-template <typename T>
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
   const int ox = blockIdx.x * blockDim.x + threadIdx.x;
   const int oy = blockIdx.y;
   const int n = blockIdx.z;
   if (ox >= p.net_w) return;
   const uint8_t* __restrict__ src = p.frames + (size_t)n * p.src_h * p.src_w * 3;
-  T* __restrict__ dst = static_cast<T*>(p.img) + (((size_t)n * p.net_h + oy) * p.net_w + ox) * 4;
+  uchar4* __restrict__ dst = static_cast<uchar4*>(p.img) + ((size_t)n * p.net_h + oy) * p.net_w + ox;
   const int ry = oy - p.top, rx = ox - p.left;
   if (ry < 0 || ry >= p.new_h || rx < 0 || rx >= p.new_w) {
-    const float pad = 114.f / 255.f;
-    store_rgb0<T>(dst, pad, pad, pad);
+    *dst = make_uchar4(114, 114, 114, 0);
     return;
   }
   int B, G, R;
@@ -124,7 +116,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
     }
     B = v[0]; G = v[1]; R = v[2];
   }
-  store_rgb0<T>(dst, (float)R / 255.f, (float)G / 255.f, (float)B / 255.f);
+  *dst = make_uchar4((unsigned char)R, (unsigned char)G, (unsigned char)B, 0);
 }
 
 // Gray-only pass for frames whose letterbox is not the exact-2x case but the stabilizer still
@@ -157,8 +149,8 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
   const bool fuse_gray = gray && p.exact2x && gh == lb.new_h && gw == lb.new_w;
   p.gray = fuse_gray ? gray : nullptr;
   dim3 grid(cdiv(lb.net_w, 256), lb.net_h, n);
-  if (dtype == DT_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, s, p);
+  (void)dtype;                 // the image is RGB0 bytes for every arithmetic
+  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, s, p);
   GTX_HIP(hipGetLastError());
   if (gray && !fuse_gray) {
     GTX_CHECK(gh * 2 == lb.src_h && gw * 2 == lb.src_w, "gray output must be half the frame size");
@@ -172,15 +164,10 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
 // x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-template <typename T> __device__ __forceinline__ void load_px4(const T* p, float (&v)[4]);
-template <> __device__ __forceinline__ void load_px4<_Float16>(const _Float16* p, float (&v)[4]) {
-  half4 h = *reinterpret_cast<const half4*>(p);
-  v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
-}
-template <> __device__ __forceinline__ void load_px4<float>(const float* p, float (&v)[4]) {
-  float4 f = *reinterpret_cast<const float4*>(p);
-  v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-}
+// value of an image byte as the network sees it: ultralytics' `im / 255` in fp32, rounded to fp16 for half=True
+template <typename T> __device__ __forceinline__ float px_value(int v);
+template <> __device__ __forceinline__ float px_value<float>(int v) { return (float)v / 255.f; }
+template <> __device__ __forceinline__ float px_value<_Float16>(int v) { return (float)(_Float16)((float)v / 255.f); }
 template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
 template <> __device__ __forceinline__ void store8<_Float16>(_Float16* dst, const float* v) {
   half8 h;
@@ -197,25 +184,31 @@ template <> __device__ __forceinline__ void store8<float>(float* dst, const floa
 // layer is bound by its 2*C0-byte-per-pixel store, not by arithmetic). Weights are read through
 // wave-uniform addresses, i.e. the scalar cache.
 template <typename T, int C0>
-__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ img, int h, int w,
+__global__ __launch_bounds__(256) void stem_kernel(const uchar4* __restrict__ img, int h, int w,
                                                    const float* __restrict__ w27,
                                                    const float* __restrict__ bias, T* __restrict__ out,
                                                    int ho, int wo) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x] = px_value<T>(threadIdx.x);
+  __syncthreads();
   const int ox = blockIdx.x * blockDim.x + threadIdx.x;
   const int oy = blockIdx.y, n = blockIdx.z;
   if (ox >= wo) return;
   float acc[C0];
 #pragma unroll
   for (int c = 0; c < C0; ++c) acc[c] = bias[c];
-  const T* base = img + (size_t)n * h * w * 4;
+  const uchar4* base = img + (size_t)n * h * w;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy * 2 - 1 + ky;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = ox * 2 - 1 + kx;
-      float px[4] = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < h && ix >= 0 && ix < w) load_px4<T>(base + ((size_t)iy * w + ix) * 4, px);
+      float px[3] = {0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+        const uchar4 u = base[(size_t)iy * w + ix];
+        px[0] = s_lut[u.x]; px[1] = s_lut[u.y]; px[2] = s_lut[u.z];
+      }
       const float* wt = w27 + (ky * 3 + kx) * 3 * C0;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci)
@@ -240,17 +233,20 @@ typedef float floatx16_t __attribute__((ext_vector_type(16)));
 // consecutive output pixels of a row; each lane gathers its B fragments straight from the NHWC4
 // image (two 8-byte pixels = 16 bytes = one k-step half), the weights stay in registers for all the
 // tiles a wave walks, the epilogue is bias + SiLU and 8-byte NHWC stores. No LDS.
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restrict__ img, int h, int w,
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict__ img, int h, int w,
                                                         const _Float16* __restrict__ wpk /*[groups][3][64][8]*/,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
                                                         int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
   constexpr int kStemPitch = 64 + 16;                   // bytes per staged pixel (+16: conflict-free 8-B writes)
   __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kStemPitch];
+  __shared__ _Float16 s_lut[256];                       // byte -> fp16(byte / 255)
+  s_lut[threadIdx.x] = (_Float16)((float)threadIdx.x / 255.f);
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   const int n = blockIdx.y;
-  const _Float16* base = img + (size_t)n * h * w * 4;
+  const uchar4* base = img + (size_t)n * h * w;
   for (int g = 0; g < groups; ++g) {
     half8 wf[3];
 #pragma unroll
@@ -271,8 +267,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restri
           if (tap < 9) {
             const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
             if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
-              const half4 px = *reinterpret_cast<const half4*>(base + ((size_t)iy * w + ix) * 4);
-              xf[4 * q] = px[0]; xf[4 * q + 1] = px[1]; xf[4 * q + 2] = px[2]; xf[4 * q + 3] = px[3];
+              const uchar4 px = base[(size_t)iy * w + ix];
+              xf[4 * q] = s_lut[px.x]; xf[4 * q + 1] = s_lut[px.y]; xf[4 * q + 2] = s_lut[px.z];
             }
           }
         }
@@ -320,17 +316,24 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const _Float16* __restri
 // parts, the weights arrive pre-split (scaled by an exact power of two, undone by `acc_scale`), a product costs three
 // MFMAs (w_lo x_hi + w_hi x_lo + w_hi x_hi). The 32-channel fp32 output row of a pixel is 128 B: the wave transposes
 // its 32 pixels through LDS and stores whole lines.
-__global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ img, int h, int w,
+__global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restrict__ img, int h, int w,
                                                          const _Float16* __restrict__ wpk /*[groups][3][hi|lo][64][8]*/,
                                                          const float* __restrict__ bias, float acc_scale, float* __restrict__ out,
                                                          int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
   constexpr int kPitch = 128 + 16;                      // bytes per staged pixel (32 fp32 channels + pad)
   __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kPitch];
+  __shared__ unsigned s_lut[256];                       // byte -> hi | lo << 16 of byte / 255 (already split)
+  {
+    const float f = (float)threadIdx.x / 255.f;
+    const _Float16 hi = (_Float16)f, lo = (_Float16)(f - (float)hi);
+    s_lut[threadIdx.x] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   const int n = blockIdx.y;
-  const float* base = img + (size_t)n * h * w * 4;
+  const uchar4* base = img + (size_t)n * h * w;
   for (int g = 0; g < groups; ++g) {
     half8 wh[3], wl[3];
 #pragma unroll
@@ -354,13 +357,12 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
           if (tap < 9) {
             const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
             if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
-              const float4 px = *reinterpret_cast<const float4*>(base + ((size_t)iy * w + ix) * 4);
-              const float v[4] = {px.x, px.y, px.z, px.w};
+              const uchar4 px = base[(size_t)iy * w + ix];
+              const unsigned e3[3] = {s_lut[px.x], s_lut[px.y], s_lut[px.z]};
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const _Float16 hi = (_Float16)v[e];       // image values are in [0, 1]
-                xh[4 * q + e] = hi;
-                xl[4 * q + e] = (_Float16)(v[e] - (float)hi);
+              for (int e = 0; e < 3; ++e) {
+                xh[4 * q + e] = __builtin_bit_cast(_Float16, (unsigned short)(e3[e] & 0xffffu));
+                xl[4 * q + e] = __builtin_bit_cast(_Float16, (unsigned short)(e3[e] >> 16));
               }
             }
           }
@@ -411,7 +413,7 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
     const int tiles_per_row = cdiv(wo, 32);
     const long n_tiles = (long)tiles_per_row * ho;
     const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
-    hipLaunchKernelGGL(stem_split_kernel, dim3(blocks, n), dim3(256), 0, s, (const float*)img, h, w, (const _Float16*)wpk_f16,
+    hipLaunchKernelGGL(stem_split_kernel, dim3(blocks, n), dim3(256), 0, s, (const uchar4*)img, h, w, (const _Float16*)wpk_f16,
                        bias, acc_scale, (float*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
     GTX_HIP(hipGetLastError());
     return;
@@ -420,7 +422,7 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
     const int tiles_per_row = cdiv(wo, 32);
     const long n_tiles = (long)tiles_per_row * ho;
     const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3(blocks, n), dim3(256), 0, s, (const _Float16*)img, h, w, (const _Float16*)wpk_f16,
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(blocks, n), dim3(256), 0, s, (const uchar4*)img, h, w, (const _Float16*)wpk_f16,
                        bias, (_Float16*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
     GTX_HIP(hipGetLastError());
     return;
@@ -429,10 +431,10 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
 #define GTX_STEM(C)                                                                              \
   if (c0 == C) {                                                                                 \
     if (dtype == DT_F16)                                                                         \
-      hipLaunchKernelGGL((stem_kernel<_Float16, C>), grid, block, 0, s, (const _Float16*)img, h, \
+      hipLaunchKernelGGL((stem_kernel<_Float16, C>), grid, block, 0, s, (const uchar4*)img, h,   \
                          w, w27, bias, (_Float16*)out, ho, wo);                                  \
     else                                                                                         \
-      hipLaunchKernelGGL((stem_kernel<float, C>), grid, block, 0, s, (const float*)img, h, w,    \
+      hipLaunchKernelGGL((stem_kernel<float, C>), grid, block, 0, s, (const uchar4*)img, h, w,   \
                          w27, bias, (float*)out, ho, wo);                                        \
     GTX_HIP(hipGetLastError());                                                                  \
     return;                                                                                      \

@@ -366,7 +366,7 @@ void Detector::set_batch(int nb) {
   for (Op& op : ops_) {
     if (op.kind == Op::STEM) {
       op.flops = 2.0 * nb * op.out.h * op.out.w * op.out.c * 27;
-      op.bytes = (double)nb * (op.in.h * op.in.w * 4 + (double)op.out.h * op.out.w * op.out.c) * es_;
+      op.bytes = (double)nb * ((double)op.in.h * op.in.w * 4 + (double)op.out.h * op.out.w * op.out.c * es_);   // RGB0 bytes in
     } else if (op.kind == Op::POOL) {
       op.flops = 0;
       op.bytes = (double)nb * op.in.h * op.in.w * op.in.c * 4 * es_;

@@ -401,13 +401,21 @@ int gtx_op_preprocess(gtx_ctx* ctx, int dtype, const uint8_t* frame, int h, int 
     lb.top = (int)std::nearbyint((net_h - lb.new_h) / 2.0 - 0.1);
     lb.left = (int)std::nearbyint((net_w - lb.new_w) / 2.0 - 0.1);
     lb.gain = r;
-    const size_t fb = (size_t)h * w * 3, ib = (size_t)net_h * net_w * 4 * gtx::dtype_size(dtype);
+    const size_t fb = (size_t)h * w * 3, npx = (size_t)net_h * net_w, ib = npx * 4;   // device image: RGB0 bytes
     gtx::DevBuf df(fb), di(ib), dg;
     if (out_gray) dg.alloc((size_t)gray_h * gray_w);
     GTX_HIP(hipMemcpy(df.p, frame, fb, hipMemcpyHostToDevice));
     gtx::launch_preprocess(dtype, df.as<uint8_t>(), 1, lb, di.p, out_gray ? dg.as<uint8_t>() : nullptr, gray_h, gray_w, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
-    GTX_HIP(hipMemcpy(out_img, di.p, ib, hipMemcpyDeviceToHost));
+    // The network's view of the image (what the stem kernels make of the bytes through their tables): byte / 255 in fp32,
+    // rounded to fp16 for dtype f16.
+    std::vector<uint8_t> raw(ib);
+    GTX_HIP(hipMemcpy(raw.data(), di.p, ib, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < npx * 4; ++i) {
+      const float f = (float)raw[i] / 255.f;
+      if (dtype == gtx::DT_F16) static_cast<_Float16*>(out_img)[i] = (_Float16)f;
+      else static_cast<float*>(out_img)[i] = f;
+    }
     if (out_gray) GTX_HIP(hipMemcpy(out_gray, dg.p, (size_t)gray_h * gray_w, hipMemcpyDeviceToHost));
   });
 }
