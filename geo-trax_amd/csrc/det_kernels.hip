@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
 __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restrict__ img, int h, int w,
                                                          const _Float16* __restrict__ wpk /*[groups][3][hi|lo][64][8]*/,
                                                          const float* __restrict__ bias, float acc_scale, float* __restrict__ out,
-                                                         int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
+                                                         int ho, int wo, int c0, int groups, int tiles_per_row, int n_tiles) {
   constexpr int kPitch = 128 + 16;                      // bytes per staged pixel (32 fp32 channels + pad)
   __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kPitch];
   __shared__ unsigned s_lut[256];                       // byte -> hi | lo << 16 of byte / 255 (already split)
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
-  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   const int n = blockIdx.y;
-  const uchar4* base = img + (size_t)n * h * w;
+  const uchar4* base = img + (size_t)n * h * w;     // offsets below fit 32 bits (one image)
   for (int g = 0; g < groups; ++g) {
     half8 wh[3], wl[3];
 #pragma unroll
@@ -341,8 +341,10 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
       wh[s] = *reinterpret_cast<const half8*>(wpk + ((((size_t)g * 3 + s) * 2 + 0) * 64 + lane) * 8);
       wl[s] = *reinterpret_cast<const half8*>(wpk + ((((size_t)g * 3 + s) * 2 + 1) * 64 + lane) * 8);
     }
-    for (long t = wave; t < n_tiles; t += nwaves) {
-      const int oy = (int)(t / tiles_per_row), ox = (int)(t % tiles_per_row) * 32 + r;
+    for (int t = wave; t < n_tiles; t += nwaves) {
+      const int oy = t / tiles_per_row, tx = t - oy * tiles_per_row, ox = tx * 32 + r;
+      // tiles whose 3x3 stride-2 footprint lies inside the image skip the per-tap bounds tests (all but the first row / column)
+      const bool interior = oy > 0 && tx > 0 && oy * 2 + 1 < h && tx * 64 + 64 < w && tx * 32 + 32 <= wo;
       floatx16_t acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
           const int tap = 2 * (2 * s + hh) + q;
           if (tap < 9) {
             const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
-            if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
-              const uchar4 px = base[(size_t)iy * w + ix];
+            if (interior || (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo)) {
+              const uchar4 px = base[(unsigned)(iy * w + ix)];
               const unsigned e3[3] = {s_lut[px.x], s_lut[px.y], s_lut[px.z]};
 #pragma unroll
               for (int e = 0; e < 3; ++e) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
           v.w = silu_f(fmaf(acc[4 * g4 + 3], acc_scale, bias[cl + 3]));
           *reinterpret_cast<float4*>(stg + r * kPitch + cl * 4) = v;
         }
-        const int ox0 = (int)(t % tiles_per_row) * 32;
+        const int ox0 = tx * 32;
         float* orow = out + (((size_t)n * ho + oy) * wo + ox0) * 32;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {                  // 8 pixels x 128 B per store instruction
@@ -411,8 +413,8 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
   if (dtype == DT_F32S) {
     GTX_CHECK(wpk_f16 != nullptr, "stem: split weights missing");
     const int tiles_per_row = cdiv(wo, 32);
-    const long n_tiles = (long)tiles_per_row * ho;
-    const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
+    const int n_tiles = tiles_per_row * ho;
+    const int blocks = std::min((n_tiles + 3) / 4, 4096);
     hipLaunchKernelGGL(stem_split_kernel, dim3(blocks, n), dim3(256), 0, s, (const uchar4*)img, h, w, (const _Float16*)wpk_f16,
                        bias, acc_scale, (float*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
     GTX_HIP(hipGetLastError());
