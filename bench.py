@@ -70,7 +70,7 @@ def parse():
                          "fp32 accumulate). Default: the library's default (geotrax_amd.detector.FP32_SPLIT_DEFAULT)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
-    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort"],
+    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort"],
                     help="default: bytetrack at N = 1 (BASELINE configs[2]), botsort at N > 1 (configs[4]; the reference's own default, default.yaml:362)")
     ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
     ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")

@@ -517,13 +517,15 @@ int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out) {
   return guarded([&] {
     need(cfg, "cfg"); need(out, "out");
     std::unique_ptr<gtx_tracker> t(new gtx_tracker);
-    t->impl.reset(new gtx::ByteTracker(*cfg));
+    if (cfg->type == 2) t->oc.reset(new gtx::OcSortTracker(*cfg));
+    else if (cfg->type == 0 || cfg->type == 1) t->impl.reset(new gtx::ByteTracker(*cfg));
+    else gtx::fail(GTX_ERR_INVALID, "tracker type %d (0 bytetrack, 1 botsort, 2 ocsort)", cfg->type);
     *out = t.release();
   });
 }
 void gtx_tracker_destroy(gtx_tracker* trk) { delete trk; }
 int gtx_tracker_reset(gtx_tracker* trk) {
-  return guarded([&] { need(trk, "trk"); trk->impl->reset(); });
+  return guarded([&] { need(trk, "trk"); if (trk->oc) trk->oc->reset(); else trk->impl->reset(); });
 }
 int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* conf, const int* cls,
                        const double* gmc_affine, int cap, int* n_out, float* out_xyxy, int* out_id, float* out_score,
@@ -531,7 +533,8 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
   return guarded([&] {
     need(trk, "trk"); need(n_out, "n_out");
     if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
-    trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+    if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+    else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
   });
 }
 

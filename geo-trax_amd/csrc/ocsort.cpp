@@ -1,0 +1,434 @@
+// OC-SORT (Cao et al., "Observation-Centric SORT", CVPR 2023) behind the gtx_tracker C ABI (type 2): the tracker the
+// reference selects with `tracker.active: ocsort` (geotrax/cfg/default.yaml:391-404; handed to ultralytics by
+// geotrax/utils/config_utils.py:127-194 and run inside model.track(), geotrax/extract.py:153).
+// Host C++, float64 throughout; statement by statement the procedure of oracle/ocsort_ref.py (which restates the
+// authors' public implementation): per-track 7-state constant-velocity Kalman filter with the observation-centric
+// re-update (ORU: freeze at the first missed frame, re-run along the straight virtual trajectory when the track is
+// observed again), velocity-direction consistency in the first association (OCM), optional BYTE pass, and a second
+// association of the leftovers against the tracks' last observations (OCR). Parameter mapping as in the oracle's header:
+// det_thresh = track_high_thresh, iou_threshold = 1 - match_thresh, max_age = track_buffer, min_hits = 3.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "tracker.hpp"
+
+namespace gtx {
+
+namespace {
+
+struct Box5 { double v[5]; };   // x1, y1, x2, y2, score
+
+inline void to_z(const double* b, double z[4]) {
+  const double w = b[2] - b[0], h = b[3] - b[1];
+  z[0] = b[0] + w / 2.0; z[1] = b[1] + h / 2.0; z[2] = w * h; z[3] = w / (h + 1e-6);
+}
+inline void to_box(const double* x, double b[4]) {
+  const double w = std::sqrt(x[2] * x[3]), h = x[2] / w;
+  b[0] = x[0] - w / 2.0; b[1] = x[1] - h / 2.0; b[2] = x[0] + w / 2.0; b[3] = x[1] + h / 2.0;
+}
+inline double iou_of(const double* a, const double* b) {
+  const double xx1 = std::max(a[0], b[0]), yy1 = std::max(a[1], b[1]), xx2 = std::min(a[2], b[2]), yy2 = std::min(a[3], b[3]);
+  const double wh = std::max(0.0, xx2 - xx1) * std::max(0.0, yy2 - yy1);
+  return wh / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - wh);
+}
+
+// filterpy's Kalman filter as the authors extend it (KalmanFilterNew): constant matrices are written out.
+struct OcKalman {
+  double x[7];
+  double P[49];
+  bool observed = false, has_saved = false;
+  double sx[7], sP[49];
+  int s_hist = 0;            // history length when frozen (includes the missed frame's entry)
+  int n_hist = 0;            // observations + misses recorded so far
+  int seen_idx = -1;         // history index and value of the last observation
+  double seen_z[4] = {0, 0, 0, 0};
+
+  OcKalman() {
+    std::memset(x, 0, sizeof x);
+    std::memset(P, 0, sizeof P);
+    for (int i = 0; i < 7; ++i) P[i * 7 + i] = i < 4 ? 10.0 : 10000.0;
+  }
+  static double q(int i) { return i < 4 ? 1.0 : (i < 6 ? 0.01 : 0.0001); }
+  static double r(int i) { return i < 2 ? 1.0 : 10.0; }
+
+  void predict() {
+    // x = F x, P = F P F^T + Q with F = I + e_0 e_4^T + e_1 e_5^T + e_2 e_6^T
+    double Fx[7];
+    for (int i = 0; i < 7; ++i) Fx[i] = x[i] + (i < 3 ? x[i + 4] : 0.0);
+    std::memcpy(x, Fx, sizeof Fx);
+    double FP[49];
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) FP[i * 7 + j] = P[i * 7 + j] + (i < 3 ? P[(i + 4) * 7 + j] : 0.0);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) P[i * 7 + j] = FP[i * 7 + j] + (j < 3 ? FP[i * 7 + j + 4] : 0.0) + (i == j ? q(i) : 0.0);
+  }
+
+  void update_none() {
+    ++n_hist;
+    if (observed) {            // first frame without an observation: freeze the prior of this frame
+      std::memcpy(sx, x, sizeof x);
+      std::memcpy(sP, P, sizeof P);
+      s_hist = n_hist;
+      has_saved = true;
+    }
+    observed = false;
+  }
+
+  void update(const double z[4]) {
+    const int idx = n_hist++;
+    if (!observed && has_saved) {
+      unfreeze(idx, z);
+    } else {
+      seen_idx = idx;
+      std::memcpy(seen_z, z, sizeof seen_z);
+    }
+    observed = true;
+    // y = z - Hx, S = H P H^T + R, K = P H^T S^-1, x += K y, P = (I - KH) P (I - KH)^T + K R K^T
+    double y[4], S[16], Si[16], K[28];
+    for (int i = 0; i < 4; ++i) y[i] = z[i] - x[i];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) S[i * 4 + j] = P[i * 7 + j] + (i == j ? r(i) : 0.0);
+    invert4(S, Si);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += P[i * 7 + k] * Si[k * 4 + j];
+        K[i * 4 + j] = s;
+      }
+    for (int i = 0; i < 7; ++i) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += K[i * 4 + k] * y[k];
+      x[i] += s;
+    }
+    double A[49], AP[49], Pn[49];            // A = I - K H
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) A[i * 7 + j] = (i == j ? 1.0 : 0.0) - (j < 4 ? K[i * 4 + j] : 0.0);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 7; ++k) s += A[i * 7 + k] * P[k * 7 + j];
+        AP[i * 7 + j] = s;
+      }
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 7; ++k) s += AP[i * 7 + k] * A[j * 7 + k];
+        double krk = 0.0;
+        for (int k = 0; k < 4; ++k) krk += K[i * 4 + k] * r(k) * K[j * 4 + k];
+        Pn[i * 7 + j] = s + krk;
+      }
+    std::memcpy(P, Pn, sizeof Pn);
+  }
+
+ private:
+  // ORU: back to the frozen state, then predict/update along the straight line between the last observation before the
+  // gap and the new one (box centre, width and height interpolated); the caller's regular update with z follows.
+  void unfreeze(int idx2, const double z2[4]) {
+    const int idx1 = seen_idx;
+    double z1[4];
+    std::memcpy(z1, seen_z, sizeof z1);
+    std::memcpy(x, sx, sizeof x);
+    std::memcpy(P, sP, sizeof P);
+    n_hist = s_hist - 1;
+    observed = true;
+    const double w1 = std::sqrt(z1[2] * z1[3]), h1 = std::sqrt(z1[2] / z1[3]);
+    const double w2 = std::sqrt(z2[2] * z2[3]), h2 = std::sqrt(z2[2] / z2[3]);
+    const int gap = idx2 - idx1;
+    const double dx = (z2[0] - z1[0]) / gap, dy = (z2[1] - z1[1]) / gap, dw = (w2 - w1) / gap, dh = (h2 - h1) / gap;
+    for (int i = 0; i < gap; ++i) {
+      const double w = w1 + (i + 1) * dw, h = h1 + (i + 1) * dh;
+      const double zv[4] = {z1[0] + (i + 1) * dx, z1[1] + (i + 1) * dy, w * h, w / h};
+      update(zv);
+      if (i != gap - 1) predict();
+    }
+  }
+
+  static void invert4(const double* M, double* inv) {   // Gauss-Jordan with partial pivoting
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { a[i][j] = M[i * 4 + j]; a[i][4 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+      int p = c;
+      for (int r2 = c + 1; r2 < 4; ++r2)
+        if (std::fabs(a[r2][c]) > std::fabs(a[p][c])) p = r2;
+      if (p != c)
+        for (int j = 0; j < 8; ++j) std::swap(a[p][j], a[c][j]);
+      const double d = 1.0 / a[c][c];
+      for (int j = 0; j < 8; ++j) a[c][j] *= d;
+      for (int r2 = 0; r2 < 4; ++r2) {
+        if (r2 == c) continue;
+        const double f = a[r2][c];
+        if (f != 0.0)
+          for (int j = 0; j < 8; ++j) a[r2][j] -= f * a[c][j];
+      }
+    }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+  }
+};
+
+struct OcTrack {
+  OcKalman kf;
+  int id = 0;
+  int tsu = 0, hits = 0, streak = 0, age = 0;
+  Box5 last_obs{{-1, -1, -1, -1, -1}};
+  std::vector<std::pair<int, Box5>> obs;    // (age, observation), ascending age; only the last delta_t + 1 ages matter
+  bool has_vel = false;
+  double vel[2] = {0, 0};                    // (dy, dx), unit length
+  float score = 0.f;
+  int cls = 0, idx = -1;
+
+  bool seen() const { return last_obs.v[0] + last_obs.v[1] + last_obs.v[2] + last_obs.v[3] + last_obs.v[4] >= 0; }
+  const Box5* obs_at(int a) const {
+    for (auto it = obs.rbegin(); it != obs.rend(); ++it) {
+      if (it->first == a) return &it->second;
+      if (it->first < a) break;
+    }
+    return nullptr;
+  }
+};
+
+inline void direction(const double* b1, const double* b2, double out[2]) {
+  const double cx1 = (b1[0] + b1[2]) / 2.0, cy1 = (b1[1] + b1[3]) / 2.0, cx2 = (b2[0] + b2[2]) / 2.0, cy2 = (b2[1] + b2[3]) / 2.0;
+  const double dy = cy2 - cy1, dx = cx2 - cx1, n = std::sqrt(dy * dy + dx * dx) + 1e-6;
+  out[0] = dy / n; out[1] = dx / n;
+}
+
+struct Det { Box5 b; int cls, idx; };
+
+}  // namespace
+
+struct OcSortTracker::Impl {
+  gtx_tracker_config cfg;
+  double det_thresh, low, new_thr, iou_thr, inertia;
+  int max_age, delta_t, min_hits;
+  bool use_byte;
+  std::vector<OcTrack> trackers;
+  int frame_count = 0, next_id = 0;
+
+  void track_update(OcTrack& t, const Det* d) {
+    if (!d) { t.kf.update_none(); return; }
+    if (t.seen()) {
+      const Box5* prev = nullptr;
+      for (int i = 0; i < delta_t && !prev; ++i) prev = t.obs_at(t.age - (delta_t - i));
+      if (!prev) prev = &t.last_obs;
+      direction(prev->v, d->b.v, t.vel);
+      t.has_vel = true;
+    }
+    t.last_obs = d->b;
+    t.obs.emplace_back(t.age, d->b);
+    if ((int)t.obs.size() > delta_t + 2) t.obs.erase(t.obs.begin(), t.obs.end() - (delta_t + 2));
+    t.tsu = 0;
+    ++t.hits;
+    ++t.streak;
+    t.score = (float)d->b.v[4]; t.cls = d->cls; t.idx = d->idx;
+    double z[4];
+    to_z(d->b.v, z);
+    t.kf.update(z);
+  }
+
+  void track_predict(OcTrack& t, double box[4]) {
+    if (t.kf.x[6] + t.kf.x[2] <= 0) t.kf.x[6] *= 0.0;
+    t.kf.predict();
+    ++t.age;
+    if (t.tsu > 0) t.streak = 0;
+    ++t.tsu;
+    to_box(t.kf.x, box);
+  }
+
+  Box5 k_previous(const OcTrack& t) const {
+    if (t.obs.empty()) return Box5{{-1, -1, -1, -1, -1}};
+    for (int i = 0; i < delta_t; ++i)
+      if (const Box5* p = t.obs_at(t.age - (delta_t - i))) return *p;
+    return t.obs.back().second;
+  }
+
+  // First association (OCM). dets: high-score detections; trks: predicted boxes.
+  void associate(const std::vector<Det>& dets, const std::vector<std::array<double, 4>>& trks, std::vector<std::pair<int, int>>& matches,
+                 std::vector<int>& u_d, std::vector<int>& u_t) const {
+    const int n = (int)dets.size(), m = (int)trks.size();
+    matches.clear(); u_d.clear(); u_t.clear();
+    if (m == 0) { for (int d = 0; d < n; ++d) u_d.push_back(d); return; }
+    if (n == 0) { for (int t = 0; t < m; ++t) u_t.push_back(t); return; }
+    std::vector<double> iou((size_t)n * m), cost((size_t)n * m);
+    std::vector<int> row_cnt(n, 0), col_cnt(m, 0);
+    for (int t = 0; t < m; ++t) {
+      const OcTrack& tr = trackers[t];
+      const Box5 po = k_previous(tr);
+      const double valid = po.v[4] >= 0 ? 1.0 : 0.0;
+      const double cx2 = (po.v[0] + po.v[2]) / 2.0, cy2 = (po.v[1] + po.v[3]) / 2.0;
+      const double vy = tr.has_vel ? tr.vel[0] : 0.0, vx = tr.has_vel ? tr.vel[1] : 0.0;
+      for (int d = 0; d < n; ++d) {
+        const double* b = dets[d].b.v;
+        const double cx1 = (b[0] + b[2]) / 2.0, cy1 = (b[1] + b[3]) / 2.0;
+        double dx = cx1 - cx2, dy = cy1 - cy2;
+        const double nrm = std::sqrt(dx * dx + dy * dy) + 1e-6;
+        dx /= nrm; dy /= nrm;
+        const double c = std::min(1.0, std::max(-1.0, vx * dx + vy * dy));
+        const double ang = (M_PI / 2.0 - std::fabs(std::acos(c))) / M_PI;
+        const double io = iou_of(b, trks[t].data());
+        iou[(size_t)d * m + t] = io;
+        cost[(size_t)d * m + t] = -(io + valid * ang * inertia * b[4]);
+        if (io > iou_thr) { ++row_cnt[d]; ++col_cnt[t]; }
+      }
+    }
+    std::vector<int> x(n, -1);
+    const int rmax = *std::max_element(row_cnt.begin(), row_cnt.end()), cmax = *std::max_element(col_cnt.begin(), col_cnt.end());
+    if (rmax == 1 && cmax == 1) {              // every candidate pair is unambiguous: no assignment problem to solve
+      for (int d = 0; d < n; ++d)
+        for (int t = 0; t < m; ++t)
+          if (iou[(size_t)d * m + t] > iou_thr) x[d] = t;
+    } else {
+      lap_full(cost, n, m, x);
+    }
+    std::vector<char> t_used(m, 0);
+    std::vector<int> back_d, back_t;
+    for (int d = 0; d < n; ++d) {
+      if (x[d] < 0) { u_d.push_back(d); continue; }
+      t_used[x[d]] = 1;
+    }
+    for (int t = 0; t < m; ++t)
+      if (!t_used[t]) u_t.push_back(t);
+    for (int d = 0; d < n; ++d) {
+      if (x[d] < 0) continue;
+      if (iou[(size_t)d * m + x[d]] < iou_thr) { u_d.push_back(d); u_t.push_back(x[d]); }
+      else matches.emplace_back(d, x[d]);
+    }
+  }
+};
+
+OcSortTracker::OcSortTracker(const gtx_tracker_config& cfg) : impl_(new Impl) {
+  Impl& S = *impl_;
+  S.cfg = cfg;
+  S.det_thresh = cfg.track_high_thresh;
+  S.low = cfg.track_low_thresh;
+  S.new_thr = cfg.new_track_thresh;
+  S.iou_thr = 1.0 - (double)cfg.match_thresh;
+  S.inertia = cfg.inertia;
+  S.max_age = cfg.track_buffer;
+  S.delta_t = std::max(cfg.delta_t, 1);
+  S.min_hits = cfg.min_hits > 0 ? cfg.min_hits : 3;
+  S.use_byte = cfg.use_byte != 0;
+}
+OcSortTracker::~OcSortTracker() = default;
+
+void OcSortTracker::reset() {
+  impl_->trackers.clear();
+  impl_->frame_count = 0;
+  impl_->next_id = 0;
+}
+
+void OcSortTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* /*gmc: OC-SORT has none*/, int cap,
+                           int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
+  Impl& S = *impl_;
+  ++S.frame_count;
+  std::vector<Det> dets, second;
+  for (int i = 0; i < n; ++i) {
+    const double c = (double)conf[i];
+    Det d{{{(double)xyxy[4 * i], (double)xyxy[4 * i + 1], (double)xyxy[4 * i + 2], (double)xyxy[4 * i + 3], c}}, cls[i], i};
+    if (c > S.det_thresh) dets.push_back(d);
+    else if (c > S.low && c < S.det_thresh) second.push_back(d);
+  }
+  // predictions; a track whose predicted box is not a number is dropped
+  std::vector<std::array<double, 4>> trks;
+  {
+    std::vector<OcTrack> keep;
+    keep.reserve(S.trackers.size());
+    for (OcTrack& t : S.trackers) {
+      std::array<double, 4> b;
+      S.track_predict(t, b.data());
+      if (std::isnan(b[0]) || std::isnan(b[1]) || std::isnan(b[2]) || std::isnan(b[3])) continue;
+      trks.push_back(b);
+      keep.push_back(std::move(t));
+    }
+    S.trackers.swap(keep);
+  }
+  std::vector<Box5> last_boxes;
+  last_boxes.reserve(S.trackers.size());
+  for (const OcTrack& t : S.trackers) last_boxes.push_back(t.last_obs);
+
+  std::vector<std::pair<int, int>> matches;
+  std::vector<int> u_d, u_t;
+  S.associate(dets, trks, matches, u_d, u_t);
+  for (auto& m : matches) S.track_update(S.trackers[m.second], &dets[m.first]);
+
+  auto second_round = [&](const std::vector<Det>& cand, const std::vector<int>& cand_idx, bool against_last, std::vector<int>& used_c) {
+    // IoU of the candidates with the leftover tracks (predicted boxes, or last observations for OCR), assignment on -IoU
+    const int a = (int)cand_idx.size(), b = (int)u_t.size();
+    std::vector<double> io((size_t)a * b), neg((size_t)a * b);
+    double mx = 0.0;
+    for (int i = 0; i < a; ++i)
+      for (int j = 0; j < b; ++j) {
+        const double* tb = against_last ? last_boxes[u_t[j]].v : trks[u_t[j]].data();
+        const double v = iou_of(cand[cand_idx[i]].b.v, tb);
+        io[(size_t)i * b + j] = v;
+        neg[(size_t)i * b + j] = -v;
+        mx = (i == 0 && j == 0) ? v : std::max(mx, v);
+      }
+    if (!(mx > S.iou_thr)) return;
+    std::vector<int> x;
+    lap_full(neg, a, b, x);
+    std::vector<int> done_t;
+    for (int i = 0; i < a; ++i) {
+      if (x[i] < 0 || io[(size_t)i * b + x[i]] < S.iou_thr) continue;
+      S.track_update(S.trackers[u_t[x[i]]], &cand[cand_idx[i]]);
+      done_t.push_back(u_t[x[i]]);
+      used_c.push_back(cand_idx[i]);
+    }
+    std::vector<int> rest;
+    for (int t : u_t)
+      if (std::find(done_t.begin(), done_t.end(), t) == done_t.end()) rest.push_back(t);
+    u_t.swap(rest);
+  };
+  if (S.use_byte && !second.empty() && !u_t.empty()) {
+    std::vector<int> all(second.size()), used;
+    for (size_t i = 0; i < second.size(); ++i) all[i] = (int)i;
+    second_round(second, all, false, used);
+  }
+  if (!u_d.empty() && !u_t.empty()) {
+    std::vector<int> used;
+    second_round(dets, u_d, true, used);
+    std::vector<int> rest;
+    for (int d : u_d)
+      if (std::find(used.begin(), used.end(), d) == used.end()) rest.push_back(d);
+    u_d.swap(rest);
+  }
+  for (int t : u_t) S.track_update(S.trackers[t], nullptr);
+  std::sort(u_d.begin(), u_d.end());
+  for (int d : u_d) {
+    if (dets[d].b.v[4] < S.new_thr) continue;
+    OcTrack t;
+    double z[4];
+    to_z(dets[d].b.v, z);
+    std::memcpy(t.kf.x, z, sizeof z);
+    t.id = ++S.next_id;
+    t.score = (float)dets[d].b.v[4]; t.cls = dets[d].cls; t.idx = dets[d].idx;
+    S.trackers.push_back(std::move(t));
+  }
+  // output, newest track first; tracks not updated for more than max_age frames leave
+  int k = 0;
+  std::vector<char> drop(S.trackers.size(), 0);
+  for (int i = (int)S.trackers.size() - 1; i >= 0; --i) {
+    const OcTrack& t = S.trackers[i];
+    if (t.tsu < 1 && (t.streak >= S.min_hits || S.frame_count <= S.min_hits) && k < cap) {
+      double b[4];
+      if (!t.seen()) to_box(t.kf.x, b);
+      else std::memcpy(b, t.last_obs.v, sizeof b);
+      for (int j = 0; j < 4; ++j) out_xyxy[4 * k + j] = (float)b[j];
+      out_id[k] = t.id; out_score[k] = t.score; out_cls[k] = t.cls; out_det_idx[k] = t.idx;
+      ++k;
+    }
+    if (t.tsu > S.max_age) drop[i] = 1;
+  }
+  *n_out = k;
+  std::vector<OcTrack> keep;
+  keep.reserve(S.trackers.size());
+  for (size_t i = 0; i < S.trackers.size(); ++i)
+    if (!drop[i]) keep.push_back(std::move(S.trackers[i]));
+  S.trackers.swap(keep);
+}
+
+}  // namespace gtx

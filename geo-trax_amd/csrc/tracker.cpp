@@ -306,6 +306,24 @@ inline void xyxy_of(const Track& t, bool xywh_state, float out[4]) {
 
 }  // namespace
 
+// Dense problem through the sparse solver: every pair is feasible and shifted by a constant large enough that one more
+// matched pair always beats any choice among fewer pairs (|cost| <= 2 here), so the optimum is the minimum-cost matching
+// of min(rows, cols) pairs.
+void lap_full(const std::vector<double>& cost, int rows, int cols, std::vector<int>& x) {
+  x.assign(rows, -1);
+  if (rows == 0 || cols == 0) return;
+  const double limit = 1.0e4;
+  SparseCost P;
+  P.rows = rows; P.cols = cols;
+  P.start.assign(rows + 1, 0);
+  for (int r = 0; r < rows; ++r) {
+    for (int c = 0; c < cols; ++c) { P.adj.push_back(c); P.w.push_back(cost[(size_t)r * cols + c] - limit); }
+    P.start[r + 1] = (int)P.adj.size();
+  }
+  std::vector<int> y;
+  linear_assignment_sparse(P, x, y);
+}
+
 struct ByteTracker::Impl {
   gtx_tracker_config cfg;
   Kalman kf;

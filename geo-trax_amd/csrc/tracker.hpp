@@ -1,6 +1,7 @@
 // Host-side multi-object tracker (ByteTrack / BoT-SORT association), C++.
 #pragma once
 #include <memory>
+#include <vector>
 
 #include "../../include/gtx.h"
 #include "common.hpp"
@@ -18,8 +19,26 @@ class ByteTracker {
   struct Impl;
   std::unique_ptr<Impl> impl_;
 };
+// OC-SORT (tracker.ocsort of the reference's config, default.yaml:391-404): ocsort.cpp. Same update() contract.
+class OcSortTracker {
+ public:
+  explicit OcSortTracker(const gtx_tracker_config& cfg);
+  ~OcSortTracker();
+  void reset();
+  void update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
+              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+
+// Minimum-cost assignment of a dense rows x cols matrix that matches min(rows, cols) pairs (what
+// scipy.optimize.linear_sum_assignment / lap.lapjv(extend_cost=True) return). x[r] = column of row r or -1.
+void lap_full(const std::vector<double>& cost, int rows, int cols, std::vector<int>& x);
 }  // namespace gtx
 
 struct gtx_tracker {
   std::unique_ptr<gtx::ByteTracker> impl;
+  std::unique_ptr<gtx::OcSortTracker> oc;
 };

@@ -41,6 +41,7 @@ class TrackerConfig(C.Structure):
         ("type", C.c_int), ("track_high_thresh", C.c_float), ("track_low_thresh", C.c_float),
         ("new_track_thresh", C.c_float), ("track_buffer", C.c_int), ("match_thresh", C.c_float),
         ("fuse_score", C.c_int), ("frame_rate", C.c_int),
+        ("delta_t", C.c_int), ("inertia", C.c_float), ("use_byte", C.c_int), ("min_hits", C.c_int),
     ]
 
 

@@ -169,7 +169,8 @@ class YOLO:
             self._gmc_method = None
         self._gmc = None
         return Tracker(ttype, **{k: v for k, v in params.items() if k in (
-            "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score")})
+            "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score",
+            "delta_t", "inertia", "use_byte")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:

@@ -2,7 +2,8 @@
 
 Reference behaviour replaced: the tracker callback ultralytics registers for
 ``model.track(..., persist=True)`` (geotrax/extract.py:153) with the active block of
-cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time.
+cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time. `tracker_type: ocsort` (default.yaml:391-404) selects the OC-SORT
+implementation (csrc/ocsort.cpp); deepocsort / fasttrack / tracktrack are not implemented and raise.
 """
 from __future__ import annotations
 
@@ -13,20 +14,22 @@ import numpy as np
 from . import _lib
 from ._lib import TrackerConfig, check, ptr
 
-TRACKER_TYPES = {"bytetrack": 0, "botsort": 1}
+TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2}
 
 
 class Tracker:
     def __init__(self, tracker_type: str = "bytetrack", track_high_thresh: float = 0.25, track_low_thresh: float = 0.1,
                  new_track_thresh: float = 0.25, track_buffer: int = 30, match_thresh: float = 0.8,
-                 fuse_score: bool = True, frame_rate: int = 30, max_tracks: int = 4096, **_ignored):
+                 fuse_score: bool = True, frame_rate: int = 30, max_tracks: int = 4096, delta_t: int = 3, inertia: float = 0.2,
+                 use_byte: bool = False, min_hits: int = 3, **_ignored):
         if tracker_type not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         self.lib = _lib.load()
         cfg = TrackerConfig(type=TRACKER_TYPES[tracker_type], track_high_thresh=track_high_thresh,
                             track_low_thresh=track_low_thresh, new_track_thresh=new_track_thresh,
                             track_buffer=track_buffer, match_thresh=match_thresh, fuse_score=int(fuse_score),
-                            frame_rate=frame_rate)
+                            frame_rate=frame_rate, delta_t=int(delta_t), inertia=float(inertia), use_byte=int(bool(use_byte)),
+                            min_hits=int(min_hits))
         h = C.c_void_p()
         check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))
         self.handle = h

@@ -217,7 +217,7 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
  * (BYTETracker / BOTSORT.update; cfg tracker.* default.yaml:361-389). */
 
 typedef struct gtx_tracker_config {
-  int type;                /* 0 = bytetrack, 1 = botsort */
+  int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404) */
   float track_high_thresh;
   float track_low_thresh;
   float new_track_thresh;
@@ -225,6 +225,11 @@ typedef struct gtx_tracker_config {
   float match_thresh;
   int fuse_score;
   int frame_rate;          /* ultralytics passes 30 */
+  /* OC-SORT only (type 2): tracker.ocsort.{delta_t, inertia, use_byte}; min_hits is OC-SORT's own default (3) */
+  int delta_t;
+  float inertia;
+  int use_byte;
+  int min_hits;
 } gtx_tracker_config;
 
 int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);
