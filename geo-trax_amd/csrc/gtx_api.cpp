@@ -635,6 +635,13 @@ int gtx_warp_frame_dev(gtx_ctx* ctx, const void* src_dptr, int h, int w, const d
   });
 }
 
+int gtx_op_clahe(gtx_ctx* ctx, const uint8_t* gray, int h, int w, uint8_t* out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(gray, "gray"); need(out, "out");
+    gtx::clahe_image(ctx, gray, h, w, out);
+  });
+}
+
 int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double H[9], uint8_t* dst_bgr) {
   return guarded([&] {
     need(ctx, "ctx"); need(src_bgr, "src"); need(H, "H"); need(dst_bgr, "dst");

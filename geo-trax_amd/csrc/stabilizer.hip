@@ -368,6 +368,7 @@ struct KeyPoint {
 __device__ __forceinline__ unsigned long long flip_key(long k) { return (unsigned long long)k ^ 0x8000000000000000ull; }
 
 constexpr int kSortCap = 8192;   // eligible candidates the in-LDS sort handles (more: radix-select path)
+constexpr int kTopCap = 2048;    // keypoints per level the radix-select path keeps (level 0 takes ~22 % of max_features)
 
 // Stage 2 of the selection: the n_want best Harris keys of the eligible set, ordered by
 // (key desc, pix asc). Usual case (n <= 8192): one bitonic sort of {key, pix} pairs in LDS.
@@ -426,15 +427,15 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restric
   __shared__ int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_need, s_nsel;
-  __shared__ unsigned long long s_key[1024];   // selected set (n_want <= 1024 per level)
-  __shared__ int s_pix[1024];
+  __shared__ unsigned long long s_key[kTopCap];   // selected set (n_want <= kTopCap per level)
+  __shared__ int s_pix[kTopCap];
   const int li = blockIdx.x;
   const Level lv = L.l[li];
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = min(cand_n[li], lv.cand_cap);
   if (n <= kSortCap) return;                      // select_sort_kernel did this level
   const Cand* c = cand + lv.cand_off;
-  const int want = min(min(lv.n_want, n), 1024);
+  const int want = min(min(lv.n_want, n), kTopCap);
   if (want == 0) {
     if (tid == 0) kp_n[li] = 0;
     return;
@@ -965,7 +966,7 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_pyr_tab, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
+  DevBuf d_frame, d_pyr, d_pyr_tab, d_clahe_lut, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
@@ -1027,7 +1028,7 @@ void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
     L.tab_off[i] = t;
     if (i > 0) t += L.l[i].w + L.l[i].h;
   }
-  GTX_CHECK(max_features * 0.25 < 1024, "stabilizer: at most ~4000 features per image are supported");
+  GTX_CHECK(max_features * 0.25 < kTopCap, "stabilizer: at most ~8000 features per image are supported");
   pyr_bytes = off;
   cand_total = coff;
   slots = koff;
@@ -1056,6 +1057,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   GTX_CHECK(l0.w > 2 * kBorder + 8 && l0.h > 2 * kBorder + 8, "stabilizer: %dx%d working image is too small", l0.w, l0.h);
   const int slots = std::max(S.slots_ref, S.slots_cur);
   S.d_pyr.alloc(S.pyr_bytes);
+  S.d_clahe_lut.alloc(kClaheLutBytes);
   S.d_rects.alloc(sizeof(int4) * kMaxRects);
   S.d_mask.alloc((size_t)S.gw * S.gh);
   GTX_HIP(hipMemset(S.d_mask.p, 255, (size_t)S.gw * S.gh));
@@ -1151,6 +1153,10 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
   Levels L = Lplan;   // level 0 is read in place from the caller's gray image when there is one
   for (int i = 0; i < L.n; ++i) L.l[i].img = pyr + L.l[i].off;
   if (gray_dev) L.l[0].img = gray_dev;
+  if (cfg.clahe) {        // equalised level 0 goes into the pyramid buffer (the caller's gray image is shared with others)
+    clahe_dev(L.l[0].img, gh, gw, d_clahe_lut.as<uint8_t>(), pyr, s);
+    L.l[0].img = pyr;
+  }
   for (int i = 1; i < L.n; ++i) {
     const unsigned* tx = d_pyr_tab.as<unsigned>() + L.tab_off[i];
     hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 1024), L.l[i].h), dim3(256), 0, s, L.l[i - 1].img, L.l[i - 1].w,
@@ -1476,6 +1482,20 @@ void Stabilizer::pattern(int8_t* out) const { std::memcpy(out, impl_->pattern.da
 
 // Blocking robust homography from matched point pairs already in HBM (registration path): the same
 // hypothesis / MSAC-score / argmin kernels as the per-frame stabilizer, then the host IRLS refit.
+// cv2.createCLAHE(2.0, (8, 8)).apply(gray) for a host image (the stabilizer's own pre-processing step, exposed for tests / tools).
+void clahe_image(gtx_ctx* ctx, const uint8_t* gray, int h, int w, uint8_t* out) {
+  GTX_HIP(hipSetDevice(ctx->device));
+  GTX_CHECK(h >= 8 && w >= 8, "clahe: image %dx%d is smaller than the tile grid", w, h);
+  const size_t bytes = (size_t)h * w;
+  DevBuf d_src(bytes), d_dst(bytes), d_lut(kClaheLutBytes);
+  hipStream_t s = ctx->stream;
+  GTX_HIP(hipMemcpyAsync(d_src.p, gray, bytes, hipMemcpyHostToDevice, s));
+  clahe_dev(d_src.as<uint8_t>(), h, w, d_lut.as<uint8_t>(), d_dst.as<uint8_t>(), s);
+  GTX_HIP(hipGetLastError());
+  GTX_HIP(hipMemcpyAsync(out, d_dst.p, bytes, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipStreamSynchronize(s));
+}
+
 bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_match, unsigned seed, int n_hyp, int frame_w, int frame_h,
                        float threshold, double H[9], int* n_inliers) {
   *n_inliers = 0;

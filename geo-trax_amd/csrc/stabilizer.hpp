@@ -37,6 +37,12 @@ class Stabilizer {
 // The steered-BRIEF sampling table [256 bins][256 tests][ax, ay, bx, by] (host only, no device needed).
 void stabilizer_pattern_table(std::vector<int8_t>& out);
 
+// clahe.hip: cv2.createCLAHE(2.0, (8, 8)).apply on a u8 image in HBM (src == dst allowed); luts: kClaheLutBytes of scratch.
+constexpr int kClaheLutBytes = 8 * 8 * 256;
+void clahe_dev(const uint8_t* src, int h, int w, uint8_t* luts, uint8_t* dst, hipStream_t s);
+// cv2.createCLAHE(2.0, (8, 8)).apply(gray), host image in / out (what `clahe: true` runs on the working gray image).
+void clahe_image(gtx_ctx* ctx, const uint8_t* gray, int h, int w, uint8_t* out);
+
 // Robust homography (MSAC hypotheses on the GPU + IRLS refit on the host, f64) from n_match point pairs
 // (x, y) -> (z, w) in HBM; threshold in pixels of the destination. false: no model.
 bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_match, unsigned seed, int n_hyp, int frame_w, int frame_h,

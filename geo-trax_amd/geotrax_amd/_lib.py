@@ -64,7 +64,7 @@ class StabConfig(C.Structure):
         ("filter_ratio", C.c_float), ("ransac_threshold", C.c_float), ("ransac_max_iter", C.c_int),
         ("ransac_confidence", C.c_float), ("mask_use", C.c_int), ("mask_margin_ratio", C.c_float),
         ("fast_threshold", C.c_int), ("n_levels", C.c_int), ("scale_factor", C.c_float),
-        ("seed", C.c_uint32), ("frame_h", C.c_int), ("frame_w", C.c_int),
+        ("seed", C.c_uint32), ("frame_h", C.c_int), ("frame_w", C.c_int), ("clahe", C.c_int),
     ]
 
 
@@ -124,6 +124,7 @@ _SIGNATURES = {
     "gtx_tracker_reset": (C.c_int, [_P]),
     "gtx_tracker_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "gtx_stabilizer_create": (C.c_int, [_P, C.POINTER(StabConfig), C.POINTER(_P)]),
+    "gtx_op_clahe": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gtx_stabilizer_destroy": (None, [_P]),
     "gtx_stabilizer_set_ref_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "gtx_stabilizer_set_ref_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),

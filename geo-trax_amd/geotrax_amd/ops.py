@@ -107,3 +107,12 @@ def match_2nn(query: np.ndarray, train: np.ndarray, iters: int = 0, ctx: _lib.Co
     check(ctx.lib.gtx_op_match_2nn(ctx.handle, ptr(q), nq, ptr(t if nt else np.zeros((1, 128), np.float32)), nt, ptr(i1), ptr(i2),
                                    ptr(d1), ptr(d2), iters, C.byref(ms)))
     return (i1, i2, d1, d2, ms.value) if iters > 0 else (i1, i2, d1, d2)
+
+
+def clahe(gray: np.ndarray, ctx=None) -> np.ndarray:
+    """cv2.createCLAHE(clipLimit=2.0, tileGridSize=(8, 8)).apply(gray) on the GPU (the stabilizer's `clahe: true` step)."""
+    ctx = ctx or _lib.default_context()
+    g = np.ascontiguousarray(gray, dtype=np.uint8)
+    out = np.empty_like(g)
+    check(ctx.lib.gtx_op_clahe(ctx.handle, ptr(g), g.shape[0], g.shape[1], ptr(out)))
+    return out

@@ -34,13 +34,11 @@ class Stabilizer:
             raise NotImplementedError("only matcher_name='bf' with filter_type='ratio' is implemented")
         if transformation_type != "projective":
             raise NotImplementedError("only transformation_type='projective' is implemented")
-        if clahe:
-            raise NotImplementedError("clahe=True is not implemented")
         self.ctx = ctx or _lib.default_context()
         self._kw = dict(downsample_ratio=downsample_ratio, max_features=max_features, ref_multiplier=ref_multiplier,
                         filter_ratio=filter_ratio, ransac_threshold=ransac_epipolar_threshold, ransac_max_iter=ransac_max_iter,
                         ransac_confidence=ransac_confidence, mask_use=int(mask_use), mask_margin_ratio=mask_margin_ratio,
-                        fast_threshold=fast_threshold, n_levels=n_levels, scale_factor=scale_factor, seed=seed)
+                        fast_threshold=fast_threshold, n_levels=n_levels, scale_factor=scale_factor, seed=seed, clahe=int(bool(clahe)))
         self.min_good, self.min_inl = min_good_match_count_warning, min_inliers_match_count_warning
         self.handle = None
         self.frame_hw = None

@@ -264,9 +264,13 @@ typedef struct gtx_stab_config {
   float scale_factor;          /* ORB pyramid scale (1.2) */
   uint32_t seed;               /* RANSAC sampling seed */
   int frame_h, frame_w;
+  int clahe;                   /* stabilo clahe (default.yaml:105): cv2.createCLAHE(2.0, (8, 8)) on the working gray image */
 } gtx_stab_config;
 
 int gtx_stabilizer_create(gtx_ctx* ctx, const gtx_stab_config* cfg, gtx_stabilizer** out);
+/* The stabilizer's optional pre-processing step on its own: cv2.createCLAHE(clipLimit=2.0, tileGridSize=(8, 8)).apply(gray)
+ * (stabilo `clahe: true`, reference default.yaml:105). gray, out: u8 [h,w] on the host. */
+int gtx_op_clahe(gtx_ctx* ctx, const uint8_t* gray, int h, int w, uint8_t* out);
 void gtx_stabilizer_destroy(gtx_stabilizer* st);
 /* Stabilizer.set_ref_frame(frame, boxes): boxes xywh [n,4] in frame pixels or NULL. */
 int gtx_stabilizer_set_ref_frame(gtx_stabilizer* st, const uint8_t* frame_bgr, int h, int w,

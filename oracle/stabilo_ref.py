@@ -401,12 +401,19 @@ class StabilizerRef:
         self.half = cfg["downsample_ratio"] == 0.5
         self.ref = self.cur = None
 
+    def _gray(self, frame_bgr):
+        g = bgr2gray(frame_bgr, self.half)
+        if self.cfg.get("clahe"):                       # stabilo: CLAHE on the working-resolution gray, before detection
+            from .clahe_ref import clahe
+            g = clahe(g)
+        return g
+
     def set_ref_frame(self, frame_bgr, boxes=None):
         n_ref = int(np.floor(self.cfg["max_features"] * self.cfg["ref_multiplier"] + 0.5))
-        self.ref = extract(bgr2gray(frame_bgr, self.half), boxes, self.cfg, n_ref, self.pattern)
+        self.ref = extract(self._gray(frame_bgr), boxes, self.cfg, n_ref, self.pattern)
 
     def stabilize(self, frame_bgr, boxes=None):
-        self.cur = extract(bgr2gray(frame_bgr, self.half), boxes, self.cfg, self.cfg["max_features"], self.pattern)
+        self.cur = extract(self._gray(frame_bgr), boxes, self.cfg, self.cfg["max_features"], self.pattern)
         self.m = match(self.cur["desc"], self.ref["desc"], self.cfg["filter_ratio"])
         qi, ti, _ = self.m
         return ransac_homography(self.cur["xy"][qi], self.ref["xy"][ti], (self.hw[1], self.hw[0]),

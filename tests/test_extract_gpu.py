@@ -197,6 +197,31 @@ def test_extract_cli_writes_reference_files(gtx_ctx, tmp_path):
     assert meta["tracker"]["active"] == "botsort" and meta["detection"]["imgsz"] == IMGSZ
 
 
+def test_extract_cli_with_the_stable_preset(gtx_ctx, tmp_path):
+    """`--cfg stable` (reference geotrax/cfg/stable.yaml: CLAHE, full-resolution stabilization, 4000 / 8000 features,
+    ratio 0.8) runs end to end: the preset name resolves, the stabilizer takes the CLAHE path, transforms come out."""
+    import os
+
+    import yaml
+    from geotrax_amd import extract as ex
+    from geotrax_amd.synth import make_scene
+
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, make_scene(seed=4, h=H, w=W).render(0), half=False)
+    src = f"synthetic://?seed=4&frames=4&h={H}&w={W}"
+    out = tmp_path / "out"
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        ex.main([src, "--cfg", "stable", "--model", str(wpath), "--output-folder", str(out)])
+    finally:
+        os.chdir(cwd)
+    tr = np.loadtxt(out / "synthetic_vid_transf.txt", delimiter=",", ndmin=2)
+    assert tr.shape == (3, 10) and np.all(np.abs(tr[:, 9] - 1) < 1e-12)
+    assert np.abs(tr[:, [3, 6]]).max() < 8                      # a few pixels of camera drift over 3 frames, not garbage
+    meta = yaml.safe_load((tmp_path / "synthetic.yaml").read_text())
+    assert meta["stabilo"]["clahe"] is True and meta["stabilo"]["downsample_ratio"] == 1.0 and meta["stabilo"]["max_features"] == 4000
+
+
 def test_error_in_loop_voids_the_video(gtx_ctx, tmp_path, caplog):
     """extract.py:198-200: one exception -> logged once, empty tables, no partial output."""
     from geotrax_amd import extract as ex

@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_iso -- python3 
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.log
 python bench.py --tracker botsort --no-cpu-baseline --no-f16-line > $O/bench_botsort.json 2>/dev/null
+python bench.py --tracker ocsort --no-cpu-baseline --no-f16-line > $O/bench_ocsort.json 2>/dev/null
 python bench.py --fp32 exact --no-cpu-baseline --no-f16-line --steps 60 > $O/bench_fp32_exact.json 2>/dev/null
 python bench.py --half 1 --no-cpu-baseline > $O/bench_f16.json 2>/dev/null
 python bench.py --workload detect --batch 1 --det-streams 1 --no-cpu-baseline --no-f16-line > $O/bench_detect_b1.json 2>/dev/null
