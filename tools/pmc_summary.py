@@ -18,6 +18,7 @@ import csv
 import glob
 import json
 import re
+import os
 import shutil
 from pathlib import Path
 
@@ -53,7 +54,7 @@ def one(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
         raise SystemExit(f"nothing matches {pattern}")
-    return sorted(files)[-1]
+    return max(files, key=os.path.getmtime)     # gpurun merges new files into the directory: older collections may still be there
 
 
 def counters(d, wanted):
