@@ -236,7 +236,7 @@ typedef float floatx16_t __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict__ img, int h, int w,
                                                         const _Float16* __restrict__ wpk /*[groups][3][64][8]*/,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
-                                                        int ho, int wo, int c0, int groups, int tiles_per_row, long n_tiles) {
+                                                        int ho, int wo, int c0, int groups, int tiles_per_row, int n_tiles) {
   constexpr int kStemPitch = 64 + 16;                   // bytes per staged pixel (+16: conflict-free 8-B writes)
   __shared__ __attribute__((aligned(16))) char s_stage[4 * 32 * kStemPitch];
   __shared__ _Float16 s_lut[256];                       // byte -> fp16(byte / 255)
@@ -244,15 +244,37 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
-  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   const int n = blockIdx.y;
   const uchar4* base = img + (size_t)n * h * w;
   for (int g = 0; g < groups; ++g) {
     half8 wf[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) wf[s] = *reinterpret_cast<const half8*>(wpk + (((size_t)g * 3 + s) * 64 + lane) * 8);
-    for (long t = wave; t < n_tiles; t += nwaves) {
-      const int oy = (int)(t / tiles_per_row), ox = (int)(t % tiles_per_row) * 32 + r;
+    // as in stem_split_kernel: the next tile's pixels are gathered before the current tile is worked on
+    auto gather = [&](int t, unsigned (&raw)[6]) {
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) raw[kk] = 0u;
+      if (t >= n_tiles) return;
+      const int oy = t / tiles_per_row, tx = t - oy * tiles_per_row, ox = tx * 32 + r;
+      const bool interior = oy > 0 && tx > 0 && oy * 2 + 1 < h && tx * 64 + 64 < w && tx * 32 + 32 <= wo;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tap = 2 * (2 * s + hh) + q;
+          if (tap < 9) {
+            const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+            if (interior || (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo))
+              raw[2 * s + q] = reinterpret_cast<const unsigned*>(base)[(unsigned)(iy * w + ix)];
+          }
+        }
+    };
+    unsigned raw[6], nxt[6];
+    gather(wave, raw);
+    for (int t = wave; t < n_tiles; t += nwaves) {
+      const int oy = t / tiles_per_row, ox = (t - oy * tiles_per_row) * 32 + r;
+      gather(t + nwaves, nxt);
       floatx16_t acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -263,14 +285,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
         for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int tap = 2 * (2 * s + hh) + q;
-          if (tap < 9) {
-            const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
-            if (iy >= 0 && iy < h && ix >= 0 && ix < w && ox < wo) {
-              const uchar4 px = base[(size_t)iy * w + ix];
-              xf[4 * q] = s_lut[px.x]; xf[4 * q + 1] = s_lut[px.y]; xf[4 * q + 2] = s_lut[px.z];
-            }
-          }
+          const unsigned px = raw[2 * s + q];
+          xf[4 * q] = s_lut[px & 255u]; xf[4 * q + 1] = s_lut[(px >> 8) & 255u]; xf[4 * q + 2] = s_lut[(px >> 16) & 255u];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], xf, acc, 0, 0, 0);
       }
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
           for (int i = 0; i < 4; ++i) v[i] = (_Float16)silu_f(acc[4 * g4 + i] + bias[cl + i]);
           *reinterpret_cast<half4*>(stg + r * kStemPitch + cl * 2) = v;
         }
-        const int ox0 = (int)(t % tiles_per_row) * 32;
+        const int ox0 = (t - oy * tiles_per_row) * 32;
         _Float16* orow = out + (((size_t)n * ho + oy) * wo + ox0) * 32;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -307,6 +323,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
           }
         }
       }
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) raw[kk] = nxt[kk];
     }
   }
 }
@@ -441,8 +459,8 @@ void launch_stem(int dtype, const void* img, int n, int h, int w, const float* w
   }
   if (dtype == DT_F16 && wpk_f16) {
     const int tiles_per_row = cdiv(wo, 32);
-    const long n_tiles = (long)tiles_per_row * ho;
-    const int blocks = (int)std::min<long>((n_tiles + 3) / 4, 4096);
+    const int n_tiles = tiles_per_row * ho;
+    const int blocks = std::min((n_tiles + 15) / 16, 4096);
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(blocks, n), dim3(256), 0, s, (const uchar4*)img, h, w, (const _Float16*)wpk_f16,
                        bias, (_Float16*)out, ho, wo, c0, cdiv(c0, 32), tiles_per_row, n_tiles);
     GTX_HIP(hipGetLastError());
