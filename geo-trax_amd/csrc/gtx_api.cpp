@@ -76,30 +76,7 @@ int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out) {
       GTX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       GTX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, greatest));
     } else {
-      // EXPERIMENT: GTX_CUMASK_SEQ = per-context-creation-index CU masks: "lo", "hi", "-" separated by commas
-      static int created = 0;
-      const int idx = created++;
-      const char* seq = getenv("GTX_CUMASK_SEQ");
-      std::string tok = "-";
-      if (seq) {
-        std::string sq(seq);
-        size_t pos = 0;
-        for (int k = 0; k <= idx; ++k) {
-          const size_t e = sq.find(',', pos);
-          tok = sq.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
-          if (e == std::string::npos) { if (k < idx) tok = "-"; break; }
-          pos = e + 1;
-        }
-      }
-      if (tok == "lo" || tok == "hi" || tok == "even" || tok == "odd") {
-        uint32_t m[8];
-        for (int w = 0; w < 8; ++w)
-          m[w] = tok == "lo" ? (w < 4 ? 0xffffffffu : 0u) : tok == "hi" ? (w < 4 ? 0u : 0xffffffffu) : tok == "even" ? 0x55555555u : 0xaaaaaaaau;
-        GTX_HIP(hipExtStreamCreateWithCUMask(&c->stream, 8, m));
-        fprintf(stderr, "ctx %d: CU mask %s\n", idx, tok.c_str());
-      } else {
-        GTX_HIP(hipStreamCreate(&c->stream));
-      }
+      GTX_HIP(hipStreamCreate(&c->stream));
     }
     *out = c.release();
   });
