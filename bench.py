@@ -625,14 +625,15 @@ def main():
             replay_rows[0] = replay_tracker(item)
 
     def replay_tracker(all_records):
-        n_last = 0
-        for rec in all_records:
-            xyxy, conf, cls, Hm = unpack_frame_record(rec, max_det)
-            bx, ids = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if shard_gmc else None)[:2]   # every frame, empty or not
-            if len(ids) and Hm is not None:
-                warp_boxes(Hm, xywh_of(bx))
-            n_last = len(ids)
-        return n_last
+        # one C call for the whole gathered run (gtx_tracker_replay: tracker.update on every frame, empty or not, with the
+        # rank's camera-motion warp for BoT-SORT), then the box warp of every frame's tracks by that frame's homography
+        per, bx, ids = tracker.replay(all_records, max_det, with_gmc=shard_gmc)[:3]
+        o = 0
+        for f, k in enumerate(per):
+            if k and all_records[f, -10] > 0:
+                warp_boxes(all_records[f, -9:].reshape(3, 3), xywh_of(bx[o:o + k]))
+            o += k
+        return int(per[-1]) if len(per) else 0
 
     n_tracks = 0
     live = [False]                                               # gathers only inside the timed region

@@ -538,6 +538,40 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
   });
 }
 
+int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int stride, int max_det, int with_gmc, int row_cap,
+                       int* rows_per_frame, float* row_xyxy, int* row_id, float* row_score, int* row_cls, int* row_det_idx) {
+  return guarded([&] {
+    need(trk, "trk"); need(rows_per_frame, "rows_per_frame");
+    if (n_recs > 0) need(recs, "recs");
+    const int tail = (with_gmc ? 7 : 0) + 10;
+    if (max_det < 0 || stride != 1 + 6 * max_det + tail) gtx::fail(GTX_ERR_INVALID, "replay: stride %d does not match max_det %d", stride, max_det);
+    std::vector<float> xyxy((size_t)4 * std::max(max_det, 1)), conf(std::max(max_det, 1));
+    std::vector<int> cls(std::max(max_det, 1));
+    int used = 0;
+    for (int f = 0; f < n_recs; ++f) {
+      const double* rec = recs + (size_t)f * stride;
+      const int n = std::min(std::max((int)rec[0], 0), max_det);
+      for (int i = 0; i < n; ++i) {
+        const double* d = rec + 1 + 6 * i;
+        xyxy[4 * i] = (float)d[0]; xyxy[4 * i + 1] = (float)d[1]; xyxy[4 * i + 2] = (float)d[2]; xyxy[4 * i + 3] = (float)d[3];
+        conf[i] = (float)d[4];
+        cls[i] = (int)d[5];
+      }
+      const double* gmc = (with_gmc && rec[stride - 17] > 0) ? rec + stride - 16 : nullptr;
+      int k = 0;
+      const int room = row_cap - used;
+      float* ox = row_xyxy ? row_xyxy + (size_t)4 * used : nullptr;
+      if (room <= 0 && n > 0) gtx::fail(GTX_ERR_INVALID, "replay: more than %d track rows", row_cap);
+      if (trk->oc)
+        trk->oc->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
+      else
+        trk->impl->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
+      rows_per_frame[f] = k;
+      used += k;
+    }
+  });
+}
+
 /* ------------------------------------------------------------------ stabilizer */
 
 int gtx_stabilizer_create(gtx_ctx* ctx, const gtx_stab_config* cfg, gtx_stabilizer** out) {

@@ -253,28 +253,14 @@ struct OcSortTracker::Impl {
     matches.clear(); u_d.clear(); u_t.clear();
     if (m == 0) { for (int d = 0; d < n; ++d) u_d.push_back(d); return; }
     if (n == 0) { for (int t = 0; t < m; ++t) u_t.push_back(t); return; }
-    std::vector<double> iou((size_t)n * m), cost((size_t)n * m);
+    std::vector<double> iou((size_t)n * m);
     std::vector<int> row_cnt(n, 0), col_cnt(m, 0);
-    for (int t = 0; t < m; ++t) {
-      const OcTrack& tr = trackers[t];
-      const Box5 po = k_previous(tr);
-      const double valid = po.v[4] >= 0 ? 1.0 : 0.0;
-      const double cx2 = (po.v[0] + po.v[2]) / 2.0, cy2 = (po.v[1] + po.v[3]) / 2.0;
-      const double vy = tr.has_vel ? tr.vel[0] : 0.0, vx = tr.has_vel ? tr.vel[1] : 0.0;
+    for (int t = 0; t < m; ++t)
       for (int d = 0; d < n; ++d) {
-        const double* b = dets[d].b.v;
-        const double cx1 = (b[0] + b[2]) / 2.0, cy1 = (b[1] + b[3]) / 2.0;
-        double dx = cx1 - cx2, dy = cy1 - cy2;
-        const double nrm = std::sqrt(dx * dx + dy * dy) + 1e-6;
-        dx /= nrm; dy /= nrm;
-        const double c = std::min(1.0, std::max(-1.0, vx * dx + vy * dy));
-        const double ang = (M_PI / 2.0 - std::fabs(std::acos(c))) / M_PI;
-        const double io = iou_of(b, trks[t].data());
+        const double io = iou_of(dets[d].b.v, trks[t].data());
         iou[(size_t)d * m + t] = io;
-        cost[(size_t)d * m + t] = -(io + valid * ang * inertia * b[4]);
         if (io > iou_thr) { ++row_cnt[d]; ++col_cnt[t]; }
       }
-    }
     std::vector<int> x(n, -1);
     const int rmax = *std::max_element(row_cnt.begin(), row_cnt.end()), cmax = *std::max_element(col_cnt.begin(), col_cnt.end());
     if (rmax == 1 && cmax == 1) {              // every candidate pair is unambiguous: no assignment problem to solve
@@ -282,6 +268,25 @@ struct OcSortTracker::Impl {
         for (int t = 0; t < m; ++t)
           if (iou[(size_t)d * m + t] > iou_thr) x[d] = t;
     } else {
+      // the velocity-direction term of every (detection, track) pair: only needed when there is an assignment to solve
+      std::vector<double> cost((size_t)n * m);
+      for (int t = 0; t < m; ++t) {
+        const OcTrack& tr = trackers[t];
+        const Box5 po = k_previous(tr);
+        const double valid = po.v[4] >= 0 ? 1.0 : 0.0;
+        const double cx2 = (po.v[0] + po.v[2]) / 2.0, cy2 = (po.v[1] + po.v[3]) / 2.0;
+        const double vy = tr.has_vel ? tr.vel[0] : 0.0, vx = tr.has_vel ? tr.vel[1] : 0.0;
+        for (int d = 0; d < n; ++d) {
+          const double* b = dets[d].b.v;
+          const double cx1 = (b[0] + b[2]) / 2.0, cy1 = (b[1] + b[3]) / 2.0;
+          double dx = cx1 - cx2, dy = cy1 - cy2;
+          const double nrm = std::sqrt(dx * dx + dy * dy) + 1e-6;
+          dx /= nrm; dy /= nrm;
+          const double c = std::min(1.0, std::max(-1.0, vx * dx + vy * dy));
+          const double ang = (M_PI / 2.0 - std::fabs(std::acos(c))) / M_PI;
+          cost[(size_t)d * m + t] = -(iou[(size_t)d * m + t] + valid * ang * inertia * b[4]);
+        }
+      }
       lap_full(cost, n, m, x);
     }
     std::vector<char> t_used(m, 0);

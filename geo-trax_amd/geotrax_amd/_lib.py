@@ -123,6 +123,7 @@ _SIGNATURES = {
     "gtx_tracker_destroy": (None, [_P]),
     "gtx_tracker_reset": (C.c_int, [_P]),
     "gtx_tracker_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
+    "gtx_tracker_replay": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gtx_stabilizer_create": (C.c_int, [_P, C.POINTER(StabConfig), C.POINTER(_P)]),
     "gtx_op_clahe": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gtx_stabilizer_destroy": (None, [_P]),

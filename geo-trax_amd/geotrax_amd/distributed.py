@@ -113,12 +113,19 @@ def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_
 
     frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms = [], [], [], [], [], [], []
     last_H = None
+    # the tracker sees every frame in clip order in one C call (gtx_tracker_replay); the bookkeeping below is per frame
+    order = [blocks[r][k] for r in range(world) for k in range(shard_range(n_frames, r, world, first)[1] - shard_range(n_frames, r, world, first)[0])]
+    per, t_xyxy, t_ids, t_score, t_cls, _ = tracker.replay(np.stack(order), max_det, with_gmc=with_gmc) if order else (np.zeros(0, np.int32),) + (np.zeros((0, 4), np.float32),) * 5
+    starts = np.concatenate([[0], np.cumsum(per)]) if len(per) else np.zeros(1, np.int64)
+    i = 0
     for r in range(world):
         s, e = shard_range(n_frames, r, world, first)
         for k, f in enumerate(range(s, e)):
             rec = blocks[r][k]
             xyxy, conf, cls, H = unpack_frame_record(rec, max_det)
-            bx, ids, sc, cl, _ = tracker.update(xyxy, conf, cls, gmc=unpack_frame_gmc(rec) if with_gmc else None)   # every frame, empty or not
+            a, b = int(starts[i]), int(starts[i + 1])
+            i += 1
+            bx, ids, sc, cl = t_xyxy[a:b], t_ids[a:b], t_score[a:b], t_cls[a:b]
             if f != first:
                 if H is None:
                     H = last_H                                   # stabilo's last known transform (see engine._stabilized)

@@ -69,3 +69,21 @@ class Tracker:
         k = self._n.value
         return (self._xyxy[:k].copy(), self._id[:k].copy(), self._score[:k].copy(), self._cls[:k].copy(),
                 self._idx[:k].copy())
+
+    def replay(self, recs: np.ndarray, max_det: int, with_gmc: bool = False):
+        """Feeds per-frame records (distributed.pack_frame_record layout, [n_frames, stride] float64, clip order) through
+        the tracker in one call (gtx_tracker_replay): the sequential half of a frame-sharded run without a Python round
+        trip per frame. -> (rows_per_frame [n_frames], xyxy [k,4], id [k], score [k], cls [k], det_idx [k]), the rows of
+        all frames back to back."""
+        recs = np.ascontiguousarray(recs, dtype=np.float64)
+        if recs.ndim != 2:
+            raise ValueError("records must be [n_frames, stride]")
+        n, stride = recs.shape
+        cap = max(n * max(min(max_det, 4096), 1), 1)
+        per = np.zeros(max(n, 1), np.int32)
+        xyxy, tid = np.zeros((cap, 4), np.float32), np.zeros(cap, np.int32)
+        score, cls, idx = np.zeros(cap, np.float32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        check(self.lib.gtx_tracker_replay(self.handle, recs.ctypes.data, n, stride, int(max_det), int(bool(with_gmc)), cap, per.ctypes.data,
+                                          xyxy.ctypes.data, tid.ctypes.data, score.ctypes.data, cls.ctypes.data, idx.ctypes.data))
+        k = int(per[:n].sum())
+        return per[:n], xyxy[:k], tid[:k], score[:k], cls[:k], idx[:k]

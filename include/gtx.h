@@ -245,6 +245,15 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
                        float* out_xyxy, int* out_id, float* out_score, int* out_cls,
                        int* out_det_idx);
 
+/* The sequential half of a frame-sharded run (rank 0): n_recs per-frame records in clip order, each `stride`
+ * doubles laid out as geotrax_amd/distributed.py::pack_frame_record writes them -- n, max_det x (x1, y1, x2, y2, conf, cls),
+ * [with_gmc: valid, 2x3 camera-motion warp,] valid, h11..h33 -- go through gtx_tracker_update one after the other
+ * (tracker.update on every frame, empty or not; the record's warp for BoT-SORT). rows_per_frame[f] = tracks of frame f;
+ * the row_* arrays (row_cap rows) receive them back to back, as gtx_tracker_update would have returned them. */
+int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int stride, int max_det, int with_gmc,
+                       int row_cap, int* rows_per_frame, float* row_xyxy, int* row_id, float* row_score,
+                       int* row_cls, int* row_det_idx);
+
 /* ------------------------------------------------------------------ stabilizer
  * Stands in for stabilo.Stabilizer as used at extract.py:139,177-187 and
  * geotrax/utils/registration.py:59-85. */

@@ -98,3 +98,34 @@ def test_config_selects_ocsort(tmp_path):
     for name in ("deepocsort", "fasttrack", "tracktrack"):
         with pytest.raises(NotImplementedError):
             m._make_tracker({"tracker_type": name})
+
+
+@pytest.mark.parametrize("kind", ["bytetrack", "botsort", "ocsort"])
+def test_batch_replay_equals_frame_by_frame_updates(kind):
+    """gtx_tracker_replay (rank 0's sequential half of a frame-sharded run, one C call per gathered run) returns exactly
+    what the per-frame gtx_tracker_update calls return on the same packed records, camera-motion warps included."""
+    from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
+    from geotrax_amd.tracker import Tracker
+
+    max_det, rng = 200, np.random.default_rng(4)
+    recs = []
+    for xyxy, conf, cls in _stream(2, n_obj=60, n_frames=50, p_miss=0.1):
+        g = np.array([[1 + 1e-4 * rng.normal(), 0, 0.3 * rng.normal()], [0, 1, 0.2 * rng.normal()]]) if rng.random() < 0.9 else None
+        recs.append(pack_frame_record(max_det, xyxy, conf, cls, None, gmc=g, with_gmc=True))
+    recs = np.stack(recs)
+    a, b = Tracker(kind), Tracker(kind)
+    per, xy, tid, sc, cl, idx = a.replay(recs, max_det, with_gmc=True)
+    o = 0
+    for f, rec in enumerate(recs):
+        x, c, k, _ = unpack_frame_record(rec, max_det)
+        bx, ids, s2, c2, i2 = b.update(x, c, k, gmc=unpack_frame_gmc(rec))
+        assert per[f] == len(ids)
+        np.testing.assert_array_equal(tid[o:o + per[f]], ids)
+        np.testing.assert_array_equal(xy[o:o + per[f]], bx)
+        np.testing.assert_array_equal(sc[o:o + per[f]], s2)
+        np.testing.assert_array_equal(cl[o:o + per[f]], c2)
+        np.testing.assert_array_equal(idx[o:o + per[f]], i2)
+        o += per[f]
+    assert o == len(tid) > 500
+    with pytest.raises(Exception):
+        a.replay(recs[:, :-1], max_det, with_gmc=True)          # a stride that does not match max_det is refused
