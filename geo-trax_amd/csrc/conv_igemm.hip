@@ -221,7 +221,7 @@ void conv_igemm_kernel(const ConvGroup g) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);
+        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);   // bias arrays are padded to whole cout tiles
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j)
@@ -300,6 +300,7 @@ void conv_igemm_kernel(const ConvGroup g) {
   // each wave transposes its 32 pixels x BN channels through LDS and stores 16 B per lane, whole
   // lines per pixel. The values are the same bits either way (rounded to fp16 before staging).
   const int oy = oy0 + trow, ox = ox0 + tcol;
+  const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
   const bool wide = sizeof(T) == 2 && (P.out_cstride % 8) == 0 && (P.out_coff % 8) == 0;
   if (wide) {
     constexpr int PITCH = BN * 2 + 16;          // bytes per staged pixel row; +16 keeps ds_write_b64 conflict free
@@ -320,7 +321,7 @@ void conv_igemm_kernel(const ConvGroup g) {
           v[i] = acc[j][4 * g4 + i];
           if (P.act) v[i] = silu(v[i]);
         }
-        if (res) {
+        if (res && cl < cvalid) {
           float rv[4];
           load4<T>(res + cl, rv);
 #pragma unroll
@@ -337,7 +338,7 @@ void conv_igemm_kernel(const ConvGroup g) {
       const int p = it * PPI + lane / LPP, q = lane % LPP;
       const int py = oy0 + 2 * wave + (p >> 4), px = ox0 + (p & 15);
       const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
-      if (py < P.Ho && px < P.Wo) {
+      if (py < P.Ho && px < P.Wo && q * 8 < cvalid) {
         T* dst = static_cast<T*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 8;
         *reinterpret_cast<uint4*>(dst) = val;
       }
@@ -358,6 +359,7 @@ void conv_igemm_kernel(const ConvGroup g) {
           v[i] = acc[j][4 * g4 + i];
           if (P.act) v[i] = silu(v[i]);
         }
+        if (cl >= cvalid) continue;               // channels past Cout (4 per lane: Cout is a multiple of 16)
         if (res) {
           float rv[4];
           load4<T>(res + cl, rv);
@@ -381,7 +383,7 @@ int env_int(const char* name, int dflt) {
 }
 }  // namespace
 
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc) {
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc, int force_bn) {
   ConvConfig c{};
   c.dtype = dtype;
   c.ks = ks;
@@ -394,9 +396,10 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     c.kc = ks == 1 ? (cin % 32 == 0 ? 32 : 16) : 16;
     if (force_kc > 0) c.kc = force_kc;
     c.bn = (cout % 64 == 0) ? 64 : 32;
+    if (force_bn > 0) c.bn = force_bn;
     c.th = 8; c.tw = 16;
     GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
-    GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
+    GTX_CHECK(cout % 16 == 0, "conv: Cout=%d is not a multiple of 16", cout);   // a last cout tile may be half empty (yolov8 n / m / x widths)
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -405,12 +408,14 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
   // 3x3 fp16: 16-channel chunks for the shallow layers (half the LDS -> twice the resident workgroups,
   // which matters when a tile has only 2-8 chunks to pipeline), 32-channel chunks for Cin > 128
   if (ks == 3 && dtype == DT_F16) cpr = env_int("GTX_CONV_CPR3", cin <= 128 ? 2 : 4);
+  if (dtype == DT_F16 && cin % (cpr * epc) != 0) cpr = 2;    // widths that are multiples of 16 only (yolov8 n / m / x: 48, 80, 144, 400 ...)
   if (force_kc > 0) cpr = force_kc / epc;    // members of a grouped launch must share one instantiation
   c.kc = cpr * epc;
   c.bn = (cout % 64 == 0) ? 64 : 32;
+  if (force_bn > 0) c.bn = force_bn;
   c.th = 8; c.tw = 16;
   GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
-  GTX_CHECK(cout % c.bn == 0, "conv: Cout=%d is not a multiple of %d", cout, c.bn);
+  GTX_CHECK(cout % 16 == 0, "conv: Cout=%d is not a multiple of 16", cout);
   return c;
 }
 
@@ -437,8 +442,8 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
   const int rb = cpr * 16;
   const int rows_per_bankrow = 256 / rb;
   const int taps = cfg.ks * cfg.ks;
-  const int n_ct = cout / cfg.bn, nchunks = cin / cfg.kc;
-  std::vector<uint8_t> out((size_t)cout * taps * cin * es);
+  const int n_ct = (cout + cfg.bn - 1) / cfg.bn, nchunks = cin / cfg.kc;   // rows past Cout in the last tile are zero weights
+  std::vector<uint8_t> out((size_t)n_ct * cfg.bn * taps * cin * es);
   for (int ct = 0; ct < n_ct; ++ct)
     for (int ch = 0; ch < nchunks; ++ch)
       for (int tap = 0; tap < taps; ++tap)
@@ -448,7 +453,7 @@ std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const 
             const size_t dst16 = ((((size_t)ct * nchunks + ch) * taps + tap) * cfg.bn + n) * cpr + cs;
             for (int e = 0; e < epc; ++e) {
               const int ci = ch * cfg.kc + c * epc + e;
-              const float v = w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci];
+              const float v = ct * cfg.bn + n < cout ? w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] : 0.f;
               if (cfg.dtype == DT_F16) {
                 const uint16_t hb = f32_to_f16_bits(v);
                 memcpy(&out[dst16 * 16 + e * 2], &hb, 2);
@@ -464,7 +469,7 @@ void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
   int total = 0;
   for (int i = 0; i < g.count; ++i) {
     ConvProblem& p = g.p[i];
-    p.n_ct = p.Cout / cfg.bn;
+    p.n_ct = (p.Cout + cfg.bn - 1) / cfg.bn;
     p.block_begin = total;
     p.tiles_x = cdiv(p.Wo, cfg.tw);
     p.tiles_y = cdiv(p.Ho, cfg.th);
@@ -501,6 +506,7 @@ void launch_dt(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
   GTX_CASE(3, 2, 1, 4) GTX_CASE(3, 2, 2, 4)
   GTX_CASE(1, 1, 1, 4) GTX_CASE(1, 1, 2, 4)
   GTX_CASE(1, 1, 1, 8) GTX_CASE(1, 1, 2, 8)
+  GTX_CASE(1, 1, 1, 2) GTX_CASE(1, 1, 2, 2)
 #undef GTX_CASE
   fail(-3, "conv: no kernel for ks=%d stride=%d bn=%d kc=%d", c.ks, c.stride, c.bn, c.kc);
 }

@@ -209,7 +209,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);
+        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);   // bias arrays are padded to whole cout tiles
     }
     const float inv_sc = __builtin_amdgcn_rcpf(P.acc_scale);     // exact: acc_scale is a power of two
 #pragma unroll
@@ -314,6 +314,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
   // BN channels through LDS so that a store instruction writes contiguous runs of BN*4 bytes per pixel.
   const float sc = P.acc_scale;
+  const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
   const bool wide = (P.out_cstride % 4) == 0 && (P.out_coff % 4) == 0;
   if (wide) __syncthreads();                    // every wave is done with the staging buffers
 #pragma unroll
@@ -338,7 +339,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
             v[i] = acc[m][j][4 * g4 + i] * sc;
             if (P.act) v[i] = silu_f(v[i]);
           }
-          if (res) {
+          if (res && cl < cvalid) {
             const float4 rv = *reinterpret_cast<const float4*>(res + cl);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
           }
@@ -352,7 +353,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
         const int p = it * PPI + lane / LPP, q = lane % LPP;
         const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
         const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
-        if (py < P.Ho && px < P.Wo) {
+        if (py < P.Ho && px < P.Wo && q * 4 < cvalid) {
           float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
           *reinterpret_cast<uint4*>(dst) = val;
         }
@@ -367,6 +368,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int cl = 32 * j + 8 * g4 + 4 * h;
+          if (cl >= cvalid) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float v = acc[m][j][4 * g4 + i] * sc;
@@ -397,7 +399,7 @@ void launch_t(const ConvGroup& g, hipStream_t stream) {
 // [cout tile][cin chunk][tap][n][swizzled 16-B chunk: hi chunks, then lo chunks], fp16; *acc_scale = 2^-shift
 std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   const int cpr = cfg.kc / 8, nch = 2 * cpr, rb = nch * 16, rpb = 256 / rb, taps = cfg.ks * cfg.ks;
-  const int n_ct = cout / cfg.bn, nchunks = cin / cfg.kc;
+  const int n_ct = (cout + cfg.bn - 1) / cfg.bn, nchunks = cin / cfg.kc;     // rows past Cout in the last tile are zero weights
   float wmax = 0.f;
   const size_t nw = (size_t)cout * taps * cin;
   for (size_t i = 0; i < nw; ++i) wmax = std::max(wmax, std::fabs(w[i]));
@@ -410,7 +412,7 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
   }
   const float up = std::ldexp(1.f, shift);
   *acc_scale = std::ldexp(1.f, -shift);
-  std::vector<uint8_t> out((size_t)cout * taps * cin * 4);
+  std::vector<uint8_t> out((size_t)n_ct * cfg.bn * taps * cin * 4);
   for (int ct = 0; ct < n_ct; ++ct)
     for (int ch = 0; ch < nchunks; ++ch)
       for (int tap = 0; tap < taps; ++tap)
@@ -420,7 +422,7 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
           for (int c = 0; c < cpr; ++c)
             for (int e = 0; e < 8; ++e) {
               const int ci = ch * cfg.kc + c * 8 + e;
-              const float v = w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] * up;   // exact (power of two)
+              const float v = ct * cfg.bn + n < cout ? w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] * up : 0.f;   // exact (power of two)
               const _Float16 hi = (_Float16)v;
               const _Float16 lo = (_Float16)(v - (float)hi);
               memcpy(&out[(row16 + (size_t)(c ^ sw)) * 16 + e * 2], &hi, 2);

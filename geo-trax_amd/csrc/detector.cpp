@@ -100,7 +100,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_);
+  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, force_bn_);
   const std::vector<float> ohwi = to_ohwi(w);
   float acc_scale = 1.f;
   const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &acc_scale);
@@ -110,7 +110,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   if (has(name + ".bias")) {
     const HostTensor& b = tensor(name + ".bias");
     GTX_CHECK((int)b.data.size() == cout, "%s: bias size", name.c_str());
-    db = (float*)alloc(cout * sizeof(float));
+    db = (float*)alloc(((cout + 63) / 64 * 64) * sizeof(float));      // zero-filled up to a whole cout tile: the kernels load a tile's bias unconditionally
     GTX_HIP(hipMemcpy(db, b.data.data(), cout * sizeof(float), hipMemcpyHostToDevice));
   }
   ConvProblem& p = op.grp.p[0];
@@ -294,13 +294,21 @@ void Detector::build_graph() {
     bs.data.insert(bs.data.end(), b30.begin(), b30.end());
     tensors_["__head" + std::to_string(l) + ".s1.bias"] = bs;
     const size_t mark = ops_.size();
-    force_kc_ = conv_dtype_ == DT_F16 ? 32 : 0;   // the three levels run as grouped launches: one K chunk for all
+    // The three levels run as grouped launches: one K chunk and one cout tile for all members of a stage. Widths that
+    // are multiples of 16 only (yolov8 n / m / x) take the 16-channel chunk; a stage with a member whose Cout is not a
+    // multiple of 64 takes the 32-cout tile.
+    bool k32 = true;
+    for (int q = 0; q < 3; ++q) k32 = k32 && lvl_in[q].c % 32 == 0;
+    force_kc_ = conv_dtype_ == DT_F16 ? (k32 ? 32 : 16) : 0;
+    force_bn_ = (cb + cc) % 64 == 0 ? 64 : 32;
     View h1 = conv("__head" + std::to_string(l) + ".s1", lvl_in[l], 1, true, nullptr, nullptr);
     View h2 = new_view(h1.h, h1.w, cb + cc);
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
+    force_kc_ = conv_dtype_ == DT_F16 ? ((cb % 32 == 0 && cc % 32 == 0) ? 32 : 16) : 0;
+    force_bn_ = (cb % 64 == 0 && cc % 64 == 0) ? 64 : 32;
     conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
     conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
-    force_kc_ = 0;
+    force_kc_ = force_bn_ = 0;
     // move the three freshly built single-problem ops into the two grouped stage ops
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];

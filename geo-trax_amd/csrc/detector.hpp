@@ -114,6 +114,7 @@ class Detector {
   std::map<std::string, View> layer_views_;
   bool finalized_ = false;
   int force_kc_ = 0;         // K chunk forced on the convs being built (grouped head stages)
+  int force_bn_ = 0;         // cout tile forced on them
   int cur_nb_ = 0;
 
   View img_;                 // [N][net_h][net_w][4]

@@ -161,12 +161,14 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   if (w) {
     packed = pack_conv_weights(w, d->cout, d->cin, st.cfg, &acc_scale);
   } else {
-    packed.assign((size_t)d->cout * d->cin * d->ksize * d->ksize * es, 0);
+    packed.assign((size_t)((d->cout + 63) / 64 * 64) * d->cin * d->ksize * d->ksize * es, 0);
   }
   st.w.alloc(packed.size());
   GTX_HIP(hipMemcpy(st.w.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
   if (bias) {
-    st.b.alloc(d->cout * sizeof(float));
+    const size_t padded = (size_t)(d->cout + 63) / 64 * 64 * sizeof(float);      // whole cout tiles: the kernels load a tile's bias unconditionally
+    st.b.alloc(padded);
+    GTX_HIP(hipMemset(st.b.p, 0, padded));
     GTX_HIP(hipMemcpy(st.b.p, bias, d->cout * sizeof(float), hipMemcpyHostToDevice));
   }
   if (d->has_residual) {

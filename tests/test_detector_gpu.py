@@ -144,3 +144,37 @@ def test_detector_batch_equals_single(gtx_ctx, weights):
         np.testing.assert_array_equal(s.xyxy, b.xyxy)
         np.testing.assert_array_equal(s.conf, b.conf)
         np.testing.assert_array_equal(s.cls, b.cls)
+
+
+@pytest.mark.parametrize("scale,gain", [("n", 1.7), ("m", 1.0), ("l", 1.0), ("x", 1.0)])
+@pytest.mark.parametrize("half,split", [(False, True), (True, False), (False, False)])
+def test_other_yolov8_scales_match_oracle(gtx_ctx, scale, gain, half, split):
+    """"Any Ultralytics-compatible model works" (reference README): the graph is read off the tensor shapes, so the other
+    YOLOv8 scales load too -- n / m / x have widths that are multiples of 16 only (16, 48, 80, 144, 400: a half-empty last
+    cout tile, 16-channel K chunks, grouped head stages on a common tile). Same per-layer bars as the s model.
+    (l / x with a smaller weight gain: the seeded random stack's activations grow with depth and at gain 1.7 pass 1e6,
+    beyond what the split path's fp16 halves can carry -- real networks stay far below that.)"""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import synthetic_yolov8
+    from oracle.yolov8_ref import YoloV8Ref, letterbox
+
+    w = synthetic_yolov8(seed=1, nc=4, scale=scale, cls_bias=-3.0, gain=gain)
+    frame = _frame(0)
+    det = Detector(w, FRAME_HW, imgsz=384, half=half, rect=False, fp32_split=split, conf=0.25, iou=0.7, max_det=300,
+                   classes=[0, 1, 2, 3], agnostic_nms=True, ctx=gtx_ctx)
+    det.detect(frame)
+    ref = YoloV8Ref(w, emulate_half=half)
+    x, _ = letterbox(frame, 384, False, half=half)
+    ref_raw = ref.forward(x)[0].numpy()
+    rel = 2e-4 if not half else 3e-2
+    for name in LAYERS:
+        a = det.layer_output(name)
+        r = ref.acts[name][0].permute(1, 2, 0).numpy()
+        assert a.shape == r.shape, name
+        assert np.isfinite(r).all(), f"{name}: the oracle itself overflows at this gain"
+        err = np.abs(a - r).max() / (np.abs(r).max() + 1e-6)
+        assert err < rel, f"{scale} {name}: rel-to-max error {err:.3e}"
+    raw = det.raw_output()
+    assert raw.shape == ref_raw.shape
+    np.testing.assert_allclose(raw[:, 4:], ref_raw[:, 4:], atol=2e-4 if not half else 3e-2)
+    det.close()

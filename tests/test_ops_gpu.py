@@ -29,6 +29,12 @@ CONV_CASES = [
     (512, 256, 1, 1, 9, 20),    # model.9.cv1
     (768, 256, 1, 1, 8, 16),    # model.12.cv1
     (128, 192, 3, 1, 20, 36),   # fused Detect stage 1 at P3 (3 cout tiles)
+    # widths that are multiples of 16 only (yolov8 n / m / x): a half-empty last cout tile, 16-channel K chunks
+    (16, 16, 3, 1, 20, 36),     # yolov8n model.2.m.0.cv1
+    (48, 48, 3, 1, 17, 33),     # yolov8m bottleneck
+    (144, 96, 1, 1, 12, 20),    # yolov8m model.2.cv2: Cin = 3 * 48
+    (80, 160, 3, 2, 21, 31),    # yolov8x model.1
+    (400, 80, 1, 1, 9, 13),     # Cin = 400: multiple of 16 only; Cout = 80: 2.5 tiles of 32
 ]
 
 
