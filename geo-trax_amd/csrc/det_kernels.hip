@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams h
       }
     }
   }
-  if (valid && sub == 0 && best > hp.conf && ((hp.class_mask >> best_c) & 1ull)) {
+  if (valid && sub == 0 && best > hp.conf && ((hp.class_mask[best_c >> 6] >> (best_c & 63)) & 1ull)) {
     const int idx = atomicAdd(&nb.count[n], 1);
     if (idx < nb.cap) {
       const size_t o = (size_t)n * nb.cap + idx;

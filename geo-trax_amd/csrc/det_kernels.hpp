@@ -58,7 +58,7 @@ struct HeadParams {
   int n_anchors;        // per image
   int nc;
   float conf;           // score threshold (strict >)
-  unsigned long long class_mask;  // bit c set = class c kept (ultralytics `classes`)
+  unsigned long long class_mask[2];  // bit c set = class c kept (ultralytics `classes`); 128 classes
 };
 
 struct NmsBuffers {

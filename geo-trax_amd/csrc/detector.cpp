@@ -10,7 +10,7 @@ namespace gtx {
 
 Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cfg) {
   GTX_CHECK(cfg.imgsz > 0 && cfg.imgsz % 32 == 0, "imgsz must be a positive multiple of 32 (got %d)", cfg.imgsz);
-  GTX_CHECK(cfg.max_det > 0 && cfg.nc > 0 && cfg.nc <= 64, "bad max_det / nc");
+  GTX_CHECK(cfg.max_det > 0 && cfg.nc > 0 && cfg.nc <= 128, "max_det must be positive and nc in [1, 128] (got %d, %d)", cfg.max_det, cfg.nc);
   GTX_CHECK(cfg.frame_h > 0 && cfg.frame_w > 0, "frame size must be given");
   if (cfg_.max_batch < 1) cfg_.max_batch = 1;
   dtype_ = cfg.half ? DT_F16 : DT_F32;
@@ -271,10 +271,9 @@ void Detector::build_graph() {
   head_.n_levels = 3;
   head_.nc = cfg_.nc;
   head_.conf = cfg_.conf;
-  head_.class_mask = 0ull;
-  if (cfg_.n_classes == 0) head_.class_mask = ~0ull;
+  head_.class_mask[0] = head_.class_mask[1] = cfg_.n_classes == 0 ? ~0ull : 0ull;
   for (int i = 0; i < cfg_.n_classes; ++i)
-    if (cfg_.classes[i] >= 0 && cfg_.classes[i] < 64) head_.class_mask |= 1ull << cfg_.classes[i];
+    if (cfg_.classes[i] >= 0 && cfg_.classes[i] < 128) head_.class_mask[cfg_.classes[i] >> 6] |= 1ull << (cfg_.classes[i] & 63);
   int anchor = 0;
   for (int l = 0; l < 3; ++l) {
     const std::string b2 = "model.22.cv2." + std::to_string(l), b3 = "model.22.cv3." + std::to_string(l);

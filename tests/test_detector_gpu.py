@@ -178,3 +178,29 @@ def test_other_yolov8_scales_match_oracle(gtx_ctx, scale, gain, half, split):
     assert raw.shape == ref_raw.shape
     np.testing.assert_allclose(raw[:, 4:], ref_raw[:, 4:], atol=2e-4 if not half else 3e-2)
     det.close()
+
+
+@pytest.mark.parametrize("nc,classes", [(80, [0, 2, 5, 7, 70]), (80, None), (1, None)])
+def test_class_counts_other_than_four(gtx_ctx, nc, classes):
+    """COCO-style heads (80 classes, a class filter that reaches past bit 63) and single-class heads, class-wise NMS:
+    same detections as the oracle (score order up to fp32 near-ties)."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import synthetic_yolov8
+    from oracle.yolov8_ref import YoloV8Ref, detect
+
+    w = synthetic_yolov8(seed=1, nc=nc, scale="s", cls_bias=-3.0)
+    frame = _frame(0)
+    det = Detector(w, FRAME_HW, imgsz=384, half=False, rect=False, fp32_split=True, conf=0.25, iou=0.7, max_det=300, classes=classes,
+                   agnostic_nms=False, ctx=gtx_ctx)
+    got = det.detect(frame)
+    xyxy, conf, cls = detect(YoloV8Ref(w), frame, 384, False, 0.25, 0.7, classes, False, 300)
+    assert len(got) == len(conf) > 20
+    if classes is not None:
+        assert set(got.cls.tolist()) <= set(classes) and 70 in got.cls
+    np.testing.assert_allclose(got.conf, conf, atol=1e-5)
+    swapped = got.cls != cls                                       # two boxes whose scores differ by < 1e-6 may trade places
+    assert swapped.sum() <= 4 and np.all(np.abs(got.conf[swapped] - conf[swapped]) < 1e-5)
+    np.testing.assert_allclose(got.xyxy[~swapped], xyxy[~swapped], atol=1e-2)
+    det.close()
+    with pytest.raises(Exception):
+        Detector(synthetic_yolov8(seed=1, nc=200, scale="s"), FRAME_HW, imgsz=384, ctx=gtx_ctx)      # more than 128 classes: refused, not truncated
