@@ -246,10 +246,10 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #define GTXS_MATRIX_PHASE()                                                                    \
     GTXS_LOAD_FRAGS(0, 0)                                                                      \
     _Pragma("unroll") for (int st = 0; st < NSTEP; ++st) {                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
       if (st + 1 < NSTEP) {                                                                    \
         if (st & 1) GTXS_LOAD_FRAGS(st + 1, 0) else GTXS_LOAD_FRAGS(st + 1, 1)                 \
       }                                                                                        \
-      __builtin_amdgcn_sched_barrier(0);                                                       \
       _Pragma("unroll") for (int m = 0; m < WM; ++m)                                           \
         _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                       \
           /* small terms first, then the leading one */                                       \
@@ -257,6 +257,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1][m], acc[m][j], 0, 0, 0); \
           acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0); \
         }                                                                                      \
+      /* one fragment read of the next step behind every MFMA of this one */                   \
+      _Pragma("unroll") for (int i__ = 0; i__ < 3 * WM * WN; ++i__) {                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
+      }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
   GTXS_PREFETCH(0)
