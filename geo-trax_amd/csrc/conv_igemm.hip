@@ -258,12 +258,20 @@ void conv_igemm_kernel(const ConvGroup g) {
       GTX_LOAD_FRAGS(0, 0)
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < NSTEP) {
           if (st & 1) GTX_LOAD_FRAGS(st + 1, 0) else GTX_LOAD_FRAGS(st + 1, 1)
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep the reads of step st+1 ahead of the MFMAs of step st
 #pragma unroll
         for (int j = 0; j < WN; ++j) Mma<T>::run(acc[j], aq[st & 1][j], bq[st & 1]);
+        // the reads of step st+1 go out one at a time between the MFMAs of step st (as in conv_igemm_split.hip) instead of
+        // as a burst in front of them
+        constexpr int NM = WN * (sizeof(T) == 2 ? 1 : 4), NR = 1 + WN;
+#pragma unroll
+        for (int i = 0; i < (NM > NR ? NM : NR); ++i) {
+          if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i < NM) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef GTX_LOAD_FRAGS
