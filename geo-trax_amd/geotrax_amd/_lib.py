@@ -70,6 +70,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
+ABI_VERSION = 2        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -161,6 +162,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.gtx_abi_version() != ABI_VERSION:       # the config structs below are laid out for exactly this version of include/gtx.h
+        raise GtxError(-101, f"{LIB_PATH} reports ABI version {lib.gtx_abi_version()}, these bindings are written for {ABI_VERSION}; rebuild it")
     _lib = lib
     return lib
 

@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define GTX_ABI_VERSION 1
+/* 2: gtx_det_config.fp32_split, gtx_tracker_config.{delta_t, inertia, use_byte, min_hits}, gtx_stab_config.clahe appended;
+ *    gtx_tracker_replay, gtx_op_clahe, gtx_warp_frame_dev, gtx_yuv420_to_bgr_dev, gtx_stabilizer_{pattern, last_ms} added.
+ *    A binder checks gtx_abi_version() against the header it was written for before passing any struct. */
+#define GTX_ABI_VERSION 2
 
 typedef enum gtx_status {
   GTX_OK = 0,
