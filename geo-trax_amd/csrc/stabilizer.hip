@@ -170,24 +170,14 @@ struct Cand {
   int score;  // FAST score (1..255)
 };
 
-// Foreground mask at level-0 resolution: 255 = usable, 0 = inside a (grown) vehicle box. One
-// block per (rectangle, slice of its rows); lanes run along x.
-__global__ __launch_bounds__(256) void mask_boxes_kernel(uint8_t* __restrict__ mask, int w, const int4* __restrict__ rects, int value) {
-  const int4 r = rects[blockIdx.x];
-  const int rw = r.z - r.x + 1, rh = r.w - r.y + 1;
-  const int rows_per = (rh + gridDim.y - 1) / gridDim.y;
-  const int y0 = r.y + blockIdx.y * rows_per, y1 = min(y0 + rows_per, r.w + 1);
-  for (int y = y0 + (threadIdx.x >> 6); y < y1; y += 4)
-    for (int x = threadIdx.x & 63; x < rw; x += 64) mask[(size_t)y * w + r.x + x] = (uint8_t)value;
-}
-
 // FAST score + 3x3 non-maximum suppression + foreground test in one pass: a block scores its
 // 64x16 tile plus a 1-pixel ring into LDS (the score image never exists in memory), keeps the
 // pixels whose score is strictly greater than all 8 neighbours and whose level-0 position is not
-// masked, appends them to the level's candidate list (order is irrelevant: the selection is by
+// inside a (grown) vehicle box, appends them to the level's candidate list (order is irrelevant: the selection is by
 // value) and counts them in the level's 256-bin FAST-score histogram.
 constexpr int kTileW = 64, kTileH = 16;
-__global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restrict__ mask, int w0, int h0, const Levels L, int thr,
+constexpr int kTileRects = 256;     // rectangles one tile's footprint can meet (a level-7 tile covers ~230 x 57 level-0 pixels)
+__global__ __launch_bounds__(256) void fast_detect_kernel(const int4* __restrict__ rects, int n_rects, int w0, int h0, const Levels L, int thr,
                                                           Cand* __restrict__ cand, int* __restrict__ cand_n, int* __restrict__ score_hist) {
   __shared__ uint8_t s_sc[(kTileH + 2) * (kTileW + 2)];
   __shared__ uint8_t s_px[(kTileH + 8) * (kTileW + 8)];   // tile + 4: 1 (NMS ring) + 3 (circle radius)
@@ -207,13 +197,27 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
   // phase A: the 5-load compass test on every pixel; the survivors (a scattered minority) are listed so that
   // phase B runs the 16-pixel arc search densely instead of dragging whole waves through it
   __shared__ unsigned short s_list[(kTileH + 2) * (kTileW + 2)];
-  __shared__ int s_nlist, s_ncand, s_base;
+  __shared__ int s_nlist, s_ncand, s_base, s_nrect;
+  __shared__ int4 s_rect[kTileRects];
   __shared__ int s_cpix[kTileH * kTileW];
   __shared__ uint8_t s_csc[kTileH * kTileW];
   __shared__ int s_hist[256];
   s_hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) { s_nlist = 0; s_ncand = 0; }
+  if (threadIdx.x == 0) { s_nlist = 0; s_ncand = 0; s_nrect = 0; }
   __syncthreads();
+  if (n_rects > 0) {
+    // rectangles (level-0 pixels, inclusive) that intersect this tile's level-0 footprint: usually none or a few of ~130;
+    // the mask used to be an image the rectangles were drawn into and erased from around this kernel (two more launches)
+    const int fx0 = (int)(((long)tx0 * w0 + lv.w / 2) / lv.w), fx1 = min((int)(((long)(tx0 + kTileW - 1) * w0 + lv.w / 2) / lv.w), w0 - 1);
+    const int fy0 = (int)(((long)ty0 * h0 + lv.h / 2) / lv.h), fy1 = min((int)(((long)(ty0 + kTileH - 1) * h0 + lv.h / 2) / lv.h), h0 - 1);
+    for (int k = threadIdx.x; k < n_rects; k += 256) {
+      const int4 r = rects[k];
+      if (r.x <= fx1 && r.z >= fx0 && r.y <= fy1 && r.w >= fy0) {
+        const int slot = atomicAdd(&s_nrect, 1);
+        if (slot < kTileRects) s_rect[slot] = r;
+      }
+    }
+  }
   for (int i = threadIdx.x; i < (kTileH + 2) * (kTileW + 2); i += 256) {
     const int lx = i % (kTileW + 2), ly = i / (kTileW + 2);
     const int x = tx0 - 1 + lx, y = ty0 - 1 + ly;
@@ -236,9 +240,21 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const uint8_t* __restr
     constexpr int S = kTileW + 2;
     if (!(sv > c[-S - 1] && sv > c[-S] && sv > c[-S + 1] && sv > c[-1] && sv > c[1] && sv > c[S - 1] && sv > c[S] && sv > c[S + 1])) continue;
     const int x = tx0 + lx, y = ty0 + ly;
-    if (mask) {
+    if (s_nrect > 0) {      // the foreground test: the corner's level-0 position against the (grown) vehicle boxes that reach this tile
       const int x0 = min((int)(((long)x * w0 + lv.w / 2) / lv.w), w0 - 1), y0 = min((int)(((long)y * h0 + lv.h / 2) / lv.h), h0 - 1);
-      if (mask[(size_t)y0 * w0 + x0] == 0) continue;
+      bool masked = false;
+      if (s_nrect <= kTileRects) {
+        for (int k = 0; k < s_nrect && !masked; ++k) {
+          const int4 r = s_rect[k];
+          masked = x0 >= r.x && x0 <= r.z && y0 >= r.y && y0 <= r.w;
+        }
+      } else {                                     // more boxes over this tile than the list holds: test against all of them
+        for (int k = 0; k < n_rects && !masked; ++k) {
+          const int4 r = rects[k];
+          masked = x0 >= r.x && x0 <= r.z && y0 >= r.y && y0 <= r.w;
+        }
+      }
+      if (masked) continue;
     }
     const int k = atomicAdd(&s_ncand, 1);                    // workgroup-local list: one global reservation per tile
     s_cpix[k] = y * lv.w + x;
@@ -719,12 +735,28 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restri
   int c = 0;
   for (int i = lo; i < hi; ++i)
     if (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i]) ++c;
-  s_cnt[tid] = c;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int i = 0; i < 1024; ++i) { const int v = s_cnt[i]; s_cnt[i] = acc; acc += v; }
-    *n_match = acc;
+  // exclusive prefix of the 1024 per-thread counts: inclusive scan inside each wave by shuffles, then the 16 wave totals
+  // (a serial walk by thread 0 over 1024 LDS words cost ~40 us of this kernel's 50)
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) s_cnt[wv] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int v = s_cnt[k];
+      if (k < wv) base += v;
+      total += v;
+    }
+    __syncthreads();
+    s_cnt[tid] = base + inc - c;
+    if (tid == 0) *n_match = total;
   }
   __syncthreads();
   int o = s_cnt[tid];
@@ -966,7 +998,7 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_pyr_tab, d_clahe_lut, d_mask, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
+  DevBuf d_frame, d_pyr, d_pyr_tab, d_clahe_lut, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
@@ -1059,8 +1091,6 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   S.d_pyr.alloc(S.pyr_bytes);
   S.d_clahe_lut.alloc(kClaheLutBytes);
   S.d_rects.alloc(sizeof(int4) * kMaxRects);
-  S.d_mask.alloc((size_t)S.gw * S.gh);
-  GTX_HIP(hipMemset(S.d_mask.p, 255, (size_t)S.gw * S.gh));
   S.d_cand.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_elig.alloc(sizeof(Cand) * (size_t)S.cand_total);
   S.d_counters.alloc(sizeof(int) * (kCounterInts));
@@ -1162,17 +1192,12 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
     hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 1024), L.l[i].h), dim3(256), 0, s, L.l[i - 1].img, L.l[i - 1].w,
                        pyr + L.l[i].off, L.l[i].w, tx, tx + L.l[i].w);
   }
-  const uint8_t* mask = nullptr;
   int n_rects = 0;
   if (cfg.mask_use && boxes && n > 0) {
     std::vector<int4> rects;
     build_rects(boxes, n, rects);
     if (!rects.empty()) {
-      // the mask image stays all-255 between frames: the rectangles are drawn here and erased again right after
-      // the one kernel that reads it (a full 2 MB memset per frame cost several fill launches on this stream)
       GTX_HIP(hipMemcpyAsync(d_rects.p, rects.data(), sizeof(int4) * rects.size(), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)rects.size(), 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>(), 0);
-      mask = d_mask.as<uint8_t>();
       n_rects = (int)rects.size();
     }
   }
@@ -1180,10 +1205,8 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
   int* cand_n = d_counters.as<int>();
   int* elig_n = cand_n + kPyrLevels * kCandSub;
   int* hist = elig_n + kPyrLevels;
-  hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, mask, gw, gh, L, cfg.fast_threshold, d_cand.as<Cand>(),
-                     cand_n, hist);
-  if (n_rects > 0)      // erase the rectangles again: the mask is all-255 for the next frame
-    hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)n_rects, 8), dim3(256), 0, s, d_mask.as<uint8_t>(), gw, d_rects.as<int4>(), 255);
+  hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_rects.as<int4>(), n_rects, gw, gh, L, cfg.fast_threshold,
+                     d_cand.as<Cand>(), cand_n, hist);
   hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
   hipLaunchKernelGGL(select_sort_kernel, dim3(L.n), dim3(1024), kSortCap * 12, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
                      d_kp_n.as<int>());

@@ -88,6 +88,32 @@ def test_mask_excludes_vehicle_boxes(gtx_ctx, seq):
     assert inside2.any()   # vehicle corners are strong features: the mask matters
 
 
+def test_mask_with_hundreds_of_boxes_over_one_tile_equals_oracle(gtx_ctx, seq):
+    """The foreground test runs against a per-tile list of the boxes that reach the tile (256 entries); a tile under more
+    boxes than that tests against all of them. 700 small boxes packed into a corner of the frame, plus the scene's own:
+    keypoints, bins and descriptors equal the oracle's (which draws every box into a mask image), none lies in a box."""
+    from oracle.stabilo_ref import StabilizerRef
+
+    sc, fr = seq
+    rng = np.random.default_rng(9)
+    dense = np.stack([rng.uniform(40, 420, 700), rng.uniform(40, 300, 700), rng.uniform(6, 14, 700), rng.uniform(6, 14, 700)], 1).astype(np.float32)
+    boxes = np.concatenate([sc.boxes(0), dense]).astype(np.float32)
+    st = _make(gtx_ctx)
+    ref = StabilizerRef(CFG, HW, n_hyp=2048)
+    st.set_ref_frame(fr[0], boxes)
+    ref.set_ref_frame(fr[0], boxes)
+    g, o = st.keypoints("ref"), ref.ref
+    assert len(g["bin"]) == len(o["bin"]) > 200
+    np.testing.assert_array_equal(g["xy"], o["xy"])
+    np.testing.assert_array_equal(g["bin"], o["bin"])
+    np.testing.assert_array_equal(g["desc"], o["desc"])
+    xy = g["xy"]
+    inside = np.zeros(len(xy), bool)
+    for cx, cy, w, h in boxes:
+        inside |= (np.abs(xy[:, 0] - cx) < w / 2) & (np.abs(xy[:, 1] - cy) < h / 2)
+    assert not inside.any()
+
+
 @pytest.mark.parametrize("t", [40, 149])
 def test_recovers_ground_truth_homography(gtx_ctx, seq, t):
     """cur -> ref mapping must equal inv(G_t) of the synthetic camera within 1.0 px over a 9x16
