@@ -160,7 +160,9 @@ class ExtractEngine:
             s.close()
         if self.gmc is not None:
             self.gmc.close()
-        self.dets, self.stabs, self.gmc = [], [], None
+        for c in self._spare:
+            c.close()
+        self.dets, self.stabs, self.gmc, self._spare = [], [], None, []
 
     # ---- feeding
     def _submit(self, det: Detector, batch) -> int:
