@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-profile --no-f16-line"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 60 --warmup 12 --no-cpu-baseline --no-f16-line > $O/bench_under_rocprof.json 2> $O/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_botsort -- python3 $R/bench.py --tracker botsort --steps 60 --warmup 12 --no-cpu-baseline --no-f16-line --no-profile > /dev/null 2> $O/stats_botsort.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $CMD > /dev/null 2> $O/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $CMD > /dev/null 2> $O/write.log
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sq1 -- python3 $R/tools/op_profile.py 2 f32s 3 > $O/sq1.log 2>&1
