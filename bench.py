@@ -792,7 +792,7 @@ def main():
                                       "process of this run after the primary measurement; secondary, not `value`"}
             except Exception as e:                                  # the secondary line must never void the primary one
                 out["f16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (the other ranks would sit in the barrier below)
             out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args)
         print(json.dumps(out), flush=True)
     if dist is not None:
