@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0
 # fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is the dense fp16 peak / 3
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0 / 3.0}
 DTYPE_NAME = {"f16": "f16", "f32": "f32", "f32s": "f32 (split-f16x3 MFMA)"}
+GMC_TRACKERS = ("botsort", "deepocsort")   # trackers that take a camera-motion warp per frame (bench runs them with gmc_method: sparseOptFlow)
 H, W = 2160, 3840
 # seeded weights of the bench: only the stride-8 head fires, DFL biases give ~120 x 60 px boxes in 4K, and the class
 # branch is spatially smooth so that candidates come in clusters and NMS suppresses about half of them
@@ -70,7 +71,7 @@ def parse():
                          "fp32 accumulate). Default: the library's default (geotrax_amd.detector.FP32_SPLIT_DEFAULT)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
-    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort"],
+    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort", "deepocsort"],
                     help="default: bytetrack at N = 1 (BASELINE configs[2]), botsort at N > 1 (configs[4]; the reference's own default, default.yaml:362)")
     ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
     ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")
@@ -355,7 +356,7 @@ def bench_extract_georef(args):
                   fp32_split=fp32_split(args), rect=bool(args.rect))
     tracker = Tracker(args.tracker)
     engine = ExtractEngine(weights, (H, W), det_kw, tracker, {}, device=0, batch=B, det_streams=args.det_streams, stab_streams=args.stab_streams,
-                           gmc=args.tracker == "botsort", detectors=[det])
+                           gmc=args.tracker in GMC_TRACKERS, detectors=[det])
     gcfg = dict(transformation=dict(source_crs="epsg:4326", target_crs="epsg:5186", cutout_width_px=None),
                 filtering=dict(filter_type="gaussian", kernel_size=14, min_traj_length=15, visibility_margin=4))
     matching = dict(detector_name="rsift", matcher_name="bf", filter_type="ratio", sift_enable_precise_upscale=True, max_features=250000, filter_ratio=0.55,
@@ -564,10 +565,10 @@ def main():
     det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
                   fp32_split=fp32_split(args), rect=bool(args.rect))
     stab_kw = {} if extract else None
-    shard_gmc = sharded and extract and args.tracker == "botsort"
+    shard_gmc = sharded and extract and args.tracker in GMC_TRACKERS
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
                            det_streams=args.det_streams, stab_streams=args.stab_streams,
-                           gmc=extract and args.tracker == "botsort", detectors=[det])
+                           gmc=extract and args.tracker in GMC_TRACKERS, detectors=[det])
     n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
     if extract:
         engine.set_reference(ref_frame)                          # every rank registers against frame 0 of the clip

@@ -7,6 +7,12 @@
 // observed again), velocity-direction consistency in the first association (OCM), optional BYTE pass, and a second
 // association of the leftovers against the tracks' last observations (OCR). Parameter mapping as in the oracle's header:
 // det_thresh = track_high_thresh, iou_threshold = 1 - match_thresh, max_age = track_buffer, min_hits = 3.
+//
+// Type 3 (`tracker.active: deepocsort`, default.yaml:406-427) is the same tracker with Deep OC-SORT's camera-motion
+// compensation (Maggiolino et al., "Deep OC-SORT", ICIP 2023): before the prediction step the frame's 2x3 warp (the GMC
+// of gmc.hip, `gmc_method: sparseOptFlow`) moves every track into the new frame's coordinates -- the Kalman position and
+// velocity with their covariance blocks, the frozen state of a lost track, the last observation, and the observations
+// the velocity direction is taken from. The appearance branch (with_reid) is not built; the host wrapper refuses it.
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -64,6 +70,19 @@ struct OcKalman {
       for (int j = 0; j < 7; ++j) FP[i * 7 + j] = P[i * 7 + j] + (i < 3 ? P[(i + 4) * 7 + j] : 0.0);
     for (int i = 0; i < 7; ++i)
       for (int j = 0; j < 7; ++j) P[i * 7 + j] = FP[i * 7 + j] + (j < 3 ? FP[i * 7 + j + 4] : 0.0) + (i == j ? q(i) : 0.0);
+  }
+
+  // Deep OC-SORT's apply_affine_correction for the (u, v, s, r) filter: position by m and t, velocity by m, their
+  // covariance blocks by m . m^T; the same for the frozen prior of a lost track and for the centre of the observation ORU
+  // will start its virtual trajectory from. Area and aspect ratio are left alone, as in the authors' code.
+  void apply_affine(const double m[4], const double t[2]) {
+    affine_state(x, P, m, t);
+    if (!observed && has_saved) affine_state(sx, sP, m, t);
+    if (seen_idx >= 0) {
+      const double u = seen_z[0], v = seen_z[1];
+      seen_z[0] = m[0] * u + m[1] * v + t[0];
+      seen_z[1] = m[2] * u + m[3] * v + t[1];
+    }
   }
 
   void update_none() {
@@ -124,6 +143,18 @@ struct OcKalman {
   }
 
  private:
+  static void affine_state(double* xs, double* Ps, const double m[4], const double t[2]) {
+    const double u = xs[0], v = xs[1], du = xs[4], dv = xs[5];
+    xs[0] = m[0] * u + m[1] * v + t[0]; xs[1] = m[2] * u + m[3] * v + t[1];
+    xs[4] = m[0] * du + m[1] * dv;      xs[5] = m[2] * du + m[3] * dv;
+    for (int o = 0; o <= 4; o += 4) {                 // the 2x2 blocks at (0,0) and (4,4): B <- m B m^T
+      const double b00 = Ps[o * 7 + o], b01 = Ps[o * 7 + o + 1], b10 = Ps[(o + 1) * 7 + o], b11 = Ps[(o + 1) * 7 + o + 1];
+      const double c00 = m[0] * b00 + m[1] * b10, c01 = m[0] * b01 + m[1] * b11, c10 = m[2] * b00 + m[3] * b10, c11 = m[2] * b01 + m[3] * b11;
+      Ps[o * 7 + o] = c00 * m[0] + c01 * m[1];       Ps[o * 7 + o + 1] = c00 * m[2] + c01 * m[3];
+      Ps[(o + 1) * 7 + o] = c10 * m[0] + c11 * m[1]; Ps[(o + 1) * 7 + o + 1] = c10 * m[2] + c11 * m[3];
+    }
+  }
+
   // ORU: back to the frozen state, then predict/update along the straight line between the last observation before the
   // gap and the new one (box centre, width and height interpolated); the caller's regular update with z follows.
   void unfreeze(int idx2, const double z2[4]) {
@@ -205,7 +236,7 @@ struct OcSortTracker::Impl {
   gtx_tracker_config cfg;
   double det_thresh, low, new_thr, iou_thr, inertia;
   int max_age, delta_t, min_hits;
-  bool use_byte;
+  bool use_byte, cmc = false;
   std::vector<OcTrack> trackers;
   int frame_count = 0, next_id = 0;
 
@@ -228,6 +259,20 @@ struct OcSortTracker::Impl {
     double z[4];
     to_z(d->b.v, z);
     t.kf.update(z);
+  }
+
+  // camera-motion compensation of one track (type 3): g = [m00 m01 t0; m10 m11 t1], previous frame -> this frame
+  void track_affine(OcTrack& t, const double* g) const {
+    const double m[4] = {g[0], g[1], g[3], g[4]}, tv[2] = {g[2], g[5]};
+    auto corners = [&](Box5& b) {
+      const double x1 = b.v[0], y1 = b.v[1], x2 = b.v[2], y2 = b.v[3];
+      b.v[0] = m[0] * x1 + m[1] * y1 + tv[0]; b.v[1] = m[2] * x1 + m[3] * y1 + tv[1];
+      b.v[2] = m[0] * x2 + m[1] * y2 + tv[0]; b.v[3] = m[2] * x2 + m[3] * y2 + tv[1];
+    };
+    if (t.seen()) corners(t.last_obs);
+    for (auto& o : t.obs)
+      if (o.first >= t.age - delta_t) corners(o.second);     // the ages the velocity direction can still be taken from
+    t.kf.apply_affine(m, tv);
   }
 
   void track_predict(OcTrack& t, double box[4]) {
@@ -317,6 +362,7 @@ OcSortTracker::OcSortTracker(const gtx_tracker_config& cfg) : impl_(new Impl) {
   S.delta_t = std::max(cfg.delta_t, 1);
   S.min_hits = cfg.min_hits > 0 ? cfg.min_hits : 3;
   S.use_byte = cfg.use_byte != 0;
+  S.cmc = cfg.type == 3;
 }
 OcSortTracker::~OcSortTracker() = default;
 
@@ -326,7 +372,7 @@ void OcSortTracker::reset() {
   impl_->next_id = 0;
 }
 
-void OcSortTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* /*gmc: OC-SORT has none*/, int cap,
+void OcSortTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap,
                            int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
   Impl& S = *impl_;
   ++S.frame_count;
@@ -337,6 +383,8 @@ void OcSortTracker::update(int n, const float* xyxy, const float* conf, const in
     if (c > S.det_thresh) dets.push_back(d);
     else if (c > S.low && c < S.det_thresh) second.push_back(d);
   }
+  if (S.cmc && gmc)
+    for (OcTrack& t : S.trackers) S.track_affine(t, gmc);
   // predictions; a track whose predicted box is not a number is dropped
   std::vector<std::array<double, 4>> trks;
   {

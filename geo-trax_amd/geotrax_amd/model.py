@@ -155,16 +155,16 @@ class YOLO:
         ttype = params.get("tracker_type", "botsort")
         if ttype not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker_type '{ttype}' is not implemented (available: {sorted(TRACKER_TYPES)})")
-        if ttype == "botsort":
+        if ttype in ("botsort", "deepocsort"):                # the two trackers that take a camera-motion warp per frame
             if params.get("with_reid"):
-                raise NotImplementedError("BoT-SORT ReID is not implemented")
+                raise NotImplementedError(f"{ttype}: the appearance (ReID) branch is not implemented")
             gm = params.get("gmc_method", "none")
             if gm in ("none", None):
                 self._gmc_method = None
             elif gm == "sparseOptFlow":
                 self._gmc_method = gm                         # GPU corners + pyramidal LK + RANSAC similarity (gmc.py)
             else:
-                raise NotImplementedError(f"BoT-SORT gmc_method '{gm}': only 'sparseOptFlow' and 'none' are implemented")
+                raise NotImplementedError(f"{ttype} gmc_method '{gm}': only 'sparseOptFlow' and 'none' are implemented")
         else:
             self._gmc_method = None
         self._gmc = None

@@ -3,7 +3,8 @@
 Reference behaviour replaced: the tracker callback ultralytics registers for
 ``model.track(..., persist=True)`` (geotrax/extract.py:153) with the active block of
 cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time. `tracker_type: ocsort` (default.yaml:391-404) selects the OC-SORT
-implementation (csrc/ocsort.cpp); deepocsort / fasttrack / tracktrack are not implemented and raise.
+implementation (csrc/ocsort.cpp), `deepocsort` (default.yaml:406-427) the same tracker with camera-motion compensation by the warp
+handed to update() (no appearance branch); fasttrack / tracktrack are not implemented and raise.
 """
 from __future__ import annotations
 
@@ -14,7 +15,7 @@ import numpy as np
 from . import _lib
 from ._lib import TrackerConfig, check, ptr
 
-TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2}
+TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2, "deepocsort": 3}
 
 
 class Tracker:

@@ -220,7 +220,8 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
  * (BYTETracker / BOTSORT.update; cfg tracker.* default.yaml:361-389). */
 
 typedef struct gtx_tracker_config {
-  int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404) */
+  int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404), 3 = deepocsort without the
+                              appearance branch: ocsort + camera-motion compensation by gmc_affine (default.yaml:406-427) */
   float track_high_thresh;
   float track_low_thresh;
   float new_track_thresh;

@@ -27,6 +27,15 @@ track_buffer, min_hits = 3, new tracks need score >= new_track_thresh; fuse_scor
 PARITY UNPINNED: neither ultralytics' port nor the authors' package can be imported here and the reference holds no
 OC-SORT output. All arithmetic is float64.
 
+`OCSortRef(cmc=True)` is `tracker.active: deepocsort` (default.yaml:406-427) without its appearance branch: the same
+tracker plus the camera-motion compensation of Deep OC-SORT (Maggiolino, Ahmad, Cao, Kitani, ICIP 2023; public code
+GerardMaggiolino/Deep-OC-SORT, `apply_affine_correction` of the track and of the (u, v, s, r) filter), applied before the
+prediction step with the 2x3 warp handed to update(): Kalman position by (m, t), velocity by m, their covariance blocks by
+m . m^T, the frozen prior of a lost track likewise, the last observation and the observations of the last delta_t ages
+corner by corner. Two deliberate differences from that code, both stated in DESIGN.md: every observation is moved once
+(there the last observation and its entry in the age table are one array and are moved twice), and the observation ORU
+starts its virtual trajectory from is moved too (there it stays in the old frame's coordinates).
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 from __future__ import annotations
@@ -114,6 +123,35 @@ class _KF:
         IKH = np.eye(7) - K @ self.H
         self.P = IKH @ self.P @ IKH.T + K @ self.R @ K.T
 
+    def apply_affine(self, m, t):
+        def state(x, P):
+            x, P = x.copy(), P.copy()
+            x[:2] = m @ x[:2] + t
+            x[4:6] = m @ x[4:6]
+            P[:2, :2] = m @ P[:2, :2] @ m.T
+            P[4:6, 4:6] = m @ P[4:6, 4:6] @ m.T
+            return x, P
+        self.x, self.P = state(self.x, self.P)
+        moved = {}
+
+        def centre(z):                                       # history entries are shared between the two lists: move each array once
+            if z is None:
+                return None
+            if id(z) not in moved:
+                z2 = z.copy()
+                z2[:2] = m @ z[:2] + t
+                moved[id(z)] = z2
+            return moved[id(z)]
+        last = max((i for i, z in enumerate(self.history) if z is not None), default=None)
+        if self.saved is not None and not self.observed:
+            sx, sP = state(self.saved[0], self.saved[1])
+            sh = list(self.saved[2])
+            if last is not None and last < len(sh):
+                sh[last] = centre(sh[last])
+            self.saved = (sx, sP, sh)
+        if last is not None:
+            self.history[last] = centre(self.history[last])
+
     def _unfreeze(self):
         if self.saved is None:
             return
@@ -169,6 +207,19 @@ class _Trk:
         self.score, self.cls, self.idx = float(det[4]), int(det[5]), int(det[6])
         self.kf.update(_to_z(box))
 
+    def apply_affine(self, g):
+        g = np.asarray(g, dtype=np.float64).reshape(2, 3)
+        m, t = g[:, :2], g[:, 2]
+
+        def corners(b):
+            b = b.copy()
+            b[:2], b[2:4] = m @ b[:2] + t, m @ b[2:4] + t
+            return b
+        if self.last_observation.sum() >= 0:
+            self.last_observation = corners(self.last_observation)
+        self.observations = {a: (corners(b) if a >= self.age - self.delta_t else b) for a, b in self.observations.items()}
+        self.kf.apply_affine(m, t)
+
     def predict(self):
         if self.kf.x[6] + self.kf.x[2] <= 0:
             self.kf.x[6] *= 0.0
@@ -190,10 +241,11 @@ class _Trk:
 
 class OCSortRef:
     def __init__(self, track_high_thresh=0.25, track_low_thresh=0.1, new_track_thresh=0.25, track_buffer=30, match_thresh=0.8,
-                 delta_t=3, inertia=0.2, use_byte=False, min_hits=3, **_ignored):
+                 delta_t=3, inertia=0.2, use_byte=False, min_hits=3, cmc=False, **_ignored):
         self.det_thresh, self.low, self.new_thr = track_high_thresh, track_low_thresh, new_track_thresh
         self.max_age, self.iou_thr = int(track_buffer), 1.0 - match_thresh
         self.delta_t, self.inertia, self.use_byte, self.min_hits = int(delta_t), float(inertia), bool(use_byte), int(min_hits)
+        self.cmc = bool(cmc)
         self.trackers = []
         self.frame_count = 0
         self._count = 0
@@ -241,6 +293,9 @@ class OCSortRef:
             if len(conf) else np.zeros((0, 7))
         second = rows[(conf > self.low) & (conf < self.det_thresh)]
         dets = rows[conf > self.det_thresh]
+        if self.cmc and gmc is not None:
+            for trk in self.trackers:
+                trk.apply_affine(gmc)
         trks = np.zeros((len(self.trackers), 5))
         keep = []
         for t, trk in enumerate(self.trackers):

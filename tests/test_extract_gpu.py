@@ -39,7 +39,7 @@ def _weights_file(tmp_path, gtx_ctx, probe_frame, half=False):
     return path, w
 
 
-def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False):
+def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=None):
     import yaml
     from geotrax_amd.config_utils import DEFAULT_CFG
 
@@ -49,6 +49,8 @@ def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False):
     cfg["ultralytics"].update(imgsz=IMGSZ, half=half, max_det=300, rect=True)
     cfg["stabilo"].update(STAB)
     cfg["tracker"]["active"] = tracker
+    if gmc_method is not None:                                 # deepocsort ships with gmc_method: none (default.yaml:421)
+        cfg["tracker"][tracker]["gmc_method"] = gmc_method
     cfg["extraction"]["model"] = str(model_path)
     cfg["extraction"]["min_track_length"] = 2
     p = tmp_path / "cfg.yaml"
@@ -69,9 +71,15 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     model = YoloV8Ref(weights, emulate_half=False)
     active = cfg["tracker"]["active"]
     tp = cfg["tracker"][active]
-    trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
-                                                                             "track_buffer", "match_thresh", "fuse_score")})
-    gmc = GmcRef(seed=0) if active == "botsort" and tp.get("gmc_method") == "sparseOptFlow" else None
+    if active in ("ocsort", "deepocsort"):
+        from oracle.ocsort_ref import OCSortRef
+
+        trk = OCSortRef(cmc=(active == "deepocsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer",
+                                                                            "match_thresh", "delta_t", "inertia", "use_byte")})
+    else:
+        trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
+                                                                                 "track_buffer", "match_thresh", "fuse_score")})
+    gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort") and tp.get("gmc_method") == "sparseOptFlow" else None
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
@@ -111,7 +119,7 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "ocsort", "deepocsort"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
@@ -123,7 +131,7 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     src = tmp_path / "clip.npy"
     np.save(src, frames)
     wpath, weights = _weights_file(tmp_path, gtx_ctx, frames[0])
-    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker)
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="sparseOptFlow" if tracker == "deepocsort" else None)
     if tracker == "botsort":
         assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,

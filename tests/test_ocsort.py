@@ -95,7 +95,7 @@ def test_config_selects_ocsort(tmp_path):
     m._gmc_method = m._gmc = None
     t = m._make_tracker({"tracker_type": "ocsort", "track_high_thresh": 0.3, "delta_t": 2, "inertia": 0.1, "use_byte": True, "match_thresh": 0.75})
     assert isinstance(t, Tracker) and m._gmc_method is None
-    for name in ("deepocsort", "fasttrack", "tracktrack"):
+    for name in ("fasttrack", "tracktrack"):
         with pytest.raises(NotImplementedError):
             m._make_tracker({"tracker_type": name})
 
@@ -129,3 +129,90 @@ def test_batch_replay_equals_frame_by_frame_updates(kind):
     assert o == len(tid) > 500
     with pytest.raises(Exception):
         a.replay(recs[:, :-1], max_det, with_gmc=True)          # a stride that does not match max_det is refused
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tracker.active: deepocsort (default.yaml:406-427) without the appearance branch = OC-SORT + camera-motion compensation
+
+
+def _camera_path(seed, n_frames, step=18.0, rot=2e-3, zoom=1e-3):
+    """Per-frame 2x3 warps previous frame -> this frame (pan with a little rotation and zoom) and their running product."""
+    rng = np.random.default_rng(seed)
+    warps, total = [], [np.eye(3)]
+    for _ in range(n_frames):
+        a, s = rng.normal(0, rot), 1 + rng.normal(0, zoom)
+        g = np.array([[s * np.cos(a), -s * np.sin(a), rng.normal(0, step)], [s * np.sin(a), s * np.cos(a), rng.normal(0, step)]])
+        warps.append(g)
+        total.append(np.vstack([g, [0, 0, 1]]) @ total[-1])
+    return warps, total[1:]
+
+
+def _moved(xyxy, T):
+    """Boxes seen through the camera transform T (3x3, affine): corners mapped, axis-aligned again."""
+    if len(xyxy) == 0:
+        return xyxy
+    p = np.stack([xyxy[:, [0, 1]], xyxy[:, [2, 3]]], 1).astype(np.float64)      # [n, 2, 2]
+    q = p @ T[:2, :2].T + T[:2, 2]
+    return np.concatenate([q.min(1), q.max(1)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("kw", [{}, {"use_byte": True, "track_high_thresh": 0.3, "new_track_thresh": 0.3}])
+def test_cpp_deepocsort_equals_oracle(seed, kw):
+    from geotrax_amd.tracker import Tracker
+    from oracle.ocsort_ref import OCSortRef
+
+    ref, trk = OCSortRef(cmc=True, **kw), Tracker("deepocsort", **kw)
+    warps, total = _camera_path(seed + 10, 90)
+    rows = 0
+    for t, (xyxy, conf, cls) in enumerate(_stream(seed, n_frames=90, p_miss=0.12)):
+        xyxy = _moved(xyxy, total[t])
+        want = ref.update(xyxy, conf, cls, warps[t])
+        got_xyxy, got_id, got_score, got_cls, got_idx = trk.update(xyxy, conf, cls, warps[t])
+        assert len(want) == len(got_id), f"frame {t}"
+        if len(want):
+            np.testing.assert_array_equal(want[:, 4].astype(np.int32), got_id, err_msg=f"frame {t}")
+            np.testing.assert_array_equal(want[:, 7].astype(np.int32), got_idx)
+            np.testing.assert_allclose(got_xyxy, want[:, :4], rtol=0, atol=2e-3)
+        rows += len(want)
+    assert rows > 1000
+
+
+def test_camera_motion_compensation_keeps_the_identities_a_panning_camera_breaks():
+    """A camera that jumps ~25 px per frame over 40-90 px objects: with the warps handed in, Deep OC-SORT ends with the
+    identity partition of the same scene seen by a still camera; plain OC-SORT on the moving view fragments it. On the still
+    scene the two trackers are the same tracker."""
+    from geotrax_amd.tracker import Tracker
+
+    warps, total = _camera_path(5, 60, step=25.0)
+    frames = list(_stream(4, n_obj=30, n_frames=60, p_miss=0.05, p_low=0.0))
+
+    def partition(tracker, moving, with_warp):
+        seen = {}
+        for t, (xyxy, conf, cls) in enumerate(frames):
+            b = _moved(xyxy, total[t]) if moving else xyxy
+            _, tid, _, _, idx = tracker.update(b, conf, cls, warps[t] if with_warp else None)
+            for i, d in zip(tid, idx):
+                seen.setdefault(int(i), []).append((t, int(d)))
+        return sorted(tuple(v) for v in seen.values())
+
+    still = partition(Tracker("ocsort"), False, False)
+    assert partition(Tracker("deepocsort"), False, False) == still
+    compensated = partition(Tracker("deepocsort"), True, True)
+    plain = partition(Tracker("ocsort"), True, False)
+    assert compensated == still
+    assert len(plain) > len(still) + 5
+
+
+def test_config_selects_deepocsort_and_refuses_the_appearance_branch():
+    from geotrax_amd.model import YOLO
+
+    m = YOLO.__new__(YOLO)
+    m._gmc = m._gmc_method = None
+    trk = m._make_tracker({"tracker_type": "deepocsort", "track_high_thresh": 0.3, "new_track_thresh": 0.3, "gmc_method": "sparseOptFlow",
+                           "with_reid": False, "delta_t": 3, "inertia": 0.2, "use_byte": False, "alpha_fixed_emb": 0.95})
+    assert m._gmc_method == "sparseOptFlow" and trk.update(np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int32))[1].size == 0
+    m._make_tracker({"tracker_type": "deepocsort", "gmc_method": "none"})
+    assert m._gmc_method is None
+    with pytest.raises(NotImplementedError):
+        m._make_tracker({"tracker_type": "deepocsort", "with_reid": True})

@@ -141,4 +141,4 @@ def test_tracker_rejects_unknown_type():
     from geotrax_amd.tracker import Tracker
 
     with pytest.raises(NotImplementedError):
-        Tracker("deepocsort")
+        Tracker("tracktrack")
