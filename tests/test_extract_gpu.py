@@ -51,6 +51,8 @@ def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=
     cfg["tracker"]["active"] = tracker
     if gmc_method is not None:                                 # deepocsort ships with gmc_method: none (default.yaml:421)
         cfg["tracker"][tracker]["gmc_method"] = gmc_method
+        # the seeded weights are calibrated so that the detections sit just above conf = 0.25: below deepocsort's own 0.3
+        cfg["tracker"][tracker].update(track_high_thresh=0.25, new_track_thresh=0.25)
     cfg["extraction"]["model"] = str(model_path)
     cfg["extraction"]["min_track_length"] = 2
     p = tmp_path / "cfg.yaml"
