@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void match_kernel(const unsigned long long* __
 // in index order).
 __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ nq_p, const int* __restrict__ nt_p, int max_q,
                                                              const int* __restrict__ part_idx, const int* __restrict__ part_d1,
-                                                             const int* __restrict__ part_d2, float ratio,
+                                                             const int* __restrict__ part_d2, float ratio, int keep_all,
                                                              const float2* __restrict__ q_xy, const float2* __restrict__ t_xy,
                                                              int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d,
                                                              int* __restrict__ m_q, int* __restrict__ m_t, int* __restrict__ m_d,
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restri
   const int lo = tid * per, hi = min(lo + per, nq);
   int c = 0;
   for (int i = lo; i < hi; ++i)
-    if (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i]) ++c;
+    if (keep_all ? (nt >= 1 && best_idx[i] >= 0) : (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i])) ++c;
   // exclusive prefix of the 1024 per-thread counts: inclusive scan inside each wave by shuffles, then the 16 wave totals
   // (50 -> 38 us in situ against a serial walk by thread 0; what remains is the wait for a CU with 16 free wave slots)
   {
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restri
   __syncthreads();
   int o = s_cnt[tid];
   for (int i = lo; i < hi; ++i)
-    if (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i]) {
+    if (keep_all ? (nt >= 1 && best_idx[i] >= 0) : (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i])) {
       m_q[o] = i; m_t[o] = best_idx[i]; m_d[o] = best_d[i];
       const float2 a = q_xy[i], b = t_xy[best_idx[i]];
       m_pts[o] = make_float4(a.x, a.y, b.x, b.y);
@@ -809,20 +809,39 @@ __device__ bool homography4(const double* px, const double* py, const double* qx
   return true;
 }
 
-// Hypothesis generation, one thread per hypothesis: 4 distinct matches drawn by a counter-based
-// hash of (seed, hypothesis, draw), exact 4-point solve in normalised coordinates, de-normalised H.
+// Affine map from 3 correspondences (Cramer's rule), as a 3x3 matrix with last row (0, 0, 1).
+__device__ bool affine3(const double* px, const double* py, const double* qx, const double* qy, double* H) {
+  const double x0 = px[0], y0 = py[0], x1 = px[1], y1 = py[1], x2 = px[2], y2 = py[2];
+  const double det = x0 * (y1 - y2) - y0 * (x1 - x2) + (x1 * y2 - x2 * y1);
+  if (!(fabs(det) > 1e-9)) return false;           // the three source points are collinear
+  const double id = 1.0 / det;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double* q = r == 0 ? qx : qy;
+    const double u0 = q[0], u1 = q[1], u2 = q[2];
+    H[r * 3 + 0] = (u0 * (y1 - y2) - y0 * (u1 - u2) + (u1 * y2 - u2 * y1)) * id;
+    H[r * 3 + 1] = (x0 * (u1 - u2) - u0 * (x1 - x2) + (x1 * u2 - x2 * u1)) * id;
+    H[r * 3 + 2] = (x0 * (y1 * u2 - y2 * u1) - y0 * (x1 * u2 - x2 * u1) + u0 * (x1 * y2 - x2 * y1)) * id;
+  }
+  H[6] = 0.0; H[7] = 0.0; H[8] = 1.0;
+  return true;
+}
+
+// Hypothesis generation, one thread per hypothesis: 4 (projective) or 3 (affine) distinct matches drawn by a counter-based
+// hash of (seed, hypothesis, draw), exact minimal solve in normalised coordinates, de-normalised H.
 __global__ __launch_bounds__(256) void ransac_solve_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, unsigned seed,
-                                                           int n_hyp, double cx, double cy, double sc,
+                                                           int n_hyp, double cx, double cy, double sc, int affine,
                                                            double* __restrict__ Hout, int* __restrict__ ok_out) {
   const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
   if (hyp >= n_hyp) return;
   const int n = *n_p;
+  const int ns = affine ? 3 : 4;
   int ok = 0;
   double H[9];
-  if (n >= 4) {
-    int idx[4];
+  if (n >= ns) {
+    int idx[4] = {0, 0, 0, 0};
     unsigned ctr = 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < ns; ++k) {
       for (;;) {
         const int cand = (int)(hash_u32(seed ^ hash_u32((unsigned)hyp * 977u + ctr)) % (unsigned)n);
         ++ctr;
@@ -838,7 +857,7 @@ __global__ __launch_bounds__(256) void ransac_solve_kernel(const float4* __restr
       qx[k] = ((double)p.z - cx) * sc; qy[k] = ((double)p.w - cy) * sc;
     }
     double Hn[9];
-    ok = homography4(px, py, qx, qy, Hn) ? 1 : 0;
+    ok = (affine ? affine3(px, py, qx, qy, Hn) : homography4(px, py, qx, qy, Hn)) ? 1 : 0;
     if (ok) {
       // de-normalise: H = T^-1 Hn T with T = [[sc,0,-sc*cx],[0,sc,-sc*cy],[0,0,1]]
       const double is = 1.0 / sc;
@@ -1229,8 +1248,10 @@ namespace {
 // geometric transfer error with iteratively re-weighted Gauss-Newton (Tukey biweight, scale from
 // the median residual), h33 = 1, in normalised coordinates.
 bool refine_homography(const std::vector<float4>& pts, double cx, double cy, double sc,
-                       double thr, double H[9], int* n_inliers) {
+                       double thr, double H[9], int* n_inliers, bool affine = false) {
   const size_t n = pts.size();
+  const int np = affine ? 6 : 8;                     // affine: h31 = h32 = 0 stay as they are, six parameters move
+  const size_t min_pts = affine ? 3 : 4;
   // to normalised coordinates: Hn = T H T^-1
   auto to_norm = [&](const double* Hp, double* Hn) {
     const double is = 1.0 / sc;
@@ -1284,7 +1305,7 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
     residual(i, rx, ry, w);
     if (std::fabs(w) > 1e-9 && rx * rx + ry * ry <= lim * lim) sup.push_back((int)i);
   }
-  if (sup.size() < 4) return false;
+  if (sup.size() < min_pts) return false;
   std::vector<double> un(sup.size());
   for (int iter = 0; iter < 8; ++iter) {
     for (size_t k = 0; k < sup.size(); ++k) {
@@ -1307,17 +1328,17 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
       const double iw = 1.0 / w, px = rx + u[i], py = ry + v[i];
       const double Jx[8] = {x[i] * iw, y[i] * iw, iw, 0, 0, 0, -px * x[i] * iw, -px * y[i] * iw};
       const double Jy[8] = {0, 0, 0, x[i] * iw, y[i] * iw, iw, -py * x[i] * iw, -py * y[i] * iw};
-      for (int a = 0; a < 8; ++a) {
+      for (int a = 0; a < np; ++a) {
         g[a] += wt * (Jx[a] * rx + Jy[a] * ry);
-        for (int b = a; b < 8; ++b) A[a * 8 + b] += wt * (Jx[a] * Jx[b] + Jy[a] * Jy[b]);
+        for (int b = a; b < np; ++b) A[a * 8 + b] += wt * (Jx[a] * Jx[b] + Jy[a] * Jy[b]);
       }
     }
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < np; ++a)
       for (int b = 0; b < a; ++b) A[a * 8 + b] = A[b * 8 + a];
     // Cholesky solve A d = g
     double Lc[64] = {0};
     bool ok = true;
-    for (int i = 0; i < 8 && ok; ++i)
+    for (int i = 0; i < np && ok; ++i)
       for (int j = 0; j <= i; ++j) {
         double s = A[i * 8 + j];
         for (int k = 0; k < j; ++k) s -= Lc[i * 8 + k] * Lc[j * 8 + k];
@@ -1330,18 +1351,18 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
       }
     if (!ok) break;
     double yv[8], d[8];
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < np; ++i) {
       double s = g[i];
       for (int k = 0; k < i; ++k) s -= Lc[i * 8 + k] * yv[k];
       yv[i] = s / Lc[i * 8 + i];
     }
-    for (int i = 7; i >= 0; --i) {
+    for (int i = np - 1; i >= 0; --i) {
       double s = yv[i];
-      for (int k = i + 1; k < 8; ++k) s -= Lc[k * 8 + i] * d[k];
+      for (int k = i + 1; k < np; ++k) s -= Lc[k * 8 + i] * d[k];
       d[i] = s / Lc[i * 8 + i];
     }
     double step = 0;
-    for (int a = 0; a < 8; ++a) { h[a] -= d[a]; step = std::max(step, std::fabs(d[a])); }
+    for (int a = 0; a < np; ++a) { h[a] -= d[a]; step = std::max(step, std::fabs(d[a])); }
     if (step < 1e-14) break;
   }
   from_norm(h, H);
@@ -1353,7 +1374,7 @@ bool refine_homography(const std::vector<float4>& pts, double cx, double cy, dou
     if (rx * rx + ry * ry <= t2) ++cnt;
   }
   if (n_inliers) *n_inliers = cnt;
-  return cnt >= 4;
+  return cnt >= (int)min_pts;
 }
 
 }  // namespace
@@ -1367,13 +1388,13 @@ void Stabilizer::Impl::submit_match() {
                      cur.n.as<int>(), ref.desc.as<unsigned long long>(), ref.n.as<int>(), max_q, d_pidx.as<int>(), d_pd1.as<int>(),
                      d_pd2.as<int>());
   hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, cur.n.as<int>(), ref.n.as<int>(), max_q, d_pidx.as<int>(),
-                     d_pd1.as<int>(), d_pd2.as<int>(), cfg.filter_ratio, cur.xy.as<float2>(), ref.xy.as<float2>(), d_bidx.as<int>(),
+                     d_pd1.as<int>(), d_pd2.as<int>(), cfg.filter_ratio, cfg.filter_type == 1 ? 1 : 0, cur.xy.as<float2>(), ref.xy.as<float2>(), d_bidx.as<int>(),
                      d_bd.as<int>(), d_sd.as<int>(), d_mq.as<int>(), d_mt.as<int>(), d_md.as<int>(), d_mpts.as<float4>(),
                      d_nmatch.as<int>());
   const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
   const float thr2 = cfg.ransac_threshold * cfg.ransac_threshold;
   hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), cfg.seed,
-                     n_hyp, cx, cy, sc, d_H.as<double>(), d_hok.as<int>());
+                     n_hyp, cx, cy, sc, cfg.affine ? 1 : 0, d_H.as<double>(), d_hok.as<int>());
   hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), n_hyp,
                      thr2, d_H.as<double>(), d_hok.as<int>(), d_cost.as<long>());
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_nmatch.as<int>(),
@@ -1399,14 +1420,14 @@ void Stabilizer::Impl::collect(double Hout[9], int* valid_out, int st[4]) {
   cur.host_n = R.n_cur;
   stats[0] = ref.host_n; stats[1] = R.n_cur; stats[2] = R.n_match; stats[3] = 0;
   valid = false;
-  if (R.n_match >= 4 && R.best >= 0) {
+  if (R.n_match >= (cfg.affine ? 3 : 4) && R.best >= 0) {
     std::vector<float4> pts(h_pts, h_pts + R.n_match);
     double Hc[9];
     std::memcpy(Hc, R.H, sizeof Hc);
     const double inv = 1.0 / Hc[8];
     for (double& v : Hc) v *= inv;
     int n_inl = 0;
-    if (refine_homography(pts, cx, cy, sc, (double)cfg.ransac_threshold, Hc, &n_inl)) {
+    if (refine_homography(pts, cx, cy, sc, (double)cfg.ransac_threshold, Hc, &n_inl, cfg.affine != 0)) {
       std::memcpy(H, Hc, sizeof H);
       valid = true;
       stats[3] = n_inl;
@@ -1529,7 +1550,7 @@ bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_mat
   GTX_HIP(hipMemcpyAsync(d_n.p, two, sizeof two, hipMemcpyHostToDevice, s));
   const double cx = frame_w / 2.0, cy = frame_h / 2.0, sc = 2.0 / frame_w;
   hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), seed, n_hyp, cx, cy, sc,
-                     d_H.as<double>(), d_ok.as<int>());
+                     0, d_H.as<double>(), d_ok.as<int>());
   hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), n_hyp, threshold * threshold,
                      d_H.as<double>(), d_ok.as<int>(), d_cost.as<long>());
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_n.as<int>(), d_n.as<int>() + 1,

@@ -64,13 +64,13 @@ class StabConfig(C.Structure):
         ("filter_ratio", C.c_float), ("ransac_threshold", C.c_float), ("ransac_max_iter", C.c_int),
         ("ransac_confidence", C.c_float), ("mask_use", C.c_int), ("mask_margin_ratio", C.c_float),
         ("fast_threshold", C.c_int), ("n_levels", C.c_int), ("scale_factor", C.c_float),
-        ("seed", C.c_uint32), ("frame_h", C.c_int), ("frame_w", C.c_int), ("clahe", C.c_int),
+        ("seed", C.c_uint32), ("frame_h", C.c_int), ("frame_w", C.c_int), ("clahe", C.c_int), ("affine", C.c_int), ("filter_type", C.c_int),
     ]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 2        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 3        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),

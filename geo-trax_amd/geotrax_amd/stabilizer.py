@@ -30,15 +30,18 @@ class Stabilizer:
                  ctx: _lib.Context | None = None, **unused):
         if detector_name != "orb":
             raise NotImplementedError(f"detector_name='{detector_name}': only 'orb' is implemented on the GPU path")
-        if matcher_name != "bf" or filter_type != "ratio":
-            raise NotImplementedError("only matcher_name='bf' with filter_type='ratio' is implemented")
-        if transformation_type != "projective":
-            raise NotImplementedError("only transformation_type='projective' is implemented")
+        if matcher_name != "bf":
+            raise NotImplementedError(f"matcher_name='{matcher_name}': only 'bf' (exact brute force) is implemented")
+        if filter_type not in ("ratio", "none"):
+            raise NotImplementedError(f"filter_type='{filter_type}': only 'ratio' and 'none' are implemented")
+        if transformation_type not in ("projective", "affine"):
+            raise ValueError(f"transformation_type='{transformation_type}' (choices: projective, affine)")
         self.ctx = ctx or _lib.default_context()
         self._kw = dict(downsample_ratio=downsample_ratio, max_features=max_features, ref_multiplier=ref_multiplier,
                         filter_ratio=filter_ratio, ransac_threshold=ransac_epipolar_threshold, ransac_max_iter=ransac_max_iter,
                         ransac_confidence=ransac_confidence, mask_use=int(mask_use), mask_margin_ratio=mask_margin_ratio,
-                        fast_threshold=fast_threshold, n_levels=n_levels, scale_factor=scale_factor, seed=seed, clahe=int(bool(clahe)))
+                        fast_threshold=fast_threshold, n_levels=n_levels, scale_factor=scale_factor, seed=seed, clahe=int(bool(clahe)),
+                        affine=int(transformation_type == "affine"), filter_type=int(filter_type == "none"))
         self.min_good, self.min_inl = min_good_match_count_warning, min_inliers_match_count_warning
         self.handle = None
         self.frame_hw = None

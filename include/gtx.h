@@ -35,8 +35,9 @@ extern "C" {
 
 /* 2: gtx_det_config.fp32_split, gtx_tracker_config.{delta_t, inertia, use_byte, min_hits}, gtx_stab_config.clahe appended;
  *    gtx_tracker_replay, gtx_op_clahe, gtx_warp_frame_dev, gtx_yuv420_to_bgr_dev, gtx_stabilizer_{pattern, last_ms} added.
- *    A binder checks gtx_abi_version() against the header it was written for before passing any struct. */
-#define GTX_ABI_VERSION 2
+ *    A binder checks gtx_abi_version() against the header it was written for before passing any struct.
+ * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort). */
+#define GTX_ABI_VERSION 3
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -278,6 +279,10 @@ typedef struct gtx_stab_config {
   uint32_t seed;               /* RANSAC sampling seed */
   int frame_h, frame_w;
   int clahe;                   /* stabilo clahe (default.yaml:105): cv2.createCLAHE(2.0, (8, 8)) on the working gray image */
+  int affine;                  /* stabilo transformation_type (default.yaml:121): 0 = projective, 1 = affine (3-point samples,
+                                  six-parameter refit; the matrix handed back is 3x3 with last row 0 0 1) */
+  int filter_type;             /* stabilo filter_type (default.yaml:117): 0 = ratio (Lowe, filter_ratio), 1 = none (every query
+                                  keypoint's nearest neighbour goes to the estimator) */
 } gtx_stab_config;
 
 int gtx_stabilizer_create(gtx_ctx* ctx, const gtx_stab_config* cfg, gtx_stabilizer** out);

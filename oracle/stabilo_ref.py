@@ -262,11 +262,12 @@ def extract(gray: np.ndarray, boxes_xywh, cfg: dict, max_features: int, pattern:
 _POP = np.array([bin(i).count("1") for i in range(256)], dtype=np.int32)
 
 
-def match(desc_q: np.ndarray, desc_t: np.ndarray, ratio: float):
+def match(desc_q: np.ndarray, desc_t: np.ndarray, ratio: float, keep_all: bool = False):
     """Hamming 2-NN of every query against the train set (ties -> lowest index), Lowe ratio test in
-    fp32. Returns (q_idx, t_idx, dist) of the good matches in query order."""
+    fp32. Returns (q_idx, t_idx, dist) of the good matches in query order. keep_all (stabilo filter_type: none,
+    default.yaml:117): every query's nearest neighbour, no test."""
     nq, nt = len(desc_q), len(desc_t)
-    if nq == 0 or nt < 2:
+    if nq == 0 or nt < (1 if keep_all else 2):
         return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
     qi, ti, di = [], [], []
     for s in range(0, nq, 256):
@@ -275,7 +276,7 @@ def match(desc_q: np.ndarray, desc_t: np.ndarray, ratio: float):
         d1 = d[np.arange(len(b)), b]
         d[np.arange(len(b)), b] = 1 << 30
         d2 = d.min(1)
-        good = d1.astype(np.float32) < np.float32(ratio) * d2.astype(np.float32)
+        good = np.ones(len(b), bool) if keep_all else d1.astype(np.float32) < np.float32(ratio) * d2.astype(np.float32)
         qi.append(np.nonzero(good)[0] + s)
         ti.append(b[good])
         di.append(d1[good])
@@ -297,10 +298,12 @@ def _denorm(Hn, cx, cy, sc):
     return np.linalg.inv(T) @ Hn @ T
 
 
-def refine_homography(H0, p, q, cx, cy, sc, thr):
+def refine_homography(H0, p, q, cx, cy, sc, thr, affine=False):
     """Iteratively re-weighted Gauss-Newton on the transfer error (Tukey biweight, scale from the
     median residual, support = matches within 3 thresholds of H0), h33 = 1, normalised
-    coordinates. Mirrors refine_homography() in csrc/stabilizer.hip."""
+    coordinates. Mirrors refine_homography() in csrc/stabilizer.hip. affine: h31 = h32 = 0 stay, six
+    parameters move, three matches suffice (stabilo transformation_type: affine, default.yaml:121)."""
+    npar, min_pts = (6, 3) if affine else (8, 4)
     T = np.array([[sc, 0, -sc * cx], [0, sc, -sc * cy], [0, 0, 1.0]])
     h = T @ H0 @ np.linalg.inv(T)
     h = (h / h[2, 2]).reshape(9).copy()
@@ -312,7 +315,7 @@ def refine_homography(H0, p, q, cx, cy, sc, thr):
 
     rx, ry, w = res(h)
     sup = np.nonzero((np.abs(w) > 1e-9) & (rx * rx + ry * ry <= (3.0 * thr * sc) ** 2))[0]
-    if len(sup) < 4:
+    if len(sup) < min_pts:
         return None, 0
     for _ in range(8):
         rx, ry, w = res(h)
@@ -327,19 +330,20 @@ def refine_homography(H0, p, q, cx, cy, sc, thr):
         z = np.zeros_like(iw)
         Jx = np.stack([x[i] * iw, y[i] * iw, iw, z, z, z, -px * x[i] * iw, -px * y[i] * iw], 1)
         Jy = np.stack([z, z, z, x[i] * iw, y[i] * iw, iw, -py * x[i] * iw, -py * y[i] * iw], 1)
+        Jx, Jy = Jx[:, :npar], Jy[:, :npar]
         A = (Jx * wt[:, None]).T @ Jx + (Jy * wt[:, None]).T @ Jy
         g = (Jx * (wt * rx[i])[:, None]).sum(0) + (Jy * (wt * ry[i])[:, None]).sum(0)
         try:
             d = np.linalg.solve(A, g)
         except np.linalg.LinAlgError:
             break
-        h[:8] -= d
+        h[:npar] -= d
         if np.abs(d).max() < 1e-14:
             break
     rx, ry, w = res(h)
     n_inl = int((rx * rx + ry * ry <= (thr * sc) ** 2).sum())
     H = np.linalg.inv(T) @ h.reshape(3, 3) @ T
-    return (H / H[2, 2], n_inl) if n_inl >= 4 else (None, 0)
+    return (H / H[2, 2], n_inl) if n_inl >= min_pts else (None, 0)
 
 
 def _errors(H, p, q):
@@ -349,10 +353,12 @@ def _errors(H, p, q):
     return dx * dx + dy * dy
 
 
-def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float, n_hyp: int, seed: int):
-    """pts_*: [n,2] float32 full-res pixels (query -> train). Returns (H 3x3 f64 or None, n_inliers)."""
+def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float, n_hyp: int, seed: int, affine: bool = False):
+    """pts_*: [n,2] float32 full-res pixels (query -> train). Returns (H 3x3 f64 or None, n_inliers).
+    affine: 3-point samples and an affine minimal solve instead of 4-point homographies; same scoring."""
     n = len(pts_q)
-    if n < 4:
+    ns = 3 if affine else 4
+    if n < ns:
         return None, 0
     p, q = pts_q.astype(np.float64), pts_t.astype(np.float64)
     cx, cy, sc = frame_wh[0] / 2.0, frame_wh[1] / 2.0, 2.0 / frame_wh[0]
@@ -360,23 +366,29 @@ def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float
     best_cost, best_H = None, None
     for hyp in range(n_hyp):
         idx, ctr = [], 0
-        while len(idx) < 4:
+        while len(idx) < ns:
             c = _hash(seed ^ _hash((hyp * 977 + ctr) & 0xFFFFFFFF)) % n
             ctr += 1
             if c not in idx:
                 idx.append(c)
         x, y = (p[idx, 0] - cx) * sc, (p[idx, 1] - cy) * sc
         u, v = (q[idx, 0] - cx) * sc, (q[idx, 1] - cy) * sc
-        A = np.zeros((8, 8))
-        rhs = np.zeros(8)
-        for i in range(4):
-            A[2 * i] = [x[i], y[i], 1, 0, 0, 0, -u[i] * x[i], -u[i] * y[i]]
-            A[2 * i + 1] = [0, 0, 0, x[i], y[i], 1, -v[i] * x[i], -v[i] * y[i]]
-            rhs[2 * i], rhs[2 * i + 1] = u[i], v[i]
-        try:
-            hvec = np.linalg.solve(A, rhs)
-        except np.linalg.LinAlgError:
-            continue
+        if affine:
+            M = np.stack([x, y, np.ones(3)], 1)
+            if not abs(np.linalg.det(M)) > 1e-9:
+                continue
+            hvec = np.concatenate([np.linalg.solve(M, u), np.linalg.solve(M, v), [0.0, 0.0]])
+        else:
+            A = np.zeros((8, 8))
+            rhs = np.zeros(8)
+            for i in range(4):
+                A[2 * i] = [x[i], y[i], 1, 0, 0, 0, -u[i] * x[i], -u[i] * y[i]]
+                A[2 * i + 1] = [0, 0, 0, x[i], y[i], 1, -v[i] * x[i], -v[i] * y[i]]
+                rhs[2 * i], rhs[2 * i + 1] = u[i], v[i]
+            try:
+                hvec = np.linalg.solve(A, rhs)
+            except np.linalg.LinAlgError:
+                continue
         H = _denorm(np.append(hvec, 1.0).reshape(3, 3), cx, cy, sc)
         if not abs(H[2, 2]) > 1e-12:
             continue
@@ -389,7 +401,7 @@ def ransac_homography(pts_q: np.ndarray, pts_t: np.ndarray, frame_wh, thr: float
             best_cost, best_H = cost, H
     if best_H is None:
         return None, 0
-    return refine_homography(best_H / best_H[2, 2], p, q, cx, cy, sc, float(np.float32(thr)))
+    return refine_homography(best_H / best_H[2, 2], p, q, cx, cy, sc, float(np.float32(thr)), affine)
 
 
 class StabilizerRef:
@@ -414,7 +426,8 @@ class StabilizerRef:
 
     def stabilize(self, frame_bgr, boxes=None):
         self.cur = extract(self._gray(frame_bgr), boxes, self.cfg, self.cfg["max_features"], self.pattern)
-        self.m = match(self.cur["desc"], self.ref["desc"], self.cfg["filter_ratio"])
+        self.m = match(self.cur["desc"], self.ref["desc"], self.cfg["filter_ratio"], keep_all=self.cfg.get("filter_type") == "none")
         qi, ti, _ = self.m
         return ransac_homography(self.cur["xy"][qi], self.ref["xy"][ti], (self.hw[1], self.hw[0]),
-                                 self.cfg["ransac_threshold"], self.n_hyp, self.cfg["seed"])
+                                 self.cfg["ransac_threshold"], self.n_hyp, self.cfg["seed"],
+                                 affine=self.cfg.get("transformation_type") == "affine")

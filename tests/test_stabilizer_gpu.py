@@ -178,3 +178,45 @@ def test_identical_frame_gives_identity_and_state_errors(gtx_ctx, seq):
     assert st.get_cur_trans_matrix() is None and st.get_cur_num_matches() == 0
     with pytest.raises(NotImplementedError):
         Stabilizer(HW, detector_name="sift")
+
+
+@pytest.mark.parametrize("opts", [dict(transformation_type="affine"), dict(filter_type="none"),
+                                  dict(transformation_type="affine", filter_type="none")])
+def test_affine_model_and_unfiltered_matches_equal_the_oracle(gtx_ctx, seq, opts):
+    """stabilo `transformation_type: affine` (default.yaml:121) and `filter_type: none` (default.yaml:117): same matches
+    as the oracle (with `none`: every query keypoint's nearest neighbour), same estimate from the same hypotheses; the
+    affine matrix has last row (0, 0, 1) exactly and, the synthetic camera being nearly a similarity, still lands within
+    1.5 px of the ground truth."""
+    from oracle.stabilo_ref import StabilizerRef
+
+    sc, fr = seq
+    st = _make(gtx_ctx, **opts)
+    ref = StabilizerRef(dict(CFG, **opts), HW, n_hyp=2048)
+    b0, b1 = sc.boxes(0), sc.boxes(40)
+    st.set_ref_frame(fr[0], b0)
+    ref.set_ref_frame(fr[0], b0)
+    st.stabilize(fr[40], b1)
+    H_ref, n_inl = ref.stabilize(fr[40], b1)
+    q, t, d = st.matches()
+    np.testing.assert_array_equal(q, ref.m[0])
+    np.testing.assert_array_equal(t, ref.m[1])
+    np.testing.assert_array_equal(d, ref.m[2])
+    if opts.get("filter_type") == "none":
+        assert len(q) == st.get_cur_num_keypoints()[1]
+    H = st.get_cur_trans_matrix()
+    assert H is not None and H_ref is not None
+    assert _grid_err(H, H_ref, HW) < 1e-3
+    assert abs(st.get_cur_inliers_count() - n_inl) <= 2
+    if opts.get("transformation_type") == "affine":
+        np.testing.assert_array_equal(H[2], [0.0, 0.0, 1.0])
+        assert _grid_err(H, np.linalg.inv(sc.camera(40)), HW) < 1.5
+    else:
+        assert _grid_err(H, np.linalg.inv(sc.camera(40)), HW) < 1.0
+
+
+def test_unsupported_stabilizer_choices_raise(gtx_ctx):
+    for kw in (dict(detector_name="sift"), dict(matcher_name="flann"), dict(filter_type="distance")):
+        with pytest.raises(NotImplementedError):
+            _make(gtx_ctx, **kw)
+    with pytest.raises(ValueError):
+        _make(gtx_ctx, transformation_type="similarity")
