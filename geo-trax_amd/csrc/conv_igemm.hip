@@ -122,20 +122,18 @@ void conv_igemm_kernel(const ConvGroup g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // XCD-aware logical block id: blocks b and b+8 share an XCD (speed only, never correctness);
-  // give each XCD a contiguous run of logical blocks so that the cout tiles of one pixel tile
-  // (same input patch) and neighbouring pixel tiles (shared halo) meet in one L2.
-  // launch header first, as one burst of scalar loads: block count, group size and every member's first block
-  const int nb = g.total_blocks, cnt = g.count;
+  // launch header first, as one burst of scalar loads: group size and every member's first block
+  const int cnt = g.count;
   int bb[kMaxGroup];
 #pragma unroll
   for (int i = 0; i < kMaxGroup; ++i) bb[i] = g.p[i].block_begin;
-  int L;
-  {
-    const int b = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  // XCD-aware logical block id: blocks b and b+8 share an XCD (speed only, never correctness); every XCD works through one
+  // contiguous range of logical blocks -- the cout tiles of one pixel tile (same input patch) and neighbouring pixel tiles
+  // (shared halo) meet in one L2 -- and the ranges hold equal work (ConvGroup::xcd_begin). Surplus blocks of the shorter
+  // ranges leave here.
+  const int xcd = blockIdx.x & 7;
+  const int L = g.xcd_begin[xcd] + (int)(blockIdx.x >> 3);
+  if (L >= g.xcd_begin[xcd + 1]) return;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
@@ -484,6 +482,31 @@ void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
     total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
   }
   g.total_blocks = total;
+  // XCD ranges of equal work. Work of a block = its K depth (members share taps, chunk and tile): with equal counts the
+  // detection head's first stage gave XCD 0 only 8-chunk blocks of the 240x240 level and XCD 7 all the 32-chunk blocks of
+  // the 60x60 level, and the launch lasted as long as XCD 7 needed (471 us instead of 290).
+  double W = 0.0;
+  for (int i = 0; i < g.count; ++i) W += (double)((i + 1 < g.count ? g.p[i + 1].block_begin : total) - g.p[i].block_begin) * g.p[i].Cin;
+  g.xcd_begin[0] = 0;
+  g.xcd_begin[8] = total;
+  for (int k = 1; k < 8; ++k) {
+    const double target = W * k / 8.0;
+    double cum = 0.0;
+    int at = total;
+    for (int i = 0; i < g.count; ++i) {
+      const int n = (i + 1 < g.count ? g.p[i + 1].block_begin : total) - g.p[i].block_begin;
+      const double w = (double)n * g.p[i].Cin;
+      if (cum + w >= target) {
+        at = g.p[i].block_begin + std::min(n, (int)std::floor((target - cum) / g.p[i].Cin + 0.5));
+        break;
+      }
+      cum += w;
+    }
+    g.xcd_begin[k] = std::max(at, g.xcd_begin[k - 1]);
+  }
+  int longest = 0;
+  for (int k = 0; k < 8; ++k) longest = std::max(longest, g.xcd_begin[k + 1] - g.xcd_begin[k]);
+  g.grid_blocks = 8 * longest;
 }
 
 double conv_flops(const ConvProblem& p, int ks) {
@@ -500,7 +523,7 @@ void launch_t(const ConvGroup& g, hipStream_t stream) {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
   });
-  hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
   GTX_HIP(hipGetLastError());
 }
 

@@ -48,6 +48,12 @@ struct ConvGroup {
   ConvProblem p[kMaxGroup];
   int count;
   int total_blocks;
+  // Hardware block b runs on XCD b & 7 and is that XCD's block number b >> 3; it takes logical block
+  // xcd_begin[b & 7] + (b >> 3) and leaves at once when that is past xcd_begin[(b & 7) + 1]. The ranges are contiguous in
+  // member order (an XCD's L2 sees neighbouring tiles of as few members as possible) and hold equal WORK, not equal
+  // counts: blocks of a member with a deeper K loop count for more (conv_group_finalize). grid_blocks = 8 x the longest range.
+  int xcd_begin[9];
+  int grid_blocks;
 };
 
 // Kernel family selector; every member of a grouped launch shares one config.

@@ -102,17 +102,18 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // launch header first, as one burst of scalar loads: block count, group size and every member's first block
-  const int nb = g.total_blocks, cnt = g.count;
+  // launch header first, as one burst of scalar loads: group size and every member's first block
+  const int cnt = g.count;
   int bb[kMaxGroup];
 #pragma unroll
   for (int i = 0; i < kMaxGroup; ++i) bb[i] = g.p[i].block_begin;
-  int L;   // XCD-aware logical block id (conv_igemm.hip)
-  {
-    const int b = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  // XCD-aware logical block id: blocks b and b+8 share an XCD (speed only, never correctness); every XCD works through one
+  // contiguous range of logical blocks -- the cout tiles of one pixel tile (same input patch) and neighbouring pixel tiles
+  // (shared halo) meet in one L2 -- and the ranges hold equal work (ConvGroup::xcd_begin). Surplus blocks of the shorter
+  // ranges leave here.
+  const int xcd = blockIdx.x & 7;
+  const int L = g.xcd_begin[xcd] + (int)(blockIdx.x >> 3);
+  if (L >= g.xcd_begin[xcd + 1]) return;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
@@ -395,7 +396,7 @@ void launch_t(const ConvGroup& g, hipStream_t stream) {
   std::call_once(once, [&] {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
   });
-  hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
   GTX_HIP(hipGetLastError());
 }
 

@@ -650,6 +650,7 @@ void Detector::profile(int nb, int iters, std::vector<std::string>& names, std::
   std::vector<hipEvent_t> ev(ops_.size() + 1);
   for (auto& e : ev) GTX_HIP(hipEventCreate(&e));
   std::map<std::string, size_t> idx;
+  const bool per_op = std::getenv("GTX_PROFILE_PER_OP") != nullptr;   // one line per launch (its module path) instead of per kernel family
   auto slot = [&](const std::string& fam) {
     auto it = idx.find(fam);
     if (it != idx.end()) return it->second;
@@ -671,7 +672,7 @@ void Detector::profile(int nb, int iters, std::vector<std::string>& names, std::
     for (size_t i = 0; i < ops_.size(); ++i) {
       float t = 0.f;
       GTX_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
-      const size_t k = slot(ops_[i].family);
+      const size_t k = slot(per_op ? (i < 10 ? "0" : "") + std::to_string(i) + " " + ops_[i].name : ops_[i].family);
       launches[k] += 1;
       ms[k] += t;
       flops[k] += ops_[i].flops;

@@ -19,7 +19,7 @@ p = ctx.dev_alloc(frames.nbytes); ctx.dev_upload(p, frames)
 det.detect_dev(p, nb)
 det.profile(nb, 2)
 tot = 0
-for f in sorted(det.profile(nb, iters), key=lambda d: -d['total_ms']):
+for f in sorted(det.profile(nb, iters), key=(lambda d: d["kernel"]) if os.environ.get("GTX_PROFILE_PER_OP") else (lambda d: -d["total_ms"])):
     us = 1000 * f['total_ms'] / f['launches']
     tot += f['total_ms'] / iters
     print(f"{f['kernel']:50s} {f['launches'] // iters:3d} launches/pass {us:8.1f} us avg {f['flops'] / max(f['total_ms'], 1e-9) / 1e9:8.1f} TF/s {f['bytes'] / max(f['total_ms'], 1e-9) / 1e6:8.0f} GB/s")
