@@ -32,8 +32,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #ifdef GTX_CLOCK_STAMP
-// Diagnostic build only (`make stamp`, tools/clock_probe.py): shader-clock and 100 MHz wall-clock ticks spent inside the K loop,
+// Diagnostic builds only (`make stamp`, tools/clock_probe.py): shader-clock and 100 MHz wall-clock ticks spent inside the K loop,
 // summed over workgroups, to read the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
+// GTX_CLOCK_STAMP=1 (libgtx_stamp.so): one pair of stamps around the K loop; =2 (libgtx_stamp2.so): a stamp after every phase too.
 // The sums live in a buffer of their own; no output value depends on them.
 __device__ unsigned long long g_clock_stamp[8];   // [0..2] loop cycles, 100 MHz ticks, workgroups; [3..7] per-phase cycles of wave 0
 #endif
@@ -269,7 +270,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #ifdef GTX_CLOCK_STAMP
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef GTX_CLOCK_STAMP
+#if defined(GTX_CLOCK_STAMP) && GTX_CLOCK_STAMP >= 2   /* per-phase stamps: they serialise the loop (libgtx_stamp2.so) */
 #define GTXS_STAMP(T)                                                                            \
   unsigned long long T;                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                             \

@@ -8,7 +8,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAMP = os.path.join(ROOT, "geo-trax_amd", "build", "libgtx_stamp.so")
+STAMP = os.path.join(ROOT, "geo-trax_amd", "build", "libgtx_stamp2.so" if os.environ.get("GTX_STAMP_PHASES") else "libgtx_stamp.so")
 os.environ["GTX_LIB"] = STAMP
 sys.path.insert(0, os.path.join(ROOT, "geo-trax_amd"))
 from geotrax_amd import _lib, ops  # noqa: E402
@@ -29,7 +29,7 @@ def read():
 
 LAYERS = [("h0.s1", 128, 192, 3, 1, 240), ("h0.s2c", 128, 128, 3, 1, 240), ("m4.m", 64, 64, 3, 1, 240), ("m6.m", 128, 128, 3, 1, 120),
           ("m8.m", 256, 256, 3, 1, 60), ("m5", 128, 256, 3, 2, 240), ("m4.cv2", 256, 128, 1, 1, 240), ("m9.cv2", 1024, 512, 1, 1, 60)]
-print(f"# batch {NB}, {SECS:.0f} s of back-to-back launches per layer on random data; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz")
+print(f"# batch {NB}, {SECS:.0f} s of back-to-back launches per layer on random data (GTX_TIME_ZEROS=1: on zeros); clock = d(s_memtime) / d(s_memrealtime) x 100 MHz")
 for nm, cin, cout, k, s, h in LAYERS:
     ops.conv2d_time(2, NB, h, h, cin, cout, k, s, iters=20, ctx=ctx)
     read()
@@ -43,4 +43,5 @@ for nm, cin, cout, k, s, h in LAYERS:
           f"   ({n} workgroups stamped, {c / max(n, 1):9.0f} cycles per K loop)")
     nch = cin // (32 if (k == 1 and cin % 32 == 0) else 16)
     names = ["barrier 1", "load wait", "commit", "barrier 2", "prefetch issue + matrix"]
-    print("           per chunk, wave 0: " + ", ".join(f"{nm_} {p / max(n, 1) / nch:6.0f}" for nm_, p in zip(names, ph)))
+    if os.environ.get("GTX_STAMP_PHASES"):
+        print("           per chunk, wave 0: " + ", ".join(f"{nm_} {p / max(n, 1) / nch:6.0f}" for nm_, p in zip(names, ph)))
