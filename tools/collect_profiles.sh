@@ -15,6 +15,7 @@ cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.log
 python bench.py --tracker botsort --no-cpu-baseline --no-f16-line > $O/bench_botsort.json 2>/dev/null
 python bench.py --tracker ocsort --no-cpu-baseline --no-f16-line > $O/bench_ocsort.json 2>/dev/null
+python bench.py --tracker deepocsort --no-cpu-baseline --no-f16-line > $O/bench_deepocsort.json 2>/dev/null
 python bench.py --fp32 exact --no-cpu-baseline --no-f16-line --steps 60 > $O/bench_fp32_exact.json 2>/dev/null
 python bench.py --half 1 --no-cpu-baseline > $O/bench_f16.json 2>/dev/null
 python bench.py --workload detect --batch 1 --det-streams 1 --no-cpu-baseline --no-f16-line > $O/bench_detect_b1.json 2>/dev/null
@@ -25,4 +26,9 @@ python bench.py --workload warp > $O/bench_warp.json 2>/dev/null
 python bench.py --workload extract+georef > $O/bench_extract_georef.json 2>/dev/null
 for p in f32s f16 f32; do python tools/op_profile.py 2 $p 10 > $O/op_profile_${p}_b2.txt 2>/dev/null; done
 python tools/conv_sweep.py 1920 2 all f32s f16 > $O/conv_layer_sweep_b2.txt 2>/dev/null
+GTX_TIME_ZEROS=1 python tools/conv_sweep.py 1920 2 all f32s > $O/conv_layer_sweep_b2_zeros.txt 2>/dev/null
+GTX_PROFILE_PER_OP=1 python tools/op_profile.py 2 f32s 10 > $O/op_profile_per_launch_f32s_b2.txt 2>/dev/null
+python tools/clock_probe.py 2 2 > $O/conv_clock.txt 2>/dev/null
+GTX_TIME_ZEROS=1 python tools/clock_probe.py 2 2 > $O/conv_clock_zeros.txt 2>/dev/null
+GTX_STAMP_PHASES=1 python tools/clock_probe.py 2 1 > $O/conv_clock_phases.txt 2>/dev/null
 ls $O
