@@ -546,6 +546,13 @@ void launch_dt(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) {
   GTX_CHECK(g.count >= 1 && g.count <= kMaxGroup, "conv: bad group size %d", g.count);
   if (g.total_blocks == 0) return;
+  for (int i = 0; i < g.count; ++i) {
+    const ConvProblem& p = g.p[i];
+    if (p.c_split == 0) continue;
+    GTX_CHECK(cfg.variant == 2 && cfg.ks == 1, "conv: a second (upsampled) source needs the split-f16x3 1x1 kernel");
+    GTX_CHECK(p.in2 && p.c_split % cfg.kc == 0 && p.c_split < p.Cin && p.H % 2 == 0 && p.W % 2 == 0 && p.in2_cstride % 4 == 0 && p.in2_coff % 4 == 0,
+              "conv: bad second source (c_split=%d, %dx%d)", p.c_split, p.W, p.H);
+  }
   if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);

@@ -39,6 +39,12 @@ struct ConvProblem {
   int act;              // 1 = SiLU, 0 = identity
   int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8)
   int n_ct;             // cout tiles (Cout / BN)
+  // Optional second source (split-f16x3 1x1 kernels only): input channels [0, c_split) are the nearest-neighbour 2x
+  // upsampling of `in2` ([N][H/2][W/2][in2_cstride], slice at in2_coff) and are read from there at (y/2, x/2); channels
+  // [c_split, Cin) come from `in` as usual. This is torch's Upsample + Concat feeding a C2f's first conv without the
+  // upsampled copy ever being written (YOLOv8 model.10-12 and model.13-15). c_split = 0: off.
+  const void* in2;
+  int in2_cstride, in2_coff, c_split;
   int block_begin;      // first logical block of this problem inside a grouped launch
   float acc_scale;      // DT_F32S: inverse of the power of two the packed weights were scaled by (else 1)
 };

@@ -132,9 +132,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;
 
   const float* __restrict__ in = static_cast<const float*>(P.in);
+  const float* __restrict__ in2 = static_cast<const float*>(P.in2);
   const int nchunks = P.Cin / KC;
 
   long goff[Tile::PATCH_SLOTS];   // element offset of the unit's 8 floats, -1 = zero fill
+  long goff2[Tile::PATCH_SLOTS];  // 1x1 only: the same unit in the half-resolution second source (ConvProblem::in2)
   int loff[Tile::PATCH_SLOTS];    // LDS byte offset of the unit's hi chunk, -1 = slot unused
   int lchk[Tile::PATCH_SLOTS];    // ... and of its lo chunk
 #pragma unroll
@@ -146,6 +148,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     const bool used = qid < Tile::PATCH_UNITS;
     const bool inb = used && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
     goff[s] = inb ? ((long)(n * P.H + iy) * P.W + ix) * P.in_cstride + P.in_coff + c * 8 : -1;
+    goff2[s] = (KS == 1 && inb) ? ((long)(n * (P.H >> 1) + (iy >> 1)) * (P.W >> 1) + (ix >> 1)) * P.in2_cstride + P.in2_coff + c * 8 : -1;
     loff[s] = used ? p * RB + ((c ^ Tile::swz(p)) << 4) : -1;
     lchk[s] = used ? p * RB + (((CPR + c) ^ Tile::swz(p)) << 4) : -1;
   }
@@ -157,10 +160,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #define GTXS_PREFETCH(CHUNK)                                                                 \
   {                                                                                          \
     const int c0__ = (CHUNK) * KC;                                                           \
+    const bool up__ = KS == 1 && c0__ < P.c_split;   /* uniform: this chunk's channels come from the upsampled source */ \
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
       uint4 va__ = make_uint4(0, 0, 0, 0), vb__ = make_uint4(0, 0, 0, 0);                    \
       if (goff[s] >= 0) {                                                                    \
-        const uint4* src__ = reinterpret_cast<const uint4*>(in + goff[s] + c0__);            \
+        const uint4* src__ = reinterpret_cast<const uint4*>(up__ ? in2 + goff2[s] + c0__ : in + goff[s] + c0__); \
         va__ = src__[0];                                                                     \
         vb__ = src__[1];                                                                     \
       }                                                                                      \

@@ -87,7 +87,7 @@ std::vector<float> to_ohwi(const HostTensor& t) {
 
 // Emits one Conv op: weights "<name>.weight" (OIHW) / "<name>.bias" (optional).
 View Detector::conv(const std::string& name, const View& x, int stride, bool act, const View* out_slice,
-                    const View* residual) {
+                    const View* residual, const View* up_src) {
   const HostTensor& w = tensor(name + ".weight");
   GTX_CHECK(w.shape.size() == 4 && w.shape[2] == w.shape[3], "%s: expected OIHW square kernel", name.c_str());
   const int cout = (int)w.shape[0], cin = (int)w.shape[1], ks = (int)w.shape[2];
@@ -123,6 +123,11 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   p.res_coff = residual ? residual->coff : 0;
   p.act = act ? 1 : 0;
   p.acc_scale = acc_scale;
+  if (up_src) {
+    GTX_CHECK(ks == 1 && stride == 1 && op.cfg.variant == 2 && up_src->h * 2 == x.h && up_src->w * 2 == x.w && up_src->c < cin,
+              "%s: upsampled source does not fit", name.c_str());
+    p.in2 = up_src->ptr; p.in2_cstride = up_src->cstride; p.in2_coff = up_src->coff; p.c_split = up_src->c;
+  }
   op.grp.count = 1;
   op.family = conv_kernel_name(op.cfg);
   ops_.push_back(op);
@@ -130,14 +135,14 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   return out;
 }
 
-View Detector::c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice) {
+View Detector::c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice, const View* up_src) {
   const HostTensor& w1 = tensor(pfx + ".cv1.conv.weight");
   const int c = (int)w1.shape[0] / 2;
   int n = 0;
   while (has(pfx + ".m." + std::to_string(n) + ".cv1.conv.weight")) ++n;
   View cat = new_view(x.h, x.w, (2 + n) * c);
   View first = cat.slice(0, 2 * c);
-  conv(pfx + ".cv1.conv", x, 1, true, &first, nullptr);
+  conv(pfx + ".cv1.conv", x, 1, true, &first, nullptr, up_src);
   View tmp = new_view(x.h, x.w, c);
   for (int k = 0; k < n; ++k) {
     const std::string m = pfx + ".m." + std::to_string(k);
@@ -243,12 +248,15 @@ void Detector::build_graph() {
     op.out = dst;
     ops_.push_back(op);
   };
-  upsample("model.10", s9, cat11.slice(0, c9));
+  // torch's Upsample + Concat in front of model.12 / model.15: the split-f16x3 path reads the low-resolution tensor in
+  // place from the C2f's first 1x1 conv (ConvProblem::in2), the other arithmetics write the upsampled copy
+  const bool fuse_up = conv_dtype_ == DT_F32S && c9 % 32 == 0 && c12 % 32 == 0;
+  if (!fuse_up) upsample("model.10", s9, cat11.slice(0, c9));
   View cat17 = new_view(H / 16, W / 16, c16 + c12);
   View s12 = cat17.slice(c16, c12);
-  c2f("model.12", cat11, false, &s12);
-  upsample("model.13", s12, cat14.slice(0, c12));
-  View a15 = c2f("model.15", cat14, false, nullptr);
+  c2f("model.12", cat11, false, &s12, fuse_up ? &s9 : nullptr);
+  if (!fuse_up) upsample("model.13", s12, cat14.slice(0, c12));
+  View a15 = c2f("model.15", cat14, false, nullptr, fuse_up ? &s12 : nullptr);
   View s16 = cat17.slice(0, c16);
   conv("model.16.conv", a15, 2, true, &s16, nullptr);
   View a18 = c2f("model.18", cat17, false, nullptr);
@@ -366,7 +374,7 @@ void Detector::set_batch(int nb) {
     for (int i = 0; i < op.grp.count; ++i) {
       const ConvProblem& p = op.grp.p[i];
       op.flops += conv_flops(p, op.cfg.ks);
-      op.bytes += ((double)p.N * p.H * p.W * p.Cin + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
+      op.bytes += ((double)p.N * p.H * p.W * (p.Cin - 0.75 * p.c_split) + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
                   (double)p.Cout * p.Cin * op.cfg.ks * op.cfg.ks * es_;
     }
   }

@@ -93,9 +93,11 @@ class Detector {
   const HostTensor& tensor(const std::string& name) const;
   bool has(const std::string& name) const { return tensors_.count(name) != 0; }
   // graph building
+  // up_src: the leading up_src->c channels of x are the 2x nearest upsampling of *up_src and are read from there
+  // (split-f16x3 1x1 convs; ConvProblem::in2) -- the slice of x they would occupy is never written
   View conv(const std::string& name, const View& x, int stride, bool act, const View* out_slice,
-            const View* residual);
-  View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice);
+            const View* residual, const View* up_src = nullptr);
+  View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice, const View* up_src = nullptr);
   void build_graph();
   void run_op(const Op& op, int nb, hipStream_t s);
   void run_forward(int nb, hipStream_t s, bool traced = false);

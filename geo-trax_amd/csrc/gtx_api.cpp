@@ -205,6 +205,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.res_cstride = d->cout; p.res_coff = 0;
   p.act = d->act;
   p.acc_scale = acc_scale;
+  p.in2 = nullptr; p.in2_cstride = p.in2_coff = p.c_split = 0;
   st.g.count = 1;
   conv_group_finalize(st.g, st.cfg);
 }
