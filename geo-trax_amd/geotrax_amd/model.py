@@ -133,6 +133,8 @@ class YOLO:
 
     # ---- lazy construction, like ultralytics' predictor setup on the first call
     def _detector(self, frame_hw, kw) -> Detector:
+        if kw.get("augment"):          # ultralytics.augment (default.yaml:243): test-time augmentation changes the detections
+            raise NotImplementedError("augment=True (test-time augmentation) is not implemented")
         key = (tuple(frame_hw),) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
         if self._det is None or key != self._det_key:
             if self._det is not None:

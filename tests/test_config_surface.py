@@ -83,3 +83,16 @@ def test_cli_flags_log_path_and_metadata_sections(tmp_path):
                           "paths", "visualization", "plotting", "batch"]
     assert meta["paths"] == {"ortho_folder": "ORTHO", "master_folder": None, "segmentation_folder": None}
     assert meta["class_names"]["mapping"] == {0: "car", 1: "bus", 2: "truck", 3: "motorcycle"} and meta["tracker"]["active"] == "botsort"
+
+
+def test_inference_options_that_would_change_the_detections_are_refused_not_ignored():
+    """ultralytics.augment (default.yaml:243) selects test-time augmentation: a different set of detections. The host class
+    raises instead of silently running the plain forward pass."""
+    import numpy as np
+    import pytest
+    from geotrax_amd.model import YOLO
+
+    m = YOLO.__new__(YOLO)
+    m._det = m._det_key = None
+    with pytest.raises(NotImplementedError):
+        m._detector((64, 64), {"augment": True, "imgsz": 64})
