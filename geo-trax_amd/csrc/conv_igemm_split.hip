@@ -30,6 +30,23 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifdef GTX_SHAPE_PROBE
+// TIMING PROBE ONLY (results are wrong): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs of the same FLOP count on the same
+// operand registers, to read what the other instruction shape does to the clock inside this kernel's loop.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx16 mfma_probe(half8 a, half8 b, floatx16 c) {
+  floatx4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
+  c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3]; c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3];
+  return c;
+}
+#define GTXS_MFMA(a, b, c) mfma_probe(a, b, c)
+#define GTXS_MFMA_PER_READ 2
+#else
+#define GTXS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define GTXS_MFMA_PER_READ 1
+#endif
 
 #ifdef GTX_CLOCK_STAMP
 // Diagnostic builds only (`make stamp`, tools/clock_probe.py): shader-clock and 100 MHz wall-clock ticks spent inside the K loop,
@@ -259,13 +276,13 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       _Pragma("unroll") for (int m = 0; m < WM; ++m)                                           \
         _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                       \
           /* small terms first, then the leading one */                                       \
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0); \
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bl[st & 1][m], acc[m][j], 0, 0, 0); \
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][j], bh[st & 1][m], acc[m][j], 0, 0, 0); \
+          acc[m][j] = GTXS_MFMA(al[st & 1][j], bh[st & 1][m], acc[m][j]); \
+          acc[m][j] = GTXS_MFMA(ah[st & 1][j], bl[st & 1][m], acc[m][j]); \
+          acc[m][j] = GTXS_MFMA(ah[st & 1][j], bh[st & 1][m], acc[m][j]); \
         }                                                                                      \
       /* one fragment read of the next step behind every MFMA of this one */                   \
       _Pragma("unroll") for (int i__ = 0; i__ < 3 * WM * WN; ++i__) {                          \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, GTXS_MFMA_PER_READ, 0);                    \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
       }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
