@@ -225,6 +225,25 @@ int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const flo
   });
 }
 
+int gtx_op_conv_xcd_ranges(int n_members, const int* blocks, const int* cin, int xcd_begin[9], int* grid_blocks) {
+  return guarded([&] {
+    need(blocks, "blocks"); need(cin, "cin"); need(xcd_begin, "xcd_begin");
+    if (n_members < 1 || n_members > gtx::kMaxGroup) gtx::fail(GTX_ERR_INVALID, "1..%d members", gtx::kMaxGroup);
+    gtx::ConvGroup g{};
+    gtx::ConvConfig c{};
+    c.bn = 64; c.th = 8; c.tw = 16;                       // one workgroup per (8 x 16 pixel tile, 64-cout tile): blocks[i] = tiles_y
+    g.count = n_members;
+    for (int i = 0; i < n_members; ++i) {
+      if (blocks[i] < 1 || cin[i] < 1) gtx::fail(GTX_ERR_INVALID, "member %d: blocks and cin must be positive", i);
+      gtx::ConvProblem& p = g.p[i];
+      p.N = 1; p.Wo = 16; p.Ho = 8 * blocks[i]; p.Cout = 64; p.Cin = cin[i];
+    }
+    gtx::conv_group_finalize(g, c);
+    for (int k = 0; k < 9; ++k) xcd_begin[k] = g.xcd_begin[k];
+    if (grid_blocks) *grid_blocks = g.grid_blocks;
+  });
+}
+
 int gtx_op_conv2d_time(gtx_ctx* ctx, const gtx_conv_desc* d, int iters, float* ms_per_launch, double* flops) {
   return guarded([&] {
     need(ms_per_launch, "ms_per_launch");

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "gtx_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "gtx_op_conv2d": (C.c_int, [_P, C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "gtx_op_conv2d_time": (C.c_int, [_P, C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "gtx_op_conv_xcd_ranges": (C.c_int, [C.c_int, _P, _P, _P, _P]),
     "gtx_op_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gtx_op_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
     "gtx_gmc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

@@ -116,3 +116,15 @@ def clahe(gray: np.ndarray, ctx=None) -> np.ndarray:
     out = np.empty_like(g)
     check(ctx.lib.gtx_op_clahe(ctx.handle, ptr(g), g.shape[0], g.shape[1], ptr(out)))
     return out
+
+
+def conv_xcd_ranges(blocks, cin):
+    """How a grouped convolution launch of len(blocks) members is cut over the 8 XCDs (host only).
+    -> (xcd_begin [9] int32, grid_blocks)."""
+    lib = _lib.load()
+    b = np.ascontiguousarray(blocks, dtype=np.int32)
+    c = np.ascontiguousarray(cin, dtype=np.int32)
+    out = np.zeros(9, np.int32)
+    grid = C.c_int()
+    check(lib.gtx_op_conv_xcd_ranges(len(b), b.ctypes.data, c.ctypes.data, out.ctypes.data, C.addressof(grid)))
+    return out, grid.value

@@ -112,6 +112,11 @@ int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const flo
  * HIP events on the launch stream, plus the algorithmic FLOPs of one launch. */
 int gtx_op_conv2d_time(gtx_ctx* ctx, const gtx_conv_desc* d, int iters, float* ms_per_launch,
                        double* flops);
+/* Host only (no GPU call): how a grouped convolution launch is cut over the 8 XCDs. n_members problems of
+ * blocks[i] workgroups with cin[i] input channels each, in launch order. xcd_begin[0..8]: hardware block b takes
+ * logical block xcd_begin[b & 7] + (b >> 3) and exits when that reaches xcd_begin[(b & 7) + 1]; the ranges hold equal
+ * work (blocks weighted by their K depth), not equal counts. grid_blocks = 8 x the longest range. */
+int gtx_op_conv_xcd_ranges(int n_members, const int* blocks, const int* cin, int xcd_begin[9], int* grid_blocks);
 
 /* SPPF max-pool cascade (three 5x5/s1/p2 pools of ultralytics SPPF.forward): reads channels
  * [0,c) of x and writes the 5x5, 9x9 and 13x13 window maxima to channels [c,2c), [2c,3c),
