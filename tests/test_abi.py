@@ -70,3 +70,15 @@ def test_brief_table_equals_the_oracles_own():
     want = brief_pattern()
     np.testing.assert_array_equal(out, want)
     assert np.abs(want.astype(int)).max() <= 17 and len(np.unique(want[0].reshape(256, 4), axis=0)) > 250
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: make (a no-op when the library is up to date), load, ABI version, package import."""
+    import importlib
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    g = importlib.import_module("__graft_entry__")
+    g.build()
