@@ -43,7 +43,24 @@ __device__ __forceinline__ floatx16 mfma_probe(half8 a, half8 b, floatx16 c) {
 }
 #define GTXS_MFMA(a, b, c) mfma_probe(a, b, c)
 #define GTXS_MFMA_PER_READ 2
+#if GTX_SHAPE_PROBE >= 2
+#define GTXS_PROBE_EXTRA_READS(SLOT)                                                                      \
+      _Pragma("unroll") for (int m = 0; m < WM; ++m)                                                      \
+        bx[SLOT][m] = *reinterpret_cast<const half8*>(lds_patch + (p0 + m * PSUB + (tap__ / KS) * PW + (tap__ % KS)) * RB + ((c__ ^ 1) << 4)); \
+      _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                      \
+        ax[SLOT][j] = *reinterpret_cast<const half8*>(lds_w + (tap__ * BN + 32 * j + prow) * RB + ((c__ ^ 1) << 4));
+#define GTXS_THIRD_A(SLOT, j) ax[SLOT][j]
+#define GTXS_THIRD_B(SLOT, m) bx[SLOT][m]
+#define GTXS_READS_PER_STEP (3 * WM + 3 * WN)
 #else
+#define GTXS_PROBE_EXTRA_READS(SLOT)
+#define GTXS_THIRD_A(SLOT, j) ah[SLOT][j]
+#define GTXS_THIRD_B(SLOT, m) bh[SLOT][m]
+#endif
+#else
+#define GTXS_PROBE_EXTRA_READS(SLOT)
+#define GTXS_THIRD_A(SLOT, j) ah[SLOT][j]
+#define GTXS_THIRD_B(SLOT, m) bh[SLOT][m]
 #define GTXS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define GTXS_MFMA_PER_READ 1
 #endif
@@ -248,6 +265,9 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 
   constexpr int NSTEP = KS * KS * (CPR / 2);
   half8 bh[2][WM], bl[2][WM], ah[2][WN], al[2][WN];
+#if defined(GTX_SHAPE_PROBE) && GTX_SHAPE_PROBE >= 2   /* probe 2: 1.5 x the fragment reads as well (timing only) */
+  half8 bx[2][WM], ax[2][WN];
+#endif
 #define GTXS_LOAD_FRAGS(STEP, SLOT)                                                            \
     {                                                                                          \
       const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
@@ -264,6 +284,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
         ah[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + ((c__ ^ Tile::swz(nrow__)) << 4)); \
         al[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + (((CPR + c__) ^ Tile::swz(nrow__)) << 4)); \
       }                                                                                        \
+      GTXS_PROBE_EXTRA_READS(SLOT)                                                             \
     }
   // The matrix phase of one K chunk: fragment reads run one (tap, k-step) ahead of the 3 * WM * WN MFMAs that consume them.
 #define GTXS_MATRIX_PHASE()                                                                    \
@@ -278,7 +299,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           /* small terms first, then the leading one */                                       \
           acc[m][j] = GTXS_MFMA(al[st & 1][j], bh[st & 1][m], acc[m][j]); \
           acc[m][j] = GTXS_MFMA(ah[st & 1][j], bl[st & 1][m], acc[m][j]); \
-          acc[m][j] = GTXS_MFMA(ah[st & 1][j], bh[st & 1][m], acc[m][j]); \
+          acc[m][j] = GTXS_MFMA(GTXS_THIRD_A(st & 1, j), GTXS_THIRD_B(st & 1, m), acc[m][j]); \
         }                                                                                      \
       /* one fragment read of the next step behind every MFMA of this one */                   \
       _Pragma("unroll") for (int i__ = 0; i__ < 3 * WM * WN; ++i__) {                          \
