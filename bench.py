@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0
 # fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is the dense fp16 peak / 3
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0 / 3.0}
 DTYPE_NAME = {"f16": "f16", "f32": "f32", "f32s": "f32 (split-f16x3 MFMA)"}
+TRACKER_LABEL = {"bytetrack": "ByteTrack", "botsort": "BoT-SORT (GPU GMC)", "ocsort": "OC-SORT", "deepocsort": "Deep OC-SORT motion half (GPU GMC)"}
 GMC_TRACKERS = ("botsort", "deepocsort")   # trackers that take a camera-motion warp per frame (bench runs them with gmc_method: sparseOptFlow)
 H, W = 2160, 3840
 # seeded weights of the bench: only the stride-8 head fires, DFL biases give ~120 x 60 px boxes in 4K, and the class
@@ -700,8 +701,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic",
             "config": {
-                "workload": ("full extract: YOLOv8s + ByteTrack + homography stabilization on 3840x2160 frames, "
-                             f"{B} frame(s) per step (BASELINE configs[2]; metric 'detect+stabilize+track')" if extract else
+                "workload": (f"full extract: YOLOv8s + {TRACKER_LABEL[args.tracker]} + homography stabilization on 3840x2160 frames, "
+                             f"{B} frame(s) per step (BASELINE {'configs[2]' if world == 1 else 'configs[4]: frames of one clip over the ranks'}; metric 'detect+stabilize+track')" if extract else
                              f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
                 "arithmetic": {"f16": "fp16 activations and weights, fp16 MFMA, fp32 accumulate",
