@@ -1,6 +1,7 @@
 // C ABI of libgtx.so (see include/gtx.h). Everything here is a thin try/catch shim that turns
 // gtx::Error into a status code + thread-local message.
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -583,6 +584,9 @@ int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int str
   return guarded([&] {
     need(trk, "trk"); need(rows_per_frame, "rows_per_frame");
     if (n_recs > 0) need(recs, "recs");
+    if (row_cap > 0) {          // every row array is written unconditionally below
+      need(row_xyxy, "row_xyxy"); need(row_id, "row_id"); need(row_score, "row_score"); need(row_cls, "row_cls"); need(row_det_idx, "row_det_idx");
+    }
     const int tail = (with_gmc ? 7 : 0) + 10;
     if (max_det < 0 || stride != 1 + 6 * max_det + tail) gtx::fail(GTX_ERR_INVALID, "replay: stride %d does not match max_det %d", stride, max_det);
     std::vector<float> xyxy((size_t)4 * std::max(max_det, 1)), conf(std::max(max_det, 1));
@@ -590,7 +594,8 @@ int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int str
     int used = 0;
     for (int f = 0; f < n_recs; ++f) {
       const double* rec = recs + (size_t)f * stride;
-      const int n = std::min(std::max((int)rec[0], 0), max_det);
+      if (!std::isfinite(rec[0])) gtx::fail(GTX_ERR_INVALID, "replay: record %d has a non-finite detection count", f);
+      const int n = (int)std::min(std::max(rec[0], 0.0), (double)max_det);
       for (int i = 0; i < n; ++i) {
         const double* d = rec + 1 + 6 * i;
         xyxy[4 * i] = (float)d[0]; xyxy[4 * i + 1] = (float)d[1]; xyxy[4 * i + 2] = (float)d[2]; xyxy[4 * i + 3] = (float)d[3];
@@ -600,7 +605,7 @@ int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int str
       const double* gmc = (with_gmc && rec[stride - 17] > 0) ? rec + stride - 16 : nullptr;
       int k = 0;
       const int room = row_cap - used;
-      float* ox = row_xyxy ? row_xyxy + (size_t)4 * used : nullptr;
+      float* ox = row_xyxy + (size_t)4 * used;
       if (room <= 0 && n > 0) gtx::fail(GTX_ERR_INVALID, "replay: more than %d track rows", row_cap);
       if (trk->oc)
         trk->oc->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
@@ -609,6 +614,30 @@ int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int str
       rows_per_frame[f] = k;
       used += k;
     }
+  });
+}
+
+int gtx_op_linear_assignment(const float* cost, int rows, int cols, double cost_limit, int* row_to_col, int* col_to_row) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0) gtx::fail(GTX_ERR_INVALID, "linear assignment: negative size");
+    if (rows > 0 && cols > 0) need(cost, "cost");
+    if (rows > 0) need(row_to_col, "row_to_col");
+    for (size_t i = 0; i < (size_t)rows * cols; ++i)
+      if (!std::isfinite(cost[i])) gtx::fail(GTX_ERR_INVALID, "linear assignment: cost %zu is not finite", i);
+    std::vector<int> x, y;
+    if (cost_limit > 0 && std::isfinite(cost_limit)) {
+      gtx::lap_limited(cost, rows, cols, cost_limit, x, y);
+    } else {
+      std::vector<double> c((size_t)rows * cols);
+      for (size_t i = 0; i < c.size(); ++i) c[i] = cost[i];
+      gtx::lap_full(c, rows, cols, x);
+      y.assign(cols, -1);
+      for (int r = 0; r < rows; ++r)
+        if (x[r] >= 0) y[x[r]] = r;
+    }
+    for (int r = 0; r < rows; ++r) row_to_col[r] = x[r];
+    if (col_to_row)
+      for (int c = 0; c < cols; ++c) col_to_row[c] = y[c];
   });
 }
 

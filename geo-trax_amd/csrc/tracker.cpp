@@ -306,6 +306,10 @@ inline void xyxy_of(const Track& t, bool xywh_state, float out[4]) {
 
 }  // namespace
 
+void lap_limited(const float* cost, int rows, int cols, double limit, std::vector<int>& x, std::vector<int>& y) {
+  linear_assignment(std::vector<float>(cost, cost + (size_t)rows * cols), rows, cols, limit, x, y);
+}
+
 // Dense rectangular assignment, rows <= cols after an optional transpose: the classic shortest-augmenting-path Hungarian
 // method with row / column potentials (O(rows^2 cols), array scans only -- the sparse solver above pays a heap and an
 // edge list per feasible pair, which for a dense 130 x 140 OC-SORT cost matrix was 0.7 ms per frame).

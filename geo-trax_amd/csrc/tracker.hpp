@@ -36,6 +36,9 @@ class OcSortTracker {
 // Minimum-cost assignment of a dense rows x cols matrix that matches min(rows, cols) pairs (what
 // scipy.optimize.linear_sum_assignment / lap.lapjv(extend_cost=True) return). x[r] = column of row r or -1.
 void lap_full(const std::vector<double>& cost, int rows, int cols, std::vector<int>& x);
+// lap.lapjv(cost, extend_cost=True, cost_limit=limit) as ByteTrack / BoT-SORT call it: a pair is matched only below `limit`,
+// leaving a row or a column unmatched costs limit / 2 each. x[r] = column or -1, y[c] = row or -1 (tracker.cpp's sparse solver).
+void lap_limited(const float* cost, int rows, int cols, double limit, std::vector<int>& x, std::vector<int>& y);
 }  // namespace gtx
 
 struct gtx_tracker {

@@ -70,7 +70,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 3        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 4        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -126,6 +126,7 @@ _SIGNATURES = {
     "gtx_tracker_reset": (C.c_int, [_P]),
     "gtx_tracker_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "gtx_tracker_replay": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "gtx_op_linear_assignment": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "gtx_stabilizer_create": (C.c_int, [_P, C.POINTER(StabConfig), C.POINTER(_P)]),
     "gtx_op_clahe": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gtx_stabilizer_destroy": (None, [_P]),

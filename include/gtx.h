@@ -36,8 +36,9 @@ extern "C" {
 /* 2: gtx_det_config.fp32_split, gtx_tracker_config.{delta_t, inertia, use_byte, min_hits}, gtx_stab_config.clahe appended;
  *    gtx_tracker_replay, gtx_op_clahe, gtx_warp_frame_dev, gtx_yuv420_to_bgr_dev, gtx_stabilizer_{pattern, last_ms} added.
  *    A binder checks gtx_abi_version() against the header it was written for before passing any struct.
- * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort). */
-#define GTX_ABI_VERSION 3
+ * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort).
+ * 4: gtx_op_linear_assignment added. */
+#define GTX_ABI_VERSION 4
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -263,6 +264,13 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
 int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int stride, int max_det, int with_gmc,
                        int row_cap, int* rows_per_frame, float* row_xyxy, int* row_id, float* row_score,
                        int* row_cls, int* row_det_idx);
+
+/* The trackers' assignment solver on its own (host only, no GPU): what `lap.lapjv(cost, extend_cost=True, cost_limit=L)`
+ * returns for ultralytics/trackers/utils/matching.py:linear_assignment (lapx, pyproject.toml:58) when cost_limit > 0 -- a pair is
+ * matched only below L, an unmatched row or column costs L/2 -- and the plain minimum-cost assignment of min(rows, cols) pairs
+ * (scipy.optimize.linear_sum_assignment) when cost_limit <= 0. cost: rows x cols row-major; row_to_col[r] = column or -1;
+ * col_to_row (may be NULL) the inverse. Exposed so that tests can hold the solver against scipy on its own. */
+int gtx_op_linear_assignment(const float* cost, int rows, int cols, double cost_limit, int* row_to_col, int* col_to_row);
 
 /* ------------------------------------------------------------------ stabilizer
  * Stands in for stabilo.Stabilizer as used at extract.py:139,177-187 and

@@ -49,3 +49,32 @@ def test_two_ranks_on_one_gpu(mode, tracker):
     assert ("one clip per rank" in d["config"]["sharding"]) == (mode == "videos")
     if tracker == "botsort":
         assert "GMC" in d["config"]["tracker"]
+
+
+def test_configs3_extract_then_georeference_as_one_chained_run():
+    """BASELINE configs[3] inside the GPU test tier: the 150-frame 4K clip through extract, straight into
+    the georeference stage (RootSIFT registration against the synthetic orthophoto, row chain, CSV; geotrax/georeference.py:109-202)
+    as one run, also paced as a 30 fps stream. Asserts the registration error against the known orthophoto camera, the row
+    counts of both stages and that the stream keeps 30 fps."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "extract+georef", "--steps", "75", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-profile"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    c = d["config"]
+    assert "configs[3]" in c["workload"] and d["n_gpus"] == 1 and d["dtype"].startswith("f32")
+    assert c["frames"] == 150 and c["track_rows"] > 100 * c["frames"] and 0.9 * c["track_rows"] < c["csv_rows"] <= c["track_rows"] and c["vehicles"] > 100
+    reg = c["registration"]
+    assert reg["inliers"] > 500 and reg["inliers"] > 0.9 * reg["matches"] and reg["max_grid_error_px_vs_known_orthophoto"] < 0.25
+    assert d["value"] > 100
+    assert d["paced"]["stream_fps"] == 30.0 and d["paced"]["sustained_fps"] > 29.5     # 150 frames arriving at 30 fps leave the pipeline at 30 fps
+
+
+def test_configs1_detector_only_batch1_one_stream():
+    """BASELINE configs[1]: YOLOv8s HIP inference only on 3840x2160 frames, batch 1, one stream."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "detect", "--batch", "1", "--det-streams", "1", "--steps", "60",
+                        "--warmup", "10", "--no-cpu-baseline", "--no-profile", "--no-f16-line"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    c = d["config"]
+    assert "configs[1]" in c["workload"] and c["frames_per_step"] == 1 and c["net_input"] == [1920, 1920] and c["half"] is False
+    assert d["steps"] == 60 and d["value"] > 200 and c["detections_per_frame"] > 100

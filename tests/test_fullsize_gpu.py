@@ -1,8 +1,11 @@
 """Parity at BASELINE.json's full sizes (3840x2160 frames, 1920x1920 network input; fp32 -- the reference's own
-precision, as split-f16x3 and as exact-fp32 MFMA -- and fp16) through
-size-independent properties: the oracle cannot finish these sizes in seconds, so each check is an
-invariant of the operation itself (bit-identity between equivalent schedules, linearity and shift
-equivariance of a convolution on exact data, NMS postconditions, round trips, a known camera)."""
+precision, as split-f16x3 and as exact-fp32 MFMA -- and fp16).
+
+Two kinds of checks: (1) the oracle itself at full size -- one 4K frame through oracle/yolov8_ref.py (torch-CPU, under a
+second on the GPU box's host cores) layer by layer, raw head output and detections, and one 4K frame pair through
+oracle/stabilo_ref.py stage by stage, bit for bit (extract.py:153,177-187 at configs[1..3]'s sizes); (2) size-independent
+invariants of the operations (bit-identity between equivalent schedules, linearity and shift equivariance of a convolution
+on exact data, NMS postconditions, round trips, a known camera)."""
 import logging
 
 import numpy as np
@@ -267,3 +270,108 @@ def test_shard_mode_mask_moves_the_homography_by_less_than_a_pixel(gtx_ctx):
         errs.append(max(grid_diff(r.H, truth), grid_diff(s.H, truth)))
     print("exact vs shard mask, max grid difference per frame:", np.round(diffs, 3), "worst error vs the known camera:", np.round(max(errs), 3))
     assert max(diffs) < 1.0 and max(errs) < 2.0
+
+
+def _same_detections(a, b, conf_atol, box_atol):
+    """a, b: (xyxy, conf, cls). Same detections; the order may differ only between neighbours whose scores tie within
+    conf_atol (the smooth class branch of the seeded weights gives neighbouring anchors nearly equal scores)."""
+    assert len(a[1]) == len(b[1]) > 50, (len(a[1]), len(b[1]))
+    np.testing.assert_allclose(a[1], b[1], atol=conf_atol)
+    oa = np.lexsort((np.round(a[0][:, 0], 0), np.round(a[0][:, 1], 0)))
+    ob = np.lexsort((np.round(b[0][:, 0], 0), np.round(b[0][:, 1], 0)))
+    np.testing.assert_allclose(a[0][oa], b[0][ob], atol=box_atol)
+    np.testing.assert_array_equal(a[2][oa], b[2][ob])
+    moved = np.nonzero(oa != ob)[0]
+    assert len(moved) <= 0.1 * len(a[1])
+    for i, j in zip(oa[moved], ob[moved]):
+        assert abs(int(i) - int(j)) <= 2 and abs(a[1][i] - a[1][j]) < conf_atol, (i, j, a[1][i], a[1][j])
+    return len(moved)
+
+
+ORACLE_LAYERS = ["model.0.conv", "model.1.conv", "model.2", "model.3.conv", "model.4", "model.6", "model.8", "model.9",
+                 "model.12", "model.15", "model.18", "model.21", "model.22.feat0", "model.22.feat1", "model.22.feat2"]
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["f32-split", "f32-exact"])
+def test_detector_4k_matches_the_oracle(gtx_ctx, scene4k, split):
+    """configs[1] at its real size against oracle/yolov8_ref.py: one 3840x2160 frame, 1920x1920 input,
+    fp32 -- every probed layer within 2e-4 of the layer maximum (the bar of tests/test_detector_gpu.py at 384 px), raw boxes
+    and class scores of all 75 600 anchors, and the same detections in the same order after NMS."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+    from oracle.yolov8_ref import YoloV8Ref, detect, letterbox
+
+    sc, fr = scene4k
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, rect=False, half=False, ctx=gtx_ctx)
+    w = synthetic_yolov8(seed=0, nc=4, level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002, smooth_cls=True, box_decay=(0.2, 0.3, 0.2, 0.3))
+    det = Detector(w, (H4, W4), fp32_split=False, **kw)
+    det.detect(fr[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 400)
+    det.close()
+    det = Detector(w, (H4, W4), fp32_split=split, **kw)
+    try:
+        got = det.detect(fr[0])
+        ref = YoloV8Ref(w)
+        x, g = letterbox(fr[0], 1920, False)
+        assert det.net_hw == (g["net_h"], g["net_w"]) == (1920, 1920)
+        ref_raw = ref.forward(x)[0].numpy()
+        worst = {}
+        for name in ORACLE_LAYERS:
+            a = det.layer_output(name)
+            r = ref.acts[name][0].permute(1, 2, 0).numpy()
+            assert a.shape == r.shape, name
+            worst[name] = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-6))
+            assert worst[name] < 2e-4, f"{name}: rel-to-max error {worst[name]:.3e}"
+        raw = det.raw_output()
+    finally:
+        det.close()
+    assert raw.shape == ref_raw.shape == (75600, 8)
+    d = np.abs(raw[:, 4:] - ref_raw[:, 4:])
+    # logits of O(100): a relative difference of a few 1e-6 between two fp32 summation orders shows as up to ~1e-4 in a score
+    # near 0.5 (same bar as test_fp32_paths_agree_at_full_size)
+    assert d.max() < 5e-4 and np.percentile(d, 99.9) < 2e-5, (d.max(), np.percentile(d, 99.9))
+    np.testing.assert_allclose(raw[:, :4], ref_raw[:, :4], rtol=2e-5, atol=5e-3)
+    xyxy, conf, cls = detect(ref, fr[0], 1920, False, 0.25, 0.7, [0, 1, 2, 3], True, 1000)
+    n_cand = int((ref_raw[:, 4:].max(1) > 0.25).sum())
+    assert n_cand > len(conf) * 1.3                                            # NMS had clustered candidates to suppress
+    moved = _same_detections((got.xyxy, got.conf, got.cls), (xyxy, conf, cls), 5e-4, 5e-2)
+    print(f"4K vs oracle ({'split' if split else 'exact'}): worst layer {max(worst.values()):.2e}, scores max {d.max():.2e} / p99.9 "
+          f"{np.percentile(d, 99.9):.2e}, {len(conf)} detections, {moved} near-tie swaps")
+
+
+def test_stabilizer_4k_stages_bit_exact_against_the_oracle(gtx_ctx, scene4k):
+    """configs[2]'s stabilizer at its real size and the reference's default parameters (default.yaml:100-145: downsample 0.5,
+    2000 / 4000 features, ratio 0.9, 2 px): keypoints, orientation bins, descriptors and matches of a 4K frame pair equal
+    oracle/stabilo_ref.py bit for bit, the homographies agree to 1e-3 px."""
+    from geotrax_amd.stabilizer import Stabilizer
+    from oracle.stabilo_ref import StabilizerRef
+
+    sc, fr = scene4k
+    cfg = dict(downsample_ratio=0.5, max_features=2000, ref_multiplier=2.0, filter_ratio=0.9, ransac_threshold=2.0,
+               mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
+    st = Stabilizer((H4, W4), ctx=gtx_ctx)                                     # the reference's defaults
+    ref = StabilizerRef(cfg, (H4, W4), n_hyp=2048)
+    b0, b1 = sc.boxes(0), sc.boxes(40)
+    st.set_ref_frame(fr[0], b0)
+    ref.set_ref_frame(fr[0], b0)
+    st.stabilize(fr[40], b1)
+    H_ref, n_inl = ref.stabilize(fr[40], b1)
+    for which, o, want in (("ref", ref.ref, 3000), ("cur", ref.cur, 1500)):
+        g = st.keypoints(which)
+        assert len(g["bin"]) == len(o["bin"]) > want, (which, len(g["bin"]), len(o["bin"]))
+        np.testing.assert_array_equal(g["level"], o["level"])
+        np.testing.assert_array_equal(g["xy"], o["xy"])
+        np.testing.assert_array_equal(g["bin"], o["bin"])
+        np.testing.assert_array_equal(g["desc"], o["desc"])
+    q, t, d = st.matches()
+    np.testing.assert_array_equal(q, ref.m[0])
+    np.testing.assert_array_equal(t, ref.m[1])
+    np.testing.assert_array_equal(d, ref.m[2])
+    assert len(q) > 500
+    H = st.get_cur_trans_matrix()
+    assert H is not None and H_ref is not None
+    ys, xs = np.meshgrid(np.linspace(0, H4 - 1, 9), np.linspace(0, W4 - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    a, b = H @ P, H_ref @ P
+    assert np.abs(a[:2] / a[2] - b[:2] / b[2]).max() < 1e-3
+    assert abs(st.get_cur_inliers_count() - n_inl) <= 2

@@ -106,3 +106,72 @@ def test_bytetrack_does_not_reproduce_it():
     trk = Tracker("bytetrack")
     pairs, _ = _replay(lambda *a: (lambda o: (o[1], o[4]))(trk.update(*a[:3])), t, Hs, False)
     assert len({p[1] for p in pairs}) == 147 and len(pairs) > 147
+
+
+def _iou_cost(a, b):
+    x1, y1 = np.maximum(a[:, None, 0], b[None, :, 0]), np.maximum(a[:, None, 1], b[None, :, 1])
+    x2, y2 = np.minimum(a[:, None, 2], b[None, :, 2]), np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    ua = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None] - inter
+    return (1.0 - inter / (ua + 1e-7)).astype(np.float32)
+
+
+def _lap(cost, limit):
+    import ctypes as C
+
+    from geotrax_amd import _lib
+
+    lib = _lib.load()
+    n, m = cost.shape
+    x, y = np.full(n, -2, np.int32), np.full(m, -2, np.int32)
+    _lib.check(lib.gtx_op_linear_assignment(_lib.ptr(np.ascontiguousarray(cost, np.float32)), n, m, C.c_double(limit), _lib.ptr(x), _lib.ptr(y)))
+    return x, y
+
+
+def test_assignment_solver_reaches_scipys_optimum_on_the_golden_frames():
+    """The C++ LAP of the trackers (csrc/tracker.cpp, exposed as gtx_op_linear_assignment; host only) against
+    scipy.optimize.linear_sum_assignment -- a third-party solver -- on the 1 - IoU matrices between the golden clip's
+    consecutive frames (~130 x 130): with lapjv's cost_limit semantics (matching.py:linear_assignment:
+    a pair only below match_thresh, an unmatched row / column costs limit / 2) the objective must equal scipy's optimum of the
+    extended matrix, and the matching itself where the optimum is unique; without a limit the plain rectangular optimum."""
+    from scipy.optimize import linear_sum_assignment
+
+    t, _ = _golden()
+    frames = np.unique(t[:, 0]).astype(int)
+    rng = np.random.default_rng(0)
+    checked = 0
+    for f in frames[:-1:7]:
+        _, a, _, _ = _frame_dets(t, f)
+        _, b, _, _ = _frame_dets(t, f + 1)
+        b = b + rng.normal(0, 6.0, b.shape).astype(np.float32)             # jitter: otherwise every IoU is ~1 and the problem trivial
+        cost = _iou_cost(a, b)
+        n, m = cost.shape
+        for limit in (0.8, 0.5):
+            x, y = _lap(cost, limit)
+            ext = np.full((n + m, n + m), limit / 2.0)
+            ext[n:, m:] = 0
+            ext[:n, :m] = cost
+            r, c = linear_sum_assignment(ext)
+            best = ext[r, c].sum()
+            matched = x >= 0
+            ours = cost[np.nonzero(matched)[0], x[matched]].astype(np.float64).sum() + (limit / 2.0) * ((~matched).sum() + m - matched.sum())
+            assert abs(ours - best) < 1e-6, (f, limit, ours, best)
+            assert (cost[np.nonzero(matched)[0], x[matched]] < limit).all()
+            assert all(y[x[i]] == i for i in np.nonzero(matched)[0]) and (y >= 0).sum() == matched.sum()
+            sx = np.full(n, -1)
+            for i, j in zip(r, c):
+                if i < n and j < m:
+                    sx[i] = j
+            assert (sx == x).mean() > 0.98                                   # identical up to exact ties
+            checked += 1
+        x, _ = _lap(cost, 0.0)
+        r, c = linear_sum_assignment(cost)
+        assert (x >= 0).sum() == min(n, m) and abs(cost[np.arange(n)[x >= 0], x[x >= 0]].astype(np.float64).sum() - cost[r, c].astype(np.float64).sum()) < 1e-6
+    assert checked >= 40
+    for n, m in ((1, 1), (3, 9), (9, 3), (40, 40)):                          # ragged, both orientations
+        cost = rng.random((n, m)).astype(np.float32)
+        x, _ = _lap(cost, 0.0)
+        r, c = linear_sum_assignment(cost)
+        assert abs(cost[np.arange(n)[x >= 0], x[x >= 0]].astype(np.float64).sum() - cost[r, c].astype(np.float64).sum()) < 1e-6
+    x, y = _lap(np.zeros((0, 5), np.float32), 0.8)
+    assert len(x) == 0 and (y == -1).all()
