@@ -9,7 +9,8 @@ The algorithm lives in third-party code that is not vendored in /root/reference 
 installed here: ultralytics>=8.4.80 (`trackers/byte_tracker.py`, `trackers/bot_sort.py`,
 `trackers/utils/{kalman_filter,matching}.py`) and lapx>=0.5.2 (`lap.lapjv`). This file restates
 the published ByteTrack / BoT-SORT procedure as those modules implement it, from memory of their
-public source; the LAP is solved with scipy.optimize.linear_sum_assignment on the same extended
+public source; the LAP is solved with scipy.optimize.linear_sum_assignment (the C++ solver is held against scipy directly on the golden
+clip's frames, tests/test_tracker_golden.py) on the same extended
 cost matrix lapjv(extend_cost=True, cost_limit=t) builds, which has the same optimum.
 
 PARITY UNPINNED against the real packages (neither can be imported here; the reference's tests

@@ -9,7 +9,8 @@ previous frame (21x21 window, 3 pyramid levels above the base, 30 iterations / 0
 cv2.estimateAffinePartial2D(RANSAC); the 2x3 result (translation scaled back by 2) is applied to every
 track's Kalman state. ultralytics and OpenCV are absent from /root/reference (pyproject pins
 ultralytics>=8.4.80), so this follows the published algorithms (Shi-Tomasi, Bouguet's pyramidal LK) and
-is **PARITY UNPINNED** against OpenCV itself. Deliberate choices: corner response from exact integer
+is **PARITY UNPINNED** against OpenCV itself (held against scikit-image's ORB + ransac(SimilarityTransform) on a
+consecutive frame pair: <= 0.25 px apart on a 9 x 16 grid, tests/test_independent.py). Deliberate choices: corner response from exact integer
 Sobel/box sums, LK in float64 with Scharr derivatives (OpenCV: 14-bit fixed point), similarity fit =
 2-point hypotheses scored by inlier count + least squares on the inliers (OpenCV: + LM refinement).
 """

@@ -21,6 +21,10 @@ the library's table (gtx_stabilizer_pattern) with it, not the other way round.
 PARITY UNPINNED against stabilo/OpenCV themselves. What pins the stage end to end: synthetic
 sequences with a known camera homography (tests/test_stabilizer_gpu.py) and the envelope of the
 reference's golden homographies (tests/golden/U_video_cut_vid_transf.txt).
+Held against an independent third-party implementation (scikit-image 0.18.3, NOT a dependency of the reference;
+tests/golden/make_independent.py -> tests/test_independent.py): `fast_score > 0` is exactly the pixel set
+skimage.feature.corner_fast(n=9) fires on; the homography of a frame pair is within 1 px (9 x 16 grid) of
+skimage's ORB + match_descriptors + ransac(ProjectiveTransform) estimate, both within 1 px of the known camera.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """

@@ -15,7 +15,8 @@ imgwarp.cpp: `warpPerspective` -> `WarpPerspectiveInvoker` -> `remap` with INTER
     holds the products (1-fx)(1-fy) ... scaled to 15 bits, which for 5-bit fractions are the exact integers
     32*(32-ax)(32-ay) ...; result = (sum + 2^14) >> 15 == (sum/32 + 512) >> 10; taps outside the image are 0.
 PARITY UNPINNED against OpenCV itself (it cannot be imported here, and the reference's tests never call the
-warp). One known freedom: OpenCV inverts M with its own LU routine; this file uses numpy.linalg.inv, the
+warp). Held against skimage.transform.warp(order=1) (exact float coordinates): <= 1 grey level except where the 1/32-pixel
+coordinate quantisation meets the crop's sharpest edges (<= 2, < 0.1 % of pixels), tests/test_independent.py. One known freedom: OpenCV inverts M with its own LU routine; this file uses numpy.linalg.inv, the
 library its adjugate formula -- the inverses agree to ~1e-16 relative, which can move a coordinate across a
 1/32-pixel rounding boundary for about one pixel in 10^4..10^5 frames' worth.
 

@@ -20,7 +20,9 @@ PARITY UNPINNED at this boundary: the reference's own tests never run a model (S
 the weights and the clip are absent, and neither ultralytics nor cv2 can be imported here, so
 nothing in this file could be checked against the real packages. It is pinned only indirectly:
 conv/pool/upsample are checked against torch.nn.functional itself, and the end-to-end
-post-processing chain is pinned by the reference's golden outputs (tests/golden/).
+post-processing chain is pinned by the reference's golden outputs (tests/golden/). The general (non-2x) bilinear of the
+letterbox is held against skimage.transform.resize(order=1, anti_aliasing=False): <= 1 grey level
+(tests/test_independent.py; scikit-image is not a dependency of the reference).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """

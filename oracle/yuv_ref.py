@@ -12,6 +12,7 @@ sample per 2x2 luma block, no interpolation):
     G = sat8((y' + (1 << 19) + CVG * (V - 128) + CUG * (U - 128)) >> 20)
     R = sat8((y' + (1 << 19) + CVR * (V - 128)) >> 20)
 
+Held against skimage.color.ycbcr2rgb (float BT.601 limited range): <= 1 level (tests/test_independent.py).
 PARITY UNPINNED against OpenCV / FFmpeg's swscale (what VideoCapture's FFmpeg backend really runs; its own tables
 differ from cvtColor's in the last bit for some inputs). Only tests/ may import this module.
 """
