@@ -18,8 +18,8 @@
 
 namespace gtx {
 
-// DT_F32S: fp32 in HBM like DT_F32, convolutions on the fp16 matrix pipe with every operand split into hi + lo
-// fp16 parts (three MFMAs per product, conv_igemm_split.hip). Only the conv kernels distinguish it from DT_F32.
+// DT_F32S: fp32-grade activations, 4 bytes per element like DT_F32, stored as (hi, lo) fp16 pairs (split_format.hpp);
+// convolutions on the fp16 matrix pipe, three MFMAs per product (conv_igemm_split.hip).
 enum DType : int { DT_F16 = 0, DT_F32 = 1, DT_F32S = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : 4; }
 
@@ -47,6 +47,11 @@ struct ConvProblem {
   int in2_cstride, in2_coff, c_split;
   int block_begin;      // first logical block of this problem inside a grouped launch
   float acc_scale;      // DT_F32S: inverse of the power of two the packed weights were scaled by (else 1)
+  // DT_F32S only (split_format.hpp): in / in2 / res / out are in pair format unless out_plain is set, which keeps the output
+  // plain fp32 (the Detect head's last conv stage, read by the decode kernels). sat_flag (may be null): set to 1 when a value
+  // had to be clamped to +-65504 on its way into the pair format.
+  int out_plain;
+  int* sat_flag;
 };
 
 constexpr int kMaxGroup = 8;
@@ -69,7 +74,8 @@ struct ConvConfig {
   int stride;  // 1 or 2
   int bn;      // cout tile: 32, 64 or 128
   int kc;      // cin elements staged per K chunk
-  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S)
+  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S),
+               // 3 = split-f16x3 3x3 stride 1 as a persistent LDS-DMA workgroup per CU (conv3x3_ring.hip)
   int th, tw;  // output pixel tile (rows x cols)
 };
 
@@ -93,6 +99,9 @@ double conv_flops(const ConvProblem& p, int ks);
 // conv_igemm_split.hip
 void conv_split_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 std::vector<uint8_t> pack_conv_weights_split(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale);
+
+// conv3x3_ring.hip (variant 3; weights packed as for variant 2)
+void conv_ring_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 
 // Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
 const char* conv_kernel_name(const ConvConfig& cfg);

@@ -1,8 +1,12 @@
 // fp32-grade implicit-GEMM Conv(+bias+SiLU[+residual]) on the fp16 matrix pipe: "split-f16x3".
-// gfx950 only. Activations and outputs stay fp32 in HBM (ultralytics.half: false, the reference default,
-// geotrax/cfg/default.yaml:245); every operand is split into two fp16 values when it enters LDS,
+// gfx950 only. Activations are fp32-grade values (ultralytics.half: false, the reference default,
+// geotrax/cfg/default.yaml:245) carried as two fp16 numbers,
 //     x = hi + lo,   hi = fp16(x),   lo = fp16(x - hi)          (x - hi is exact in fp32)
-// and a product w*x is formed by three fp16 MFMAs with fp32 accumulation,
+// and they are stored in HBM ALREADY SPLIT ("pair format", split_format.hpp): the 32 bytes that would hold 8 fp32
+// channels of a pixel hold their 8 hi halves followed by their 8 lo halves. The split is done once, by the epilogue that
+// produces a value, instead of every time a consumer stages it (once per cout tile and per halo copy, 2 330 of 8 755
+// cycles per K chunk in round 2's kernel): staging is now a straight 16-byte copy into the LDS row.
+// A product w*x is formed by three fp16 MFMAs with fp32 accumulation,
 //     w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi                   (the lo*lo term is < 2^-22 relative)
 // i.e. 22 significand bits per operand instead of fp32's 24, at 3/16 of the cost of the exact-fp32 MFMA
 // (v_mfma_f32_32x32x2_f32 runs at 1/16 of the fp16 rate, MI355X_MICROARCH.md "Matrix cores").
@@ -11,7 +15,7 @@
 // the inverse power of two (exact). Activations are not scaled: x_lo is subnormal for |x| < 2^-3, where the
 // absolute error floor 2^-25 is below fp32's own rounding error for |x| >= 0.5. Values beyond +-65504 are
 // clamped when they are split (an fp32 network never gets there after BN + SiLU; the clamp only keeps an
-// out-of-range value from turning into inf - inf).
+// out-of-range value from turning into inf - inf) and the launch raises ConvProblem::sat_flag so that the host can say so.
 //
 // Work decomposition and LDS staging are those of conv_igemm.hip (8x16 output pixels x 32*WN couts per
 // 4-wave workgroup, per K chunk the input patch and the KS*KS weight taps staged once, taps read shifted
@@ -30,47 +34,14 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-#ifdef GTX_SHAPE_PROBE
-// TIMING PROBE ONLY (results are wrong): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs of the same FLOP count on the same
-// operand registers, to read what the other instruction shape does to the clock inside this kernel's loop.
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ floatx16 mfma_probe(half8 a, half8 b, floatx16 c) {
-  floatx4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
-  q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
-  q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
-  c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3]; c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3];
-  return c;
-}
-#define GTXS_MFMA(a, b, c) mfma_probe(a, b, c)
-#define GTXS_MFMA_PER_READ 2
-#if GTX_SHAPE_PROBE >= 2
-#define GTXS_PROBE_EXTRA_READS(SLOT)                                                                      \
-      _Pragma("unroll") for (int m = 0; m < WM; ++m)                                                      \
-        bx[SLOT][m] = *reinterpret_cast<const half8*>(lds_patch + (p0 + m * PSUB + (tap__ / KS) * PW + (tap__ % KS)) * RB + ((c__ ^ 1) << 4)); \
-      _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                      \
-        ax[SLOT][j] = *reinterpret_cast<const half8*>(lds_w + (tap__ * BN + 32 * j + prow) * RB + ((c__ ^ 1) << 4));
-#define GTXS_THIRD_A(SLOT, j) ax[SLOT][j]
-#define GTXS_THIRD_B(SLOT, m) bx[SLOT][m]
-#define GTXS_READS_PER_STEP (3 * WM + 3 * WN)
-#else
-#define GTXS_PROBE_EXTRA_READS(SLOT)
-#define GTXS_THIRD_A(SLOT, j) ah[SLOT][j]
-#define GTXS_THIRD_B(SLOT, m) bh[SLOT][m]
-#endif
-#else
-#define GTXS_PROBE_EXTRA_READS(SLOT)
-#define GTXS_THIRD_A(SLOT, j) ah[SLOT][j]
-#define GTXS_THIRD_B(SLOT, m) bh[SLOT][m]
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define GTXS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define GTXS_MFMA_PER_READ 1
-#endif
 
-#ifdef GTX_CLOCK_STAMP
-// Diagnostic builds only (`make stamp`, tools/clock_probe.py): shader-clock and 100 MHz wall-clock ticks spent inside the K loop,
-// summed over workgroups, to read the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
-// GTX_CLOCK_STAMP=1 (libgtx_stamp.so): one pair of stamps around the K loop; =2 (libgtx_stamp2.so): a stamp after every phase too.
-// The sums live in a buffer of their own; no output value depends on them.
-__device__ unsigned long long g_clock_stamp[8];   // [0..2] loop cycles, 100 MHz ticks, workgroups; [3..7] per-phase cycles of wave 0
+// Diagnostic builds (`make stamp`) force-include csrc/diag/conv_split_diag.hpp, which defines these two hooks as clock
+// stamps around the K loop; the shipped object has none.
+#ifndef GTXS_DIAG_LOOP_BEGIN
+#define GTXS_DIAG_LOOP_BEGIN()
+#define GTXS_DIAG_LOOP_END()
 #endif
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -100,20 +71,19 @@ struct SplitTile {
 // x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-// 8 fp32 values (two 16-B loads) -> 8 hi halves + 8 lo halves
-__device__ __forceinline__ void split8(const uint4& a, const uint4& b, uint4& hi, uint4& lo) {
-  const float f[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
-                      __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
-  half8 h, l;
+// 4 fp32 values -> their 4 hi halves and 4 lo halves (8 bytes each); *sat becomes true when a value had to be clamped
+__device__ __forceinline__ void split4(const float (&v)[4], uint2& hi, uint2& lo, bool& sat) {
+  half4 h, l;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x = __builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
+  for (int i = 0; i < 4; ++i) {
+    const float x = __builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
+    sat |= x != v[i];                    // also true for a NaN (it is clamped to -65504 by v_med3)
     const _Float16 hh = (_Float16)x;
     h[i] = hh;
     l[i] = (_Float16)(x - (float)hh);
   }
-  hi = *reinterpret_cast<const uint4*>(&h);
-  lo = *reinterpret_cast<const uint4*>(&l);
+  hi = *reinterpret_cast<const uint2*>(&h);
+  lo = *reinterpret_cast<const uint2*>(&l);
 }
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -169,7 +139,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const float* __restrict__ in2 = static_cast<const float*>(P.in2);
   const int nchunks = P.Cin / KC;
 
-  long goff[Tile::PATCH_SLOTS];   // element offset of the unit's 8 floats, -1 = zero fill
+  long goff[Tile::PATCH_SLOTS];   // element offset of the unit (8 channels = 32 B: hi chunk, lo chunk), -1 = zero fill
   long goff2[Tile::PATCH_SLOTS];  // 1x1 only: the same unit in the half-resolution second source (ConvProblem::in2)
   int loff[Tile::PATCH_SLOTS];    // LDS byte offset of the unit's hi chunk, -1 = slot unused
   int lchk[Tile::PATCH_SLOTS];    // ... and of its lo chunk
@@ -215,11 +185,9 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #define GTXS_COMMIT()                                                                        \
   {                                                                                          \
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
-      if (loff[s] >= 0) {                                                                    \
-        uint4 hi__, lo__;                                                                    \
-        split8(pre_a[s], pre_b[s], hi__, lo__);                                              \
-        *reinterpret_cast<uint4*>(lds_patch + loff[s]) = hi__;                               \
-        *reinterpret_cast<uint4*>(lds_patch + lchk[s]) = lo__;                               \
+      if (loff[s] >= 0) {                              /* pair format: the two halves of the unit ARE the LDS chunks */ \
+        *reinterpret_cast<uint4*>(lds_patch + loff[s]) = pre_a[s];                           \
+        *reinterpret_cast<uint4*>(lds_patch + lchk[s]) = pre_b[s];                           \
       }                                                                                      \
     }                                                                                        \
     _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
@@ -265,9 +233,6 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 
   constexpr int NSTEP = KS * KS * (CPR / 2);
   half8 bh[2][WM], bl[2][WM], ah[2][WN], al[2][WN];
-#if defined(GTX_SHAPE_PROBE) && GTX_SHAPE_PROBE >= 2   /* probe 2: 1.5 x the fragment reads as well (timing only) */
-  half8 bx[2][WM], ax[2][WN];
-#endif
 #define GTXS_LOAD_FRAGS(STEP, SLOT)                                                            \
     {                                                                                          \
       const int tap__ = (STEP) / (CPR / 2), ks__ = (STEP) % (CPR / 2);                         \
@@ -284,7 +249,6 @@ void conv_igemm_split_kernel(const ConvGroup g) {
         ah[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + ((c__ ^ Tile::swz(nrow__)) << 4)); \
         al[SLOT][j] = *reinterpret_cast<const half8*>(wr__ + (((CPR + c__) ^ Tile::swz(nrow__)) << 4)); \
       }                                                                                        \
-      GTXS_PROBE_EXTRA_READS(SLOT)                                                             \
     }
   // The matrix phase of one K chunk: fragment reads run one (tap, k-step) ahead of the 3 * WM * WN MFMAs that consume them.
 #define GTXS_MATRIX_PHASE()                                                                    \
@@ -299,45 +263,17 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           /* small terms first, then the leading one */                                       \
           acc[m][j] = GTXS_MFMA(al[st & 1][j], bh[st & 1][m], acc[m][j]); \
           acc[m][j] = GTXS_MFMA(ah[st & 1][j], bl[st & 1][m], acc[m][j]); \
-          acc[m][j] = GTXS_MFMA(GTXS_THIRD_A(st & 1, j), GTXS_THIRD_B(st & 1, m), acc[m][j]); \
+          acc[m][j] = GTXS_MFMA(ah[st & 1][j], bh[st & 1][m], acc[m][j]); \
         }                                                                                      \
       /* one fragment read of the next step behind every MFMA of this one */                   \
       _Pragma("unroll") for (int i__ = 0; i__ < 3 * WM * WN; ++i__) {                          \
-        __builtin_amdgcn_sched_group_barrier(0x008, GTXS_MFMA_PER_READ, 0);                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
       }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
   GTXS_PREFETCH(0)
-#ifdef GTX_CLOCK_STAMP
-  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#if defined(GTX_CLOCK_STAMP) && GTX_CLOCK_STAMP >= 2   /* per-phase stamps: they serialise the loop (libgtx_stamp2.so) */
-#define GTXS_STAMP(T)                                                                            \
-  unsigned long long T;                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                             \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory");                      \
-  __builtin_amdgcn_sched_barrier(0);
-  unsigned long long ph[5] = {0, 0, 0, 0, 0};
-  unsigned long long st_prev = st_c0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();
-    GTXS_STAMP(ta)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GTXS_STAMP(tb)
-    GTXS_COMMIT()
-    GTXS_STAMP(tc)
-    __syncthreads();
-    GTXS_STAMP(td)
-    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
-    GTXS_MATRIX_PHASE()
-    GTXS_STAMP(te)
-    ph[0] += ta - st_prev; ph[1] += tb - ta; ph[2] += tc - tb; ph[3] += td - tc; ph[4] += te - td;
-    st_prev = te;
-  }
-  if (tid == 0)
-    for (int i = 0; i < 5; ++i) atomicAdd(&g_clock_stamp[3 + i], ph[i]);
-#else
+  GTXS_DIAG_LOOP_BEGIN()
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
     GTXS_COMMIT()
@@ -345,90 +281,77 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
     GTXS_MATRIX_PHASE()
   }
-#endif
+  GTXS_DIAG_LOOP_END()
 #undef GTXS_MATRIX_PHASE
 #undef GTXS_LOAD_FRAGS
-#ifdef GTX_CLOCK_STAMP
-  {
-    const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
-      atomicAdd(&g_clock_stamp[0], st_c1 - st_c0);
-      atomicAdd(&g_clock_stamp[1], st_r1 - st_r0);
-      atomicAdd(&g_clock_stamp[2], 1ull);
-    }
-  }
-#endif
 
-  // ---- epilogue: acc * 2^-shift + bias -> SiLU (+ residual) -> fp32 NHWC, whole 128-B lines per store ----
-  // After the MFMAs a lane holds 4 consecutive channels of one pixel (16 B). Each wave transposes its 32 pixels x
-  // BN channels through LDS so that a store instruction writes contiguous runs of BN*4 bytes per pixel.
+  // ---- epilogue: acc * 2^-shift (bias is already in) -> SiLU (+ residual) -> split into hi / lo -> NHWC pair format ----
+  // After the MFMAs a lane holds 4 consecutive channels of one pixel; lanes l and l + 32 hold the two halves of one
+  // 8-channel group. Two v_permlane32_swap turn that into the group's 16-byte hi chunk (lane l) and 16-byte lo chunk
+  // (lane l + 32), which land in the LDS staging row at the byte offset the fp32 float4 would have had; the wave then
+  // stores whole BN*4-byte runs per pixel. ConvProblem::out_plain keeps plain fp32 (the Detect head's last stage, read by
+  // the decode kernels).
   const float sc = P.acc_scale;
   const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
-  const bool wide = (P.out_cstride % 4) == 0 && (P.out_coff % 4) == 0;
-  if (wide) __syncthreads();                    // every wave is done with the staging buffers
+  const bool plain = P.out_plain != 0;
+  bool sat = false;
+  __syncthreads();                              // every wave is done with the staging buffers
 #pragma unroll
   for (int m = 0; m < WM; ++m) {
     const int trow = trow0 + 2 * m;
     const int oy = oy0 + trow, ox = ox0 + tcol;
-    if (wide) {
-      constexpr int PITCH = Tile::EPI_PITCH;
-      char* stg = smem + wave * (32 * PITCH);   // wave-private: its own LDS writes are ordered before its reads
-      const bool inside = oy < P.Ho && ox < P.Wo;
-      const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
-      const float* __restrict__ res =
-          (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+    constexpr int PITCH = Tile::EPI_PITCH;
+    char* stg = smem + wave * (32 * PITCH);     // wave-private: its own LDS writes are ordered before its reads
+    const bool inside = oy < P.Ho && ox < P.Wo;
+    const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
+    const float* __restrict__ res =
+        (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
+    for (int j = 0; j < WN; ++j) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int cl = 32 * j + 8 * g4 + 4 * h;
-          float v[4];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = 32 * j + 8 * g4 + 4 * h;
+        float v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[m][j][4 * g4 + i] * sc;
-            if (P.act) v[i] = silu_f(v[i]);
-          }
-          if (res && cl < cvalid) {
-            const float4 rv = *reinterpret_cast<const float4*>(res + cl);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          }
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[m][j][4 * g4 + i] * sc;
+          if (P.act) v[i] = silu_f(v[i]);
+        }
+        if (P.res) {                               // uniform; the swaps below need every lane
+          uint4 rc = make_uint4(0, 0, 0, 0);       // lane l: the group's hi chunk, lane l + 32: its lo chunk
+          if (res && cl < cvalid) rc = *reinterpret_cast<const uint4*>(res + cl);
+          const auto sx = __builtin_amdgcn_permlane32_swap(rc.x, rc.z, false, false);   // -> (hi, lo) of this lane's channels 0, 1
+          const auto sy = __builtin_amdgcn_permlane32_swap(rc.y, rc.w, false, false);   // ... and 2, 3
+          const unsigned hw[2] = {sx[0], sy[0]}, lw[2] = {sx[1], sy[1]};
+          const half4 rh = *reinterpret_cast<const half4*>(hw), rl = *reinterpret_cast<const half4*>(lw);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += (float)rh[i] + (float)rl[i];             // hi + lo is exact in fp32
+        }
+        if (plain) {
           *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      constexpr int LPP = BN / 4;                 // lanes per pixel (16 B each)
-      constexpr int PPI = 64 / LPP;               // pixels per store instruction
-#pragma unroll
-      for (int it = 0; it < 32 / PPI; ++it) {
-        const int p = it * PPI + lane / LPP, q = lane % LPP;
-        const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
-        const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
-        if (py < P.Ho && px < P.Wo && q * 4 < cvalid) {
-          float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
-          *reinterpret_cast<uint4*>(dst) = val;
-        }
-      }
-    } else if (oy < P.Ho && ox < P.Wo) {
-      const size_t pix = ((size_t)n * P.Ho + oy) * P.Wo + ox;
-      float* __restrict__ out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + ct * BN;
-      const float* __restrict__ res =
-          P.res ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int cl = 32 * j + 8 * g4 + 4 * h;
-          if (cl >= cvalid) continue;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float v = acc[m][j][4 * g4 + i] * sc;
-            if (P.act) v = silu_f(v);
-            if (res) v += res[cl + i];
-            out[cl + i] = v;
-          }
+        } else {
+          uint2 hi, lo;
+          split4(v, hi, lo, sat);
+          const auto sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+          *reinterpret_cast<uint4*>(stg + prow * PITCH + cl * 4) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
       }
     }
+    constexpr int LPP = BN / 4;                 // lanes per pixel (16 B each)
+    constexpr int PPI = 64 / LPP;               // pixels per store instruction
+#pragma unroll
+    for (int it = 0; it < 32 / PPI; ++it) {
+      const int p = it * PPI + lane / LPP, q = lane % LPP;
+      const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
+      const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
+      if (py < P.Ho && px < P.Wo && (q >> 1) * 8 < cvalid) {     // cvalid is a multiple of 16: whole groups
+        float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
+        *reinterpret_cast<uint4*>(dst) = val;
+      }
+    }
   }
+  if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
 }
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -494,13 +417,3 @@ void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 
 }  // namespace gtx
 
-#ifdef GTX_CLOCK_STAMP
-// out = {shader-clock ticks, 100 MHz ticks, workgroups, then wave 0's cycles in: first barrier, load wait, commit, second
-// barrier, prefetch issue + matrix phase} summed since the last call; clears the sums.
-extern "C" int gtx_debug_conv_clock(unsigned long long out[8]) {
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtx::g_clock_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(gtx::g_clock_stamp), zero, sizeof zero) == hipSuccess ? 0 : -1;
-}
-#endif

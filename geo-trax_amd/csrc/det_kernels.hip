@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uchar4* __restrict
 }
 
 // fp32 stem on the fp16 matrix pipe ("split-f16x3", see conv_igemm_split.hip): the same implicit GEMM as
-// stem_mfma_kernel on fp32 NHWC4 pixels and fp32 outputs. Every lane splits the pixels it gathers into hi + lo fp16
+// stem_mfma_kernel on RGB0 bytes, output in the pair format of split_format.hpp. Every lane splits the pixels it gathers into hi + lo fp16
 // parts, the weights arrive pre-split (scaled by an exact power of two, undone by `acc_scale`), a product costs three
 // MFMAs (w_lo x_hi + w_hi x_lo + w_hi x_hi). The 32-channel fp32 output row of a pixel is 128 B: the wave transposes
 // its 32 pixels through LDS and stores whole lines.
@@ -408,18 +408,31 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc, 0, 0, 0);
       }
+      // Output in pair format (split_format.hpp): lanes l and l + 32 hold the two halves of an 8-channel group; two
+      // v_permlane32_swap make the group's 16-byte hi chunk (lane l) and lo chunk (lane l + 32), as in the conv epilogue.
+      uint4 chunk[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = g * 32 + 8 * g4 + 4 * hh;
+        half4 hv, lv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // SiLU of a sum of 27 products with inputs in [0, 1]: inside fp16's range for any sane weights; the clamp only keeps
+          // an absurd checkpoint from producing inf - inf (bias is padded to whole 32-channel groups)
+          const float v = __builtin_amdgcn_fmed3f(silu_f(fmaf(acc[4 * g4 + i], acc_scale, bias[cl + i])), -65504.f, 65504.f);
+          const _Float16 hi = (_Float16)v;
+          hv[i] = hi;
+          lv[i] = (_Float16)(v - (float)hi);
+        }
+        const uint2 hu = *reinterpret_cast<const uint2*>(&hv), lu = *reinterpret_cast<const uint2*>(&lv);
+        const auto sx = __builtin_amdgcn_permlane32_swap(hu.x, lu.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(hu.y, lu.y, false, false);
+        chunk[g4] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
       if (c0 == 32) {
         char* stg = s_stage + (threadIdx.x >> 6) * (32 * kPitch);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int cl = 8 * g4 + 4 * hh;
-          float4 v;
-          v.x = silu_f(fmaf(acc[4 * g4 + 0], acc_scale, bias[cl + 0]));
-          v.y = silu_f(fmaf(acc[4 * g4 + 1], acc_scale, bias[cl + 1]));
-          v.z = silu_f(fmaf(acc[4 * g4 + 2], acc_scale, bias[cl + 2]));
-          v.w = silu_f(fmaf(acc[4 * g4 + 3], acc_scale, bias[cl + 3]));
-          *reinterpret_cast<float4*>(stg + r * kPitch + cl * 4) = v;
-        }
+        for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<uint4*>(stg + r * kPitch + (8 * g4 + 4 * hh) * 4) = chunk[g4];
         const int ox0 = tx * 32;
         float* orow = out + (((size_t)n * ho + oy) * wo + ox0) * 32;
 #pragma unroll
@@ -431,13 +444,8 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const uchar4* __restric
       } else if (ox < wo) {
         float* o = out + (((size_t)n * ho + oy) * wo + ox) * c0 + g * 32;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int cl = 8 * g4 + 4 * hh;
-          if (g * 32 + cl < c0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[cl + i] = silu_f(fmaf(acc[4 * g4 + i], acc_scale, bias[g * 32 + cl + i]));
-          }
-        }
+        for (int g4 = 0; g4 < 4; ++g4)
+          if (g * 32 + 8 * g4 < c0) *reinterpret_cast<uint4*>(o + 8 * g4 + 4 * hh) = chunk[g4];   // c0 is a multiple of 8: whole groups
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) raw[k] = nxt[k];
@@ -560,14 +568,63 @@ __device__ __forceinline__ half8 vneg_inf(half8) {
 }
 __device__ __forceinline__ float4 vneg_inf(float4) { return make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
 
+// Pair format (split_format.hpp): a "vector" is 4 channels of one pixel = 8 bytes of hi halves and, 16 bytes further, 8 bytes
+// of lo halves. The maximum is taken on hi + lo (exact in fp32) and the winner's two halves are carried along unchanged.
+struct PairTag {};
+struct PairV { uint2 hi, lo; };
+template <> struct Vec16<PairTag> { using type = PairV; static constexpr int N = 4; };
+__device__ __forceinline__ PairV vmax(const PairV& a, const PairV& b) {
+  const half4 ah = *reinterpret_cast<const half4*>(&a.hi), al = *reinterpret_cast<const half4*>(&a.lo);
+  const half4 bh = *reinterpret_cast<const half4*>(&b.hi), bl = *reinterpret_cast<const half4*>(&b.lo);
+  half4 rh, rl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ta = (float)ah[i] + (float)al[i] >= (float)bh[i] + (float)bl[i];
+    rh[i] = ta ? ah[i] : bh[i];
+    rl[i] = ta ? al[i] : bl[i];
+  }
+  PairV r;
+  r.hi = *reinterpret_cast<const uint2*>(&rh);
+  r.lo = *reinterpret_cast<const uint2*>(&rl);
+  return r;
+}
+__device__ __forceinline__ PairV vneg_inf(PairV) {
+  PairV r;
+  r.hi = make_uint2(0xFC00FC00u, 0xFC00FC00u);       // four fp16 -inf
+  r.lo = make_uint2(0u, 0u);
+  return r;
+}
+// element type in memory, and the load / store of vector `v` (in units of N channels) of the pixel record at `px`
+template <typename T> struct PoolMem { using elem = T; };
+template <> struct PoolMem<PairTag> { using elem = float; };
+template <typename T> __device__ __forceinline__ typename Vec16<T>::type pool_load(const typename PoolMem<T>::elem* px, int v) {
+  return *reinterpret_cast<const typename Vec16<T>::type*>(px + v * Vec16<T>::N);
+}
+template <> __device__ __forceinline__ PairV pool_load<PairTag>(const float* px, int v) {
+  const char* g = reinterpret_cast<const char*>(px) + (v >> 1) * 32 + (v & 1) * 8;
+  PairV r;
+  r.hi = *reinterpret_cast<const uint2*>(g);
+  r.lo = *reinterpret_cast<const uint2*>(g + 16);
+  return r;
+}
+template <typename T> __device__ __forceinline__ void pool_store(typename PoolMem<T>::elem* px, int v, const typename Vec16<T>::type& val) {
+  *reinterpret_cast<typename Vec16<T>::type*>(px + v * Vec16<T>::N) = val;
+}
+template <> __device__ __forceinline__ void pool_store<PairTag>(float* px, int v, const PairV& val) {
+  char* g = reinterpret_cast<char*>(px) + (v >> 1) * 32 + (v & 1) * 8;
+  *reinterpret_cast<uint2*>(g) = val.hi;
+  *reinterpret_cast<uint2*>(g + 16) = val.lo;
+}
+
 // The three cascaded 5x5/s1/p2 max-pools of SPPF in one pass: a block takes a 16x16 spatial tile of
 // one 16-byte channel vector, stages the tile plus a 6-pixel halo in LDS (out-of-image = -inf,
 // which is what the framework's padding does at every stage) and runs the three pools as separable
 // row/column passes on shrinking regions (28 -> 24 -> 20 -> 16), storing the 5x5, 9x9 and 13x13
 // results of the centre.
 template <typename T>
-__global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h, int w, int c) {
+__global__ __launch_bounds__(256) void sppf_pool_kernel(typename PoolMem<T>::elem* __restrict__ x, int h, int w, int c) {
   using V = typename Vec16<T>::type;
+  using E = typename PoolMem<T>::elem;
   constexpr int VN = Vec16<T>::N, TS = 16, R = 6, P = TS + 2 * R;   // 28
   __shared__ V s_a[P * P], s_b[P * P];
   const int vecs = c / VN;
@@ -575,11 +632,11 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h
   const int v = blockIdx.x % vecs, tile = blockIdx.x / vecs;
   const int tx0 = (tile % tiles_x) * TS, ty0 = (tile / tiles_x) * TS;
   const int n = blockIdx.y, cs = 4 * c;
-  T* img = x + (size_t)n * h * w * cs + v * VN;
+  E* img = x + (size_t)n * h * w * cs;
   const V ninf = vneg_inf(V());
   for (int i = threadIdx.x; i < P * P; i += 256) {
     const int yy = ty0 - R + i / P, xx = tx0 - R + i % P;
-    s_a[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? *reinterpret_cast<const V*>(img + ((size_t)yy * w + xx) * cs) : ninf;
+    s_a[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? pool_load<T>(img + ((size_t)yy * w + xx) * cs, v) : ninf;
   }
   __syncthreads();
   int lo = 0;   // valid region of s_a is [lo, P-lo) in both axes
@@ -602,7 +659,7 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h
       const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
       s_a[yo * P + xo] = inside ? m : ninf;
       if (inside && yo >= R && yo < R + TS && xo >= R && xo < R + TS)
-        *reinterpret_cast<V*>(img + ((size_t)yy * w + xx) * cs + (stage + 1) * c) = m;
+        pool_store<T>(img + ((size_t)yy * w + xx) * cs + (stage + 1) * c, v, m);
     }
     __syncthreads();
     lo += 2;
@@ -611,10 +668,11 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(T* __restrict__ x, int h
 
 void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s) {
   const int vn = dtype == DT_F16 ? 8 : 4;
-  GTX_CHECK(c % vn == 0, "sppf: channels %d not a multiple of %d", c, vn);
+  GTX_CHECK(c % (dtype == DT_F32 ? 4 : 8) == 0, "sppf: channels %d not a multiple of %d", c, dtype == DT_F32 ? 4 : 8);
   const int tiles = cdiv(w, 16) * cdiv(h, 16);
   dim3 grid((unsigned)(tiles * (c / vn)), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, grid, block, 0, s, (_Float16*)x, h, w, c);
+  else if (dtype == DT_F32S) hipLaunchKernelGGL(sppf_pool_kernel<PairTag>, grid, block, 0, s, (float*)x, h, w, c);   // pair format
   else hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, block, 0, s, (float*)x, h, w, c);
   GTX_HIP(hipGetLastError());
 }

@@ -2,6 +2,7 @@
 // cfg/models/v8/yolov8.yaml (backbone 0-9, head 10-22); channel widths and bottleneck counts
 // are read off the tensor shapes, so every v8 scale (n/s/m/l/x) loads unchanged.
 #include "detector.hpp"
+#include "split_format.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -25,6 +26,7 @@ Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cf
 
 Detector::~Detector() {
   if (h_out_n_) (void)hipHostFree(h_out_n_);
+  if (h_sat_) (void)hipHostFree(h_sat_);
   if (h_out_rows_) (void)hipHostFree(h_out_rows_);
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
@@ -96,6 +98,13 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   const int ho = (x.h + 2 * pad - ks) / stride + 1, wo = (x.w + 2 * pad - ks) / stride + 1;
   View out = out_slice ? *out_slice : new_view(ho, wo, cout);
   GTX_CHECK(out.h == ho && out.w == wo && out.c == cout, "%s: output view mismatch", name.c_str());
+  if (conv_dtype_ == DT_F32S) {     // pair format: whole 8-channel groups everywhere
+    out.plain = plain_out_;
+    GTX_CHECK(!x.plain && (!residual || !residual->plain) && (!up_src || !up_src->plain), "%s: a plain fp32 tensor cannot feed a split convolution", name.c_str());
+    GTX_CHECK(x.cstride % 8 == 0 && x.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0 &&
+                  (!residual || (residual->cstride % 8 == 0 && residual->coff % 8 == 0)),
+              "%s: channel strides / offsets of the split-f16x3 path must be multiples of 8", name.c_str());
+  }
 
   Op op;
   op.kind = Op::CONV;
@@ -123,6 +132,8 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   p.res_coff = residual ? residual->coff : 0;
   p.act = act ? 1 : 0;
   p.acc_scale = acc_scale;
+  p.out_plain = out.plain ? 1 : 0;
+  p.sat_flag = conv_dtype_ == DT_F32S ? sat_dev_ : nullptr;
   if (up_src) {
     GTX_CHECK(ks == 1 && stride == 1 && op.cfg.variant == 2 && up_src->h * 2 == x.h && up_src->w * 2 == x.w && up_src->c < cin,
               "%s: upsampled source does not fit", name.c_str());
@@ -159,6 +170,11 @@ View Detector::c2f(const std::string& pfx, const View& x, bool shortcut, const V
 void Detector::build_graph() {
   const int H = lb_.net_h, W = lb_.net_w;
   img_ = new_view(H, W, 4);
+  if (conv_dtype_ == DT_F32S) {
+    sat_dev_ = (int*)alloc(sizeof(int));
+    GTX_HIP(hipHostMalloc((void**)&h_sat_, sizeof(int)));
+    *h_sat_ = 0;
+  }
 
   // ---- layer 0: stem (dedicated 3-channel kernel) ----
   const HostTensor& w0 = tensor("model.0.conv.weight");
@@ -176,7 +192,7 @@ void Detector::build_graph() {
     GTX_HIP(hipMemcpy(dw, w27.data(), w27.size() * sizeof(float), hipMemcpyHostToDevice));
     std::vector<float> b(c0, 0.f);
     if (has("model.0.conv.bias")) b = tensor("model.0.conv.bias").data;
-    float* db = (float*)alloc(c0 * sizeof(float));
+    float* db = (float*)alloc((size_t)(c0 + 31) / 32 * 32 * sizeof(float));   // zero-filled up to whole 32-channel groups (the MFMA stems read a group's bias unconditionally)
     GTX_HIP(hipMemcpy(db, b.data(), c0 * sizeof(float), hipMemcpyHostToDevice));
     Op op;
     op.kind = Op::STEM;
@@ -313,8 +329,11 @@ void Detector::build_graph() {
     View h1b = h1.slice(0, cb), h1c = h1.slice(cb, cc), h2b = h2.slice(0, cb), h2c = h2.slice(cb, cc);
     force_kc_ = conv_dtype_ == DT_F16 ? ((cb % 32 == 0 && cc % 32 == 0) ? 32 : 16) : 0;
     force_bn_ = (cb % 64 == 0 && cc % 64 == 0) ? 64 : 32;
+    plain_out_ = true;            // the decode kernels read these two as plain fp32
     conv(b2 + ".1.conv", h1b, 1, true, &h2b, nullptr);
     conv(b3 + ".1.conv", h1c, 1, true, &h2c, nullptr);
+    plain_out_ = false;
+    h2.plain = conv_dtype_ == DT_F32S;
     force_kc_ = force_bn_ = 0;
     // move the three freshly built single-problem ops into the two grouped stage ops
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
@@ -433,7 +452,7 @@ void Detector::run_op(const Op& op, int nb, hipStream_t s) {
       launch_stem(dtype_ == DT_F32 ? conv_dtype_ : dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.wpk, op.out.c, op.out.ptr, op.out.h,
                   op.out.w, s, op.stem_scale);
       break;
-    case Op::POOL: launch_sppf_pool(dtype_, op.out.ptr, nb, op.in.h, op.in.w, op.in.c, s); break;
+    case Op::POOL: launch_sppf_pool(conv_dtype_ == DT_F32S ? DT_F32S : dtype_, op.out.ptr, nb, op.in.h, op.in.w, op.in.c, s); break;
     case Op::UPSAMPLE:
       launch_upsample2x(dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.in.c, op.in.cstride, op.in.coff, op.out.ptr,
                         op.out.cstride, op.out.coff, s);
@@ -518,6 +537,19 @@ void Detector::run_post(int nb, hipStream_t s) {
   launch_nms(nms_, nb, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
   GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
+  if (sat_dev_) GTX_HIP(hipMemcpyAsync(h_sat_, sat_dev_, sizeof(int), hipMemcpyDeviceToHost, s));
+}
+
+bool Detector::saturated(bool clear) {
+  const bool r = sat_seen_;
+  if (clear) {
+    sat_seen_ = false;
+    if (sat_dev_) {
+      GTX_HIP(hipSetDevice(ctx_->device));
+      GTX_HIP(hipMemsetAsync(sat_dev_, 0, sizeof(int), ctx_->stream));
+    }
+  }
+  return r;
 }
 
 // Asynchronous half: enqueue preprocess -> forward -> decode/NMS -> D2H of the result rows on the
@@ -553,6 +585,7 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
   GTX_HIP(hipEventSynchronize(ev_[3]));
   in_flight_ = false;
   collected_gray_slot_ = gray_slot_;
+  if (h_sat_ && *h_sat_) sat_seen_ = true;
   if (flight_traced_) {
     for (size_t i = 0; i < ops_.size(); ++i) {
       float t = 0.f;
@@ -638,7 +671,9 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
     for (int k = 0; k < v.c; ++k) {
       const size_t src = p * v.cstride + v.coff + k;
       float f;
-      if (dtype_ == DT_F16) {
+      if (conv_dtype_ == DT_F32S && !v.plain) {
+        f = pair_element(host.data(), src);
+      } else if (dtype_ == DT_F16) {
         _Float16 hv;
         memcpy(&hv, host.data() + src * 2, 2);
         f = (float)hv;

@@ -34,6 +34,7 @@ struct View {
   void* ptr = nullptr;
   int n = 0, h = 0, w = 0;
   int cstride = 0, coff = 0, c = 0;
+  bool plain = false;      // split-f16x3 path: plain fp32 instead of the pair format (the Detect head's last stage)
   View slice(int off, int cnt) const {
     View v = *this;
     v.coff = coff + off;
@@ -86,6 +87,9 @@ class Detector {
   void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
                     std::vector<double>& flops, std::vector<double>& bytes);
   int max_det() const { return cfg_.max_det; }
+  // split-f16x3 path: true when some activation of the most recently collected pass (or any pass since the last call with
+  // clear) had to be clamped to fp16's range on its way into the pair format; such a checkpoint needs fp32_split = 0.
+  bool saturated(bool clear);
 
  private:
   void* alloc(size_t bytes);
@@ -132,6 +136,10 @@ class Detector {
   HeadParams head_{};
   NmsBuffers nms_{};
   DevBuf raw_;               // debug raw output
+  int* sat_dev_ = nullptr;   // set by the split convolutions when they clamp (ConvProblem::sat_flag)
+  int* h_sat_ = nullptr;     // pinned copy, refreshed by every pass
+  bool sat_seen_ = false;
+  bool plain_out_ = false;   // convs being built write plain fp32 (head stage 2)
   int* h_out_n_ = nullptr;   // pinned
   float* h_out_rows_ = nullptr;
   hipEvent_t ev_[4]{};

@@ -1,0 +1,33 @@
+// DIAGNOSTIC BUILD ONLY (`make -C geo-trax_amd stamp` -> build/libgtx_stamp.so, read by tools/clock_probe.py); force-included
+// in front of conv_igemm_split.hip / conv3x3_ring.hip, never part of libgtx.so. Shader-clock and 100 MHz wall-clock ticks
+// spent inside the K loop of the convolution, summed over workgroups (ring kernel: over tiles), to read the clock the chip
+// holds under the kernel (MI355X_MICROARCH.md, DVFS give-back item 6) and the cycles a K loop takes. The sums live in a buffer
+// of their own; no output value depends on them. GTX_DIAG_FN names the translation unit's read-out function.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gtx {
+namespace {
+__device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MHz ticks, [2] K loops stamped
+}
+}
+
+#define GTXS_DIAG_LOOP_BEGIN() \
+  const unsigned long long st_c0__ = __builtin_amdgcn_s_memtime(), st_r0__ = __builtin_amdgcn_s_memrealtime();
+#define GTXS_DIAG_LOOP_END()                                                                                \
+  {                                                                                                         \
+    const unsigned long long st_c1__ = __builtin_amdgcn_s_memtime(), st_r1__ = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0) {                                                                                 \
+      atomicAdd(&gtx::g_clock_stamp[0], st_c1__ - st_c0__);                                                 \
+      atomicAdd(&gtx::g_clock_stamp[1], st_r1__ - st_r0__);                                                 \
+      atomicAdd(&gtx::g_clock_stamp[2], 1ull);                                                              \
+    }                                                                                                       \
+  }
+
+// out = {shader-clock ticks, 100 MHz ticks, K loops, 0...} summed since the last call; clears the sums.
+extern "C" int GTX_DIAG_FN(unsigned long long out[8]) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtx::g_clock_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(gtx::g_clock_stamp), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}

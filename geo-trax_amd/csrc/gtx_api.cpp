@@ -16,6 +16,7 @@
 #include "match_l2.hpp"
 #include "register.hpp"
 #include "sift.hpp"
+#include "split_format.hpp"
 #include "stabilizer.hpp"
 #include "tracker.hpp"
 
@@ -147,9 +148,11 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   st.ho = (d->h + 2 * pad - d->ksize) / d->stride + 1;
   st.wo = (d->w + 2 * pad - d->ksize) / d->stride + 1;
   st.cfg = conv_pick_config(d->dtype, d->ksize, d->stride, d->cin, d->cout);
-  const int vn = 16 / (int)es;
-  GTX_CHECK(d->in_cstride % vn == 0 && d->in_coff % vn == 0 && d->out_cstride % 4 == 0 && d->out_coff % 4 == 0,
-            "conv: channel strides/offsets must keep 16-byte (input) / 4-element (output) alignment");
+  const bool pairs = d->dtype == GTX_F32S;       // host arrays are plain fp32; the device buffers hold the pair format (split_format.hpp)
+  const int vn = pairs ? 8 : 16 / (int)es;
+  GTX_CHECK(d->in_cstride % vn == 0 && d->in_coff % vn == 0 && d->out_cstride % (pairs ? 8 : 4) == 0 && d->out_coff % (pairs ? 8 : 4) == 0 &&
+                (!pairs || d->cout % 8 == 0),
+            "conv: channel strides/offsets must keep 16-byte (input) / 4-element (output) alignment, whole 8-channel groups for the split-f16x3 path");
   GTX_CHECK(d->in_coff + d->cin <= d->in_cstride && d->out_coff + d->cout <= d->out_cstride, "conv: slice outside buffer");
   const size_t xin = (size_t)d->n * d->h * d->w * d->in_cstride * es;
   const size_t yout = (size_t)d->n * st.ho * st.wo * d->out_cstride * es;
@@ -160,8 +163,14 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   unsigned long long lcg = 0x2545F4914F6CDD1Dull;
   const bool zeros = std::getenv("GTX_TIME_ZEROS") != nullptr;      // the old behaviour, to show the difference
   auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return zeros ? 0.f : (float)((lcg >> 40) * (1.0 / 8388608.0) - 1.0); };
+  auto upload = [&](void* dst, const void* src, size_t bytes) {           // plain fp32 host array -> pair format on the device
+    if (!pairs) { GTX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    std::vector<uint8_t> tmp(bytes);
+    f32_to_pairs(static_cast<const float*>(src), tmp.data(), bytes / 4);
+    GTX_HIP(hipMemcpy(dst, tmp.data(), bytes, hipMemcpyHostToDevice));
+  };
   if (x) {
-    GTX_HIP(hipMemcpy(st.x.p, x, xin, hipMemcpyHostToDevice));
+    upload(st.x.p, x, xin);
   } else if (es == 2) {
     std::vector<_Float16> hx(xin / 2);
     for (auto& v : hx) v = (_Float16)uni();
@@ -169,9 +178,9 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   } else {
     std::vector<float> hx(xin / 4);
     for (auto& v : hx) v = uni();
-    GTX_HIP(hipMemcpy(st.x.p, hx.data(), xin, hipMemcpyHostToDevice));
+    upload(st.x.p, hx.data(), xin);
   }
-  if (y_init) GTX_HIP(hipMemcpy(st.y.p, y_init, yout, hipMemcpyHostToDevice));
+  if (y_init) upload(st.y.p, y_init, yout);
   std::vector<uint8_t> packed;
   float acc_scale = 1.f;
   if (w) {
@@ -193,7 +202,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   if (d->has_residual) {
     const size_t rb = (size_t)d->n * st.ho * st.wo * d->cout * es;
     st.r.alloc(rb);
-    if (residual) GTX_HIP(hipMemcpy(st.r.p, residual, rb, hipMemcpyHostToDevice));
+    if (residual) upload(st.r.p, residual, rb);
     else GTX_HIP(hipMemset(st.r.p, 0, rb));
   }
   ConvProblem& p = st.g.p[0];
@@ -207,6 +216,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.act = d->act;
   p.acc_scale = acc_scale;
   p.in2 = nullptr; p.in2_cstride = p.in2_coff = p.c_split = 0;
+  p.out_plain = 0; p.sat_flag = nullptr;
   st.g.count = 1;
   conv_group_finalize(st.g, st.cfg);
 }
@@ -221,8 +231,14 @@ int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const flo
     conv_setup(ctx, d, x, w_ohwi, bias, residual, y, st);
     gtx::conv_launch(st.g, st.cfg, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
-    GTX_HIP(hipMemcpy(y, st.y.p, st.y.bytes >= 256 ? (size_t)d->n * st.ho * st.wo * d->out_cstride * gtx::dtype_size(d->dtype) : 0,
-                      hipMemcpyDeviceToHost));
+    const size_t yb = (size_t)d->n * st.ho * st.wo * d->out_cstride * gtx::dtype_size(d->dtype);
+    if (d->dtype == GTX_F32S) {                       // pair format -> the caller's plain fp32 array
+      std::vector<uint8_t> tmp(yb);
+      GTX_HIP(hipMemcpy(tmp.data(), st.y.p, yb, hipMemcpyDeviceToHost));
+      gtx::pairs_to_f32(tmp.data(), static_cast<float*>(y), yb / 4);
+    } else {
+      GTX_HIP(hipMemcpy(y, st.y.p, yb, hipMemcpyDeviceToHost));
+    }
   });
 }
 
@@ -274,10 +290,16 @@ int gtx_op_sppf_pool(gtx_ctx* ctx, int dtype, int n, int h, int w, int c, void* 
     GTX_HIP(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)n * h * w * 4 * c * gtx::dtype_size(dtype);
     gtx::DevBuf d(bytes);
-    GTX_HIP(hipMemcpy(d.p, x_inout, bytes, hipMemcpyHostToDevice));
+    std::vector<uint8_t> tmp;
+    if (dtype == GTX_F32S) {                          // plain fp32 host array <-> pair format on the device
+      tmp.resize(bytes);
+      gtx::f32_to_pairs(static_cast<const float*>(x_inout), tmp.data(), bytes / 4);
+    }
+    GTX_HIP(hipMemcpy(d.p, dtype == GTX_F32S ? tmp.data() : x_inout, bytes, hipMemcpyHostToDevice));
     gtx::launch_sppf_pool(dtype, d.p, n, h, w, c, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
-    GTX_HIP(hipMemcpy(x_inout, d.p, bytes, hipMemcpyDeviceToHost));
+    GTX_HIP(hipMemcpy(dtype == GTX_F32S ? tmp.data() : x_inout, d.p, bytes, hipMemcpyDeviceToHost));
+    if (dtype == GTX_F32S) gtx::pairs_to_f32(tmp.data(), static_cast<float*>(x_inout), bytes / 4);
   });
 }
 
@@ -527,6 +549,9 @@ int gtx_detector_raw_logits(gtx_detector* det, int b, float* out, int* n_anchors
 }
 int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out, int* h, int* w, int* c) {
   return guarded([&] { need(det, "det"); need(layer, "layer"); det->impl->layer_output(b, layer, out, h, w, c); });
+}
+int gtx_detector_saturated(gtx_detector* det, int clear, int* flag) {
+  return guarded([&] { need(det, "det"); need(flag, "flag"); *flag = det->impl->saturated(clear != 0) ? 1 : 0; });
 }
 int gtx_detector_trace(gtx_detector* det, int every_n) {
   return guarded([&] { need(det, "det"); det->impl->set_trace(every_n); });

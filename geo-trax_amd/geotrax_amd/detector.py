@@ -8,6 +8,7 @@ class-agnostic NMS, scaling back to frame pixels -- with the config keys the ref
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 from dataclasses import dataclass
 
@@ -15,6 +16,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import DetConfig, check, ptr
+
+logger = logging.getLogger(__name__)
 
 
 # which fp32-grade convolution a half=False detector uses unless told otherwise (see Detector.__init__)
@@ -80,6 +83,7 @@ class Detector:
         self._conf = np.zeros((max_batch, max_det), np.float32)
         self._cls = np.zeros((max_batch, max_det), np.int32)
         self._speed = np.zeros(3, np.float32)
+        self._sat_warned = False
 
     def close(self):
         if getattr(self, "handle", None):
@@ -92,7 +96,20 @@ class Detector:
         except Exception:
             pass
 
+    def saturated(self, clear: bool = False) -> bool:
+        """fp32_split only: an activation of a collected pass lay beyond fp16's range and was clamped where the split-f16x3 path
+        stores it (include/gtx.h: gtx_detector_saturated). Such a checkpoint needs fp32_split=False."""
+        if not self.fp32_split:
+            return False
+        f = C.c_int()
+        check(self.ctx.lib.gtx_detector_saturated(self.handle, int(clear), C.byref(f)))
+        return bool(f.value)
+
     def _collect(self, nb: int) -> list[Detections]:
+        if self.fp32_split and not self._sat_warned and self.saturated():
+            self._sat_warned = True
+            logger.warning("activations beyond fp16's range (|x| > 65504) were clamped by the split-f16x3 convolutions: detections differ "
+                           "from an fp32 run of this checkpoint; set fp32_split: false (GTX_FP32_SPLIT=0) for the exact-fp32 MFMA path")
         sp = dict(preprocess=float(self._speed[0]), inference=float(self._speed[1]), postprocess=float(self._speed[2]))
         out = []
         for b in range(nb):

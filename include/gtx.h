@@ -37,7 +37,8 @@ extern "C" {
  *    gtx_tracker_replay, gtx_op_clahe, gtx_warp_frame_dev, gtx_yuv420_to_bgr_dev, gtx_stabilizer_{pattern, last_ms} added.
  *    A binder checks gtx_abi_version() against the header it was written for before passing any struct.
  * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort).
- * 4: gtx_op_linear_assignment added. */
+ * 4: gtx_op_linear_assignment and gtx_detector_saturated added; GTX_F32S activations live in HBM as (hi, lo) fp16 pairs
+ *    (host arrays handed to gtx_op_* stay plain fp32). */
 #define GTX_ABI_VERSION 4
 
 typedef enum gtx_status {
@@ -213,6 +214,12 @@ int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float
 /* Per-kernel-family profile of one forward pass: launches, total ms (HIP events around every
  * launch on the launch stream, graph disabled) and algorithmic FLOPs / bytes. `names` receives
  * up to cap entries of 96 chars. Feeds bench.py's roofline object. */
+/* fp32_split only. *flag = 1 when an activation of a collected pass (since the last call with clear != 0) lay beyond fp16's
+ * range and was clamped to +-65504 where the split-f16x3 path stores it as a (hi, lo) fp16 pair: the detections then differ
+ * from an fp32 run and the checkpoint needs fp32_split = 0 (exact fp32 MFMA). Trained, BN-folded YOLOv8 weights never get
+ * there; the flag exists so that a fine-tuned or unfused model cannot saturate silently. */
+int gtx_detector_saturated(gtx_detector* det, int clear, int* flag);
+
 /* Live variant: after gtx_detector_trace(det, n) every n-th submitted pass carries a HIP event in
  * front of every launch of its forward graph; gtx_detector_profile(det, 0, 0, ...) then returns (and
  * clears) the per-family totals of the traced passes, i.e. kernel durations as they were inside the

@@ -94,7 +94,12 @@ def test_conv2d_split_slices_residual_and_exact_integers(gtx_ctx):
     res = np.ascontiguousarray(buf[..., 32:64])
     got = ops.conv2d(buf, wt, b, in_coff=32, cin=32, out=buf.copy(), out_coff=64, residual=res, split=True, ctx=gtx_ctx)
     np.testing.assert_allclose(got[..., 64:96], conv2d_nhwc(buf[..., 32:64], wt, b, residual=res), rtol=2e-5, atol=2e-5)
-    np.testing.assert_array_equal(got[..., :64], buf[..., :64])
+    # The slices the convolution does not write come back as they went in: as (hi, lo) fp16 pairs, the form GTX_F32S
+    # tensors have on the device (csrc/split_format.hpp) -- 22 significant bits of the fp32 host values
+    hi = buf[..., :64].astype(np.float16)
+    lo = (buf[..., :64] - hi.astype(np.float32)).astype(np.float16)
+    np.testing.assert_array_equal(got[..., :64], hi.astype(np.float32) + lo.astype(np.float32))
+    np.testing.assert_allclose(got[..., :64], buf[..., :64], rtol=3e-7, atol=6e-8)
     # small integers: hi parts carry everything, lo parts are zero, every partial sum is exact
     for (cin, cout, k, s) in [(32, 64, 3, 1), (64, 32, 3, 2), (128, 64, 1, 1), (48, 32, 1, 1)]:
         x = rng.integers(-3, 4, (1, 21, 35, cin)).astype(np.float32)
@@ -187,3 +192,24 @@ def test_preprocess_matches_oracle(gtx_ctx, dtype, shape, imgsz, rect):
     np.testing.assert_array_equal(img[..., :3].astype(np.float32), ref_nhwc.astype(dtype).astype(np.float32))
     assert not img[..., 3].any()
     np.testing.assert_array_equal(gray, bgr2gray_half(frame))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,residual", [(64, 64, 37, 50, False), (128, 192, 24, 40, True), (32, 32, 19, 33, False), (64, 48, 16, 16, True)])
+def test_ring_kernel_equals_the_default_split_kernel(gtx_ctx, monkeypatch, cin, cout, h, w, residual):
+    """GTX_CONV_RING=1 routes 3x3 stride-1 split-f16x3 convolutions through the persistent LDS-DMA kernel
+    (csrc/conv3x3_ring.hip: one workgroup per CU walking tiles, buffer_load ... lds staging, out-of-image pixels and ragged
+    cout tiles by the buffer range check). Same tiles, same K order, same three MFMAs per product: the outputs must be the
+    default kernel's bit for bit -- ragged sizes, a half-empty last cout tile, residual, batch 3."""
+    from geotrax_amd import ops
+
+    rng = np.random.default_rng(cin + cout + h)
+    x = (rng.standard_normal((3, h, w, cin)) * 10.0 ** rng.uniform(-3, 1, (3, h, w, cin))).astype(np.float32)
+    wt = (rng.standard_normal((cout, 3, 3, cin)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    res = rng.standard_normal((3, h, w, cout)).astype(np.float32) if residual else None
+    monkeypatch.delenv("GTX_CONV_RING", raising=False)
+    want = ops.conv2d(x, wt, b, residual=res, split=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_CONV_RING", "1")
+    got = ops.conv2d(x, wt, b, residual=res, split=True, ctx=gtx_ctx)
+    np.testing.assert_array_equal(got, want)
+    assert np.abs(want).max() > 0.1

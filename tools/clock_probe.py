@@ -8,7 +8,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAMP = os.path.join(ROOT, "geo-trax_amd", "build", "libgtx_stamp2.so" if os.environ.get("GTX_STAMP_PHASES") else "libgtx_stamp.so")
+STAMP = os.environ.get("GTX_STAMP_LIB") or os.path.join(ROOT, "geo-trax_amd", "build", "libgtx_stamp.so")
 os.environ["GTX_LIB"] = STAMP
 sys.path.insert(0, os.path.join(ROOT, "geo-trax_amd"))
 from geotrax_amd import _lib, ops  # noqa: E402
@@ -17,14 +17,19 @@ NB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 SECS = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 ctx = _lib.default_context(0)
 dbg = ctypes.CDLL(STAMP)
-dbg.gtx_debug_conv_clock.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-dbg.gtx_debug_conv_clock.restype = ctypes.c_int
+for fn in (dbg.gtx_debug_conv_clock, dbg.gtx_debug_ring_clock):
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    fn.restype = ctypes.c_int
 
 
 def read():
-    out = (ctypes.c_ulonglong * 8)()
-    assert dbg.gtx_debug_conv_clock(out) == 0
-    return list(out)
+    """Sums of the two stamped translation units (a layer runs in one of them: the other's are zero)."""
+    tot = [0] * 8
+    for fn in (dbg.gtx_debug_conv_clock, dbg.gtx_debug_ring_clock):
+        out = (ctypes.c_ulonglong * 8)()
+        assert fn(out) == 0
+        tot = [a + b for a, b in zip(tot, out)]
+    return tot
 
 
 LAYERS = [("h0.s1", 128, 192, 3, 1, 240), ("h0.s2c", 128, 128, 3, 1, 240), ("m4.m", 64, 64, 3, 1, 240), ("m6.m", 128, 128, 3, 1, 120),
@@ -40,8 +45,4 @@ for nm, cin, cout, k, s, h in LAYERS:
     c, r, n, *ph = read()
     ghz = c / max(r, 1) * 0.1
     print(f"{nm:8s} {cin:4d}->{cout:4d} k{k} s{s} {h:4d}^2  {ms * 1000:8.1f} us  {fl / ms / 1e9:7.1f} TF/s   in-kernel clock {ghz:5.2f} GHz"
-          f"   ({n} workgroups stamped, {c / max(n, 1):9.0f} cycles per K loop)")
-    nch = cin // (32 if (k == 1 and cin % 32 == 0) else 16)
-    names = ["barrier 1", "load wait", "commit", "barrier 2", "prefetch issue + matrix"]
-    if os.environ.get("GTX_STAMP_PHASES"):
-        print("           per chunk, wave 0: " + ", ".join(f"{nm_} {p / max(n, 1) / nch:6.0f}" for nm_, p in zip(names, ph)))
+          f"   ({n} K loops stamped, {c / max(n, 1):9.0f} cycles per K loop)")

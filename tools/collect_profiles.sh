@@ -30,5 +30,4 @@ GTX_TIME_ZEROS=1 python tools/conv_sweep.py 1920 2 all f32s > $O/conv_layer_swee
 GTX_PROFILE_PER_OP=1 python tools/op_profile.py 2 f32s 10 > $O/op_profile_per_launch_f32s_b2.txt 2>/dev/null
 python tools/clock_probe.py 2 2 > $O/conv_clock.txt 2>/dev/null
 GTX_TIME_ZEROS=1 python tools/clock_probe.py 2 2 > $O/conv_clock_zeros.txt 2>/dev/null
-GTX_STAMP_PHASES=1 python tools/clock_probe.py 2 1 > $O/conv_clock_phases.txt 2>/dev/null
 ls $O
