@@ -134,14 +134,28 @@ def pmc_traffic(kernel, batch):
     written by tools/pmc_summary.py from two rocprofv3 --pmc runs of this command: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950, plus WRITE_SIZE), or None when
     no summary for this batch size is present."""
-    f = ROOT / "profiles" / "r02_pmc_traffic.json"
+    files = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))      # the newest round's collection
     try:
+        f = files[-1]
         rec = json.loads(f.read_text())
         if rec.get("batch") != batch:
             return None
         return rec["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
+
+
+def host_cores() -> int:
+    """Host cores this job may use: the cgroup quota when there is one (the GPU boxes give 16 of 256), else the affinity mask."""
+    cores = len(os.sched_getaffinity(0))
+    for f in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = Path(f).read_text().split()[:2]
+            if quota != "max":
+                cores = max(1, min(cores, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    return cores
 
 
 def cpu_baseline(weights, ref_frame, frame, args):
@@ -745,7 +759,7 @@ def main():
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                    "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / MFMA_PEAK_TFLOPS[dt]),
                                    "traffic": pmc_traffic(top["kernel"], B),
-                                   "traffic_source": "profiles/r02_pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                   "traffic_source": "profiles/rNN_pmc_traffic.json (newest round): committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                                      "(tools/collect_profiles.sh), NOT measured in this run; null when no pass for this kernel and batch is committed",
                                    "avg_launch_us": 1000.0 * top["total_ms"] / top["launches"],
                                    "launches_timed": top["launches"],
@@ -794,6 +808,27 @@ def main():
                                       "process of this run after the primary measurement; secondary, not `value`"}
             except Exception as e:                                  # the secondary line must never void the primary one
                 out["f16"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and dist is None and not args.half and det.fp32_split and not args.no_f16_line:
+            # secondary key: the strict fp32 arithmetic (v_mfma_f32_32x32x2_f32, no split) of the same workload, so that the
+            # driver's line carries the exact-fp32 number next to the split-f16x3 one
+            import subprocess
+
+            nx = max(args.steps // 4, 10)
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--fp32", "exact", "--steps", str(nx), "--warmup", str(min(args.warmup, 6)), "--no-cpu-baseline",
+                   "--no-profile", "--no-f16-line", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams", str(args.det_streams),
+                   "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
+                   "--imgsz", str(args.imgsz), "--rect", str(args.rect)]
+            try:
+                px = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                dx = json.loads([ln for ln in px.stdout.splitlines() if ln.startswith("{")][-1])
+                out["f32_exact"] = {"value": dx["value"], "unit": "frames/s", "steps": dx["steps"], "ms_per_step": dx["ms_per_step"], "dtype": dx["dtype"],
+                                    "note": "same workload with the exact-fp32 MFMA convolutions (fp32_split = 0), measured by a child process of this run "
+                                            "after the primary measurement; secondary, not `value`"}
+            except Exception as e:
+                out["f32_exact"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        out["host"] = {"cores": host_cores(), "threads_per_rank": engine.host_threads + (1 if (sharded and extract and rank == 0) else 0) + 1,
+                       "note": "engine stage threads (blocking waits: they sleep while the GPU works) + the main thread" +
+                               (" + rank 0's tracker replay thread" if (sharded and extract) else "")}
         if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (the other ranks would sit in the barrier below)
             out["cpu_baseline"] = cpu_baseline(weights, ref_frame, frames[1], args)
         print(json.dumps(out), flush=True)

@@ -1,14 +1,16 @@
 """Frame-sharded extraction across the GPUs of one node.
 
 Detection and stabilization of a frame depend only on that frame (and on the reference frame's
-keypoints), the tracker is a sequential scan. So: one process per GPU, contiguous frame ranges
-per rank, every rank registers against the same reference frame (it reads that one frame itself
--- cheaper than a broadcast and bit-identical on every rank), per-frame fixed-stride records are
-gathered to rank 0 over ``torch.distributed`` (RCCL on GPUs, gloo in the CPU tests), and rank 0
-replays the tracker over the frames in order and warps the tracker boxes with each frame's H.
+keypoints), the tracker is a sequential scan. So: one process per GPU; the clip is dealt to the ranks
+in runs of consecutive frames, round-robin (shard_runs); every rank registers against the same
+reference frame (it reads that one frame itself -- cheaper than a broadcast and bit-identical on
+every rank); after every round the per-frame fixed-stride records of the round are gathered to rank 0
+over ``torch.distributed`` (RCCL on GPUs, gloo in the CPU tests), where a second host thread replays
+the tracker over them in clip order and warps the tracker boxes with each frame's H while the GPUs
+work on the next round: no serial tail remains after the last frame but the last round itself.
 
-The only exchange on the data path is that one gather of KB-sized records; weights are loaded by
-every rank from the same file. Difference from the single-GPU ("exact") order, by construction: the
+The only exchange on the data path is that gather of KB-sized records (and the all-reduce of a
+failure flag in front of it); weights are loaded by every rank from the same file. Difference from the single-GPU ("exact") order, by construction: the
 stabilizer mask of a frame is built from the raw detections instead of the tracker-output boxes
 (extract.py:181 uses the latter), because the tracker has not run yet when a shard rank stabilizes.
 """
@@ -85,7 +87,7 @@ def gather_records(local: np.ndarray, failed: bool, dist=None, device=None):
     (padded to the same `per`) and a failure flag; rank 0 gets (list of blocks by rank, any_failed), the others
     (None, any_failed). A rank that failed on its shard still takes part (with zeros), so nobody waits for a
     timeout; rank 0 then voids the whole video like the reference does for any exception (extract.py:198-200)."""
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return [local], bool(failed)
     import torch
 
@@ -103,34 +105,56 @@ def gather_records(local: np.ndarray, failed: bool, dist=None, device=None):
     return [b.cpu().numpy() for b in bufs], any_failed
 
 
-def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_boxes, max_det: int, with_gmc: bool = False):
-    """Rank 0: the sequential half of the loop over the gathered records, in clip order (extract.py:153-187 with the
-    detector and stabilizer results taken from the records): tracker.update on every frame (with the rank's
-    camera-motion warp for BoT-SORT), ids -1 when the tracker returns nothing, boxes warped by the frame's H, the first
-    frame passes through as the reference frame. -> (frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms)."""
-    def xywh_of(b):
+def shard_runs(n_frames: int, world: int, first: int = 0, run_frames: int | None = None) -> list[list[tuple[int, int]]]:
+    """How frames [first, n_frames) are dealt to the ranks: rounds[k][r] = [start, stop) of rank r in round k.
+    run_frames None: one round of contiguous ranges (shard_range). Otherwise the clip is cut into runs of run_frames
+    consecutive frames dealt round-robin, `world` runs per round: after a round the records of world * run_frames consecutive
+    frames can go to rank 0, whose tracker replays them while the GPUs work on the next round (no serial tail after the
+    last frame has been detected). Runs keep frames consecutive so that BoT-SORT's GMC needs one priming frame per run."""
+    if run_frames is None or world == 1:
+        return [[shard_range(n_frames, r, world, first) for r in range(world)]]
+    rounds, pos = [], first
+    while pos < n_frames:
+        row = []
+        for _ in range(world):
+            e = min(pos + run_frames, n_frames)
+            row.append((pos, e))
+            pos = e
+        rounds.append(row)
+    return rounds or [[(first, first)] * world]
+
+
+class Replayer:
+    """Rank 0: the sequential half of the loop over gathered records, fed in clip order, any number of frames at a time
+    (extract.py:153-187 with the detector and stabilizer results taken from the records): tracker.update on every frame (with
+    the rank's camera-motion warp for BoT-SORT) in one C call per feed (gtx_tracker_replay), ids -1 when the tracker returns
+    nothing, boxes warped by the frame's H, the first frame passes through as the reference frame."""
+
+    def __init__(self, first: int, tracker, warp_boxes, max_det: int, with_gmc: bool = False):
+        self.first, self.tracker, self.warp_boxes, self.max_det, self.with_gmc = first, tracker, warp_boxes, max_det, with_gmc
+        self.lists = ([], [], [], [], [], [], [])            # frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms
+        self.last_H = None
+
+    @staticmethod
+    def _xywh(b):
         return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32)
 
-    frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms = [], [], [], [], [], [], []
-    last_H = None
-    # the tracker sees every frame in clip order in one C call (gtx_tracker_replay); the bookkeeping below is per frame
-    order = [blocks[r][k] for r in range(world) for k in range(shard_range(n_frames, r, world, first)[1] - shard_range(n_frames, r, world, first)[0])]
-    per, t_xyxy, t_ids, t_score, t_cls, _ = tracker.replay(np.stack(order), max_det, with_gmc=with_gmc) if order else (np.zeros(0, np.int32),) + (np.zeros((0, 4), np.float32),) * 5
-    starts = np.concatenate([[0], np.cumsum(per)]) if len(per) else np.zeros(1, np.int64)
-    i = 0
-    for r in range(world):
-        s, e = shard_range(n_frames, r, world, first)
-        for k, f in enumerate(range(s, e)):
-            rec = blocks[r][k]
-            xyxy, conf, cls, H = unpack_frame_record(rec, max_det)
+    def feed(self, frames, recs) -> None:
+        """frames: frame numbers (clip order, continuing the previous feed); recs: their packed records."""
+        if len(frames) == 0:
+            return
+        frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms = self.lists
+        per, t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.replay(np.stack(recs), self.max_det, with_gmc=self.with_gmc)
+        starts = np.concatenate([[0], np.cumsum(per)])
+        for i, (f, rec) in enumerate(zip(frames, recs)):
+            xyxy, conf, cls, H = unpack_frame_record(rec, self.max_det)
             a, b = int(starts[i]), int(starts[i + 1])
-            i += 1
             bx, ids, sc, cl = t_xyxy[a:b], t_ids[a:b], t_score[a:b], t_cls[a:b]
-            if f != first:
+            if f != self.first:
                 if H is None:
-                    H = last_H                                   # stabilo's last known transform (see engine._stabilized)
+                    H = self.last_H                              # stabilo's last known transform (see engine._stabilized)
                 else:
-                    last_H = H
+                    self.last_H = H
                 if H is not None:
                     transforms.append(np.hstack((np.array([[f]]), H.reshape(1, -1))))
             if len(conf) == 0:
@@ -138,36 +162,97 @@ def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_
             if len(ids) == 0:
                 bx, ids, sc, cl = xyxy, np.full(len(conf), -1), conf, cls
             n = len(ids)
-            xywh = xywh_of(bx)
+            xywh = self._xywh(bx)
             frame_arr.append(np.full((n, 1), f, dtype=np.uint32))
             track_id.append(np.asarray(ids).reshape(-1, 1).astype(np.uint16) if (np.asarray(ids) >= 0).all() else np.full((n, 1), -1))
             bbox.append(xywh)
             class_id.append(np.asarray(cl).astype(np.uint8).reshape(-1, 1))
             confs.append(np.asarray(sc, dtype=np.float32).reshape(-1, 1))
-            bbox_stab.append(xywh if f == first or H is None else warp_boxes(H, xywh))
-    return frame_arr, track_id, bbox, bbox_stab, class_id, confs, transforms
+            bbox_stab.append(xywh if f == self.first or H is None else self.warp_boxes(H, xywh))
 
 
-def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max_det: int, dist=None, device=None, with_gmc: bool = False):
-    """One video, frames [first, n_frames) sharded in contiguous ranges over the ranks of `dist` (None: one process).
-    `produce(start, stop)` yields this rank's packed records in frame order (geotrax_amd.extract drives the HIP engine
-    there; the CPU tests a deterministic stand-in). Rank 0 returns the per-frame lists aggregate_results() expects, the
-    other ranks None. If any rank fails, every rank raises RuntimeError after the (still completed) collective."""
+def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_boxes, max_det: int, with_gmc: bool = False):
+    """One-shot form (contiguous ranges, everything gathered): blocks[r][k] = record of rank r's k-th frame.
+    -> (frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms)."""
+    rp = Replayer(first, tracker, warp_boxes, max_det, with_gmc)
+    frames, recs = [], []
+    for r in range(world):
+        s, e = shard_range(n_frames, r, world, first)
+        frames += list(range(s, e))
+        recs += [blocks[r][k] for k in range(e - s)]
+    rp.feed(frames, recs)
+    return rp.lists
+
+
+def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max_det: int, dist=None, device=None, with_gmc: bool = False,
+                    run_frames: int | None = None):
+    """One video, frames [first, n_frames) sharded over the ranks of `dist` (None: one process) as shard_runs() deals them.
+    `produce(runs)` yields this rank's packed records, frame by frame, for its list of [start, stop) runs in order
+    (geotrax_amd.extract drives the HIP engine there, one pipeline across the runs; the CPU tests a deterministic stand-in).
+    After every round each rank contributes its run's records to one gather (preceded by an all-reduce of a failure flag);
+    rank 0 hands the round to a replay thread (tracker + box warps, in clip order) and goes on producing, so the tracker works
+    while the GPUs do and nothing is left to replay serially after the last round but that round itself.
+    Rank 0 returns the per-frame lists aggregate_results() expects, the other ranks None. If any rank fails, every rank raises
+    RuntimeError after the collective of the round in which it failed (a failing rank still takes part, with zeros: nobody
+    waits for a timeout)."""
+    import queue
+    import threading
+
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
-    start, stop = shard_range(n_frames, rank, world, first)
-    per = -(-max(n_frames - first, 0) // world)                  # records per rank, padded
+    rounds = shard_runs(n_frames, world, first, run_frames)
+    mine = [row[rank] for row in rounds]
+    per = max(max(e - s for s, e in row) for row in rounds)      # records per rank and round, padded
     stride = 1 + max_det * 6 + (7 if with_gmc else 0) + 10
-    local = np.zeros((per, stride), dtype=np.float64)
     failed, err = False, None
+    gen = None
+    replayer = Replayer(first, tracker, warp_boxes, max_det, with_gmc) if rank == 0 else None
+    work: queue.Queue = queue.Queue()
+    replay_err: list = []
+
+    def replay_loop():
+        try:
+            while True:
+                item = work.get()
+                if item is None:
+                    return
+                replayer.feed(*item)
+        except BaseException as e:                               # surfaced on the main thread after the join
+            replay_err.append(e)
+
+    th = None
+    if rank == 0:
+        th = threading.Thread(target=replay_loop, name="gtx-replay", daemon=True)
+        th.start()
     try:
-        for k, rec in enumerate(produce(start, stop)):
-            local[k] = rec
-    except Exception as e:                                       # this rank's shard is lost: tell the others through the collective
-        failed, err = True, e
-    blocks, any_failed = gather_records(local, failed, dist, device)
-    if any_failed:
-        raise RuntimeError(f"frame-sharded extraction failed on {'this rank: ' + repr(err) if failed else 'another rank'}")
+        for k, row in enumerate(rounds):
+            local = np.zeros((per, stride), dtype=np.float64)
+            s, e = mine[k]
+            if not failed and e > s:
+                try:
+                    if gen is None:
+                        gen = iter(produce([r for r in mine if r[1] > r[0]]))
+                    for i in range(e - s):
+                        local[i] = next(gen)
+                except (Exception, SystemExit) as ex:            # this rank's shard is lost (SystemExit: initialize_streams on an unreadable
+                    failed, err = True, ex                       # source): tell the others through the collective
+            blocks, any_failed = gather_records(local, failed, dist, device)
+            if any_failed:
+                raise RuntimeError(f"frame-sharded extraction failed on {'this rank: ' + repr(err) if failed else 'another rank'}")
+            if rank == 0:
+                frames, recs = [], []
+                for r, (rs, re_) in enumerate(row):
+                    frames += list(range(rs, re_))
+                    recs += [blocks[r][i] for i in range(re_ - rs)]
+                work.put((frames, recs))
+    finally:
+        if gen is not None and hasattr(gen, "close"):
+            gen.close()
+        if th is not None:
+            work.put(None)
+            th.join()
+    if replay_err:
+        raise replay_err[0]
     if rank != 0:
         return None
-    return replay_records(blocks, n_frames, first, world, tracker, warp_boxes, max_det, with_gmc)
+    return replayer.lists

@@ -121,6 +121,11 @@ class ExtractEngine:
         self._last_H = None              # last valid current->reference transform, in frame order
         self._gmc_sub = self._gmc_col = 0   # frames queued on the GMC stream / warps taken (one writer thread each)
 
+    #: host threads the engine adds to the caller's: the detector stage and the GMC + tracker stage (the stabilizer stage runs on
+    #: the thread that iterates run()). All three wait on HIP events with hipEventBlockingSync, i.e. asleep while the GPU works:
+    #: 8 ranks x 3 threads + rank 0's replay thread fit the 16 host cores a GPU box grants without spinning against each other.
+    host_threads = 2
+
     # ---- lifecycle
     def set_reference(self, frame: np.ndarray) -> None:
         """Registers every stabilizer against `frame` (host BGR) ahead of run(): the frames fed afterwards are all

@@ -131,15 +131,19 @@ def frame_sharding_active() -> bool:
     this off (GTX_FRAME_SHARDING=0)."""
     import os
 
-    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("GTX_FRAME_SHARDING", "1") != "0"
+    mode = os.environ.get("GTX_FRAME_SHARDING", "1")
+    if mode == "force":                                   # the sharded path with whatever world size the launcher gave, even 1 (tests:
+        return "RANK" in os.environ                       # RCCL's code path on a one-GPU box)
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and mode != "0"
 
 
 def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray] | None:
     """The hot loop with the frames of the video sharded over the ranks of the launcher (one process per GPU):
-    contiguous frame ranges, every rank registers against the same reference frame and detects + stabilizes its range
-    (foreground mask from the raw detections; BoT-SORT: the rank's GMC is primed with the frame before its range),
-    fixed-stride records go to rank 0 in ONE gather (RCCL when every rank has its own GPU), and rank 0 replays the
-    tracker in clip order. Rank 0 returns (tracks, transforms); the other ranks None. A failure on any rank voids the
+    runs of consecutive frames dealt round-robin (distributed.shard_runs), every rank registers against the same reference
+    frame and detects + stabilizes its runs through one engine pipeline (foreground mask from the raw detections; BoT-SORT:
+    the rank's GMC is primed with the frame before each run), fixed-stride records go to rank 0 in one gather per round
+    (RCCL when every rank has its own GPU), and rank 0 replays the tracker in clip order on a second thread while the
+    GPUs work on the next round. Rank 0 returns (tracks, transforms); the other ranks None. A failure on any rank voids the
     video on all of them (geotrax_amd.distributed.extract_sharded)."""
     from . import distributed as D
     from .engine import ExtractEngine
@@ -156,7 +160,9 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
     max_det = det_kw['max_det']
     state = {}
 
-    def produce(start, stop):
+    def produce(runs):
+        """This rank's records, frame by frame, for its [start, stop) runs in order: ONE engine pipeline across the runs; a run
+        opens with the clip's frame before it as the GMC's priming frame (BoT-SORT), batches never span two runs."""
         reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
         state['reader'] = reader
         n_total = reader.frame_count if last is None else min(reader.frame_count, last + 1)
@@ -164,67 +170,79 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, None, stab_kw, device=local, batch=int(eng_cfg.get('batch', 2)),
                                det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)), gmc=with_gmc)
         state['engine'] = engine
-        ref, prev, f = None, None, 0
-        if hasattr(reader, 'seek') and start > first:       # seekable source (.y4m): jump, reading only the two frames needed
-            reader.seek(first)
-            ok, ref = reader.read()
-            reader.seek(start - 1)
-            ok2, prev = reader.read()
-            if not (ok and ok2):
-                raise RuntimeError(f"frames {first} / {start - 1} could not be read")
-            f = start
-        while f < start:                                    # sequential source: skip to the range, keeping the two frames needed
-            ok, frame = reader.read()
-            if not ok:
+        seekable = hasattr(reader, 'seek')
+        cursor = {'pos': 0, 'last': None}                    # sequential sources: next frame read() returns, and the one before it
+        fail_at = os.environ.get("GTX_TEST_FAIL_AT_FRAME")   # fault injection for the failure-path test
+
+        def frame_at(f):
+            """Frame f of the clip (f never decreases between calls except for the reference / priming frames of a seekable source)."""
+            if seekable:
+                if cursor['pos'] != f:
+                    reader.seek(f)
+                ok, frame = reader.read()
+                cursor['pos'] = f + 1
+            else:
+                if f == cursor['pos'] - 1 and cursor['last'] is not None:
+                    return cursor['last']
+                ok, frame = True, None
+                while ok and cursor['pos'] <= f:
+                    ok, frame = reader.read()
+                    cursor['pos'] += 1
+                cursor['last'] = frame
+            if not ok or frame is None or (fail_at is not None and f == int(fail_at)):
                 raise RuntimeError(f"frame {f} could not be read")
-            if f == first:
-                ref = frame
-            if f == start - 1:
-                prev = frame
-            f += 1
+            return frame
+
+        prime = []                                           # device copies of priming frames: a ring, the engine reads them asynchronously
+
+        def prime_ptr(frame):
+            ctx0 = engine.dets[0].ctx
+            if len(prime) < 4:
+                prime.append(ctx0.dev_alloc(frame.nbytes))   # (.nbytes of a Yuv420Frame is that of its BGR frame)
+                state.setdefault('prime', (ctx0, prime))
+            p = prime[state.get('prime_i', 0) % 4]
+            state['prime_i'] = state.get('prime_i', 0) + 1
+            ctx0.dev_upload(p, np.ascontiguousarray(frame.bgr() if hasattr(frame, "bgr") else frame, np.uint8))
+            return p
 
         def batches():
-            nonlocal ref
-            group, opened = [], False
-            prev_ptr = None
-            if with_gmc and prev is not None and start > first:
-                ctx0 = engine.dets[0].ctx
-                prev_ptr = ctx0.dev_alloc(prev.nbytes)          # (.nbytes of a Yuv420Frame is that of its BGR frame)
-                state['prev_ptr'] = (ctx0, prev_ptr)
-                ctx0.dev_upload(prev_ptr, np.ascontiguousarray(prev.bgr() if hasattr(prev, "bgr") else prev, np.uint8))
-            fail_at = os.environ.get("GTX_TEST_FAIL_AT_FRAME")          # fault injection for the failure-path test
-            for f in range(start, stop):
-                ok, frame = reader.read()
-                if not ok or (fail_at is not None and f == int(fail_at)):
-                    raise RuntimeError(f"frame {f} could not be read")
-                if f == first:
-                    ref = frame
-                if ref is not None and not state.get('have_ref') and do_stab:
-                    engine.set_reference(ref)               # every rank registers against the clip's reference frame
+            for start, stop in runs:
+                prev_ptr = None
+                if do_stab and not state.get('have_ref'):
+                    engine.set_reference(frame_at(first))    # every rank registers against the clip's reference frame
                     state['have_ref'] = True
-                group.append(frame)
-                if len(group) == engine.B or f == stop - 1:
-                    yield group if opened else (group, prev_ptr)    # the range does not continue another batch: (re)start the GMC
-                    opened, group = True, []
+                if with_gmc and start > first:
+                    prev_ptr = prime_ptr(frame_at(start - 1))
+                group, opened = [], False
+                for f in range(start, stop):
+                    group.append(frame_at(f))
+                    if len(group) == engine.B or f == stop - 1:
+                        yield group if opened else (group, prev_ptr)    # a run does not continue the previous batch: (re)start the GMC
+                        opened, group = True, []
 
-        if start < stop:
-            if do_stab and ref is not None and start > first:
-                engine.set_reference(ref)
-                state['have_ref'] = True
-            for r in engine.run(batches()):
-                yield D.pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None if r.H_fallback else r.H, r.gmc, with_gmc=with_gmc)
+        for r in engine.run(batches()):
+            yield D.pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None if r.H_fallback else r.H, r.gmc, with_gmc=with_gmc)
 
     try:
         probe = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
         state['n_frames'] = probe.frame_count if last is None else min(probe.frame_count, last + 1)
         probe.release()
-        lists = D.extract_sharded(state['n_frames'], first, produce, tracker, warp_boxes, max_det, dist=dist, device=dev, with_gmc=with_gmc)
-    except Exception as e:
+        # frames per rank and round: whole batches, at most the config's `engine.shard_run_frames` (16), and no more than an even
+        # share of the clip so that short clips still reach every rank (0 / null: one contiguous range per rank, one gather)
+        run_frames = eng_cfg.get('shard_run_frames', 16)
+        if run_frames:
+            bsz = max(int(eng_cfg.get('batch', 2)), 1)
+            share = -(-max(state['n_frames'] - first, 1) // dist.get_world_size())
+            run_frames = max(bsz, min(-(-int(run_frames) // bsz) * bsz, -(-share // bsz) * bsz))
+        lists = D.extract_sharded(state['n_frames'], first, produce, tracker, warp_boxes, max_det, dist=dist, device=dev, with_gmc=with_gmc,
+                                  run_frames=run_frames or None)
+    except (Exception, SystemExit) as e:                     # SystemExit: initialize_streams on a missing / unopenable source
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return (np.empty((0, 12), dtype=np.float32), np.empty((0, 10))) if rank == 0 else None
     finally:
-        if 'prev_ptr' in state:
-            state['prev_ptr'][0].dev_free(state['prev_ptr'][1])
+        if 'prime' in state:
+            for p_ in state['prime'][1]:
+                state['prime'][0].dev_free(p_)
         if 'reader' in state:
             state['reader'].release()
         if 'engine' in state:

@@ -131,25 +131,30 @@ class Y4mReader(FrameReader):
         self.frame_hw = (self.h, self.w)
         self.frame_bytes = self.h * self.w + 2 * ((self.h + 1) // 2) * ((self.w + 1) // 2)
         self.data_start = self.f.tell()
-        first = self.f.readline()                          # 'FRAME...\n' lines normally have no parameters: fixed stride then
-        self.frame_head = len(first)
+        # Index of the frames: 'FRAME' lines normally carry no parameters (fixed stride), but the format allows them, so the
+        # payload offsets come from one scan of the headers (a seek and a short read per frame) instead of from arithmetic:
+        # frame-sharded ranks seek by frame number and must all agree on the frame count.
         size = self.path.stat().st_size
-        self.frame_count = (size - self.data_start) // (self.frame_head + self.frame_bytes) if first.startswith(b"FRAME") else 0
+        self.offsets, pos = [], self.data_start
+        while pos < size:
+            self.f.seek(pos)
+            line = self.f.readline(256)
+            if not line.startswith(b"FRAME") or not line.endswith(b"\n"):
+                raise ValueError(f"'{path}': byte {pos} should start a FRAME header (frame {len(self.offsets)}); the file is damaged or not 8-bit 4:2:0")
+            pos += len(line) + self.frame_bytes
+            if pos > size:
+                raise ValueError(f"'{path}': frame {len(self.offsets)} is cut short ({pos - size} bytes missing)")
+            self.offsets.append(pos - self.frame_bytes)
+        self.frame_count = len(self.offsets)
         self.i, self._open = 0, self.frame_count > 0
-        self.f.seek(self.data_start)
 
     def seek(self, i: int) -> None:
         self.i = int(i)
-        self.f.seek(self.data_start + self.i * (self.frame_head + self.frame_bytes))
 
     def read(self):
         if self.i >= self.frame_count:
             return False, None
-        line = self.f.readline()
-        if not line.startswith(b"FRAME"):
-            return False, None
-        if len(line) != self.frame_head:                   # a frame with parameters: the fixed stride no longer holds
-            self.frame_count = self.i + 1
+        self.f.seek(self.offsets[self.i])
         buf = np.frombuffer(self.f.read(self.frame_bytes), dtype=np.uint8)
         if len(buf) != self.frame_bytes:
             return False, None

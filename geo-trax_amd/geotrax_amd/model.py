@@ -170,9 +170,16 @@ class YOLO:
         else:
             self._gmc_method = None
         self._gmc = None
+        if ttype in ("ocsort", "deepocsort") and not getattr(self, "_ocsort_warned", False):
+            self._ocsort_warned = True
+            logger.warning(f"tracker '{ttype}': this build follows the authors' published OC-SORT (observation-centric re-update, momentum, "
+                           "recovery, optional BYTE pass); how the pinned ultralytics maps its config keys onto it is an assumption "
+                           "(det_thresh = track_high_thresh, iou_threshold = 1 - match_thresh, max_age = track_buffer, min_hits = 3 unless "
+                           f"'min_hits' is given) and 'fuse_score'{' (set in this config)' if params.get('fuse_score') else ''} is ignored: "
+                           "tracks may differ from a geo-trax run of the same tracker. Score a reference run with tools/score_run.py to pin it.")
         return Tracker(ttype, **{k: v for k, v in params.items() if k in (
             "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score",
-            "delta_t", "inertia", "use_byte")})
+            "delta_t", "inertia", "use_byte", "min_hits")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:

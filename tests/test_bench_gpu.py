@@ -78,3 +78,31 @@ def test_configs1_detector_only_batch1_one_stream():
     c = d["config"]
     assert "configs[1]" in c["workload"] and c["frames_per_step"] == 1 and c["net_input"] == [1920, 1920] and c["half"] is False
     assert d["steps"] == 60 and d["value"] > 200 and c["detections_per_frame"] > 100
+
+
+def test_bench_distributed_code_path_over_rccl_with_one_rank():
+    """bench.py's N > 1 path (RCCL weight broadcast, per-run record gathers on a side stream, tracker replay thread, max-over-
+    ranks timing) with ONE rank on the nccl backend: RCCL cannot put two ranks on one GPU, this is what a one-GPU box can run
+    of it (GTX_BENCH_FORCE_DIST=1)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GTX_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "2", "--gather-every", "4",
+           "--no-cpu-baseline", "--no-profile", "--no-f16-line", "--backend", "nccl", "--tracker", "botsort"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["value"] > 100 and "error" not in d and "GMC" in d["config"]["tracker"]
+
+
+def test_eight_ranks_on_one_gpu_botsort():
+    """BASELINE configs[4]'s rank count and tracker: 8 ranks sharing the one GPU over gloo, a short last run (9 steps, gathers
+    every 2): the record order / GMC priming arithmetic for world == 8 executes and the line is whole."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", str(ROOT / "bench.py"), "--gpus", "8", "--steps", "9", "--warmup", "1", "--gather-every", "2",
+           "--no-cpu-baseline", "--no-profile", "--backend", "gloo", "--tracker", "botsort", "--det-streams", "1", "--stab-streams", "1", "--frames", "4"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 8 and d["steps"] == 9 and d["value"] > 20 and "error" not in d and d["scaling"] == "weak"
+    assert d["host"]["threads_per_rank"] >= 3 and d["host"]["cores"] >= 1

@@ -53,36 +53,37 @@ def _producer(first, fail_at=None):
     stab = _FakeStab()
     stab.set_ref(_frame(first), None)
 
-    def produce(start, stop):
-        for f in range(start, stop):
-            if f == fail_at:
-                raise RuntimeError("decoder exploded")
-            xyxy, conf, cls = _fake_detect(_frame(f))
-            H = None if f == first else stab.stabilize(_frame(f), _xywh(xyxy))
-            yield pack_frame_record(MAX_DET, xyxy, conf, cls, H)
+    def produce(runs):
+        for start, stop in runs:
+            for f in range(start, stop):
+                if f == fail_at:
+                    raise RuntimeError("decoder exploded")
+                xyxy, conf, cls = _fake_detect(_frame(f))
+                H = None if f == first else stab.stabilize(_frame(f), _xywh(xyxy))
+                yield pack_frame_record(MAX_DET, xyxy, conf, cls, H)
     return produce
 
 
-def _run(dist_mod, fail_at=None):
+def _run(dist_mod, fail_at=None, run_frames=None):
     from geotrax_amd.geometry import warp_boxes
     from geotrax_amd.tracker import Tracker
 
-    return extract_sharded(N_FRAMES, 2, _producer(2, fail_at), Tracker("bytetrack"), warp_boxes, MAX_DET, dist=dist_mod)
+    return extract_sharded(N_FRAMES, 2, _producer(2, fail_at), Tracker("bytetrack"), warp_boxes, MAX_DET, dist=dist_mod, run_frames=run_frames)
 
 
-def _worker(rank, world, port, q, fail_at=None):
+def _worker(rank, world, port, q, fail_at=None, run_frames=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if fail_at is not None:
             try:
-                _run(dist, fail_at)
+                _run(dist, fail_at, run_frames)
             except RuntimeError as e:                   # EVERY rank learns of the failure through the collective and returns
                 q.put((rank, str(e)))
             else:
                 q.put((rank, "no error"))
             return
-        out = _run(dist)
+        out = _run(dist, run_frames=run_frames)
         if rank == 0:
             q.put([[np.asarray(a) for a in lst] for lst in out])
         else:
@@ -91,13 +92,13 @@ def _worker(rank, world, port, q, fail_at=None):
         dist.destroy_process_group()
 
 
-def _spawn(world, fail_at=None):
+def _spawn(world, fail_at=None, run_frames=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fail_at)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fail_at, run_frames)) for r in range(world)]
     for p in procs:
         p.start()
     return q, procs
@@ -133,6 +134,47 @@ def test_world2_gloo_equals_single_process():
     assert frames.min() == 2 and frames.max() == N_FRAMES - 1
     assert len(single[6]) == N_FRAMES - 4                # frames 4.. all carry a transform: frame 3 (no model) has none yet,
     #                                                       later failures (10, 17) fall back to the last known one
+
+
+@pytest.mark.parametrize("world,run_frames", [(2, 3), (8, 2), (8, None)])
+def test_round_robin_runs_and_eight_ranks_equal_single_process(world, run_frames):
+    """The overlapped form (runs of run_frames consecutive frames dealt round-robin, one gather per round, rank 0 replaying
+    each round in a side thread while the ranks produce the next) and 8 ranks -- BASELINE configs[4]'s rank count, with a
+    short last round and ranks that get no frames in it -- give exactly what one process gives, in clip order."""
+    single = _run(None)
+    q, procs = _spawn(world, run_frames=run_frames)
+    multi = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(single) == len(multi) == 7
+    for a, b in zip(single, multi):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x), y)
+    frames = np.concatenate(multi[0])[:, 0]
+    assert (np.diff(frames.astype(int)) >= 0).all()          # clip order
+
+
+def test_a_rank_failing_in_a_later_round_stops_every_rank_in_that_round():
+    q, procs = _spawn(2, fail_at=N_FRAMES - 3, run_frames=4)
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted("decoder exploded" in g[1] for g in got) == [False, True] and all("failed" in g[1] for g in got)
+
+
+def test_shard_runs_partition_the_frames_in_clip_order():
+    from geotrax_amd.distributed import shard_runs
+
+    for n, first, world, rf in [(150, 0, 8, 16), (23, 2, 2, 4), (23, 2, 8, 2), (5, 0, 8, 16), (0, 0, 3, 4), (150, 0, 8, None)]:
+        rounds = shard_runs(n, world, first, rf)
+        seen = [f for row in rounds for (s, e) in row for f in range(s, e)]
+        assert seen == list(range(first, n))                  # round by round, rank by rank = clip order
+        assert all(len(row) == world for row in rounds)
+        if rf is not None:
+            assert all(e - s <= rf for row in rounds for (s, e) in row)
 
 
 def test_shard_ranges_partition_the_frames():

@@ -587,8 +587,8 @@ def _run_sharded_cli(tmp_path, cfg_path, clip, out, n_ranks, backend, port, extr
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
 
 
-@pytest.mark.parametrize("tracker", ["botsort", "bytetrack"])
-def test_cli_under_a_launcher_shards_the_frames_of_one_video(gtx_ctx, tmp_path, tracker):
+@pytest.mark.parametrize("tracker,run_frames", [("botsort", None), ("bytetrack", None), ("botsort", 2)])
+def test_cli_under_a_launcher_shards_the_frames_of_one_video(gtx_ctx, tmp_path, tracker, run_frames):
     """`torchrun ... -m geotrax_amd.extract <video>`: contiguous frame ranges per rank, one gather, tracker replay on rank 0
     (the product path of geotrax_amd.distributed). Two ranks share the one GPU here over gloo. Against the
     single-process run: same rows, ids, raw boxes, classes, scores (the tracker sees the same detections and, with
@@ -602,7 +602,12 @@ def test_cli_under_a_launcher_shards_the_frames_of_one_video(gtx_ctx, tmp_path, 
     clip = tmp_path / "U_clip.npy"
     np.save(clip, frames)
     wpath, _ = _weights_file(tmp_path, gtx_ctx, frames[0])
-    cfg_path, _ = _cfg_file(tmp_path, wpath, tracker=tracker)
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker)
+    if run_frames is not None:                           # runs of 2 frames dealt round-robin: three rounds, a GMC priming frame per run
+        import yaml
+
+        cfg["engine"] = {"shard_run_frames": run_frames}
+        cfg_path.write_text(yaml.safe_dump(cfg))
     ex.main([str(clip), "--cfg", str(cfg_path), "--output-folder", str(tmp_path / "single")])
     p = _run_sharded_cli(tmp_path, cfg_path, clip, tmp_path / "sharded", 2, "gloo", 29547)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
@@ -625,13 +630,38 @@ def test_cli_under_a_launcher_shards_the_frames_of_one_video(gtx_ctx, tmp_path, 
     assert "Error processing" in p.stderr + p.stdout
 
 
+def test_cli_sharded_path_over_rccl_with_one_rank(gtx_ctx, tmp_path):
+    """RCCL cannot place two ranks on one GPU, so on a one-GPU box the N > 1 collectives cannot run; what can run is the same
+    code path with ONE rank on the nccl backend (GTX_FRAME_SHARDING=force): process-group init on the device, the failure
+    flag's all-reduce and the record gather on device tensors, the replay thread. Output == the single-process run."""
+    from geotrax_amd import extract as ex
+    from geotrax_amd.synth import make_scene
+
+    sc = make_scene(seed=4, h=H, w=W)
+    frames = np.stack([sc.render(3 * t, 150) for t in range(7)])
+    clip = tmp_path / "U_clip.npy"
+    np.save(clip, frames)
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, frames[0])
+    cfg_path, _ = _cfg_file(tmp_path, wpath, tracker="botsort")
+    ex.main([str(clip), "--cfg", str(cfg_path), "--output-folder", str(tmp_path / "single")])
+    p = _run_sharded_cli(tmp_path, cfg_path, clip, tmp_path / "sharded", 1, "nccl", 29551, {"GTX_FRAME_SHARDING": "force"})
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    a = np.loadtxt(tmp_path / "single" / "U_clip.txt", delimiter=",", ndmin=2)
+    b = np.loadtxt(tmp_path / "sharded" / "U_clip.txt", delimiter=",", ndmin=2)
+    assert a.shape == b.shape and len(a) > 50
+    np.testing.assert_array_equal(a[:, [0, 1, 10, 11]], b[:, [0, 1, 10, 11]])
+    np.testing.assert_allclose(a[:, 2:6], b[:, 2:6], rtol=0, atol=1e-3)
+
+
 def test_cli_frame_sharding_over_rccl_with_two_gpus(gtx_ctx, tmp_path):
     """The same run with one GPU per rank and the records gathered over RCCL (backend nccl). Needs two visible GPUs: the
     builder's and the driver's single-GPU boxes skip it, an 8-GPU node runs it."""
     import torch
 
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL gather between ranks)")
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        pytest.skip(f"torch.cuda.device_count() = {n_gpu}: RCCL refuses two ranks on one device, so the 2-rank nccl run needs a second GPU "
+                    "(the 1-rank nccl run above and the 2- and 8-rank gloo runs cover the code path on this box)")
     from geotrax_amd import extract as ex
     from geotrax_amd.synth import make_scene
 

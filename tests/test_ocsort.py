@@ -216,3 +216,24 @@ def test_config_selects_deepocsort_and_refuses_the_appearance_branch():
     assert m._gmc_method is None
     with pytest.raises(NotImplementedError):
         m._make_tracker({"tracker_type": "deepocsort", "with_reid": True})
+
+
+def test_ocsort_choice_is_announced_and_min_hits_is_a_config_key(caplog):
+    """tracker.active: ocsort | deepocsort runs an OC-SORT whose mapping onto ultralytics' config keys is unpinned and
+    which ignores fuse_score -- the run says so once, and min_hits (the authors' probation length) can be set from the config."""
+    import logging
+
+    from geotrax_amd.model import YOLO
+
+    m = YOLO.__new__(YOLO)
+    with caplog.at_level(logging.WARNING):
+        t = m._make_tracker({"tracker_type": "ocsort", "fuse_score": True, "min_hits": 1, "track_high_thresh": 0.3})
+        m._make_tracker({"tracker_type": "ocsort"})
+    msgs = [r.message for r in caplog.records if "OC-SORT" in r.message]
+    assert len(msgs) == 1 and "fuse_score" in msgs[0] and "min_hits" in msgs[0]
+    # min_hits = 1: a new track is reported on its second frame already (3: only after three consecutive hits)
+    box = np.array([[100, 100, 160, 140]], np.float32)
+    seen = [len(t.update(box + 2 * k, np.array([0.9], np.float32), np.array([0], np.int32))[1]) for k in range(3)]
+    t3 = m._make_tracker({"tracker_type": "ocsort", "track_high_thresh": 0.3})
+    seen3 = [len(t3.update(box + 2 * k, np.array([0.9], np.float32), np.array([0], np.int32))[1]) for k in range(3)]
+    assert sum(seen) >= sum(seen3) and seen[1] == 1

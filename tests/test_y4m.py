@@ -56,3 +56,59 @@ def test_conversion_known_answers():
     np.testing.assert_array_equal(px(235, 128, 128), [255, 255, 255])
     assert np.abs(px(81, 90, 240).astype(int) - [0, 0, 255]).max() <= 1
     np.testing.assert_array_equal(px(0, 128, 128), [0, 0, 0])                         # below black clamps
+
+
+def test_frame_headers_with_parameters_and_damaged_files(tmp_path):
+    """YUV4MPEG2 allows parameters on FRAME lines: the reader indexes the headers instead of assuming a fixed stride, so every
+    frame stays reachable by number (frame-sharded ranks seek) and the count is the same however it is derived; a file that
+    ends inside a frame or has garbage where a header should be is refused with a message instead of silently shortened."""
+    from geotrax_amd.frames import Y4mReader, write_y4m
+
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (18, 26, 3), dtype=np.uint8) for _ in range(5)]
+    plain = tmp_path / "plain.y4m"
+    write_y4m(plain, frames)
+    raw = plain.read_bytes()
+    head_end = raw.index(b"\n") + 1
+    fb = 18 * 26 + 2 * 9 * 13
+    parts = [raw[:head_end]]
+    for k in range(5):
+        body = raw[head_end + k * (6 + fb) + 6:head_end + (k + 1) * (6 + fb)]
+        parts += [b"FRAME Ip\n" if k in (1, 3) else b"FRAME\n", body]        # two frames carry a parameter
+    odd = tmp_path / "odd.y4m"
+    odd.write_bytes(b"".join(parts))
+    a, b = Y4mReader(plain), Y4mReader(odd)
+    assert a.frame_count == b.frame_count == 5
+    for k in (4, 1, 3, 0, 2):                                                 # any order
+        a.seek(k)
+        b.seek(k)
+        (oka, fa), (okb, fb_) = a.read(), b.read()
+        assert oka and okb
+        np.testing.assert_array_equal(fa.bgr(), fb_.bgr())
+    a.release()
+    b.release()
+    (tmp_path / "short.y4m").write_bytes(raw[:-7])
+    with pytest.raises(ValueError, match="cut short"):
+        Y4mReader(tmp_path / "short.y4m")
+    (tmp_path / "bad.y4m").write_bytes(raw[:head_end + 6 + fb] + b"JUNK!\n" + raw[head_end + 6 + fb + 6:])
+    with pytest.raises(ValueError, match="FRAME header"):
+        Y4mReader(tmp_path / "bad.y4m")
+
+
+def test_compressed_sources_need_a_decoder_and_say_so(tmp_path):
+    """.mp4 and friends go through cv2.VideoCapture when OpenCV is installed (frames.Cv2Reader, the reference's own reader,
+    extract.py:248); this image has no decoder, so the source is refused with the way out spelled out. Where cv2 exists the
+    reader is exercised instead."""
+    from geotrax_amd.frames import open_source
+
+    clip = tmp_path / "clip.mp4"
+    clip.write_bytes(b"\x00" * 64)
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="video decoder"):
+            open_source(clip)
+        return
+    r = open_source(clip)                                   # not a video: VideoCapture reports it closed, read() fails
+    assert not r.isOpened() or r.read()[0] is False
+    r.release()
