@@ -40,8 +40,10 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // Diagnostic builds (`make stamp`) force-include csrc/diag/conv_split_diag.hpp, which defines these two hooks as clock
 // stamps around the K loop; the shipped object has none.
 #ifndef GTXS_DIAG_LOOP_BEGIN
+#define GTXS_DIAG_ENTRY()
 #define GTXS_DIAG_LOOP_BEGIN()
 #define GTXS_DIAG_LOOP_END()
+#define GTXS_DIAG_EXIT()
 #endif
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -103,6 +105,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   char* lds_patch = smem;
   char* lds_w = smem + Tile::PATCH_BYTES;
 
+  GTXS_DIAG_ENTRY()
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +128,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     if (i < cnt && L >= bb[i]) pi = i;
   const ConvProblem P = g.p[pi];            // by value: one burst of wide scalar loads instead of a load (and a wait) per field
 
-  const int lb = L - P.block_begin;
+  // split-K (single-member launches): the innermost index of a logical block is its K split
+  const int ks_n = P.ksplit > 1 ? P.ksplit : 1;
+  const int lbs = L - P.block_begin;
+  const int ksi = lbs % ks_n;
+  const int lb = lbs / ks_n;
   const int ct = lb % P.n_ct;
   const int pt = lb / P.n_ct;
   const int tx = pt % P.tiles_x;
@@ -138,6 +145,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   const float* __restrict__ in = static_cast<const float*>(P.in);
   const float* __restrict__ in2 = static_cast<const float*>(P.in2);
   const int nchunks = P.Cin / KC;
+  const int c_begin = ksi * nchunks / ks_n, c_end = (ksi + 1) * nchunks / ks_n;      // this block's K chunks
 
   long goff[Tile::PATCH_SLOTS];   // element offset of the unit (8 channels = 32 B: hi chunk, lo chunk), -1 = zero fill
   long goff2[Tile::PATCH_SLOTS];  // 1x1 only: the same unit in the half-resolution second source (ConvProblem::in2)
@@ -158,6 +166,13 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   }
   const uint4* __restrict__ wsrc =
       reinterpret_cast<const uint4*>(P.wpack) + (size_t)ct * nchunks * Tile::W_CHUNKS + tid;
+
+  const int prow = lane & 31, h = lane >> 5;
+  const int tcol = prow & 15;
+  // sub-tile m of this wave: tile rows 2*(WM*wave + m) and +1
+  const int trow0 = 2 * WM * wave + (prow >> 4);
+  const int p0 = trow0 * STRIDE * PW + tcol * STRIDE;
+  constexpr int PSUB = 2 * STRIDE * PW;              // patch rows between two sub-tiles
 
   uint4 pre_a[Tile::PATCH_SLOTS], pre_b[Tile::PATCH_SLOTS];
   uint4 pre_w[Tile::W_SLOTS];
@@ -196,12 +211,10 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     }                                                                                        \
   }
 
-  const int prow = lane & 31, h = lane >> 5;
-  const int tcol = prow & 15;
-  // sub-tile m of this wave: tile rows 2*(WM*wave + m) and +1
-  const int trow0 = 2 * WM * wave + (prow >> 4);
-  const int p0 = trow0 * STRIDE * PW + tcol * STRIDE;
-  constexpr int PSUB = 2 * STRIDE * PW;              // patch rows between two sub-tiles
+  // The first chunk's loads go out before anything else waits on memory: the bias fetch below then shares their round trip
+  // instead of adding one of its own in front of them (a launch of this network lasts 20-60 us, ~13 us of which do not
+  // depend on its K depth).
+  GTXS_PREFETCH(c_begin)
 
   // The accumulators start at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue is one multiply and
   // has no loads of its own: the bias fetch overlaps the first global -> LDS round trip instead of opening the epilogue.
@@ -212,7 +225,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias) {                             // one uniform branch, eight independent loads
+    if (P.bias && ksi == 0) {                 // one uniform branch, eight independent loads (split-K: the bias enters with split 0)
       const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);
 #pragma unroll
       for (int j = 0; j < WN; ++j)
@@ -272,13 +285,12 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-  GTXS_PREFETCH(0)
   GTXS_DIAG_LOOP_BEGIN()
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
     GTXS_COMMIT()
     __syncthreads();
-    if (chunk + 1 < nchunks) GTXS_PREFETCH(chunk + 1)
+    if (chunk + 1 < c_end) GTXS_PREFETCH(chunk + 1)
     GTXS_MATRIX_PHASE()
   }
   GTXS_DIAG_LOOP_END()
@@ -292,8 +304,13 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   // stores whole BN*4-byte runs per pixel. ConvProblem::out_plain keeps plain fp32 (the Detect head's last stage, read by
   // the decode kernels).
   const float sc = P.acc_scale;
-  const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
-  const bool plain = P.out_plain != 0;
+  const bool partial = ks_n > 1;                // split-K: raw partial sums, plain fp32, into this split's plane of P.partial
+  const int cvalid = partial ? BN : P.Cout - ct * BN;   // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
+  const bool plain = partial || P.out_plain != 0;
+  const bool act = !partial && P.act != 0;
+  const void* const res_p = partial ? nullptr : P.res;
+  const int o_cstride = partial ? P.n_ct * BN : P.out_cstride, o_coff = partial ? 0 : P.out_coff;
+  float* const o_base = partial ? P.partial + (size_t)ksi * P.N * P.Ho * P.Wo * o_cstride : static_cast<float*>(P.out);
   bool sat = false;
   __syncthreads();                              // every wave is done with the staging buffers
 #pragma unroll
@@ -305,7 +322,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     const bool inside = oy < P.Ho && ox < P.Wo;
     const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
     const float* __restrict__ res =
-        (P.res && inside) ? static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
+        (res_p && inside) ? static_cast<const float*>(res_p) + pix * P.res_cstride + P.res_coff + ct * BN : nullptr;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
 #pragma unroll
@@ -315,9 +332,9 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[i] = acc[m][j][4 * g4 + i] * sc;
-          if (P.act) v[i] = silu_f(v[i]);
+          if (act) v[i] = silu_f(v[i]);
         }
-        if (P.res) {                               // uniform; the swaps below need every lane
+        if (res_p) {                               // uniform; the swaps below need every lane
           uint4 rc = make_uint4(0, 0, 0, 0);       // lane l: the group's hi chunk, lane l + 32: its lo chunk
           if (res && cl < cvalid) rc = *reinterpret_cast<const uint4*>(res + cl);
           const auto sx = __builtin_amdgcn_permlane32_swap(rc.x, rc.z, false, false);   // -> (hi, lo) of this lane's channels 0, 1
@@ -346,12 +363,61 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
       const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
       if (py < P.Ho && px < P.Wo && (q >> 1) * 8 < cvalid) {     // cvalid is a multiple of 16: whole groups
-        float* dst = static_cast<float*>(P.out) + (((size_t)n * P.Ho + py) * P.Wo + px) * P.out_cstride + P.out_coff + ct * BN + q * 4;
+        float* dst = o_base + (((size_t)n * P.Ho + py) * P.Wo + px) * o_cstride + o_coff + ct * BN + q * 4;
         *reinterpret_cast<uint4*>(dst) = val;
       }
     }
   }
   if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
+  GTXS_DIAG_EXIT()
+}
+
+// Second launch of a split-K convolution: one thread per 8-channel group of an output pixel adds the ksplit partial sums in
+// split order (fixed: the result does not depend on which workgroup finished first), applies SiLU and the residual and
+// writes the group in pair format (or plain fp32, ConvProblem::out_plain).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvProblem P, int pstride /* channels per pixel in a partial plane */) {
+  const int groups = P.Cout >> 3;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npix = (long)P.N * P.Ho * P.Wo;
+  if (gid >= npix * groups) return;
+  const long pix = gid / groups;
+  const int c0 = (int)(gid - pix * groups) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  for (int s = 0; s < P.ksplit; ++s) {
+    const float4* src = reinterpret_cast<const float4*>(P.partial + ((size_t)s * npix + pix) * pstride + c0);
+    const float4 a = src[0], b = src[1];
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (P.act) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+  }
+  if (P.res) {
+    const char* r = reinterpret_cast<const char*>(static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + c0);
+    const half8 rh = *reinterpret_cast<const half8*>(r), rl = *reinterpret_cast<const half8*>(r + 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i];
+  }
+  float* out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + c0;
+  if (P.out_plain) {
+    reinterpret_cast<float4*>(out)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(out)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    return;
+  }
+  half8 hi, lo;
+  bool sat = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = __builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
+    sat |= x != v[i];
+    hi[i] = (_Float16)x;
+    lo[i] = (_Float16)(x - (float)hi[i]);
+  }
+  reinterpret_cast<half8*>(out)[0] = hi;
+  reinterpret_cast<half8*>(out)[1] = lo;
+  if (sat && P.sat_flag) atomicOr(P.sat_flag, 1);
 }
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -404,7 +470,23 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
   return out;
 }
 
+size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg) {
+  if (p.ksplit <= 1) return 0;
+  const size_t pstride = (size_t)((p.Cout + cfg.bn - 1) / cfg.bn) * cfg.bn;
+  return (size_t)p.ksplit * p.N * p.Ho * p.Wo * pstride * sizeof(float);
+}
+
+void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t s) {
+  GTX_CHECK(p.ksplit > 1 && p.partial && p.Cout % 8 == 0, "split-K reduce: not a split problem");
+  const int pstride = (p.Cout + cfg.bn - 1) / cfg.bn * cfg.bn;
+  const long work = (long)p.N * p.Ho * p.Wo * (p.Cout / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, p, pstride);
+  GTX_HIP(hipGetLastError());
+}
+
 void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
+  for (int i = 0; i < g.count; ++i)
+    GTX_CHECK(g.p[i].ksplit <= 1 || (g.count == 1 && g.p[i].partial && g.p[i].ksplit <= g.p[i].Cin / c.kc), "conv: split-K needs a single-member launch, a scratch buffer and at most one split per K chunk");
   const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;
 #define GTX_CASE(KS, ST, WN, CPR, WM) \
   if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR && wm == WM) return launch_t<KS, ST, WN, CPR, WM>(g, s);

@@ -8,15 +8,29 @@
 
 namespace gtx {
 namespace {
-__device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MHz ticks, [2] K loops stamped
+__device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MHz ticks, [2] K loops stamped, [3] cycles entry -> loop, [4] loop end -> stores retired
 }
 }
 
+#ifndef GTXS_DIAG_NO_ENTRY
+#define GTXS_DIAG_ENTRY() const unsigned long long st_e0__ = __builtin_amdgcn_s_memtime();
+#define GTXS_DIAG_EXIT()                                                                                    \
+  {                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the workgroup's stores have left */            \
+    const unsigned long long st_e1__ = __builtin_amdgcn_s_memtime();                                        \
+    if (threadIdx.x == 0) {                                                                                 \
+      atomicAdd(&gtx::g_clock_stamp[3], st_c0__ - st_e0__);     /* entry -> K loop */                        \
+      atomicAdd(&gtx::g_clock_stamp[4], st_e1__ - st_c1s__);    /* K loop end -> stores retired */           \
+    }                                                                                                       \
+  }
+#endif
 #define GTXS_DIAG_LOOP_BEGIN() \
-  const unsigned long long st_c0__ = __builtin_amdgcn_s_memtime(), st_r0__ = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long st_c0__ = __builtin_amdgcn_s_memtime(), st_r0__ = __builtin_amdgcn_s_memrealtime(); \
+  unsigned long long st_c1s__ = 0;
 #define GTXS_DIAG_LOOP_END()                                                                                \
   {                                                                                                         \
     const unsigned long long st_c1__ = __builtin_amdgcn_s_memtime(), st_r1__ = __builtin_amdgcn_s_memrealtime(); \
+    st_c1s__ = st_c1__;                                                                                     \
     if (threadIdx.x == 0) {                                                                                 \
       atomicAdd(&gtx::g_clock_stamp[0], st_c1__ - st_c0__);                                                 \
       atomicAdd(&gtx::g_clock_stamp[1], st_r1__ - st_r0__);                                                 \

@@ -45,4 +45,4 @@ for nm, cin, cout, k, s, h in LAYERS:
     c, r, n, *ph = read()
     ghz = c / max(r, 1) * 0.1
     print(f"{nm:8s} {cin:4d}->{cout:4d} k{k} s{s} {h:4d}^2  {ms * 1000:8.1f} us  {fl / ms / 1e9:7.1f} TF/s   in-kernel clock {ghz:5.2f} GHz"
-          f"   ({n} K loops stamped, {c / max(n, 1):9.0f} cycles per K loop)")
+          f"   ({n} K loops stamped, {c / max(n, 1):9.0f} cycles per K loop; entry -> loop {ph[0] / max(n, 1):7.0f}, loop end -> stores retired {ph[1] / max(n, 1):7.0f})")
