@@ -120,9 +120,12 @@ def _engine_kwargs(config: dict) -> tuple[dict, dict | None, dict]:
     det_kw = dict(imgsz=int(max(imgsz) if isinstance(imgsz, (list, tuple)) else imgsz), conf=float(ul.get('conf') or 0.1),
                   iou=float(ul.get('iou', 0.7)), max_det=int(ul.get('max_det', 300)), classes=ul.get('classes'),
                   agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', True)))
+    eng_cfg = config['main'].get('engine') or {}
+    if eng_cfg.get('fp32_split') is not None:             # `engine: {fp32_split: false}` in the config: the exact-fp32 MFMA convolutions
+        det_kw['fp32_split'] = bool(eng_cfg['fp32_split'])   # instead of split-f16x3 (half: false only; default: GTX_FP32_SPLIT or on)
     do_stab = config['main']['extraction']['stabilize']
     stab_kw = {k: v for k, v in config['stabilo'].items() if k not in ('gpu', 'viz', 'benchmark')} if do_stab else None
-    return det_kw, stab_kw, (config['main'].get('engine') or {})
+    return det_kw, stab_kw, eng_cfg
 
 
 def frame_sharding_active() -> bool:

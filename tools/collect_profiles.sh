@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects everything profiles/r02_* is made from into gpurun_out/final/ (run on an MI355X; then tools/pmc_summary.py
+# Collects everything profiles/r03_* is made from into gpurun_out/final/ (run on an MI355X; then tools/pmc_summary.py
 # and plain copies turn it into the committed files; delete the local gpurun_out/final first, gpurun only ever adds files). rocprofv3 counter passes are separate runs with --kernel-trace only.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
