@@ -72,7 +72,9 @@ def init_process_group(local_device_count: int | None = None):
     world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     n_dev = torch.cuda.device_count() if local_device_count is None else local_device_count
     backend = os.environ.get("GTX_DIST_BACKEND") or ("nccl" if n_dev >= min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))) and n_dev > 0 else "gloo")
+    global _created_group
     if not dist.is_initialized():
+        _created_group = True
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -80,6 +82,21 @@ def init_process_group(local_device_count: int | None = None):
             dist.init_process_group("gloo")
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     return dist, dev, (local % max(n_dev, 1))
+
+
+_created_group = False
+
+
+def shutdown_process_group() -> None:
+    """Destroys the process group if init_process_group() above created it (a launcher-started `geotrax_amd.extract` run ends
+    with it; a caller that brought its own group keeps it)."""
+    global _created_group
+    if _created_group:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _created_group = False
 
 
 def gather_records(local: np.ndarray, failed: bool, dist=None, device=None):

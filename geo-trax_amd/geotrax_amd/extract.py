@@ -516,7 +516,13 @@ def setup_logger(name: str, verbose: bool = False, log_path=None, dry_run: bool 
 def main(argv=None) -> None:
     args = parse_cli_args(argv)
     logger = setup_logger('geotrax_amd.extract', args.verbose, args.log_path)
-    detect_track_stabilize(args, logger)
+    try:
+        detect_track_stabilize(args, logger)
+    finally:
+        if frame_sharding_active():                      # the launcher-started run created a process group: leave it cleanly
+            from . import distributed as D
+
+            D.shutdown_process_group()
 
 
 if __name__ == '__main__':
