@@ -491,7 +491,7 @@ def main():
     from geotrax_amd.synth import make_scene
     from geotrax_amd.tracker import Tracker
 
-    ctx = _lib.Context(local)
+    ctx = _lib.Context(local, int((os.environ.get("GTX_ENGINE_PRIO") or "0,0").split(",")[0]))   # the first detector lives on this context
     scene = make_scene(seed=0 if args.sharding == "frames" else rank, h=H, w=W)   # frames: one clip, ranks take different batches of it; videos: a clip per rank
     n_pool = max(args.frames, 2)
     frames = [scene.render(t, 150) for t in range(n_pool)]    # every rank holds the clip; it processes its own batches of it

@@ -60,6 +60,15 @@ struct ConvProblem {
   // batch 1): same arithmetic per product, a fixed summation order, 2 launches instead of 1.
   int ksplit;
   float* partial;
+  // DT_F32S, 3x3 stride-2 launches whose workgroup holds every output channel (Cout == the cout tile): a 1x1 convolution
+  // fused behind the 3x3 one ("post stage": YOLOv8 model.1 -> model.2.cv1). post_w != null: the tile's SiLU(conv) values are
+  // split and staged in LDS as pair rows, multiplied there by the Cout x Cout 1x1 weights (post_w: the packed LDS image of the
+  // 1x1 layer, pack_conv_weights_split with 32-channel chunks; post_bias, post_scale = its acc_scale, post_act) and only
+  // the 1x1 layer's output is written to `out`: the 3x3 layer's own output never reaches HBM (a launch and 2 x its bytes less).
+  const void* post_w;
+  const float* post_bias;
+  float post_scale;
+  int post_act;
 };
 
 constexpr int kMaxGroup = 8;

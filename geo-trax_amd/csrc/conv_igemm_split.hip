@@ -285,6 +285,17 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       }                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
+  // post stage (below): the 1x1 layer's weights (16 KB per workgroup at 64 channels, L2-resident) are requested here, in front
+  // of the K loop, and wait in registers: after the loop their round trip would be exposed once per workgroup
+  constexpr int W2_CHUNKS = BN * BN * 4 / 16, W2_SLOTS = (KS == 3 && STRIDE == 2 && WM == 1) ? (W2_CHUNKS + 255) / 256 : 1;
+  uint4 w2r[W2_SLOTS];
+  if constexpr (KS == 3 && STRIDE == 2 && WM == 1) {
+    if (P.post_w != nullptr) {
+#pragma unroll
+      for (int i = 0; i < W2_SLOTS; ++i)
+        w2r[i] = tid + 256 * i < W2_CHUNKS ? static_cast<const uint4*>(P.post_w)[tid + 256 * i] : make_uint4(0, 0, 0, 0);
+    }
+  }
   GTXS_DIAG_LOOP_BEGIN()
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
@@ -297,17 +308,90 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #undef GTXS_MATRIX_PHASE
 #undef GTXS_LOAD_FRAGS
 
+  // ---- post stage (ConvProblem::post_w; 3x3 stride 2, one cout tile = all channels): a 1x1 convolution on the tile ----
+  // y = SiLU(acc * 2^-shift) is split and staged as pair rows in this wave's LDS area (what the epilogue would have stored),
+  // the 1x1 weights come into LDS as the packed image of the stand-alone 1x1 kernel (32-channel chunks, 128-byte rows), and
+  // the wave multiplies its own 32 pixels: same k-step order, same three MFMAs per product as the stand-alone launch, so the
+  // result is that launch's bit for bit. The accumulators are reused; the epilogue below then runs on the 1x1 layer.
+  bool post = false;
+  if constexpr (KS == 3 && STRIDE == 2 && WM == 1) {
+    if (P.post_w != nullptr) {
+      post = true;
+      constexpr int PITCH = Tile::EPI_PITCH;
+      constexpr int W2_OFF = 4 * 32 * PITCH;                                      // behind the waves' staging rows
+      static_assert(W2_OFF + W2_CHUNKS * 16 <= Tile::LDS_BYTES, "post stage: the 1x1 weights do not fit behind the staging rows");
+      float4 b2[WN][4];
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          b2[j][g4] = P.post_bias ? *reinterpret_cast<const float4*>(P.post_bias + 32 * j + 8 * g4 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();                            // every wave is done with the staging buffers of the K loop
+      char* stg = smem + wave * (32 * PITCH);
+      bool sat_y = false;
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cl = 32 * j + 8 * g4 + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[0][j][4 * g4 + i] * P.acc_scale;
+            if (P.act) v[i] = silu_f(v[i]);
+          }
+          uint2 hi, lo;
+          split4(v, hi, lo, sat_y);
+          const auto sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+          *reinterpret_cast<uint4*>(stg + prow * PITCH + cl * 4) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat_y) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
+#pragma unroll
+      for (int i = 0; i < W2_SLOTS; ++i)
+        if (tid + 256 * i < W2_CHUNKS) *reinterpret_cast<uint4*>(smem + W2_OFF + (tid + 256 * i) * 16) = w2r[i];
+      __syncthreads();                            // the 1x1 weights are in LDS (the y rows are wave-private)
+      const float inv2 = __builtin_amdgcn_rcpf(P.post_scale);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          acc[0][j][4 * g4 + 0] = b2[j][g4].x * inv2; acc[0][j][4 * g4 + 1] = b2[j][g4].y * inv2;
+          acc[0][j][4 * g4 + 2] = b2[j][g4].z * inv2; acc[0][j][4 * g4 + 3] = b2[j][g4].w * inv2;
+        }
+      constexpr int K2 = BN / 32;                 // 32-channel chunks of the 1x1 layer's K = BN
+#pragma unroll
+      for (int k2 = 0; k2 < K2; ++k2)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int grp = 2 * (2 * k2 + ks) + h;  // the 8-channel group this half-wave feeds to the k-step
+          const half8 yh = *reinterpret_cast<const half8*>(stg + prow * PITCH + grp * 32);
+          const half8 yl = *reinterpret_cast<const half8*>(stg + prow * PITCH + grp * 32 + 16);
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int nrow = 32 * j + prow, sw = (nrow >> 1) & 7, ci = 2 * ks + h;
+            const char* wr = smem + W2_OFF + (k2 * BN + nrow) * 128;
+            const half8 wh = *reinterpret_cast<const half8*>(wr + ((ci ^ sw) << 4));
+            const half8 wl = *reinterpret_cast<const half8*>(wr + (((4 + ci) ^ sw) << 4));
+            acc[0][j] = GTXS_MFMA(wl, yh, acc[0][j]);
+            acc[0][j] = GTXS_MFMA(wh, yl, acc[0][j]);
+            acc[0][j] = GTXS_MFMA(wh, yh, acc[0][j]);
+          }
+        }
+    }
+  }
+
   // ---- epilogue: acc * 2^-shift (bias is already in) -> SiLU (+ residual) -> split into hi / lo -> NHWC pair format ----
   // After the MFMAs a lane holds 4 consecutive channels of one pixel; lanes l and l + 32 hold the two halves of one
   // 8-channel group. Two v_permlane32_swap turn that into the group's 16-byte hi chunk (lane l) and 16-byte lo chunk
   // (lane l + 32), which land in the LDS staging row at the byte offset the fp32 float4 would have had; the wave then
   // stores whole BN*4-byte runs per pixel. ConvProblem::out_plain keeps plain fp32 (the Detect head's last stage, read by
   // the decode kernels).
-  const float sc = P.acc_scale;
+  const float sc = post ? P.post_scale : P.acc_scale;
   const bool partial = ks_n > 1;                // split-K: raw partial sums, plain fp32, into this split's plane of P.partial
   const int cvalid = partial ? BN : P.Cout - ct * BN;   // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
   const bool plain = partial || P.out_plain != 0;
-  const bool act = !partial && P.act != 0;
+  const bool act = !partial && (post ? P.post_act : P.act) != 0;
   const void* const res_p = partial ? nullptr : P.res;
   const int o_cstride = partial ? P.n_ct * BN : P.out_cstride, o_coff = partial ? 0 : P.out_coff;
   float* const o_base = partial ? P.partial + (size_t)ksi * P.N * P.Ho * P.Wo * o_cstride : static_cast<float*>(P.out);
@@ -485,6 +569,9 @@ void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t
 }
 
 void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
+  for (int i = 0; i < g.count; ++i)
+    GTX_CHECK(g.p[i].post_w == nullptr || (c.ks == 3 && c.stride == 2 && c.th == 8 && g.p[i].Cout == c.bn && g.p[i].ksplit <= 1 && !g.p[i].res),
+              "conv: the fused 1x1 post stage needs a 3x3 stride-2 launch whose cout tile holds every channel (Cout %d, tile %d)", g.p[i].Cout, c.bn);
   for (int i = 0; i < g.count; ++i)
     GTX_CHECK(g.p[i].ksplit <= 1 || (g.count == 1 && g.p[i].partial && g.p[i].ksplit <= g.p[i].Cin / c.kc), "conv: split-K needs a single-member launch, a scratch buffer and at most one split per K chunk");
   const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;

@@ -397,6 +397,33 @@ void Detector::build_graph() {
   ops_.push_back(st2);
 }
 
+// model.1.conv (3x3 stride 2, all of its output channels in one cout tile) and model.2.cv1.conv (the 1x1 that is its only
+// consumer) become one launch: ConvProblem::post_w. The 3x3 layer's output is never written; the launch writes the 1x1
+// layer's. GTX_FUSE_FRONT=0 keeps the two launches. YOLOv8 n and s qualify (32 / 64 channels); the wider scales do not.
+void Detector::fuse_front() {
+  const char* e = getenv("GTX_FUSE_FRONT");
+  if (conv_dtype_ != DT_F32S || (e && e[0] == '0')) return;
+  for (size_t i = 0; i + 1 < ops_.size(); ++i) {
+    if (ops_[i].name != "model.1.conv" || ops_[i + 1].name != "model.2.cv1.conv") continue;
+    const Op &a = ops_[i], &b = ops_[i + 1];
+    if (a.kind != Op::CONV || b.kind != Op::CONV || a.grp.count != 1 || b.grp.count != 1) return;
+    const ConvProblem &pa = a.grp.p[0], &pb = b.grp.p[0];
+    const bool ok = a.cfg.variant == 2 && a.cfg.ks == 3 && a.cfg.stride == 2 && pa.Cout == a.cfg.bn && !pa.res && pa.ksplit <= 1 &&
+                    b.cfg.variant == 2 && b.cfg.ks == 1 && b.cfg.kc == 32 && b.cfg.bn == pb.Cout && pb.Cin == pa.Cout && pb.Cout == pa.Cout &&
+                    pb.in == pa.out && pb.in_cstride == pa.out_cstride && pb.in_coff == pa.out_coff && !pb.res && !pb.in2 && pb.ksplit <= 1;
+    if (!ok) return;
+    unfused_ = {a, b};
+    Op f = a;
+    f.name = "model.1.conv+model.2.cv1.conv";
+    ConvProblem& p = f.grp.p[0];
+    p.post_w = pb.wpack; p.post_bias = pb.bias; p.post_scale = pb.acc_scale; p.post_act = pb.act;
+    p.out = pb.out; p.out_cstride = pb.out_cstride; p.out_coff = pb.out_coff; p.out_plain = pb.out_plain;
+    ops_[i] = f;
+    ops_.erase(ops_.begin() + (long)i + 1);
+    return;
+  }
+}
+
 void Detector::set_batch(int nb) {
   if (nb == cur_nb_) return;
   for (Op& op : ops_) {
@@ -410,6 +437,10 @@ void Detector::set_batch(int nb) {
       op.flops += conv_flops(p, op.cfg.ks);
       op.bytes += ((double)p.N * p.H * p.W * (p.Cin - 0.75 * p.c_split) + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
                   (double)p.Cout * p.Cin * op.cfg.ks * op.cfg.ks * es_;
+      if (p.post_w) {                     // the fused 1x1 layer: its FLOPs and weights; its output replaces the 3x3 layer's (same size)
+        op.flops += 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * p.Cout;
+        op.bytes += (double)p.Cout * p.Cout * es_;
+      }
     }
   }
   for (Op& op : ops_) {
@@ -431,6 +462,7 @@ void Detector::finalize() {
   GTX_CHECK(!finalized_, "finalize called twice");
   GTX_HIP(hipSetDevice(ctx_->device));
   build_graph();
+  fuse_front();
   const int N = cfg_.max_batch;
   gray_h_ = cfg_.frame_h / 2;
   gray_w_ = cfg_.frame_w / 2;
@@ -684,6 +716,16 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
   auto it = layer_views_.find(layer);
   if (it == layer_views_.end()) fail(-1, "unknown layer '%s'", layer.c_str());
   const View& v = it->second;
+  if (out) {
+    if (!unfused_.empty() && unfused_[0].name == layer && cur_nb_ > 0) {   // the intermediate a fused launch no longer writes:
+      Op o = unfused_[0];                                                   // run its stand-alone launch now (its input is still in HBM)
+      GTX_HIP(hipSetDevice(ctx_->device));
+      for (int i = 0; i < o.grp.count; ++i) o.grp.p[i].N = cur_nb_;
+      conv_group_finalize(o.grp, o.cfg);
+      conv_launch(o.grp, o.cfg, ctx_->stream);
+      GTX_HIP(hipStreamSynchronize(ctx_->stream));
+    }
+  }
   if (h) *h = v.h;
   if (w) *w = v.w;
   if (c) *c = v.c;

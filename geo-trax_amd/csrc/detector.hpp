@@ -103,6 +103,7 @@ class Detector {
             const View* residual, const View* up_src = nullptr);
   View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice, const View* up_src = nullptr);
   void build_graph();
+  void fuse_front();         // model.1 (3x3 stride 2) + model.2.cv1 (1x1) as one launch on the split-f16x3 path
   void run_op(const Op& op, int nb, hipStream_t s);
   void run_forward(int nb, hipStream_t s, bool traced = false);
   void run_post(int nb, hipStream_t s);
@@ -140,6 +141,7 @@ class Detector {
   int* h_sat_ = nullptr;     // pinned copy, refreshed by every pass
   bool sat_seen_ = false;
   bool plain_out_ = false;   // convs being built write plain fp32 (head stage 2)
+  std::vector<Op> unfused_;  // the stand-alone forms of fused ops (layer_output of an intermediate runs them on demand)
   size_t splitk_bytes_ = 0;  // scratch for the partial sums of the split-K convolutions (batch-1 detectors)
   int* h_out_n_ = nullptr;   // pinned
   float* h_out_rows_ = nullptr;

@@ -74,10 +74,10 @@ int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out) {
     GTX_HIP(hipGetDeviceProperties(&c->prop, device));
     if (std::string(c->prop.gcnArchName).find("gfx950") == std::string::npos)
       gtx::fail(GTX_ERR_UNSUPPORTED, "libgtx is built for gfx950 only; device %d is %s", device, c->prop.gcnArchName);
-    if (high_priority) {
+    if (high_priority != 0) {        // > 0: the device's highest stream priority, < 0: its lowest
       int least = 0, greatest = 0;   // numerically lower = higher priority
       GTX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      GTX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, greatest));
+      GTX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, high_priority > 0 ? greatest : least));
     } else {
       GTX_HIP(hipStreamCreate(&c->stream));
     }
@@ -218,6 +218,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.in2 = nullptr; p.in2_cstride = p.in2_coff = p.c_split = 0;
   p.out_plain = 0; p.sat_flag = nullptr;
   p.ksplit = 0; p.partial = nullptr;
+  p.post_w = nullptr; p.post_bias = nullptr; p.post_scale = 1.f; p.post_act = 0;
   if (const char* e = std::getenv("GTX_OP_KSPLIT")) {          // test hook: the split-K form of a split-f16x3 convolution
     const int ks = std::atoi(e);
     if (ks > 1 && st.cfg.variant == 2 && ks <= d->cin / st.cfg.kc) {

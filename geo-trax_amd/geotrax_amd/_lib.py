@@ -188,7 +188,8 @@ def ptr(a: np.ndarray | None):
 class Context:
     """A device + one HIP stream (include/gtx.h: gtx_ctx_create[_prio])."""
 
-    def __init__(self, device: int = 0, high_priority: bool = False):
+    def __init__(self, device: int = 0, high_priority: bool | int = False):
+        """high_priority: True / 1 = the device's highest stream priority, -1 = its lowest, False / 0 = default."""
         self.lib = load()
         h = C.c_void_p()
         check(self.lib.gtx_ctx_create_prio(device, int(high_priority), C.byref(h)))

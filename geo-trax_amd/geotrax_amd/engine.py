@@ -91,29 +91,31 @@ class ExtractEngine:
             # former order (d,g,s,s,d,s,s), with identical kernels.
             default += ["x", "g"]
         order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(default)
+        # stream priorities of (detectors, stabilizers + GMC): 1 highest, 0 default, -1 lowest
+        p_det, p_stab = (int(v) for v in (os.environ.get("GTX_ENGINE_PRIO") or "0,0").split(","))
         have_d = len(self.dets)          # adopted detectors already own their streams
         made_d = 0
         for tok in order.split(","):
             if tok == "d":
                 made_d += 1
                 if made_d > have_d and len(self.dets) < n_dets:
-                    self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device), **det_kw))
+                    self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device, p_det), **det_kw))
             elif tok == "g" and gmc and self.gmc is None:
                 from .gmc import GMC
 
-                self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device))
+                self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device, p_stab))
             elif tok == "s" and len(self.stabs) < n_stab:
-                self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device), **stab_kw))
+                self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device, p_stab), **stab_kw))
             elif tok == "x":
                 self._spare.append(_lib.Context(self.device))
         while len(self.dets) < n_dets:
-            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device), **det_kw))
+            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device, p_det), **det_kw))
         while len(self.stabs) < n_stab:
-            self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device), **stab_kw))
+            self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device, p_stab), **stab_kw))
         if gmc and self.gmc is None:
             from .gmc import GMC
 
-            self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device))
+            self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device, p_stab))
         self.use_dev_gray = bool(self.stabs) and float(stab_kw.get("downsample_ratio", 0.5)) == 0.5
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer

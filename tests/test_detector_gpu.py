@@ -204,3 +204,30 @@ def test_class_counts_other_than_four(gtx_ctx, nc, classes):
     det.close()
     with pytest.raises(Exception):
         Detector(synthetic_yolov8(seed=1, nc=200, scale="s"), FRAME_HW, imgsz=384, ctx=gtx_ctx)      # more than 128 classes: refused, not truncated
+
+
+def test_fused_front_equals_the_two_launches(gtx_ctx, weights, monkeypatch):
+    """model.1 (3x3 stride 2) and model.2.cv1 (1x1) run as one launch on the default path (ConvProblem::post_w: the 3x3 tile is
+    split and staged in LDS and multiplied there by the 1x1 weights; model.1's output never reaches HBM). Same k-step order and
+    MFMAs as the stand-alone 1x1 launch: every layer after it, the raw head output and the detections must equal the
+    two-launch detector's bit for bit; model.1's own activations stay reachable (the stand-alone launch runs on demand)."""
+    from geotrax_amd.detector import Detector
+
+    frame = _frame(0)
+    kw = dict(imgsz=384, half=False, rect=False, fp32_split=True, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_FUSE_FRONT", "0")
+    two = Detector(weights, FRAME_HW, **kw)
+    monkeypatch.delenv("GTX_FUSE_FRONT")
+    one = Detector(weights, FRAME_HW, **kw)
+    try:
+        a, b = two.detect(frame), one.detect(frame)
+        assert len(two.profile(1, 1)) and sum(f["launches"] for f in two.profile(1, 1)) == sum(f["launches"] for f in one.profile(1, 1)) + 1
+        np.testing.assert_array_equal(a.xyxy, b.xyxy)
+        np.testing.assert_array_equal(a.conf, b.conf)
+        np.testing.assert_array_equal(two.raw_output(), one.raw_output())
+        for name in ("model.1.conv", "model.2", "model.4", "model.9", "model.22.feat0"):
+            np.testing.assert_array_equal(two.layer_output(name), one.layer_output(name), err_msg=name)
+        assert len(a) > 0
+    finally:
+        two.close()
+        one.close()
