@@ -375,3 +375,58 @@ def test_stabilizer_4k_stages_bit_exact_against_the_oracle(gtx_ctx, scene4k):
     a, b = H @ P, H_ref @ P
     assert np.abs(a[:2] / a[2] - b[:2] / b[2]).max() < 1e-3
     assert abs(st.get_cur_inliers_count() - n_inl) <= 2
+
+
+def test_engine_4k_fp32_default_equals_blocking_calls(gtx_ctx):
+    """configs[2] at its real size and the reference's precision through the ENGINE: 3840x2160 frames,
+    1920x1920 input, half = false (split-f16x3 default, fused front launch), ByteTrack, stabilizer at its defaults -- the
+    pipelined engine (2 detector streams x batch 2, 3 stabilizer streams, an odd last batch) must return what blocking
+    per-frame calls of the same objects return, bit for bit: ids, tracker boxes, homographies; and the homographies must stay
+    within 1 px of the clip's known camera."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.stabilizer import Stabilizer
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    scene = make_scene(seed=0, h=H4, w=W4)
+    frames = [scene.render(10 * k, 150) for k in range(5)]
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, half=False, rect=False)
+    w = synthetic_yolov8(seed=0, nc=4, level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002)        # ~85 px boxes, as in bench.py
+    det = Detector(w, (H4, W4), ctx=gtx_ctx, **kw)
+    assert det.fp32_split
+    det.detect(frames[0])
+    w = calibrate_cls_bias(w, det.raw_output(logits=True)[:, 4:], 0.25, 132)
+    det.close()
+    det = Detector(w, (H4, W4), max_batch=2, ctx=gtx_ctx, **kw)
+    trk, st = Tracker("bytetrack"), Stabilizer((H4, W4), ctx=gtx_ctx)
+    want = []
+    for i, f in enumerate(frames):
+        d = det.detect(f)
+        bx, ids = trk.update(d.xyxy, d.conf, d.cls)[:2]
+        xywh = np.stack([(bx[:, 0] + bx[:, 2]) / 2, (bx[:, 1] + bx[:, 3]) / 2, bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1).astype(np.float32)
+        if i == 0:
+            st.set_ref_frame(f, xywh)
+            want.append((ids, xywh, None))
+        else:
+            st.stabilize(f, xywh)
+            want.append((ids, xywh, st.get_cur_trans_matrix()))
+    det.close()
+    assert all(len(x[0]) > 50 for x in want)
+    eng = ExtractEngine(w, (H4, W4), kw, Tracker("bytetrack"), {}, batch=2, det_streams=2, stab_streams=3)
+    try:
+        got = list(eng.run([frames[0:2], frames[2:4], frames[4:5]]))
+    finally:
+        eng.close()
+    ys, xs = np.meshgrid(np.linspace(0, H4 - 1, 9), np.linspace(0, W4 - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    for k, (r, (ids, xywh, Hm)) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(r.ids, ids)
+        np.testing.assert_array_equal(r.xywh, xywh)
+        assert (r.H is None) == (Hm is None)
+        if Hm is not None:
+            np.testing.assert_array_equal(r.H, Hm)
+            truth = np.linalg.inv(scene.camera(10 * k, 150)) @ scene.camera(0, 150)
+            a, b = r.H @ P, truth @ P
+            assert np.abs(a[:2] / a[2] - b[:2] / b[2]).max() < 1.0
