@@ -15,6 +15,10 @@ yolov8_ref.resize_linear_u8, yuv_ref.py) and the HIP kernels against:
     resize_out         transform.resize(order=1, anti_aliasing=False) of a colour crop by a non-2x ratio (the general
                        letterbox path)
     yuv_bgr            color.ycbcr2rgb of an I420 image
+    match_pairs        feature.match_descriptors(metric="hamming", cross_check=False, max_ratio=0.9) on seeded 256-bit
+                       descriptor sets (planted near-duplicates + distractors): the Hamming 2-NN + Lowe ratio stage alone
+    ransac_H           measure.ransac(ProjectiveTransform) on seeded point matches (known homography, 0.5 px noise, 30 %
+                       outliers): the estimation stage alone
 
 Run (build container only):   python tests/golden/make_independent.py
 The script renders the inputs with the repository's own seeded generator under the default interpreter, hands them to
@@ -76,8 +80,30 @@ def inputs() -> dict:
     U = rng.integers(60, 200, (yh // 2, yw // 2), dtype=np.uint8)
     V = rng.integers(60, 200, (yh // 2, yw // 2), dtype=np.uint8)
     i420 = np.concatenate([Y.ravel(), U.ravel(), V.ravel()])
+    # descriptor sets for the matcher: 1200 random 256-bit train descriptors; 600 queries = a train row with 0-70 random bits
+    # flipped (most pass the ratio test, the heavily damaged ones do not) or, for a fifth of them, unrelated random bits
+    rd = np.random.default_rng(23)
+    d_train = rd.integers(0, 256, (1200, 32), dtype=np.uint8)
+    src_rows = rd.integers(0, 1200, 600)
+    d_query = d_train[src_rows].copy()
+    bits = np.unpackbits(d_query, axis=1)
+    for i in range(600):
+        if i % 5 == 4:
+            bits[i] = rd.integers(0, 2, 256)
+        else:
+            flip = rd.choice(256, size=int(rd.integers(0, 71)), replace=False)
+            bits[i, flip] ^= 1
+    d_query = np.packbits(bits, axis=1)
+    # point matches for the estimator: a homography of the size the stabilizer sees, 0.5 px noise, 30 % gross outliers
+    H_true = np.array([[1.002, -0.004, 7.5], [0.0035, 0.998, -4.25], [2.0e-6, -1.5e-6, 1.0]])
+    pts_p = np.stack([rd.uniform(0, HW[1], 500), rd.uniform(0, HW[0], 500)], 1)
+    qh = np.c_[pts_p, np.ones(500)] @ H_true.T
+    pts_q = qh[:, :2] / qh[:, 2:] + rd.normal(0, 0.5, (500, 2))
+    out_idx = rd.choice(500, 150, replace=False)
+    pts_q[out_idx] = np.stack([rd.uniform(0, HW[1], 150), rd.uniform(0, HW[0], 150)], 1)
     return dict(f0=fr[0], f1=fr[1], f40=fr[40], f149=fr[149], fast0=g_half, fast1=g_sub, warp_src=crop, resize_src=rsrc,
-                i420=i420, yuv_hw=np.array([yh, yw]), scene=sc)
+                i420=i420, yuv_hw=np.array([yh, yw]), d_query=d_query, d_train=d_train, pts_p=pts_p.astype(np.float32),
+                pts_q=pts_q.astype(np.float32), H_true=H_true, scene=sc)
 
 
 def stage_skimage(tmp: str) -> None:
@@ -139,6 +165,17 @@ def stage_skimage(tmp: str) -> None:
     rgb = ycbcr2rgb(ycc)                                                 # ITU-R BT.601, limited range -> RGB in [0, 1]
     out["yuv_bgr"] = np.clip(np.rint(rgb[..., ::-1] * 255.0), 0, 255).astype(np.uint8)
     out["i420_crc"] = np.array(crc(i420), dtype=np.uint32)
+    # Hamming 2-NN + Lowe ratio on bit descriptors (rows of booleans: scipy's hamming = fraction of differing bits)
+    bq, bt = np.unpackbits(d["d_query"], axis=1).astype(bool), np.unpackbits(d["d_train"], axis=1).astype(bool)
+    out["match_pairs"] = match_descriptors(bq, bt, metric="hamming", cross_check=False, max_ratio=0.9).astype(np.int32)
+    out["d_query_crc"] = np.array(crc(d["d_query"]), dtype=np.uint32)
+    out["d_train_crc"] = np.array(crc(d["d_train"]), dtype=np.uint32)
+    model, inl = ransac((d["pts_p"].astype(np.float64), d["pts_q"].astype(np.float64)), ProjectiveTransform, min_samples=4, residual_threshold=2.0,
+                        max_trials=3000, random_state=np.random.RandomState(0))
+    out["ransac_H"] = model.params.astype(np.float64)
+    out["ransac_inliers"] = np.array(int(inl.sum()))
+    out["pts_p_crc"] = np.array(crc(d["pts_p"]), dtype=np.uint32)
+    out["pts_q_crc"] = np.array(crc(d["pts_q"]), dtype=np.uint32)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: (v.shape if v.ndim else v.item()) for k, v in out.items() if "stats" in k or "version" in k})
 

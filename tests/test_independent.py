@@ -39,7 +39,7 @@ def fx():
 @pytest.fixture(scope="module")
 def inp(mi, fx):
     d = mi.inputs()
-    for k in ("f0", "f1", "f40", "f149", "fast0", "fast1", "warp_src", "resize_src", "i420"):
+    for k in ("f0", "f1", "f40", "f149", "fast0", "fast1", "warp_src", "resize_src", "i420", "d_query", "d_train", "pts_p", "pts_q"):
         assert mi.crc(d[k]) == int(fx[k + "_crc"]), f"input {k} is not the one the fixture was made from: regenerate with make_independent.py"
     return d
 
@@ -152,6 +152,35 @@ def test_oracle_yuv_agrees_with_skimage_ycbcr(inp, fx):
     yh, yw = (int(v) for v in inp["yuv_hw"])
     d = np.abs(i420_to_bgr(inp["i420"], yh, yw).astype(np.int16) - fx["yuv_bgr"].astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() < 0.1, (d.max(), (d > 0).mean())
+
+
+def test_oracle_matcher_equals_skimage_match_descriptors(inp, fx):
+    """The Hamming 2-NN + Lowe ratio stage on its own (oracle.stabilo_ref.match; the HIP matcher equals it bit for bit in
+    tests/test_stabilizer_gpu.py): the same (query, train) pairs as skimage.feature.match_descriptors(metric='hamming',
+    cross_check=False, max_ratio=0.9) on seeded 256-bit descriptors -- nearest neighbour with ties to the lowest index, strict
+    ratio test."""
+    from oracle.stabilo_ref import match
+
+    q, t, d = match(inp["d_query"], inp["d_train"], 0.9)
+    pairs = fx["match_pairs"]
+    assert 200 < len(pairs) < 560                                      # the ratio test rejects the damaged / unrelated queries
+    np.testing.assert_array_equal(np.stack([q, t], 1), pairs)
+    bits = np.unpackbits(inp["d_query"][q] ^ inp["d_train"][t], axis=1).sum(1)
+    np.testing.assert_array_equal(d, bits)
+
+
+def test_oracle_estimator_agrees_with_skimage_ransac_on_given_matches(inp, fx):
+    """The estimation stage on its own: oracle.stabilo_ref.ransac_homography (MSAC-scored hypotheses + IRLS refit) and
+    skimage.measure.ransac(ProjectiveTransform) on the same 500 seeded matches (30 % outliers): within 0.3 px of each other
+    and of the homography the matches were made with, on the 9 x 16 grid."""
+    from oracle.stabilo_ref import ransac_homography
+
+    H, n_inl = ransac_homography(inp["pts_p"], inp["pts_q"], (HW[1], HW[0]), 2.0, 2048, 0)
+    P = _grid(HW)
+    assert H is not None and abs(n_inl - int(fx["ransac_inliers"])) <= 10 and n_inl > 300
+    assert np.abs(_proj(fx["ransac_H"], P) - _proj(inp["H_true"], P)).max() < 0.3
+    assert np.abs(_proj(H, P) - _proj(inp["H_true"], P)).max() < 0.3
+    assert np.abs(_proj(H, P) - _proj(fx["ransac_H"], P)).max() < 0.3
 
 
 # ------------------------------------------------------------------------------------------------ HIP path vs scikit-image
