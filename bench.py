@@ -580,12 +580,14 @@ def main():
     det_kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=max_det, classes=[0, 1, 2, 3], agnostic_nms=True, half=bool(args.half),
                   fp32_split=fp32_split(args), rect=bool(args.rect))
     stab_kw = {} if extract else None
+    if os.environ.get("GTX_BENCH_NO_STAB") == "1":               # experiment: the extract loop without its stabilizer stage (tracker only)
+        stab_kw = None
     shard_gmc = sharded and extract and args.tracker in GMC_TRACKERS
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
                            det_streams=args.det_streams, stab_streams=args.stab_streams,
                            gmc=extract and args.tracker in GMC_TRACKERS, detectors=[det])
     n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
-    if extract:
+    if extract and stab_kw is not None:
         engine.set_reference(ref_frame)                          # every rank registers against frame 0 of the clip
     records = []
 

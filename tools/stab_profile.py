@@ -1,0 +1,31 @@
+"""The stabilizer alone on the GPU (no detector running beside it): per-frame GPU time of a pass, and -- under
+`rocprofv3 --kernel-trace --stats -- python3 tools/stab_profile.py` -- the duration of each of its kernels when nothing competes
+for CU slots. Usage: python tools/stab_profile.py [frames]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "geo-trax_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from geotrax_amd import _lib  # noqa: E402
+from geotrax_amd.stabilizer import Stabilizer  # noqa: E402
+from geotrax_amd.synth import make_scene  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ctx = _lib.default_context(0)
+sc = make_scene(seed=0, h=2160, w=3840)
+frames = [sc.render(t, 150) for t in (0, 3, 6, 9)]
+boxes = [sc.boxes(t) for t in (0, 3, 6, 9)]
+st = Stabilizer((2160, 3840), ctx=ctx)
+st.set_ref_frame(frames[0], boxes[0])
+for k in range(4):
+    st.stabilize(frames[k % 4], boxes[k % 4])
+t0 = time.perf_counter()
+ms = []
+for k in range(n):
+    st.stabilize(frames[k % 4], boxes[k % 4])
+    ms.append(st.last_ms() if hasattr(st, "last_ms") else 0.0)
+dt = time.perf_counter() - t0
+print(f"{n} blocking stabilize() calls on host frames: {1000 * dt / n:.2f} ms per frame wall (upload included); GPU time of a pass: median {np.median(ms):.3f} ms")
