@@ -189,9 +189,20 @@ __global__ __launch_bounds__(256) void fast_detect_kernel(const int4* __restrict
   const int t = blockIdx.x - lv.tile_begin;
   const int tx0 = (t % lv.tiles_x) * kTileW, ty0 = (t / lv.tiles_x) * kTileH;
   constexpr int PP = kTileW + 8;
-  for (int i = threadIdx.x; i < (kTileH + 8) * PP; i += 256) {
-    const int x = min(max(tx0 - 4 + i % PP, 0), lv.w - 1), y = min(max(ty0 - 4 + i / PP, 0), lv.h - 1);
-    s_px[i] = lv.img[(size_t)y * lv.w + x];     // clamped addresses; clamped pixels are never used by a scored pixel
+  {
+    // Every load of the tile is issued before the first one is stored: as a plain loop (load, store to LDS, next) the seven byte
+    // loads of a thread were seven dependent round trips to memory, ~15 us of a workgroup's life and most of this kernel's 58 us.
+    constexpr int NPX = (kTileH + 8) * PP, NIT = (NPX + 255) / 256;
+    uint8_t v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = min((int)threadIdx.x + 256 * k, NPX - 1);
+      const int x = min(max(tx0 - 4 + i % PP, 0), lv.w - 1), y = min(max(ty0 - 4 + i / PP, 0), lv.h - 1);
+      v[k] = lv.img[(size_t)y * lv.w + x];       // clamped addresses; clamped pixels are never used by a scored pixel
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if ((int)threadIdx.x + 256 * k < NPX) s_px[threadIdx.x + 256 * k] = v[k];
   }
   __syncthreads();
   // phase A: the 5-load compass test on every pixel; the survivors (a scattered minority) are listed so that
