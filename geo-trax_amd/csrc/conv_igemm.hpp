@@ -69,6 +69,15 @@ struct ConvProblem {
   const float* post_bias;
   float post_scale;
   int post_act;
+  // DT_F32S, single 3x3 stride-2 launches with one cout tile: "front stage" (conv_igemm_split.hip, FrontTile). front_img != null:
+  // the layer's input is YOLOv8's stem applied to the RGB0 byte image front_img [N][front_h][front_w_px] (H = front_h / 2,
+  // W = front_w_px / 2, Cin = the stem's channels), computed patch by patch inside the workgroup; `in` is not read.
+  // front_w: pack_front_weights_split; front_bias: the stem's [Cin] bias; front_scale: its acc_scale.
+  const void* front_img;
+  const void* front_w;
+  const float* front_bias;
+  float front_scale;
+  int front_h, front_w_px;
 };
 
 constexpr int kMaxGroup = 8;
@@ -120,6 +129,7 @@ void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t
 // bytes of ConvProblem::partial a problem needs (0 when ksplit <= 1)
 size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg);
 std::vector<uint8_t> pack_conv_weights_split(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale);
+std::vector<uint16_t> pack_front_weights_split(const float* w27, int c0, float* acc_scale);
 
 // conv3x3_ring.hip (variant 3; weights packed as for variant 2)
 void conv_ring_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);

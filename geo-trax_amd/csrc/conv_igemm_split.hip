@@ -35,6 +35,7 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define GTXS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // Diagnostic builds (`make stamp`) force-include csrc/diag/conv_split_diag.hpp, which defines these two hooks as clock
@@ -44,6 +45,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define GTXS_DIAG_LOOP_BEGIN()
 #define GTXS_DIAG_LOOP_END()
 #define GTXS_DIAG_EXIT()
+#define GTXS_DIAG_PHASE(K)
 #endif
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -73,19 +75,57 @@ struct SplitTile {
 // x * sigmoid(x) with v_exp_f32 and v_rcp_f32 (1 ulp each); hipcc expands __fdividef to a full IEEE division (10 instructions)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-// 4 fp32 values -> their 4 hi halves and 4 lo halves (8 bytes each); *sat becomes true when a value had to be clamped
-__device__ __forceinline__ void split4(const float (&v)[4], uint2& hi, uint2& lo, bool& sat) {
-  half4 h, l;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x = __builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
-    sat |= x != v[i];                    // also true for a NaN (it is clamped to -65504 by v_med3)
-    const _Float16 hh = (_Float16)x;
-    h[i] = hh;
-    l[i] = (_Float16)(x - (float)hh);
-  }
-  hi = *reinterpret_cast<const uint2*>(&h);
-  lo = *reinterpret_cast<const uint2*>(&l);
+// The epilogues work on PAIRS of values: gfx950 has packed fp32 multiply / add / fma (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32: two values per lane and issue slot) and a packed fp32 -> fp16 conversion, so SiLU + the hi / lo split cost
+// 8.5 vector instructions per value instead of 12.5 -- the epilogue is the VALU-bound part of a workgroup's life. Same
+// operations in the same order as the scalar forms (silu_f; hi = fp16(x), lo = fp16(x - hi)): the results are theirs bit for bit.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v silu2(const float2v v) {
+  const float2v t = v * -1.44269504088896341f;                      // exp(-v) = exp2(-v log2 e): what __expf compiles to
+  const float2v d = float2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
+  return v * float2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+// 2 fp32 values -> their two hi halves and two lo halves (one register each); sat becomes true when a value had to be clamped
+__device__ __forceinline__ void split2(const float2v v, unsigned& hi, unsigned& lo, bool& sat) {
+  const float2v x = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
+  sat |= x.x != v.x || x.y != v.y;                                  // also true for a NaN (it is clamped to -65504 by v_med3)
+  const half2v h = __builtin_convertvector(x, half2v);
+  const half2v l = __builtin_convertvector(x - __builtin_convertvector(h, float2v), half2v);   // x - hi is exact in fp32
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// 4 fp32 values -> their 4 hi halves and 4 lo halves (8 bytes each)
+__device__ __forceinline__ void split4(const float2v (&v)[2], uint2& hi, uint2& lo, bool& sat) {
+  split2(v[0], hi.x, lo.x, sat);
+  split2(v[1], hi.y, lo.y, sat);
+}
+
+// Front stage (ConvProblem::front_img, 3x3 stride-2 launches): the layer's input is YOLOv8's stem, SiLU(conv 3x3 stride 2 of
+// the RGB0 byte image), and the workgroup computes the 17 x 33 patch of it that its tile reads instead of loading it -- the
+// stem's output (236 MB per two 1920 x 1920 frames, written once and read back once) never exists in HBM. Per 16-channel K
+// chunk: the 35 x 67 image pixels under the patch sit in LDS as {3 hi halves, 0, 3 lo halves, 0} of byte / 255 (16 B per
+// pixel, in the region the chunk's weight taps take over afterwards), a wave walks 16-pixel tiles of the patch with
+// v_mfma_f32_16x16x16_f16 (K = 4 taps x RGB0, three k-steps for the nine taps, three MFMAs per product like everything on
+// this path: D[cout 16][pixel 16]), and bias + SiLU + the hi / lo split put the lane's four channels straight into the
+// patch row the K loop reads. Positions of the patch outside the stem's output are the 3x3 layer's zero padding.
+struct FrontTile {
+  static constexpr int PH = 17, PW = 33, NPIX = PH * PW;       // the stride-2 kernel's patch, in stem-output pixels
+  static constexpr int IH = 2 * PH + 1, IW = 2 * PW + 1;       // image pixels under it: 35 x 67
+  static constexpr int IN_PIX = IH * IW;
+  static constexpr int IN_SLOTS = (IN_PIX + 255) / 256;        // image words a thread keeps (both chunks stage from them)
+  static constexpr int IN_BYTES = IN_PIX * 16;
+  static constexpr int TILES = (NPIX + 15) / 16;               // 36 tiles of 16 patch pixels, 9 per wave
+  static constexpr int LUT_BYTES = 256 * 4;
+};
+
+template <int KS, int STRIDE, int WN, int CPR, int WM, int FRONT>
+constexpr int split_lds_bytes() {
+  using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
+  if (!FRONT) return Tile::LDS_BYTES;
+  const int wreg = Tile::STAGE_BYTES - Tile::PATCH_BYTES > FrontTile::IN_BYTES ? Tile::STAGE_BYTES - Tile::PATCH_BYTES : FrontTile::IN_BYTES;
+  const int stage = Tile::PATCH_BYTES + wreg;
+  return (stage > Tile::EPI_BYTES ? stage : Tile::EPI_BYTES) + FrontTile::LUT_BYTES;
 }
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -95,10 +135,10 @@ constexpr int split_min_waves() {
   return WN == 1 ? 5 : 4;
 }
 
-template <int KS, int STRIDE, int WN, int CPR, int WM>
-__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR, WM>()))))
-void conv_igemm_split_kernel(const ConvGroup g) {
+template <int KS, int STRIDE, int WN, int CPR, int WM, int FRONT>
+__device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
+  static_assert(!FRONT || (KS == 3 && STRIDE == 2 && WM == 1 && CPR == 2), "front stage: 3x3 stride 2, 16-channel chunks");
   constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB, KC = Tile::KC;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,6 +191,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   long goff2[Tile::PATCH_SLOTS];  // 1x1 only: the same unit in the half-resolution second source (ConvProblem::in2)
   int loff[Tile::PATCH_SLOTS];    // LDS byte offset of the unit's hi chunk, -1 = slot unused
   int lchk[Tile::PATCH_SLOTS];    // ... and of its lo chunk
+  if constexpr (FRONT == 0) {
 #pragma unroll
   for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {
     const int qid = tid + 256 * s;
@@ -163,6 +204,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     goff2[s] = (KS == 1 && inb) ? ((long)(n * (P.H >> 1) + (iy >> 1)) * (P.W >> 1) + (ix >> 1)) * P.in2_cstride + P.in2_coff + c * 8 : -1;
     loff[s] = used ? p * RB + ((c ^ Tile::swz(p)) << 4) : -1;
     lchk[s] = used ? p * RB + (((CPR + c) ^ Tile::swz(p)) << 4) : -1;
+  }
   }
   const uint4* __restrict__ wsrc =
       reinterpret_cast<const uint4*>(P.wpack) + (size_t)ct * nchunks * Tile::W_CHUNKS + tid;
@@ -180,6 +222,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   {                                                                                          \
     const int c0__ = (CHUNK) * KC;                                                           \
     const bool up__ = KS == 1 && c0__ < P.c_split;   /* uniform: this chunk's channels come from the upsampled source */ \
+    if constexpr (FRONT == 0) {                          /* front stage: the patch is computed, not loaded */ \
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
       uint4 va__ = make_uint4(0, 0, 0, 0), vb__ = make_uint4(0, 0, 0, 0);                    \
       if (goff[s] >= 0) {                                                                    \
@@ -190,6 +233,7 @@ void conv_igemm_split_kernel(const ConvGroup g) {
       pre_a[s] = va__;                                                                       \
       pre_b[s] = vb__;                                                                       \
     }                                                                                        \
+    }                                                                                        \
     const uint4* w__ = wsrc + (size_t)(CHUNK) * Tile::W_CHUNKS;                              \
     _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
       uint4 v__ = make_uint4(0, 0, 0, 0);                                                    \
@@ -199,11 +243,13 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   }
 #define GTXS_COMMIT()                                                                        \
   {                                                                                          \
+    if constexpr (FRONT == 0) {                                                                  \
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
       if (loff[s] >= 0) {                              /* pair format: the two halves of the unit ARE the LDS chunks */ \
         *reinterpret_cast<uint4*>(lds_patch + loff[s]) = pre_a[s];                           \
         *reinterpret_cast<uint4*>(lds_patch + lchk[s]) = pre_b[s];                           \
       }                                                                                      \
+    }                                                                                        \
     }                                                                                        \
     _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
       if (Tile::W_CHUNKS % 256 == 0 || tid + 256 * s < Tile::W_CHUNKS)                       \
@@ -211,10 +257,149 @@ void conv_igemm_split_kernel(const ConvGroup g) {
     }                                                                                        \
   }
 
-  // The first chunk's loads go out before anything else waits on memory: the bias fetch below then shares their round trip
-  // instead of adding one of its own in front of them (a launch of this network lasts 20-60 us, ~13 us of which do not
-  // depend on its K depth).
-  GTXS_PREFETCH(c_begin)
+  // ---- front stage: what a thread keeps for it (FRONT = the stem's 16-channel groups = this launch's K chunks, 1 or 2) ----
+  constexpr int FN = FRONT > 0 ? FRONT : 1;
+  unsigned f_raw[FrontTile::IN_SLOTS];              // its image pixels (RGB0 words)
+  uint2 f_wh[FN][3], f_wl[FN][3];                   // stem weights: chunk, k-step s, this lane's (cout, tap) 4 halves
+  float4 f_bias[FN];                                // ... and the bias of the lane's 4 output channels per chunk
+  uint2 f_keep[FN > 1 ? FrontTile::TILES / 4 : 1][2];   // second chunk's patch values (hi, lo) of the lane, until the first chunk's matrix phase is over
+  char* const f_stage = lds_w;                      // the image patch shares the weight taps' region
+  unsigned* const f_lut = reinterpret_cast<unsigned*>(smem + split_lds_bytes<KS, STRIDE, WN, CPR, WM, FRONT>() - FrontTile::LUT_BYTES);
+  int f_toff[3];                                    // byte offset of the lane's tap inside the staged image, per k-step
+  if constexpr (FRONT > 0) {
+    const unsigned* __restrict__ img = static_cast<const unsigned*>(P.front_img) + (size_t)n * P.front_h * P.front_w_px;
+    const int gy0 = 2 * iy0 - 1, gx0 = 2 * ix0 - 1;   // image pixel under (row 0, col 0) of the staged patch
+#pragma unroll
+    for (int s = 0; s < FrontTile::IN_SLOTS; ++s) {
+      const int i = tid + 256 * s;
+      const int r = i / FrontTile::IW, c = i - r * FrontTile::IW;
+      const int gy = gy0 + r, gx = gx0 + c;
+      // byte 0 = value 0.0 = the stem's zero padding
+      f_raw[s] = (i < FrontTile::IN_PIX && gy >= 0 && gy < P.front_h && gx >= 0 && gx < P.front_w_px) ? img[gy * P.front_w_px + gx] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < FN; ++c) {
+      const uint2* fw = static_cast<const uint2*>(P.front_w) + (size_t)c * (3 * 2 * 64) + lane;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f_wh[c][s] = fw[(2 * s + 0) * 64];
+        f_wl[c][s] = fw[(2 * s + 1) * 64];
+      }
+      f_bias[c] = *reinterpret_cast<const float4*>(P.front_bias + c * KC + 4 * (lane >> 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int tap = min(4 * s + (lane >> 4), 8);    // taps 9..11 carry zero weights: any staged pixel will do
+      f_toff[s] = ((tap / 3) * FrontTile::IW + tap % 3) * 16;
+    }
+    {                                                  // byte -> hi | lo << 16 of byte / 255 (ultralytics' `im / 255`, already split)
+      const float f = (float)tid / 255.f;
+      const _Float16 hi = (_Float16)f, lo = (_Float16)(f - (float)hi);
+      f_lut[tid] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+  }
+  // bias + SiLU + split of one tile's accumulator (4 channels of one patch pixel) -> the lane's 8 bytes of hi and of lo halves
+#define GTXS_FRONT_EPI(ACC, BIAS, HV, LV)                                                    \
+  {                                                                                          \
+    /* SiLU of a sum of 27 products with inputs in [0, 1]: inside fp16's range for any sane weights; split2's clamp only keeps \
+       an absurd checkpoint from producing inf - inf (no flag: stem_split_kernel has none either) */ \
+    float2v v__[2] = {silu2(__builtin_elementwise_fma(float2v{(ACC)[0], (ACC)[1]}, float2v{P.front_scale, P.front_scale}, float2v{(BIAS).x, (BIAS).y})), \
+                      silu2(__builtin_elementwise_fma(float2v{(ACC)[2], (ACC)[3]}, float2v{P.front_scale, P.front_scale}, float2v{(BIAS).z, (BIAS).w}))}; \
+    if (!in__) v__[0] = v__[1] = float2v{0.f, 0.f};                                          \
+    bool sat__ = false;                                                                      \
+    split4(v__, HV, LV, sat__);                                                              \
+  }
+  // LDS patch row position of the lane's (hi, lo) 8-byte pieces for tile t__ (lanes past the patch's last pixel recomputed
+  // that pixel: same bytes, same address)
+#define GTXS_FRONT_PUT(T, HV, LV)                                                            \
+  {                                                                                          \
+    const int qq__ = min((wave + 4 * (T)) * 16 + (lane & 15), FrontTile::NPIX - 1);          \
+    const int cg__ = lane >> 4;                              /* the lane's channels 4 cg .. 4 cg + 3 of the chunk */ \
+    char* row__ = lds_patch + qq__ * RB + (cg__ & 1) * 8;                                    \
+    *reinterpret_cast<uint2*>(row__ + (((cg__ >> 1) ^ Tile::swz(qq__)) << 4)) = (HV);        \
+    *reinterpret_cast<uint2*>(row__ + (((CPR + (cg__ >> 1)) ^ Tile::swz(qq__)) << 4)) = (LV); \
+  }
+  // The front stage proper, once per workgroup: image patch -> LDS (GTXS_FRONT_STAGE), then the stem for every patch pixel
+  // (GTXS_FRONT_TILES); the first chunk's 16 channels go to lds_patch, the second chunk's wait in f_keep (the B operands --
+  // the staged pixels -- are read once for both).
+#define GTXS_FRONT_STAGE()                                                                   \
+  {                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < FrontTile::IN_SLOTS; ++s) {                        \
+      const int i__ = tid + 256 * s;                                                         \
+      if (FrontTile::IN_PIX % 256 == 0 || i__ < FrontTile::IN_PIX) {                         \
+        const unsigned px__ = f_raw[s];                                                      \
+        const unsigned e0__ = f_lut[px__ & 255u], e1__ = f_lut[(px__ >> 8) & 255u], e2__ = f_lut[(px__ >> 16) & 255u]; \
+        *reinterpret_cast<uint4*>(f_stage + i__ * 16) =                                      \
+            make_uint4((e0__ & 0xffffu) | (e1__ << 16), e2__ & 0xffffu, (e0__ >> 16) | (e1__ & 0xffff0000u), e2__ >> 16); \
+      }                                                                                      \
+    }                                                                                        \
+    __syncthreads();                                                                         \
+  }
+#define GTXS_FRONT_X(T)                              /* tile T's staged pixels: one 16-byte read per k-step */ \
+  {                                                                                          \
+    const int qc__ = min((wave + 4 * (T)) * 16 + (lane & 15), FrontTile::NPIX - 1);   /* patch pixel of this lane's MFMA column */ \
+    const int py__ = qc__ / FrontTile::PW, px__ = qc__ - py__ * FrontTile::PW;               \
+    const char* src__ = f_stage + (2 * py__ * FrontTile::IW + 2 * px__) * 16;                \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) f_x[(T) % 3][s] = *reinterpret_cast<const uint4*>(src__ + f_toff[s]); \
+    const int sy__ = iy0 + py__, sx__ = ix0 + px__;                                          \
+    f_in[(T) % 3] = sy__ >= 0 && sy__ < P.H && sx__ >= 0 && sx__ < P.W;   /* else: the 3x3 layer's zero padding */ \
+  }
+#define GTXS_FRONT_M(T)                              /* tile T's 9 MFMAs per chunk */          \
+  {                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < FN; ++c) f_a[(T) % 2][c] = floatx4{0.f, 0.f, 0.f, 0.f}; \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                          \
+      const uint4 x__ = f_x[(T) % 3][s];                                                     \
+      const uint2 xh2__ = make_uint2(x__.x, x__.y), xl2__ = make_uint2(x__.z, x__.w);        \
+      const half4 xh__ = *reinterpret_cast<const half4*>(&xh2__), xl__ = *reinterpret_cast<const half4*>(&xl2__); \
+      _Pragma("unroll") for (int c = 0; c < FN; ++c) {                                       \
+        const half4 wh__ = *reinterpret_cast<const half4*>(&f_wh[c][s]), wl__ = *reinterpret_cast<const half4*>(&f_wl[c][s]); \
+        f_a[(T) % 2][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl__, xh__, f_a[(T) % 2][c], 0, 0, 0); \
+        f_a[(T) % 2][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh__, xl__, f_a[(T) % 2][c], 0, 0, 0); \
+        f_a[(T) % 2][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh__, xh__, f_a[(T) % 2][c], 0, 0, 0); \
+      }                                                                                      \
+    }                                                                                        \
+  }
+  // Software pipeline over a wave's 9 tiles: the LDS reads run two tiles, the MFMAs one tile ahead of the bias + SiLU + split
+  // of the current one, and the scheduler is told to put four vector instructions of that epilogue behind every MFMA.
+#define GTXS_FRONT_TILES()                                                                   \
+  {                                                                                          \
+    constexpr int NT__ = FrontTile::TILES / 4;                                               \
+    uint4 f_x[3][3];                                                                         \
+    bool f_in[3];                                                                            \
+    floatx4 f_a[2][FN];                                                                      \
+    GTXS_FRONT_X(0)                                                                          \
+    GTXS_FRONT_X(1)                                                                          \
+    GTXS_FRONT_M(0)                                                                          \
+    _Pragma("unroll") for (int t__ = 0; t__ < NT__; ++t__) {                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (t__ + 2 < NT__) GTXS_FRONT_X(t__ + 2)                                              \
+      if (t__ + 1 < NT__) GTXS_FRONT_M(t__ + 1)                                              \
+      const bool in__ = f_in[t__ % 3];                                                       \
+      uint2 hv0__, lv0__;                                                                    \
+      GTXS_FRONT_EPI(f_a[t__ % 2][0], f_bias[0], hv0__, lv0__)                               \
+      GTXS_FRONT_PUT(t__, hv0__, lv0__)                                                      \
+      if constexpr (FN > 1) GTXS_FRONT_EPI(f_a[t__ % 2][FN - 1], f_bias[FN - 1], f_keep[t__][0], f_keep[t__][1]) \
+      if (t__ + 1 < NT__) {                                                                  \
+        _Pragma("unroll") for (int i__ = 0; i__ < 9 * FN; ++i__) {                           \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                 \
+        }                                                                                    \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+  }
+
+  if constexpr (FRONT > 0) {
+    // Front stage first: the accumulators and the post stage's weights do not exist yet (register room for f_keep); the first
+    // chunk's weight taps are requested between the two halves and arrive while the stem is computed. The K loop's opening
+    // barrier is also the one after which the weight taps may overwrite the staged image.
+    __syncthreads();                                // the byte table is complete
+    GTXS_FRONT_STAGE()
+    GTXS_PREFETCH(c_begin)
+    GTXS_FRONT_TILES()
+  } else {
+    GTXS_PREFETCH(c_begin)
+  }
 
   // The accumulators start at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue is one multiply and
   // has no loads of its own: the bias fetch overlaps the first global -> LDS round trip instead of opening the epilogue.
@@ -299,14 +484,26 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   GTXS_DIAG_LOOP_BEGIN()
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
+    if constexpr (FRONT > 1) {
+      if (chunk != c_begin) {                       // the second chunk's 16 channels of the patch
+        _Pragma("unroll") for (int t = 0; t < FrontTile::TILES / 4; ++t) GTXS_FRONT_PUT(t, f_keep[t][0], f_keep[t][1])
+      }
+    }
     GTXS_COMMIT()
     __syncthreads();
     if (chunk + 1 < c_end) GTXS_PREFETCH(chunk + 1)
     GTXS_MATRIX_PHASE()
+    GTXS_DIAG_PHASE(7)
   }
   GTXS_DIAG_LOOP_END()
 #undef GTXS_MATRIX_PHASE
 #undef GTXS_LOAD_FRAGS
+#undef GTXS_FRONT_STAGE
+#undef GTXS_FRONT_TILES
+#undef GTXS_FRONT_M
+#undef GTXS_FRONT_X
+#undef GTXS_FRONT_PUT
+#undef GTXS_FRONT_EPI
 
   // ---- post stage (ConvProblem::post_w; 3x3 stride 2, one cout tile = all channels): a 1x1 convolution on the tile ----
   // y = SiLU(acc * 2^-shift) is split and staged as pair rows in this wave's LDS area (what the epilogue would have stored),
@@ -334,11 +531,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int cl = 32 * j + 8 * g4 + 4 * h;
-          float v[4];
+          float2v v[2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[0][j][4 * g4 + i] * P.acc_scale;
-            if (P.act) v[i] = silu_f(v[i]);
+          for (int q = 0; q < 2; ++q) {
+            v[q] = float2v{acc[0][j][4 * g4 + 2 * q], acc[0][j][4 * g4 + 2 * q + 1]} * P.acc_scale;
+            if (P.act) v[q] = silu2(v[q]);
           }
           uint2 hi, lo;
           split4(v, hi, lo, sat_y);
@@ -412,11 +609,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int cl = 32 * j + 8 * g4 + 4 * h;
-        float v[4];
+        float2v v[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = acc[m][j][4 * g4 + i] * sc;
-          if (act) v[i] = silu_f(v[i]);
+        for (int q = 0; q < 2; ++q) {
+          v[q] = float2v{acc[m][j][4 * g4 + 2 * q], acc[m][j][4 * g4 + 2 * q + 1]} * sc;
+          if (act) v[q] = silu2(v[q]);
         }
         if (res_p) {                               // uniform; the swaps below need every lane
           uint4 rc = make_uint4(0, 0, 0, 0);       // lane l: the group's hi chunk, lane l + 32: its lo chunk
@@ -426,10 +623,11 @@ void conv_igemm_split_kernel(const ConvGroup g) {
           const unsigned hw[2] = {sx[0], sy[0]}, lw[2] = {sx[1], sy[1]};
           const half4 rh = *reinterpret_cast<const half4*>(hw), rl = *reinterpret_cast<const half4*>(lw);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += (float)rh[i] + (float)rl[i];             // hi + lo is exact in fp32
+          for (int q = 0; q < 2; ++q)                                                   // hi + lo is exact in fp32
+            v[q] += float2v{(float)rh[2 * q], (float)rh[2 * q + 1]} + float2v{(float)rl[2 * q], (float)rl[2 * q + 1]};
         }
         if (plain) {
-          *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(stg + prow * PITCH + cl * 4) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
         } else {
           uint2 hi, lo;
           split4(v, hi, lo, sat);
@@ -454,6 +652,19 @@ void conv_igemm_split_kernel(const ConvGroup g) {
   }
   if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
   GTXS_DIAG_EXIT()
+}
+
+template <int KS, int STRIDE, int WN, int CPR, int WM>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR, WM>()))))
+void conv_igemm_split_kernel(const ConvGroup g) {
+  conv_split_body<KS, STRIDE, WN, CPR, WM, 0>(g);
+}
+
+// model.0 (the stem) + model.1 (3x3 stride 2) [+ model.2.cv1, the post stage] as one launch: see FrontTile
+template <int WN, int NCH>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu(2)))
+void conv_front_split_kernel(const ConvGroup g) {
+  conv_split_body<3, 2, WN, 2, 1, NCH>(g);
 }
 
 // Second launch of a split-K convolution: one thread per 8-channel group of an output pixel adds the ksplit partial sums in
@@ -516,6 +727,19 @@ void launch_t(const ConvGroup& g, hipStream_t stream) {
   GTX_HIP(hipGetLastError());
 }
 
+template <int WN, int NCH>
+void launch_front_t(const ConvGroup& g, hipStream_t stream) {
+  constexpr int lds = split_lds_bytes<3, 2, WN, 2, 1, NCH>();
+  static_assert(FrontTile::TILES % 4 == 0 && 2 * lds <= 160 * 1024, "front stage: 9 patch tiles per wave, two workgroups per CU");
+  auto kern = conv_front_split_kernel<WN, NCH>;
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  });
+  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), lds, stream, g);
+  GTX_HIP(hipGetLastError());
+}
+
 }  // namespace
 
 // [cout tile][cin chunk][tap][n][swizzled 16-B chunk: hi chunks, then lo chunks], fp16; *acc_scale = 2^-shift
@@ -554,6 +778,36 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
   return out;
 }
 
+// Stem weights for the front stage: [chunk of 16 couts][k-step 3][hi | lo][lane 64][4 halves]; lane (cout = lane % 16,
+// kg = lane / 16) holds tap 4 s + kg (taps 9..11: zeros), channels R, G, B, 0 -- the A operand of v_mfma_f32_16x16x16_f16.
+// Scaled by the power of two that puts max |w| in [2^13, 2^14) like every split weight; *acc_scale receives its inverse.
+std::vector<uint16_t> pack_front_weights_split(const float* w27 /*[27][c0], (tap*3+ch) major*/, int c0, float* acc_scale) {
+  const int chunks = (c0 + 15) / 16;
+  float wmax = 0.f;
+  for (int i = 0; i < 27 * c0; ++i) wmax = std::max(wmax, std::fabs(w27[i]));
+  int shift = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int e;
+    std::frexp(wmax, &e);
+    shift = std::max(-100, std::min(100, 14 - e));
+  }
+  const float up = std::ldexp(1.f, shift);
+  *acc_scale = std::ldexp(1.f, -shift);
+  std::vector<uint16_t> out((size_t)chunks * 3 * 2 * 64 * 4, 0);
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int s = 0; s < 3; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = ch * 16 + (lane & 15), tap = 4 * s + (lane >> 4);
+        for (int c = 0; c < 3; ++c) {
+          const float v = (tap < 9 && co < c0) ? w27[(size_t)(tap * 3 + c) * c0 + co] * up : 0.f;
+          const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+          memcpy(&out[((((size_t)ch * 3 + s) * 2 + 0) * 64 + lane) * 4 + c], &hi, 2);
+          memcpy(&out[((((size_t)ch * 3 + s) * 2 + 1) * 64 + lane) * 4 + c], &lo, 2);
+        }
+      }
+  return out;
+}
+
 size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg) {
   if (p.ksplit <= 1) return 0;
   const size_t pstride = (size_t)((p.Cout + cfg.bn - 1) / cfg.bn) * cfg.bn;
@@ -575,6 +829,15 @@ void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
   for (int i = 0; i < g.count; ++i)
     GTX_CHECK(g.p[i].ksplit <= 1 || (g.count == 1 && g.p[i].partial && g.p[i].ksplit <= g.p[i].Cin / c.kc), "conv: split-K needs a single-member launch, a scratch buffer and at most one split per K chunk");
   const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;
+  if (g.p[0].front_img != nullptr) {
+    const ConvProblem& p = g.p[0];
+    GTX_CHECK(g.count == 1 && c.ks == 3 && c.stride == 2 && cpr == 2 && wm == 1 && (wn == 1 || wn == 2) && p.Cout <= c.bn && p.ksplit <= 1 &&
+                  p.front_w && p.front_bias && p.front_h == 2 * p.H && p.front_w_px == 2 * p.W,
+              "conv: the front stage needs a single 3x3 stride-2 launch with one cout tile on a stem output of half the image size");
+    if (wn == 1 && p.Cin == 16) return launch_front_t<1, 1>(g, s);     // YOLOv8n: 16 -> 32 channels
+    if (wn == 2 && p.Cin == 32) return launch_front_t<2, 2>(g, s);     // YOLOv8s: 32 -> 64
+    fail(-3, "conv: no front-stage kernel for %d -> %d channels", p.Cin, p.Cout);
+  }
 #define GTX_CASE(KS, ST, WN, CPR, WM) \
   if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR && wm == WM) return launch_t<KS, ST, WN, CPR, WM>(g, s);
   GTX_CASE(3, 1, 1, 2, 1) GTX_CASE(3, 1, 2, 2, 1) GTX_CASE(3, 2, 1, 2, 1) GTX_CASE(3, 2, 2, 2, 1)

@@ -227,6 +227,12 @@ void Detector::build_graph() {
       void* dp = alloc(pk.size() * 2);
       GTX_HIP(hipMemcpy(dp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
       op.wpk = dp;
+      if (c0 % 16 == 0) {                       // fuse_stem(): whole 16-channel K chunks of model.1
+        const std::vector<uint16_t> fk = pack_front_weights_split(w27.data(), c0, &op.front_scale);
+        void* fp = alloc(fk.size() * 2);
+        GTX_HIP(hipMemcpy(fp, fk.data(), fk.size() * 2, hipMemcpyHostToDevice));
+        op.front_wpk = fp;
+      }
     }
     ops_.push_back(op);
     layer_views_["model.0.conv"] = a0;
@@ -424,6 +430,34 @@ void Detector::fuse_front() {
   }
 }
 
+// model.0.conv (the stem) moves into the launch of its only consumer, model.1.conv (already carrying model.2.cv1 when
+// fuse_front() applied): ConvProblem::front_img. The stem's output -- the largest tensor of the network, 236 MB per two
+// 1920 x 1920 frames -- is neither written nor read back; the workgroup recomputes the one-pixel halo of its patch (9.6 %).
+// Built for model.1 in one cout tile and at most two 16-channel K chunks: YOLOv8 n (16 -> 32) and s (32 -> 64).
+// GTX_FUSE_STEM=0 keeps the stem's own launch.
+void Detector::fuse_stem() {
+  const char* e = getenv("GTX_FUSE_STEM");
+  if (conv_dtype_ != DT_F32S || (e && e[0] == '0') || ops_.size() < 2) return;
+  const Op& st = ops_[0];
+  Op& cv = ops_[1];
+  if (st.kind != Op::STEM || cv.kind != Op::CONV || cv.grp.count != 1 || !st.front_wpk) return;
+  ConvProblem& p = cv.grp.p[0];
+  const bool ok = cv.cfg.variant == 2 && cv.cfg.ks == 3 && cv.cfg.stride == 2 && cv.cfg.kc == 16 && cv.cfg.th == 8 && ((cv.cfg.bn == 32 && p.Cin == 16) || (cv.cfg.bn == 64 && p.Cin == 32)) &&
+                  p.Cout <= cv.cfg.bn && p.ksplit <= 1 && !p.res && p.in == st.out.ptr && p.in_cstride == st.out.c && p.in_coff == 0 && p.Cin == st.out.c &&
+                  st.in.h == 2 * st.out.h && st.in.w == 2 * st.out.w && p.H == st.out.h && p.W == st.out.w;
+  if (!ok) return;
+  unfused_.insert(unfused_.begin(), st);
+  p.front_img = st.in.ptr;
+  p.front_w = st.front_wpk;
+  p.front_bias = st.bias;
+  p.front_scale = st.front_scale;
+  p.front_h = st.in.h;
+  p.front_w_px = st.in.w;
+  cv.name = "model.0.conv+" + cv.name;
+  cv.family = "conv_front_split_kernel";
+  ops_.erase(ops_.begin());
+}
+
 void Detector::set_batch(int nb) {
   if (nb == cur_nb_) return;
   for (Op& op : ops_) {
@@ -440,6 +474,10 @@ void Detector::set_batch(int nb) {
       if (p.post_w) {                     // the fused 1x1 layer: its FLOPs and weights; its output replaces the 3x3 layer's (same size)
         op.flops += 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * p.Cout;
         op.bytes += (double)p.Cout * p.Cout * es_;
+      }
+      if (p.front_img) {                  // the fused stem: its FLOPs; RGB0 bytes are read instead of the stem's output
+        op.flops += 2.0 * p.N * p.H * p.W * (double)p.Cin * 27;
+        op.bytes += (double)p.N * p.front_h * p.front_w_px * 4 - (double)p.N * p.H * p.W * p.Cin * es_;
       }
     }
   }
@@ -463,6 +501,7 @@ void Detector::finalize() {
   GTX_HIP(hipSetDevice(ctx_->device));
   build_graph();
   fuse_front();
+  fuse_stem();
   const int N = cfg_.max_batch;
   gray_h_ = cfg_.frame_h / 2;
   gray_w_ = cfg_.frame_w / 2;
@@ -717,12 +756,24 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
   if (it == layer_views_.end()) fail(-1, "unknown layer '%s'", layer.c_str());
   const View& v = it->second;
   if (out) {
-    if (!unfused_.empty() && unfused_[0].name == layer && cur_nb_ > 0) {   // the intermediate a fused launch no longer writes:
-      Op o = unfused_[0];                                                   // run its stand-alone launch now (its input is still in HBM)
+    // an intermediate the fused launches no longer write (the stem's output, model.1's): run the stand-alone launches up to
+    // it now -- the network input of the last pass is still in HBM. The last entry of unfused_ is a layer the fused launch
+    // does write.
+    int k = -1;
+    for (size_t i = 0; i < unfused_.size(); ++i) {
+      const bool still_written = i + 1 == unfused_.size() && unfused_[i].kind != Op::STEM;   // the fused launch's own output layer
+      if (!still_written && unfused_[i].name == layer) k = (int)i;
+    }
+    if (k >= 0 && cur_nb_ > 0) {
       GTX_HIP(hipSetDevice(ctx_->device));
-      for (int i = 0; i < o.grp.count; ++i) o.grp.p[i].N = cur_nb_;
-      conv_group_finalize(o.grp, o.cfg);
-      conv_launch(o.grp, o.cfg, ctx_->stream);
+      for (int j = 0; j <= k; ++j) {
+        Op o = unfused_[(size_t)j];
+        if (o.kind == Op::CONV) {
+          for (int i = 0; i < o.grp.count; ++i) o.grp.p[i].N = cur_nb_;
+          conv_group_finalize(o.grp, o.cfg);
+        }
+        run_op(o, cur_nb_, ctx_->stream);
+      }
       GTX_HIP(hipStreamSynchronize(ctx_->stream));
     }
   }

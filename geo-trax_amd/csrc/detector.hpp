@@ -55,6 +55,8 @@ struct Op {
   const float* bias = nullptr;
   const void* wpk = nullptr;   // fp16 MFMA / split-f16x3 stem weights
   float stem_scale = 1.f;      // split-f16x3 stem: inverse of the weights' power-of-two scaling
+  const void* front_wpk = nullptr;   // the same weights packed for the front stage of model.1 (ConvProblem::front_w)
+  float front_scale = 1.f;
   double flops = 0;      // algorithmic 2*MAC
   double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
 };
@@ -104,6 +106,7 @@ class Detector {
   View c2f(const std::string& pfx, const View& x, bool shortcut, const View* out_slice, const View* up_src = nullptr);
   void build_graph();
   void fuse_front();         // model.1 (3x3 stride 2) + model.2.cv1 (1x1) as one launch on the split-f16x3 path
+  void fuse_stem();          // model.0 (the stem) computed inside model.1's launch: its output never reaches HBM
   void run_op(const Op& op, int nb, hipStream_t s);
   void run_forward(int nb, hipStream_t s, bool traced = false);
   void run_post(int nb, hipStream_t s);

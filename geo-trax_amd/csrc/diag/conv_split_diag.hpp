@@ -12,13 +12,20 @@ __device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MH
 }
 }
 
+// -DGTXS_DIAG_FRONT_ONLY (conv_igemm_split.hip only): stamp nothing but the front launch (tools/front_probe.py)
+#ifdef GTXS_DIAG_FRONT_ONLY
+#define GTXS_DIAG_ON (FRONT)
+#else
+#define GTXS_DIAG_ON (true)
+#endif
+
 #ifndef GTXS_DIAG_NO_ENTRY
 #define GTXS_DIAG_ENTRY() const unsigned long long st_e0__ = __builtin_amdgcn_s_memtime();
 #define GTXS_DIAG_EXIT()                                                                                    \
   {                                                                                                         \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the workgroup's stores have left */            \
     const unsigned long long st_e1__ = __builtin_amdgcn_s_memtime();                                        \
-    if (threadIdx.x == 0) {                                                                                 \
+    if (GTXS_DIAG_ON && threadIdx.x == 0) {                                                                                 \
       atomicAdd(&gtx::g_clock_stamp[3], st_c0__ - st_e0__);     /* entry -> K loop */                        \
       atomicAdd(&gtx::g_clock_stamp[4], st_e1__ - st_c1s__);    /* K loop end -> stores retired */           \
     }                                                                                                       \
@@ -26,12 +33,19 @@ __device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MH
 #endif
 #define GTXS_DIAG_LOOP_BEGIN() \
   const unsigned long long st_c0__ = __builtin_amdgcn_s_memtime(), st_r0__ = __builtin_amdgcn_s_memrealtime(); \
-  unsigned long long st_c1s__ = 0;
+  unsigned long long st_c1s__ = 0, st_ph__ = st_c0__;
+// cycles since the previous phase stamp, summed into g_clock_stamp[K] (7: a K chunk's weight commit + matrix phase)
+#define GTXS_DIAG_PHASE(K)                                                                                  \
+  {                                                                                                         \
+    const unsigned long long st_p__ = __builtin_amdgcn_s_memtime();                                         \
+    if (GTXS_DIAG_ON && threadIdx.x == 0) atomicAdd(&gtx::g_clock_stamp[K], st_p__ - st_ph__);                              \
+    st_ph__ = st_p__;                                                                                       \
+  }
 #define GTXS_DIAG_LOOP_END()                                                                                \
   {                                                                                                         \
     const unsigned long long st_c1__ = __builtin_amdgcn_s_memtime(), st_r1__ = __builtin_amdgcn_s_memrealtime(); \
     st_c1s__ = st_c1__;                                                                                     \
-    if (threadIdx.x == 0) {                                                                                 \
+    if (GTXS_DIAG_ON && threadIdx.x == 0) {                                                                                 \
       atomicAdd(&gtx::g_clock_stamp[0], st_c1__ - st_c0__);                                                 \
       atomicAdd(&gtx::g_clock_stamp[1], st_r1__ - st_r0__);                                                 \
       atomicAdd(&gtx::g_clock_stamp[2], 1ull);                                                              \

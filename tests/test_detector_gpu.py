@@ -231,3 +231,37 @@ def test_fused_front_equals_the_two_launches(gtx_ctx, weights, monkeypatch):
     finally:
         two.close()
         one.close()
+
+
+@pytest.mark.parametrize("imgsz,rect", [(384, False), (416, True), (352, False)])
+def test_fused_stem_matches_the_stem_launch(gtx_ctx, weights, monkeypatch, imgsz, rect):
+    """model.0 (the stem) is computed inside model.1's launch on the default path (ConvProblem::front_img: a workgroup builds the
+    17 x 33 stem patch its tile reads from the RGB0 image with 16x16x16 MFMAs; the stem's output never reaches HBM). Same
+    products (three MFMAs each, the same split weights and byte / 255 table) as `stem_split_kernel`, summed in another order: the layers behind
+    it agree with the three-launch detector's to 1e-5 of the layer's largest value, the detections to the bar the oracle tests
+    use, and the stem's own activations stay reachable. 416 and 352 leave partial 8 x 16 tiles and odd patch origins at the borders."""
+    from geotrax_amd.detector import Detector
+
+    frame = _frame(0)
+    kw = dict(imgsz=imgsz, half=False, rect=rect, fp32_split=True, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_FUSE_STEM", "0")
+    sep = Detector(weights, FRAME_HW, **kw)
+    monkeypatch.delenv("GTX_FUSE_STEM")
+    one = Detector(weights, FRAME_HW, **kw)
+    try:
+        a, b = sep.detect(frame), one.detect(frame)
+        fam_sep, fam_one = [f["kernel"] for f in sep.profile(1, 1)], [f["kernel"] for f in one.profile(1, 1)]
+        assert "stem_split_kernel" in fam_sep and "stem_split_kernel" not in fam_one and "conv_front_split_kernel" in fam_one
+        assert sum(f["launches"] for f in sep.profile(1, 1)) == sum(f["launches"] for f in one.profile(1, 1)) + 1
+        for name in ("model.0.conv", "model.1.conv"):              # on demand, from the stand-alone launches
+            np.testing.assert_array_equal(sep.layer_output(name), one.layer_output(name), err_msg=name)
+        for name in ("model.2", "model.4", "model.9", "model.22.feat0"):
+            x, y = sep.layer_output(name), one.layer_output(name)
+            assert x.shape == y.shape and np.isfinite(y).all()
+            assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max(), name
+        assert len(a) == len(b) > 0
+        np.testing.assert_allclose(a.conf, b.conf, atol=1e-5)
+        np.testing.assert_allclose(a.xyxy, b.xyxy, atol=1e-2)
+    finally:
+        sep.close()
+        one.close()
