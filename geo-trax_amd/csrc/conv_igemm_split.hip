@@ -389,34 +389,36 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
     }                                                                                        \
   }
 
+  // The accumulators start at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue is one multiply and
+  // has no loads of its own: the bias fetch overlaps the first global -> LDS round trip instead of opening the epilogue.
+  float4 b4[WN][4];
+#define GTXS_LOAD_BIAS()                                                                     \
+  {                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < WN; ++j)                                           \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f); \
+    if (P.bias && ksi == 0) {                 /* one uniform branch, eight independent loads (split-K: the bias enters with split 0) */ \
+      const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);                 \
+      _Pragma("unroll") for (int j = 0; j < WN; ++j)                                         \
+        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);   /* bias arrays are padded to whole cout tiles */ \
+    }                                                                                        \
+  }
   if constexpr (FRONT > 0) {
     // Front stage first: the accumulators and the post stage's weights do not exist yet (register room for f_keep); the first
-    // chunk's weight taps are requested between the two halves and arrive while the stem is computed. The K loop's opening
-    // barrier is also the one after which the weight taps may overwrite the staged image.
+    // chunk's weight taps and the bias are requested between the two halves and arrive while the stem is computed. The K
+    // loop's opening barrier is also the one after which the weight taps may overwrite the staged image.
     __syncthreads();                                // the byte table is complete
     GTXS_FRONT_STAGE()
     GTXS_PREFETCH(c_begin)
+    GTXS_LOAD_BIAS()
     GTXS_FRONT_TILES()
   } else {
     GTXS_PREFETCH(c_begin)
+    GTXS_LOAD_BIAS()
   }
+#undef GTXS_LOAD_BIAS
 
-  // The accumulators start at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue is one multiply and
-  // has no loads of its own: the bias fetch overlaps the first global -> LDS round trip instead of opening the epilogue.
   floatx16 acc[WM][WN];
   {
-    float4 b4[WN][4];
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias && ksi == 0) {                 // one uniform branch, eight independent loads (split-K: the bias enters with split 0)
-      const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);   // bias arrays are padded to whole cout tiles
-    }
     const float inv_sc = __builtin_amdgcn_rcpf(P.acc_scale);     // exact: acc_scale is a power of two
 #pragma unroll
     for (int j = 0; j < WN; ++j)
