@@ -571,30 +571,27 @@ __device__ __forceinline__ half8 vneg_inf(half8) {
 __device__ __forceinline__ float4 vneg_inf(float4) { return make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
 
 // Pair format (split_format.hpp): a "vector" is 4 channels of one pixel = 8 bytes of hi halves and, 16 bytes further, 8 bytes
-// of lo halves. The maximum is taken on hi + lo (exact in fp32) and the winner's two halves are carried along unchanged.
+// of lo halves. The pools work on one 32-bit KEY per channel: (hi, lo) with both fp16 patterns mapped to unsigned codes that
+// order like the numbers (sign bit flipped for positive, all bits for negative values), hi in the upper half. Keys order
+// like hi + lo: hi = fp16(x) and |lo| is at most half the spacing on its side of hi, so a larger hi is never the smaller
+// value, and with equal hi the lo decides. A maximum is one v_max_u32 per channel (the arithmetic form -- two conversions
+// and an add per operand, a compare and two selects -- made the three cascaded pools the most expensive 30 MB of the pass),
+// the winner's two halves travel inside the key unchanged, and the keys are made / unmade once per element.
 struct PairTag {};
-struct PairV { uint2 hi, lo; };
-template <> struct Vec16<PairTag> { using type = PairV; static constexpr int N = 4; };
-__device__ __forceinline__ PairV vmax(const PairV& a, const PairV& b) {
-  const half4 ah = *reinterpret_cast<const half4*>(&a.hi), al = *reinterpret_cast<const half4*>(&a.lo);
-  const half4 bh = *reinterpret_cast<const half4*>(&b.hi), bl = *reinterpret_cast<const half4*>(&b.lo);
-  half4 rh, rl;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool ta = (float)ah[i] + (float)al[i] >= (float)bh[i] + (float)bl[i];
-    rh[i] = ta ? ah[i] : bh[i];
-    rl[i] = ta ? al[i] : bl[i];
-  }
-  PairV r;
-  r.hi = *reinterpret_cast<const uint2*>(&rh);
-  r.lo = *reinterpret_cast<const uint2*>(&rl);
-  return r;
+template <> struct Vec16<PairTag> { using type = uint4; static constexpr int N = 4; };
+__device__ __forceinline__ uint4 vmax(const uint4& a, const uint4& b) { return make_uint4(max(a.x, b.x), max(a.y, b.y), max(a.z, b.z), max(a.w, b.w)); }
+__device__ __forceinline__ uint4 vneg_inf(uint4) { return make_uint4(0x03FF8000u, 0x03FF8000u, 0x03FF8000u, 0x03FF8000u); }   // (-inf, +0)
+// two fp16 bit patterns -> two 16-bit codes that compare like the numbers as unsigned integers, and back
+__device__ __forceinline__ unsigned pair_code2(unsigned x) { return x ^ ((((x >> 15) & 0x00010001u) * 0xFFFFu) | 0x80008000u); }
+__device__ __forceinline__ unsigned pair_uncode2(unsigned s) { return s ^ ((((~s >> 15) & 0x00010001u) * 0xFFFFu) | 0x80008000u); }
+// 8 bytes of hi halves + 8 bytes of lo halves (4 channels) <-> 4 keys
+__device__ __forceinline__ uint4 pair_keys(uint2 hi, uint2 lo) {
+  const unsigned h0 = pair_code2(hi.x), h1 = pair_code2(hi.y), l0 = pair_code2(lo.x), l1 = pair_code2(lo.y);
+  return make_uint4((h0 << 16) | (l0 & 0xFFFFu), (h0 & 0xFFFF0000u) | (l0 >> 16), (h1 << 16) | (l1 & 0xFFFFu), (h1 & 0xFFFF0000u) | (l1 >> 16));
 }
-__device__ __forceinline__ PairV vneg_inf(PairV) {
-  PairV r;
-  r.hi = make_uint2(0xFC00FC00u, 0xFC00FC00u);       // four fp16 -inf
-  r.lo = make_uint2(0u, 0u);
-  return r;
+__device__ __forceinline__ void pair_unkeys(const uint4& k, uint2& hi, uint2& lo) {
+  hi = make_uint2(pair_uncode2((k.x >> 16) | (k.y & 0xFFFF0000u)), pair_uncode2((k.z >> 16) | (k.w & 0xFFFF0000u)));
+  lo = make_uint2(pair_uncode2((k.x & 0xFFFFu) | (k.y << 16)), pair_uncode2((k.z & 0xFFFFu) | (k.w << 16)));
 }
 // element type in memory, and the load / store of vector `v` (in units of N channels) of the pixel record at `px`
 template <typename T> struct PoolMem { using elem = T; };
@@ -602,20 +599,19 @@ template <> struct PoolMem<PairTag> { using elem = float; };
 template <typename T> __device__ __forceinline__ typename Vec16<T>::type pool_load(const typename PoolMem<T>::elem* px, int v) {
   return *reinterpret_cast<const typename Vec16<T>::type*>(px + v * Vec16<T>::N);
 }
-template <> __device__ __forceinline__ PairV pool_load<PairTag>(const float* px, int v) {
+template <> __device__ __forceinline__ uint4 pool_load<PairTag>(const float* px, int v) {
   const char* g = reinterpret_cast<const char*>(px) + (v >> 1) * 32 + (v & 1) * 8;
-  PairV r;
-  r.hi = *reinterpret_cast<const uint2*>(g);
-  r.lo = *reinterpret_cast<const uint2*>(g + 16);
-  return r;
+  return pair_keys(*reinterpret_cast<const uint2*>(g), *reinterpret_cast<const uint2*>(g + 16));
 }
 template <typename T> __device__ __forceinline__ void pool_store(typename PoolMem<T>::elem* px, int v, const typename Vec16<T>::type& val) {
   *reinterpret_cast<typename Vec16<T>::type*>(px + v * Vec16<T>::N) = val;
 }
-template <> __device__ __forceinline__ void pool_store<PairTag>(float* px, int v, const PairV& val) {
+template <> __device__ __forceinline__ void pool_store<PairTag>(float* px, int v, const uint4& val) {
   char* g = reinterpret_cast<char*>(px) + (v >> 1) * 32 + (v & 1) * 8;
-  *reinterpret_cast<uint2*>(g) = val.hi;
-  *reinterpret_cast<uint2*>(g + 16) = val.lo;
+  uint2 hi, lo;
+  pair_unkeys(val, hi, lo);
+  *reinterpret_cast<uint2*>(g) = hi;
+  *reinterpret_cast<uint2*>(g + 16) = lo;
 }
 
 // The three cascaded 5x5/s1/p2 max-pools of SPPF in one pass: a block takes a 16x16 spatial tile of
@@ -668,9 +664,114 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(typename PoolMem<T>::ele
   }
 }
 
+// Pair format, maps that fit LDS whole (60 x 60 at 1920 input: 115 KB per 8-channel unit): one 512-thread workgroup per
+// (image, 32-byte unit) holds the whole map as keys and runs the six separable passes in place. A thread owns a run of 9
+// consecutive positions along the pass direction (of one row or column and one half of the unit): 13 LDS reads, nine
+// 5-window maxima as v_max3_u32 pairs, a barrier, 9 writes -- 1.4 reads per result instead of 5, and LDS bandwidth is what
+// bounds this kernel once the maxima are integer. Against the tiled kernel above: no halo (a 16 x 16 tile with its 6-pixel
+// ring reads 3.06 x its own pixels), 32 contiguous bytes per pixel instead of two 8-byte pieces 16 bytes apart, 128
+// workgroups instead of 2 048. Positions outside the map read the edge cell again, which is what -inf padding amounts to.
+// (Runs of 9 pixels are 288 bytes apart: the 16 lanes of an LDS access cycle fall on 16 different bank groups.)
+constexpr int kPoolRun = 9, kPoolMaxRuns = 2, kPoolThreads = 512;   // two runs per thread and direction: maps up to 64 x 64 (at 1024 threads the runs spill: 128 registers)
+__global__ __launch_bounds__(kPoolThreads) void sppf_pool_image_kernel(float* __restrict__ x, int h, int w, int c) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  uint4* s_m = reinterpret_cast<uint4*>(s_raw);            // [pixel][2]: keys of channels 0-3 and 4-7 of the unit
+  constexpr int NT = kPoolThreads, RUN = kPoolRun, LD_IT = 8;      // h * w <= NT * LD_IT (launch_sppf_pool checks)
+  const int u = blockIdx.x, n = blockIdx.y, cs = 4 * c, npx = h * w;
+  char* img = reinterpret_cast<char*>(x + (size_t)n * npx * cs) + (size_t)u * 32;
+  const size_t pstride = (size_t)cs * 4;                   // bytes per pixel record [x | y1 | y2 | y3]
+  {
+    uint4 hi[LD_IT], lo[LD_IT];                            // every load of the map is issued before the first key is made
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      const int p = min((int)threadIdx.x + NT * it, npx - 1);
+      hi[it] = *reinterpret_cast<const uint4*>(img + p * pstride);
+      lo[it] = *reinterpret_cast<const uint4*>(img + p * pstride + 16);
+    }
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      const int p = threadIdx.x + NT * it;
+      if (p < npx) {
+        s_m[2 * p] = pair_keys(make_uint2(hi[it].x, hi[it].y), make_uint2(lo[it].x, lo[it].y));
+        s_m[2 * p + 1] = pair_keys(make_uint2(hi[it].z, hi[it].w), make_uint2(lo[it].z, lo[it].w));
+      }
+    }
+  }
+  // the thread's runs: [pass direction][run] -> LDS index of the run's first cell and its first position (-1: none)
+  int r_base[2][kPoolMaxRuns], r_pos[2][kPoolMaxRuns];
+  {
+    const int nsx = (w + RUN - 1) / RUN, nsy = (h + RUN - 1) / RUN;
+#pragma unroll
+    for (int r = 0; r < kPoolMaxRuns; ++r) {
+      const int idx = threadIdx.x + NT * r, k = idx & 1, t = idx >> 1;
+      const int y = t / nsx, sx = t - y * nsx;              // along rows: lanes walk (half, segment) of one row
+      r_pos[0][r] = y < h ? sx * RUN : -1;
+      r_base[0][r] = (y * w + sx * RUN) * 2 + k;
+      const int sy = t / w, xx = t - sy * w;                // along columns: lanes walk (half, x) of one band of rows
+      r_pos[1][r] = sy < nsy ? sy * RUN : -1;
+      r_base[1][r] = (sy * RUN * w + xx) * 2 + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int stage = 0; stage < 3; ++stage) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {                 // 0: along rows, 1: along columns
+      const int lim = pass == 0 ? w : h, step = pass == 0 ? 2 : 2 * w;
+      uint4 out[kPoolMaxRuns][RUN];
+#pragma unroll
+      for (int r = 0; r < kPoolMaxRuns; ++r) {
+        const int pos0 = r_pos[pass][r], base = r_base[pass][r];
+        if (pos0 >= 0) {
+          uint4 in[RUN + 4];
+#pragma unroll
+          for (int j = 0; j < RUN + 4; ++j)               // positions outside the map: the edge cell again (it is in every window that reaches them)
+            in[j] = s_m[base + (min(max(pos0 - 2 + j, 0), lim - 1) - pos0) * step];
+#pragma unroll
+          for (int j = 0; j < RUN; ++j) out[r][j] = vmax(vmax(vmax(in[j], in[j + 1]), vmax(in[j + 2], in[j + 3])), in[j + 4]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // one run's 13 inputs at a time (both at once do not fit the registers)
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kPoolMaxRuns; ++r) {
+        const int pos0 = r_pos[pass][r], base = r_base[pass][r];
+        if (pos0 >= 0) {
+#pragma unroll
+          for (int j = 0; j < RUN; ++j)
+            if (pos0 + j < lim) s_m[base + j * step] = out[r][j];
+        }
+      }
+      __syncthreads();
+    }
+    char* dst = img + (size_t)(stage + 1) * c * 4;          // slice y1 / y2 / y3 of the record
+    for (int p = threadIdx.x; p < npx; p += NT) {
+      uint2 ah, al, bh, bl;
+      pair_unkeys(s_m[2 * p], ah, al);
+      pair_unkeys(s_m[2 * p + 1], bh, bl);
+      *reinterpret_cast<uint4*>(dst + p * pstride) = make_uint4(ah.x, ah.y, bh.x, bh.y);
+      *reinterpret_cast<uint4*>(dst + p * pstride + 16) = make_uint4(al.x, al.y, bl.x, bl.y);
+    }
+  }
+}
+
 void launch_sppf_pool(int dtype, void* x, int n, int h, int w, int c, hipStream_t s) {
   const int vn = dtype == DT_F16 ? 8 : 4;
   GTX_CHECK(c % (dtype == DT_F32 ? 4 : 8) == 0, "sppf: channels %d not a multiple of %d", c, dtype == DT_F32 ? 4 : 8);
+  const bool runs_fit = h * 2 * cdiv(w, kPoolRun) <= kPoolThreads * kPoolMaxRuns && w * 2 * cdiv(h, kPoolRun) <= kPoolThreads * kPoolMaxRuns;
+  if (dtype == DT_F32S && runs_fit && h * w <= 8 * kPoolThreads && (size_t)h * w * 32 <= 144 * 1024 && c % 8 == 0) {      // the whole map in LDS (<= 64 x 64)
+    static const bool tiled = [] { const char* e = getenv("GTX_POOL_TILED"); return e && e[0] == '1'; }();
+    if (!tiled) {
+      const int lds = h * w * 32;
+      static std::once_flag once;
+      std::call_once(once, [] {
+        GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      });
+      hipLaunchKernelGGL(sppf_pool_image_kernel, dim3((unsigned)(c / 8), n), dim3(kPoolThreads), lds, s, (float*)x, h, w, c);
+      GTX_HIP(hipGetLastError());
+      return;
+    }
+  }
   const int tiles = cdiv(w, 16) * cdiv(h, 16);
   dim3 grid((unsigned)(tiles * (c / vn)), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, grid, block, 0, s, (_Float16*)x, h, w, c);

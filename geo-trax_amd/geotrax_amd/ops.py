@@ -63,13 +63,14 @@ def conv2d_time(dtype, n, h, w, cin, cout, ksize, stride, iters=20, ctx=None):
     return ms.value, fl.value
 
 
-def sppf_pool(x: np.ndarray, c: int, ctx=None) -> np.ndarray:
-    """x: [n,h,w,4c]; fills channels [c,4c) with the 5/9/13 window maxima of channels [0,c)."""
+def sppf_pool(x: np.ndarray, c: int, ctx=None, split: bool = False) -> np.ndarray:
+    """x: [n,h,w,4c]; fills channels [c,4c) with the 5/9/13 window maxima of channels [0,c). split (float32 only): the
+    device tensor is in the pair format of the default fp32 path (values come back as hi + lo, i.e. 22-bit rounded)."""
     ctx = ctx or _lib.default_context()
     x = np.ascontiguousarray(x).copy()
     n, h, w, cs = x.shape
-    assert cs == 4 * c
-    check(ctx.lib.gtx_op_sppf_pool(ctx.handle, _dt(x), n, h, w, c, ptr(x)))
+    assert cs == 4 * c and (not split or x.dtype == np.float32)
+    check(ctx.lib.gtx_op_sppf_pool(ctx.handle, GTX_F32S if split else _dt(x), n, h, w, c, ptr(x)))
     return x
 
 

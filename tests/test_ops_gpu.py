@@ -177,6 +177,25 @@ def test_sppf_pool_and_upsample(gtx_ctx, dtype):
     np.testing.assert_array_equal(got[..., 72:], dst[..., 72:])
 
 
+@pytest.mark.parametrize("hw", [(13, 22), (60, 60), (5, 3), (64, 64), (68, 68), (70, 72)])
+def test_sppf_pool_pair_format(gtx_ctx, hw):
+    """The pools of the default fp32 path work on (hi, lo) pairs: maxima are taken on hi + lo and the winner's two halves are
+    carried along, so the result is exactly the oracle's pools of the 22-bit rounded input. Maps up to 64 x 64 go through the
+    whole-map kernel (one workgroup per image and 8-channel unit, 60 x 60 at the 1920 input), larger ones through the tiled one."""
+    from geotrax_amd import ops
+    from oracle.yolov8_ref import sppf_pools_nhwc
+
+    rng = np.random.default_rng(3)
+    c = 32
+    h, w = hw
+    x = np.zeros((2, h, w, 4 * c), np.float32)
+    x[..., :c] = (rng.standard_normal((2, h, w, c)) * 3).astype(np.float32)
+    hi = x.astype(np.float16).astype(np.float32)
+    x22 = hi + (x - hi).astype(np.float16).astype(np.float32)               # what the pair format holds
+    got = ops.sppf_pool(x, c, ctx=gtx_ctx, split=True)
+    np.testing.assert_array_equal(got, sppf_pools_nhwc(x22[..., :c]))
+
+
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
 @pytest.mark.parametrize("shape,imgsz,rect", [((216, 384), 192, False), ((216, 384), 192, True), ((200, 300), 256, False)])
 def test_preprocess_matches_oracle(gtx_ctx, dtype, shape, imgsz, rect):
