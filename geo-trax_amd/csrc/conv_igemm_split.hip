@@ -324,14 +324,16 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   // the staged pixels -- are read once for both).
 #define GTXS_FRONT_STAGE()                                                                   \
   {                                                                                          \
+    unsigned e__[FrontTile::IN_SLOTS][3];           /* every table read is issued before the first record is packed */ \
+    _Pragma("unroll") for (int s = 0; s < FrontTile::IN_SLOTS; ++s) {                        \
+      const unsigned px__ = f_raw[s];                                                        \
+      e__[s][0] = f_lut[px__ & 255u]; e__[s][1] = f_lut[(px__ >> 8) & 255u]; e__[s][2] = f_lut[(px__ >> 16) & 255u]; \
+    }                                                                                        \
     _Pragma("unroll") for (int s = 0; s < FrontTile::IN_SLOTS; ++s) {                        \
       const int i__ = tid + 256 * s;                                                         \
-      if (FrontTile::IN_PIX % 256 == 0 || i__ < FrontTile::IN_PIX) {                         \
-        const unsigned px__ = f_raw[s];                                                      \
-        const unsigned e0__ = f_lut[px__ & 255u], e1__ = f_lut[(px__ >> 8) & 255u], e2__ = f_lut[(px__ >> 16) & 255u]; \
+      if (FrontTile::IN_PIX % 256 == 0 || i__ < FrontTile::IN_PIX)                           \
         *reinterpret_cast<uint4*>(f_stage + i__ * 16) =                                      \
-            make_uint4((e0__ & 0xffffu) | (e1__ << 16), e2__ & 0xffffu, (e0__ >> 16) | (e1__ & 0xffff0000u), e2__ >> 16); \
-      }                                                                                      \
+            make_uint4((e__[s][0] & 0xffffu) | (e__[s][1] << 16), e__[s][2] & 0xffffu, (e__[s][0] >> 16) | (e__[s][1] & 0xffff0000u), e__[s][2] >> 16); \
     }                                                                                        \
     __syncthreads();                                                                         \
   }
