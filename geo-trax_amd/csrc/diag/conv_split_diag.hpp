@@ -33,7 +33,7 @@ __device__ unsigned long long g_clock_stamp[8];   // [0] loop cycles, [1] 100 MH
 #endif
 #define GTXS_DIAG_LOOP_BEGIN() \
   const unsigned long long st_c0__ = __builtin_amdgcn_s_memtime(), st_r0__ = __builtin_amdgcn_s_memrealtime(); \
-  unsigned long long st_c1s__ = 0, st_ph__ = st_c0__;
+  [[maybe_unused]] unsigned long long st_c1s__ = 0, st_ph__ = st_c0__;
 // cycles since the previous phase stamp, summed into g_clock_stamp[K] (7: a K chunk's weight commit + matrix phase)
 #define GTXS_DIAG_PHASE(K)                                                                                  \
   {                                                                                                         \
