@@ -135,6 +135,47 @@ __global__ __launch_bounds__(256) void gray_half_kernel(const uint8_t* __restric
   gray[((size_t)n * gh + y) * gw + x] = (uint8_t)((g00 + g01 + g10 + g11 + 2) >> 2);
 }
 
+// The exact-2x case (a 3840 x 2160 frame into a 1920-wide letterbox: every frame of the headline workload) with 4 output pixels
+// per thread: the 2 x 24 source bytes of a thread arrive as six 8-byte loads instead of 48 byte loads, the four RGB0 pixels
+// leave as one 16-byte store and the four gray pixels as one word. Same integers as preprocess_kernel.
+__global__ __launch_bounds__(256) void preprocess2x_kernel(const PreParams p) {
+  const int groups = p.net_w >> 2;                                   // 4-pixel groups per row (launch_preprocess checks divisibility)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (gid >= groups * p.net_h) return;
+  const int oy = gid / groups, ox = (gid - oy * groups) << 2;
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(static_cast<uchar4*>(p.img) + ((size_t)n * p.net_h + oy) * p.net_w + ox);
+  const int ry = oy - p.top, rx = ox - p.left;
+  if (ry < 0 || ry >= p.new_h || rx < 0 || rx >= p.new_w) {
+    const unsigned pad = 114u | (114u << 8) | (114u << 16);
+    *dst = make_uint4(pad, pad, pad, pad);
+    return;
+  }
+  const uint8_t* r0p = p.frames + (size_t)n * p.src_h * p.src_w * 3 + ((size_t)(2 * ry) * p.src_w + 2 * rx) * 3;
+  const uint2* r0 = reinterpret_cast<const uint2*>(r0p);
+  const uint2* r1 = reinterpret_cast<const uint2*>(r0p + (size_t)p.src_w * 3);
+  const uint2 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+  const unsigned wa[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y}, wb[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+  auto A = [&](int i) { return (int)((wa[i >> 2] >> (8 * (i & 3))) & 255u); };     // byte i of the 24 of the upper row
+  auto Bq = [&](int i) { return (int)((wb[i >> 2] >> (8 * (i & 3))) & 255u); };    // ... of the lower row
+  unsigned out[4], gray4 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = 6 * k;                                              // source pixels 2k and 2k + 1: bytes o .. o + 5 (B G R B G R)
+    const int B = (A(o) + A(o + 3) + Bq(o) + Bq(o + 3) + 2) >> 2;
+    const int G = (A(o + 1) + A(o + 4) + Bq(o + 1) + Bq(o + 4) + 2) >> 2;
+    const int R = (A(o + 2) + A(o + 5) + Bq(o + 2) + Bq(o + 5) + 2) >> 2;
+    out[k] = (unsigned)R | ((unsigned)G << 8) | ((unsigned)B << 16);
+    if (p.gray) {
+      const int g = (bgr2gray(A(o), A(o + 1), A(o + 2)) + bgr2gray(A(o + 3), A(o + 4), A(o + 5)) + bgr2gray(Bq(o), Bq(o + 1), Bq(o + 2)) +
+                     bgr2gray(Bq(o + 3), Bq(o + 4), Bq(o + 5)) + 2) >> 2;
+      gray4 |= (unsigned)g << (8 * k);
+    }
+  }
+  *dst = make_uint4(out[0], out[1], out[2], out[3]);
+  if (p.gray) *reinterpret_cast<unsigned*>(p.gray + ((size_t)n * p.gh + ry) * p.gw + rx) = gray4;
+}
+
 void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox& lb, void* img,
                        uint8_t* gray, int gh, int gw, hipStream_t s) {
   PreParams p{};
@@ -152,7 +193,12 @@ void launch_preprocess(int dtype, const uint8_t* frames, int n, const Letterbox&
   p.gray = fuse_gray ? gray : nullptr;
   dim3 grid(cdiv(lb.net_w, 256), lb.net_h, n);
   (void)dtype;                 // the image is RGB0 bytes for every arithmetic
-  hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, s, p);
+  const bool wide = p.exact2x && lb.net_w % 4 == 0 && lb.left % 4 == 0 && lb.new_w % 4 == 0 && lb.src_w % 8 == 0 &&
+                    reinterpret_cast<uintptr_t>(frames) % 8 == 0 && (!p.gray || (gw % 4 == 0 && reinterpret_cast<uintptr_t>(gray) % 4 == 0));
+  if (wide)
+    hipLaunchKernelGGL(preprocess2x_kernel, dim3(cdiv((lb.net_w / 4) * lb.net_h, 256), n), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, s, p);
   GTX_HIP(hipGetLastError());
   if (gray && !fuse_gray) {
     GTX_CHECK(gh * 2 == lb.src_h && gw * 2 == lb.src_w, "gray output must be half the frame size");

@@ -197,7 +197,8 @@ def test_sppf_pool_pair_format(gtx_ctx, hw):
 
 
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
-@pytest.mark.parametrize("shape,imgsz,rect", [((216, 384), 192, False), ((216, 384), 192, True), ((200, 300), 256, False)])
+@pytest.mark.parametrize("shape,imgsz,rect", [((216, 384), 192, False), ((216, 384), 192, True), ((200, 300), 256, False), ((384, 216), 192, False),
+                                              ((432, 768), 384, False)])     # exact 2x: 4 pixels per thread when the letterbox offsets allow, else 1
 def test_preprocess_matches_oracle(gtx_ctx, dtype, shape, imgsz, rect):
     from geotrax_amd import ops
     from oracle.yolov8_ref import bgr2gray_half, letterbox
