@@ -17,6 +17,10 @@
 // clamped when they are split (an fp32 network never gets there after BN + SiLU; the clamp only keeps an
 // out-of-range value from turning into inf - inf) and the launch raises ConvProblem::sat_flag so that the host can say so.
 //
+// Two optional stages wrap the K loop of the 3x3 stride-2 instantiation (YOLOv8's first layers as ONE launch): the front stage
+// (FrontTile below: the layer's input patch is computed from the RGB0 image, i.e. the stem, instead of loaded) and the post
+// stage (ConvProblem::post_w: a 1x1 convolution on the output tile before it is stored).
+//
 // Work decomposition and LDS staging are those of conv_igemm.hip (8x16 output pixels x 32*WN couts per
 // 4-wave workgroup, per K chunk the input patch and the KS*KS weight taps staged once, taps read shifted
 // fragments); an LDS row holds the CPR hi chunks of its 8*CPR channels followed by the CPR lo chunks.
