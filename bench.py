@@ -828,6 +828,25 @@ def main():
                                             "after the primary measurement; secondary, not `value`"}
             except Exception as e:
                 out["f32_exact"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line:
+            # secondary key: the N > 1 default workload (BoT-SORT + GPU GMC, BASELINE configs[4]) on this one GPU, so that a scaling
+            # series started from this line has its like-for-like single-GPU base in it (the primary line here is configs[2], ByteTrack)
+            import subprocess
+
+            nb_ = max(args.steps // 2, 10)
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--tracker", "botsort", "--steps", str(nb_), "--warmup", str(min(args.warmup, 10)), "--no-cpu-baseline",
+                   "--no-profile", "--no-f16-line", "--workload", args.workload, "--batch", str(B), "--det-streams", str(args.det_streams),
+                   "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
+                   "--imgsz", str(args.imgsz), "--rect", str(args.rect)]
+            try:
+                pb = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                db = json.loads([ln for ln in pb.stdout.splitlines() if ln.startswith("{")][-1])
+                out["botsort"] = {"value": db["value"], "unit": "frames/s", "steps": db["steps"], "ms_per_step": db["ms_per_step"], "dtype": db["dtype"],
+                                  "note": "same pipeline with BoT-SORT + sparse-optical-flow GMC on the GPU, the default workload of `--gpus N` for N > 1 "
+                                          "(BASELINE configs[4]): divide an N-GPU `value` by N times THIS number for a like-for-like scaling efficiency; "
+                                          "measured by a child process of this run, secondary, not `value`"}
+            except Exception as e:
+                out["botsort"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         out["host"] = {"cores": host_cores(), "threads_per_rank": engine.host_threads + (1 if (sharded and extract and rank == 0) else 0) + 1,
                        "note": "engine stage threads (blocking waits: they sleep while the GPU works) + the main thread" +
                                (" + rank 0's tracker replay thread" if (sharded and extract) else "")}

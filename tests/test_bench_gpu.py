@@ -32,6 +32,9 @@ def test_single_gpu_line_has_the_contract_fields():
     # the default line is the reference's own precision (ultralytics.half: false, default.yaml:245); fp16 rides along
     assert d["dtype"].startswith("f32") and d["config"]["half"] is False
     assert d["f16"]["dtype"] == "f16" and d["f16"]["value"] > d["value"]
+    # ... and so do the strict fp32 arithmetic and the N > 1 default workload (BoT-SORT + GMC: the like-for-like base of a scaling series)
+    assert 0 < d["f32_exact"]["value"] < d["value"]
+    assert d["botsort"]["value"] > 100 and d["botsort"]["dtype"] == d["dtype"]
     # NMS sees clustered candidates: more candidates than detections in the calibration frame
     assert d["config"]["candidates_per_frame"] > 1.3 * d["config"]["detections_per_frame"]
 
