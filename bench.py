@@ -833,8 +833,7 @@ def main():
             # series started from this line has its like-for-like single-GPU base in it (the primary line here is configs[2], ByteTrack)
             import subprocess
 
-            nb_ = max(args.steps // 2, 10)
-            cmd = [sys.executable, str(ROOT / "bench.py"), "--tracker", "botsort", "--steps", str(nb_), "--warmup", str(min(args.warmup, 10)), "--no-cpu-baseline",
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--tracker", "botsort", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",   # the primary line's own length: this number is a base others are divided by
                    "--no-profile", "--no-f16-line", "--workload", args.workload, "--batch", str(B), "--det-streams", str(args.det_streams),
                    "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
                    "--imgsz", str(args.imgsz), "--rect", str(args.rect)]
