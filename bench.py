@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--sharding", default="frames", choices=["frames", "videos"],
                     help="N > 1: frames = batches of ONE clip dealt to the ranks, tracks gathered to rank 0 (BASELINE north star); "
                          "videos = every rank runs the whole reference-order pipeline on its own clip, no data-path collective (SURVEY 8e best case)")
+    ap.add_argument("--host-frames", action="store_true", help="N = 1: feed the engine frames from host memory instead of frames resident in HBM (the PCIe-inclusive rate: a different measurement, labelled as such in the line, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -553,7 +554,10 @@ def main():
         return base + c * CH * world + rank * n_c + j
 
     def batch_ptr(k):
-        return pool + ((global_batch(k) * B) % len(order)) * fbytes
+        i0 = (global_batch(k) * B) % len(order)
+        if args.host_frames and world == 1:
+            return [frames[seq[i0 + j]] for j in range(B)]       # host arrays: the engine uploads them (one staged copy per frame)
+        return pool + i0 * fbytes
 
     def batch_item(k):
         """What the engine is fed for local step k. Frame-sharded BoT-SORT run: the first batch of a run does not continue
@@ -715,7 +719,7 @@ def main():
         out = {
             "metric": "4K frames/sec through detect+stabilize+track", "value": (args.steps * B * world / elapsed) if failure is None else 0.0, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic" + (" (frames uploaded from host memory inside the timed region: PCIe-inclusive)" if getattr(args, "host_frames", False) else ""),
             "config": {
                 "workload": (f"full extract: YOLOv8s + {TRACKER_LABEL[args.tracker]} + homography stabilization on 3840x2160 frames, "
                              f"{B} frame(s) per step (BASELINE {'configs[2]' if world == 1 else 'configs[4]: frames of one clip over the ranks'}; metric 'detect+stabilize+track')" if extract else
