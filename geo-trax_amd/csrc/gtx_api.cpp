@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/gtx.h"
+#include "api_guard.hpp"
 #include "common.hpp"
 #include "conv_igemm.hpp"
 #include "det_kernels.hpp"
@@ -21,25 +22,8 @@
 #include "tracker.hpp"
 
 namespace {
-thread_local std::string g_last_error;
-
-template <typename F>
-int guarded(F&& f) {
-  try {
-    f();
-    g_last_error.clear();
-    return GTX_OK;
-  } catch (const gtx::Error& e) {
-    g_last_error = e.what();
-    return e.code;
-  } catch (const std::exception& e) {
-    g_last_error = e.what();
-    return GTX_ERR_INTERNAL;
-  } catch (...) {
-    g_last_error = "unknown exception";
-    return GTX_ERR_INTERNAL;
-  }
-}
+using gtx::g_last_error;
+using gtx::guarded;
 
 void need(const void* p, const char* what) {
   if (!p) gtx::fail(GTX_ERR_INVALID, "%s is NULL", what);

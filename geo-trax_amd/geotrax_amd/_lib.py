@@ -70,7 +70,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 4        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 5        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -147,6 +147,16 @@ _SIGNATURES = {
     "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gtx_warp_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gtx_yuv420_to_bgr_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "gtx_feeder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gtx_feeder_destroy": (None, [_P]),
+    "gtx_feeder_open_file": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int]),
+    "gtx_feeder_open_push": (C.c_int, [_P]),
+    "gtx_feeder_push": (C.c_int, [_P, _P, C.c_size_t]),
+    "gtx_feeder_finish": (C.c_int, [_P]),
+    "gtx_feeder_stop": (C.c_int, [_P]),
+    "gtx_feeder_next": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "gtx_feeder_wait": (C.c_int, [_P, C.c_int64, _P]),
+    "gtx_feeder_release": (C.c_int, [_P, C.c_int64]),
 }
 
 _lib = None

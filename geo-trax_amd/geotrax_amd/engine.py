@@ -60,6 +60,20 @@ def xyxy_to_xywh(b: np.ndarray) -> np.ndarray | None:
     return np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32)
 
 
+def parse_prio(text: str | None) -> tuple[int, int]:
+    """GTX_ENGINE_PRIO = "<detectors>,<stabilizers + GMC>" (1 highest, 0 default, -1 lowest); one value sets both."""
+    vals = [v.strip() for v in (text or "0,0").split(",") if v.strip()]
+    try:
+        nums = [int(v) for v in vals]
+    except ValueError:
+        nums = []
+    if len(nums) == 1:
+        nums = nums * 2
+    if len(nums) != 2 or any(v not in (-1, 0, 1) for v in nums):
+        raise ValueError(f"GTX_ENGINE_PRIO must be one or two of -1, 0, 1 separated by a comma (detectors, stabilizers), got {text!r}")
+    return nums[0], nums[1]
+
+
 class ExtractEngine:
     def __init__(self, weights: dict, frame_hw: tuple[int, int], det_kw: dict, tracker: Tracker | None, stab_kw: dict | None, *,
                  device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool = False,
@@ -92,7 +106,7 @@ class ExtractEngine:
             default += ["x", "g"]
         order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(default)
         # stream priorities of (detectors, stabilizers + GMC): 1 highest, 0 default, -1 lowest
-        p_det, p_stab = (int(v) for v in (os.environ.get("GTX_ENGINE_PRIO") or "0,0").split(","))
+        p_det, p_stab = parse_prio(os.environ.get("GTX_ENGINE_PRIO"))
         have_d = len(self.dets)          # adopted detectors already own their streams
         made_d = 0
         for tok in order.split(","):
@@ -176,7 +190,17 @@ class ExtractEngine:
         if isinstance(batch, (int, np.integer)):                # device pointer to B contiguous frames
             det.submit_dev(int(batch), self.B)
             return self.B
+        from .feeder import DeviceBatch
         from .frames import Yuv420Frame
+
+        if isinstance(batch, DeviceBatch):                      # frames a read-ahead feeder is bringing into HBM: the detector's
+            if not 1 <= batch.n <= self.B:                      # stream waits for their upload, this thread does not
+                raise ValueError(f"a batch holds 1..{self.B} frames, got {batch.n}")
+            if self.stabs and not self.use_dev_gray:
+                raise ValueError("device batches need the stabilizer to work on the detector's gray image (downsample_ratio 0.5)")
+            batch.wait_on(det.ctx)
+            det.submit_dev(batch.ptr, batch.n)
+            return batch.n
 
         frames = [f if isinstance(f, Yuv420Frame) else np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
         if not 1 <= len(frames) <= self.B:
@@ -203,7 +227,8 @@ class ExtractEngine:
         return len(frames)
 
     def run(self, batches):
-        """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM) or of lists of <= B host frames.
+        """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM), of feeder.DeviceBatch objects (<= B frames
+        on their way into HBM) or of lists of <= B host frames.
         Yields one FrameResult per frame, in feeding order. An item may also be a pair (batch, prev): the batch does not
         continue the previous one (a shard rank of the frame-sharded run) and the GMC is primed with `prev`, the
         device pointer of the frame that precedes the batch in the clip (None: the batch opens the clip).

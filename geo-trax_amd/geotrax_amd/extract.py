@@ -258,29 +258,72 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
     return aggregate_results(frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms, logger)
 
 
+def _frames_in_range(reader, first: int, last):
+    """Frames first..last of the source one by one (the skipped prefix is read and dropped, extract.py:147-151)."""
+    for group in _frame_batches(reader, first, last, 1, []):
+        yield group[0]
+
+
+def _read_ahead_batches(reader, engine, eng_cfg: dict, first: int, last, frame_nums: list, logger: logging.Logger):
+    """The frames of `reader` as feeder.DeviceBatch objects: read, uploaded (and colour-converted) beside the pipeline by
+    geotrax_amd.feeder instead of on the detector stage thread. Returns (batches iterable, feeder) or (None, None) when the
+    run needs host frames (a stabilizer that makes its own gray image) or `engine: {read_ahead: false}` / GTX_FEEDER=0."""
+    from .feeder import FrameFeeder
+
+    off = os.environ.get("GTX_FEEDER", "1") == "0" or eng_cfg.get('read_ahead', True) is False
+    if off or (engine.stabs and not engine.use_dev_gray):
+        return None, None
+    layout = reader.raw_layout() if hasattr(reader, 'raw_layout') else None
+    n_dets = len(engine.dets)
+    ring = max(int(eng_cfg.get('read_ahead_batches', 3)), 1) + n_dets + 1
+    stop = reader.frame_count if last is None else min(reader.frame_count, last + 1)
+    if layout is not None:
+        path, kind, offsets = layout
+        feeder = FrameFeeder(reader.frame_hw, kind=kind, batch=engine.B, ring=ring, device=engine.device)
+        feeder.open_file(path, offsets[first:stop], n_threads=int(eng_cfg.get('reader_threads', 3)))
+        frame_nums.extend(range(first, max(stop, first)))
+    else:
+        from .frames import Y4mReader
+
+        feeder = FrameFeeder(reader.frame_hw, kind="i420" if isinstance(reader, Y4mReader) else "bgr", batch=engine.B, ring=ring,
+                             device=engine.device)
+
+        def numbered():
+            for k, f in enumerate(_frames_in_range(reader, first, last)):
+                frame_nums.append(first + k)
+                yield f
+
+        feeder.open_reader(numbered())
+    return feeder.batches(n_dets), feeder
+
+
 def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray]:
     """The hot loop (extract.py:134-214): read -> detect+track -> stabilize, through the pipelined engine
     (geotrax_amd.engine: batches on the detector streams, tracker in clip order, stabilizers on their own
-    streams; per-frame results identical to the frame-at-a-time order). Any exception voids the whole
+    streams; per-frame results identical to the frame-at-a-time order); the frames come through the read-ahead
+    feeder (geotrax_amd.feeder), so the stage threads never wait for the file. Any exception voids the whole
     video (empty tables), exactly like the reference (:198-200)."""
     from .engine import ExtractEngine
 
     args = config['main']['args']
-    reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
     do_stab = config['main']['extraction']['stabilize']
     ul = config['ultralytics']
     det_kw, stab_kw, eng_cfg = _engine_kwargs(config)
-    first, last = args.cut_frame_left, args.cut_frame_right
+    first, last = args.cut_frame_left or 0, args.cut_frame_right
     out, frame_nums, det_ms, stab_ms, n_frames = _Collector(), [], [], [], 0
+    engine = feeder = None
+    reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)   # exits on a missing / unopenable source, like the reference
     t_wall = time.time()
-    engine = None
     try:
         tracker = model._make_tracker(ul.get('tracker', {'tracker_type': 'botsort'}))
         engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, tracker, stab_kw, batch=int(eng_cfg.get('batch', 2)),
                                det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)),
                                gmc=model._gmc_method is not None)
         model._det = engine.dets[0]                        # introspection (names, gray) keeps working on the model object
-        for r in engine.run(_frame_batches(reader, first, last, engine.B, frame_nums)):
+        batches, feeder = _read_ahead_batches(reader, engine, eng_cfg, first, last, frame_nums, logger)
+        if batches is None:
+            batches = _frame_batches(reader, first, last, engine.B, frame_nums)
+        for r in engine.run(batches):
             frame_num = frame_nums[r.index]
             n_frames += 1
             det_ms.append(r.det_ms)
@@ -304,13 +347,21 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
         if n_frames:
             # the reference's three averages (extract.py:205-207), same wording. Its loop is blocking, so its pipeline
             # figure is 1000 n / (sum yolo + sum stab); here the stages overlap on the GPU: the first two lines are the
-            # per-frame GPU times of the detector pass and of the stabilizer pass, the third is the wall clock
+            # per-frame GPU times of the detector pass and of the stabilizer pass, the third line is that same formula
+            # (what the reference would print for these stage times) followed by what the run really delivered, file to result
             wall = time.time() - t_wall
             logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(det_ms) / len(det_ms):5.1f}ms.")
             if stab_ms:
                 logger.info(f"Average stabilization time: {sum(stab_ms) / len(stab_ms):5.1f}ms")
-            logger.info(f"Average pipeline time: {n_frames / wall:4.1f}fps.")
+            logger.info(f"Average pipeline time: {1000 * len(det_ms) / (sum(det_ms) + sum(stab_ms)):4.1f}fps. "
+                        f"(wall clock, stages overlapped: {n_frames / wall:4.1f}fps over {n_frames} frames)")
+            model.last_run = dict(frames=n_frames, wall_s=wall, wall_fps=n_frames / wall,
+                                  reference_convention_fps=1000 * len(det_ms) / (sum(det_ms) + sum(stab_ms)),
+                                  det_ms=sum(det_ms) / len(det_ms), stab_ms=(sum(stab_ms) / len(stab_ms)) if stab_ms else None,
+                                  read_ahead=feeder is not None)
     finally:
+        if feeder is not None:
+            feeder.close()
         reader.release()
         if engine is not None:
             model._det = None
@@ -351,7 +402,11 @@ def initialize_streams(config: dict, imgsz: int, logger: logging.Logger):
     if not source_exists(source):
         logger.critical(f"Video file '{source}' not found.")
         sys.exit(1)
-    reader = open_source(source)
+    try:
+        reader = open_source(source)
+    except Exception as e:                                  # a damaged header, a container without a decoder: the source cannot be
+        logger.error(f"Failed to open: '{source}' ({e}).")  # opened -- same exit as cv2's isOpened() == False (extract.py:250-252)
+        sys.exit(1)
     if not reader.isOpened():
         logger.error(f"Failed to open: '{source}'.")
         sys.exit(1)

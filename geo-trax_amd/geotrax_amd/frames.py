@@ -50,6 +50,24 @@ class ArrayReader(FrameReader):
         return True, f
 
 
+class NpyReader(ArrayReader):
+    """One [F,H,W,3] uint8 array in a .npy file, memory-mapped; raw_layout() tells the read-ahead feeder where the frames are."""
+
+    def __init__(self, path: Path):
+        self.path = Path(path)
+        arr = np.load(self.path, mmap_mode="r")
+        if arr.ndim != 4 or arr.shape[-1] != 3 or arr.dtype != np.uint8:
+            raise ValueError(f"'{path}': expected a uint8 array of shape [frames, height, width, 3], found {arr.dtype} {arr.shape}")
+        super().__init__(arr)
+
+    def raw_layout(self):
+        a = self.frames
+        if not (isinstance(a, np.memmap) and a.flags["C_CONTIGUOUS"]):
+            return None
+        step = int(a.shape[1]) * int(a.shape[2]) * 3
+        return self.path, "bgr", int(a.offset) + step * np.arange(len(a), dtype=np.int64)
+
+
 class DirReader(FrameReader):
     def __init__(self, path: Path):
         self.files = sorted(p for p in path.iterdir() if p.suffix.lower() in (".npy", ".png", ".jpg", ".jpeg", ".bmp"))
@@ -120,11 +138,13 @@ class Y4mReader(FrameReader):
         head = self.f.readline()
         tok = head.split()
         if not tok or tok[0] != b"YUV4MPEG2":
+            self.f.close()
             raise ValueError(f"'{path}' is not a YUV4MPEG2 file")
         par = {t[:1]: t[1:].decode() for t in tok[1:]}
         self.w, self.h = int(par[b"W"]), int(par[b"H"])
         cs = par.get(b"C", "420jpeg")
         if not cs.startswith("420") or "p1" in cs or "p12" in cs or "p16" in cs:
+            self.f.close()
             raise NotImplementedError(f"'{path}': colour space C{cs} -- only 8-bit 4:2:0 is implemented (ffmpeg -pix_fmt yuv420p)")
         num, den = (int(v) for v in par.get(b"F", "30:1").split(":"))
         self.fps = num / den if den else 0.0
@@ -134,19 +154,36 @@ class Y4mReader(FrameReader):
         # Index of the frames: 'FRAME' lines normally carry no parameters (fixed stride), but the format allows them, so the
         # payload offsets come from one scan of the headers (a seek and a short read per frame) instead of from arithmetic:
         # frame-sharded ranks seek by frame number and must all agree on the frame count.
+        # A file that ends inside a frame (an interrupted export) or whose headers go wrong after some complete frames is
+        # played up to its last complete frame, like the reference's cv2 loop, which reads until the first failed read
+        # (extract.py:146-148); only a file without a single readable frame is refused.
         size = self.path.stat().st_size
         self.offsets, pos = [], self.data_start
+        self.truncated = None                              # why the index stops before the end of the file, if it does
         while pos < size:
             self.f.seek(pos)
             line = self.f.readline(256)
             if not line.startswith(b"FRAME") or not line.endswith(b"\n"):
-                raise ValueError(f"'{path}': byte {pos} should start a FRAME header (frame {len(self.offsets)}); the file is damaged or not 8-bit 4:2:0")
+                self.truncated = f"byte {pos} should start a FRAME header (frame {len(self.offsets)}); the file is damaged or not 8-bit 4:2:0"
+                break
             pos += len(line) + self.frame_bytes
             if pos > size:
-                raise ValueError(f"'{path}': frame {len(self.offsets)} is cut short ({pos - size} bytes missing)")
+                self.truncated = f"frame {len(self.offsets)} is cut short ({pos - size} bytes missing)"
+                break
             self.offsets.append(pos - self.frame_bytes)
         self.frame_count = len(self.offsets)
+        if self.truncated is not None:
+            if self.frame_count == 0:
+                self.f.close()
+                raise ValueError(f"'{path}': {self.truncated}")
+            import logging
+
+            logging.getLogger(__name__).warning(f"'{path}': {self.truncated}; playing the {self.frame_count} complete frames before it")
         self.i, self._open = 0, self.frame_count > 0
+
+    def raw_layout(self):
+        """(path, 'i420', payload offset of every frame): what the read-ahead feeder needs to read the frames itself."""
+        return self.path, "i420", np.asarray(self.offsets, dtype=np.int64)
 
     def seek(self, i: int) -> None:
         self.i = int(i)
@@ -166,26 +203,33 @@ class Y4mReader(FrameReader):
         self.f.close()
 
 
+def bgr_to_i420(frame: np.ndarray) -> bytes:
+    """One BGR frame as I420 planes (BT.601 limited range, 2x2 chroma averaging): the payload of a .y4m FRAME."""
+    h, w = frame.shape[:2]
+    b, g, r = (frame[..., k].astype(np.float64) for k in range(3))
+    y = 16 + (65.481 * r + 128.553 * g + 24.966 * b) / 255
+    cb = 128 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255
+    cr = 128 + (112.0 * r - 93.786 * g - 18.214 * b) / 255
+
+    def sub(c):
+        c = np.pad(c, ((0, h % 2), (0, w % 2)), mode="edge")
+        return (c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2]) / 4
+
+    return b"".join(np.clip(np.rint(plane), 0, 255).astype(np.uint8).tobytes() for plane in (y, sub(cb), sub(cr)))
+
+
 def write_y4m(path, frames_bgr, fps=(30000, 1001)) -> None:
     """Writes BGR frames as a .y4m file (BT.601 limited range, 2x2 chroma averaging) -- for tests and for exporting the
-    synthetic clips; real footage comes from `ffmpeg -pix_fmt yuv420p`."""
+    synthetic clips; real footage comes from `ffmpeg -pix_fmt yuv420p`. An item may also be the bytes bgr_to_i420() made
+    (a clip that repeats frames converts each of them once)."""
     frames_bgr = list(frames_bgr)
-    h, w = frames_bgr[0].shape[:2]
+    first = next(f for f in frames_bgr if not isinstance(f, (bytes, bytearray)))
+    h, w = first.shape[:2]
     with open(path, "wb") as f:
         f.write(f"YUV4MPEG2 W{w} H{h} F{fps[0]}:{fps[1]} Ip A1:1 C420jpeg\n".encode())
         for fr in frames_bgr:
-            b, g, r = (fr[..., k].astype(np.float64) for k in range(3))
-            y = 16 + (65.481 * r + 128.553 * g + 24.966 * b) / 255
-            cb = 128 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255
-            cr = 128 + (112.0 * r - 93.786 * g - 18.214 * b) / 255
-
-            def sub(c):
-                c = np.pad(c, ((0, h % 2), (0, w % 2)), mode="edge")
-                return (c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2]) / 4
-
             f.write(b"FRAME\n")
-            for plane in (y, sub(cb), sub(cr)):
-                f.write(np.clip(np.rint(plane), 0, 255).astype(np.uint8).tobytes())
+            f.write(fr if isinstance(fr, (bytes, bytearray)) else bgr_to_i420(fr))
 
 
 class SyntheticReader(FrameReader):
@@ -229,7 +273,7 @@ def open_source(source) -> FrameReader:
     if p.is_dir():
         return DirReader(p)
     if p.suffix == ".npy":
-        return ArrayReader(np.load(p, mmap_mode="r"))
+        return NpyReader(p)
     if p.suffix.lower() == ".y4m":
         return Y4mReader(p)
     try:

@@ -38,8 +38,10 @@ extern "C" {
  *    A binder checks gtx_abi_version() against the header it was written for before passing any struct.
  * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort).
  * 4: gtx_op_linear_assignment and gtx_detector_saturated added; GTX_F32S activations live in HBM as (hi, lo) fp16 pairs
- *    (host arrays handed to gtx_op_* stay plain fp32). */
-#define GTX_ABI_VERSION 4
+ *    (host arrays handed to gtx_op_* stay plain fp32).
+ * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
+ *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened). */
+#define GTX_ABI_VERSION 5
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -86,6 +88,36 @@ int gtx_dev_download(gtx_ctx* ctx, void* host, const void* dptr, size_t bytes);
  * constants of cv2.cvtColor(COLOR_YUV2BGR_I420), one chroma sample per 2x2 luma block. yuv_dptr: h*w luma bytes, then
  * the U and V planes of ((h+1)/2)*((w+1)/2) bytes each; bgr_dptr: h*w*3 bytes. Enqueued on the context's stream. */
 int gtx_yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv_dptr, int h, int w, void* bgr_dptr);
+
+/* Read-ahead frame source: the `cap.read()` at the top of the reference's loop (geotrax/extract.py:146) taken off
+ * the thread that drives the detector. Frames of an uncompressed file (.y4m payloads, the data block of a .npy) are
+ * read by the feeder's own threads with pread() straight into a ring of pinned host slots, copied to a ring of
+ * device batches on the feeder's own stream (I420 frames converted to BGR there, as gtx_yuv420_to_bgr_dev does) and
+ * handed out in clip order as device pointers of `batch` contiguous BGR frames.
+ *   kind: 0 = frames are BGR u8 [h][w][3]; 1 = I420 planes (h*w + 2*((h+1)/2)*((w+1)/2) bytes).
+ *   ring: device batches (and pinned slots x batch) the feeder owns; it reads ahead until all of them are full.
+ * gtx_feeder_open_file: deliver the n_frames frames whose payloads start at offsets[i] (delivery order = array order),
+ *   read by n_threads reader threads. gtx_feeder_open_push / _push / _finish: the caller's thread supplies host frames
+ *   (any source without a flat file layout); push blocks while the ring is full, finish marks the end of the source.
+ * gtx_feeder_next: blocks until the next batch's copies are enqueued; *n = frames in it (batch, fewer for the last one,
+ *   0 at the end of the source: *dptr = NULL). A read error surfaces here as a negative status after the batches that
+ *   preceded it were delivered. gtx_feeder_wait: the consumer context's stream waits for batch `batch_index` to be
+ *   resident (no host thread blocks); consumer NULL: the calling thread waits. gtx_feeder_release: the first n_batches
+ *   batches have been consumed (the kernels reading them are complete); their slots are read into again.
+ * Thread safety: next / wait / release from one consumer thread, push / finish from one producer thread. */
+typedef struct gtx_feeder gtx_feeder;
+int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, gtx_feeder** out);
+void gtx_feeder_destroy(gtx_feeder* f);
+int gtx_feeder_open_file(gtx_feeder* f, const char* path, const int64_t* offsets, int64_t n_frames, int n_threads);
+int gtx_feeder_open_push(gtx_feeder* f);
+int gtx_feeder_push(gtx_feeder* f, const void* frame, size_t bytes);
+int gtx_feeder_finish(gtx_feeder* f);
+/* Abandons the source: worker threads end, a blocked gtx_feeder_push / gtx_feeder_next returns with an error. Call it
+ * (and join the pushing thread) before gtx_feeder_destroy when the run is given up half way. */
+int gtx_feeder_stop(gtx_feeder* f);
+int gtx_feeder_next(gtx_feeder* f, void** dptr, int* n, int64_t* batch_index);
+int gtx_feeder_wait(gtx_feeder* f, int64_t batch_index, gtx_ctx* consumer);
+int gtx_feeder_release(gtx_feeder* f, int64_t n_batches);
 
 /* ------------------------------------------------------------------ operator level
  * Single operators of the detector, exposed so the parity tests can check every kernel

@@ -58,10 +58,12 @@ def test_conversion_known_answers():
     np.testing.assert_array_equal(px(0, 128, 128), [0, 0, 0])                         # below black clamps
 
 
-def test_frame_headers_with_parameters_and_damaged_files(tmp_path):
+def test_frame_headers_with_parameters_and_damaged_files(tmp_path, caplog):
     """YUV4MPEG2 allows parameters on FRAME lines: the reader indexes the headers instead of assuming a fixed stride, so every
     frame stays reachable by number (frame-sharded ranks seek) and the count is the same however it is derived; a file that
-    ends inside a frame or has garbage where a header should be is refused with a message instead of silently shortened."""
+    ends inside a frame or has garbage where a header should be is played up to its last complete frame with a warning (the
+    reference's cv2 loop reads until the first failed read, extract.py:146-148) -- the same count on every rank --, and only a
+    file without one readable frame is refused (with its handle closed)."""
     from geotrax_amd.frames import Y4mReader, write_y4m
 
     rng = np.random.default_rng(0)
@@ -88,11 +90,28 @@ def test_frame_headers_with_parameters_and_damaged_files(tmp_path):
     a.release()
     b.release()
     (tmp_path / "short.y4m").write_bytes(raw[:-7])
-    with pytest.raises(ValueError, match="cut short"):
-        Y4mReader(tmp_path / "short.y4m")
+    with caplog.at_level("WARNING"):
+        s = Y4mReader(tmp_path / "short.y4m")
+    assert s.frame_count == 4 and "cut short" in s.truncated and "cut short" in caplog.text
+    s.seek(3)
+    ok, f3 = s.read()
+    assert ok and s.read() == (False, None)
+    s.release()
     (tmp_path / "bad.y4m").write_bytes(raw[:head_end + 6 + fb] + b"JUNK!\n" + raw[head_end + 6 + fb + 6:])
+    g = Y4mReader(tmp_path / "bad.y4m")
+    assert g.frame_count == 1 and "FRAME header" in g.truncated
+    g.release()
+    (tmp_path / "none.y4m").write_bytes(raw[:head_end + 6 + fb - 3])              # not even one complete frame
+    with pytest.raises(ValueError, match="cut short"):
+        Y4mReader(tmp_path / "none.y4m")
+    (tmp_path / "junk.y4m").write_bytes(raw[:head_end] + b"JUNK!\n" + raw[head_end + 6:])
     with pytest.raises(ValueError, match="FRAME header"):
-        Y4mReader(tmp_path / "bad.y4m")
+        Y4mReader(tmp_path / "junk.y4m")
+    # the layout the read-ahead feeder reads from: payload offsets of the complete frames
+    path, kind, off = Y4mReader(odd).raw_layout()
+    assert kind == "i420" and len(off) == 5 and path == odd
+    for k in range(5):
+        assert odd.read_bytes()[off[k]:off[k] + fb] == raw[head_end + k * (6 + fb) + 6:head_end + (k + 1) * (6 + fb)]
 
 
 def test_compressed_sources_need_a_decoder_and_say_so(tmp_path):
