@@ -543,7 +543,8 @@ def bench_cli(args):
         wall = time.perf_counter() - t0
         lr = dict(getattr(model, "last_run", {}) or {})
         assert len(tracks) and lr.get("frames") == len(seq), (len(tracks), lr)
-        return dict(frames_per_s=lr["wall_fps"], reference_convention_fps=lr["reference_convention_fps"], det_ms_per_frame=lr["det_ms"],
+        return dict(frames_per_s=lr["loop_fps"], frames_per_s_incl_setup=lr["wall_fps"], engine_setup_s=lr["engine_setup_s"], reader_setup_s=lr["reader_setup_s"],
+                    loop_s=lr["loop_s"], reference_convention_fps=lr["reference_convention_fps"], det_ms_per_frame=lr["det_ms"],
                     stab_ms_per_frame=lr["stab_ms"], track_with_model_s=wall, track_rows=int(len(tracks)), transforms=int(len(transforms)))
 
     res = {}
@@ -554,7 +555,7 @@ def bench_cli(args):
         r["file_gbs"] = r["bytes_per_frame"] * r["frames_per_s"] / 1e9
         if args.cli_compare_sync:
             s_ = one_run(path, False)
-            r["synchronous_reader"] = {"frames_per_s": s_["frames_per_s"], "reference_convention_fps": s_["reference_convention_fps"],
+            r["synchronous_reader"] = {"frames_per_s": s_["frames_per_s"], "frames_per_s_incl_setup": s_["frames_per_s_incl_setup"], "reference_convention_fps": s_["reference_convention_fps"],
                                        "note": "GTX_FEEDER=0: f.read() + pageable upload on the detector stage thread (round 3's reader)"}
         res[fmt] = r
     os.environ.pop("GTX_FEEDER", None)
