@@ -609,7 +609,7 @@ def main():
 
     cdev = f"cuda:{local}" if args.backend == "nccl" else "cpu"     # where the collectives' tensors live
     from geotrax_amd import _lib
-    from geotrax_amd.distributed import pack_frame_record, unpack_frame_gmc, unpack_frame_record
+    from geotrax_amd.distributed import gather_records, pack_frame_record, pin_to_core, reserve_replay_core
     from geotrax_amd.geometry import warp_boxes
     from geotrax_amd.synth import make_scene
     from geotrax_amd.tracker import Tracker
@@ -628,28 +628,18 @@ def main():
         # over RCCL (~44 MB); every rank then builds its detector from the same bytes
         import torch
         from geotrax_amd.detector import Detector
-        from geotrax_amd.weights import synthetic_yolov8
 
-        template = synthetic_yolov8(**SYNTH_KW)
-        names = sorted(template)
+        from geotrax_amd.distributed import broadcast_weights
+
         meta = torch.zeros(2, dtype=torch.int64)
+        weights = None
         if rank == 0:
             det, weights, n_det, n_cand = calibrated_detector(ctx, ref_frame, args, args.detections)
             det.close()
-            flat = torch.from_numpy(np.concatenate([np.asarray(weights[k], np.float32).ravel() for k in names]))
             meta[0], meta[1] = n_det, n_cand
-        else:
-            flat = torch.empty(sum(int(np.asarray(template[k]).size) for k in names), dtype=torch.float32)
-        flat, meta = flat.to(cdev), meta.to(cdev)
-        dist.broadcast(flat, src=0)
+        weights, _ = broadcast_weights(weights, None, dist, cdev)   # the product's own exchange (geotrax_amd/distributed.py)
+        meta = meta.to(cdev)
         dist.broadcast(meta, src=0)
-        host = flat.cpu().numpy()
-        weights, off = {}, 0
-        for k in names:
-            shp = np.asarray(template[k]).shape
-            n = int(np.prod(shp))
-            weights[k] = host[off:off + n].reshape(shp).copy()
-            off += n
         n_det, n_cand = int(meta[0]), int(meta[1])
         det = Detector(weights, (H, W), imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
                        half=bool(args.half), fp32_split=fp32_split(args), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
@@ -664,6 +654,7 @@ def main():
         ctx.dev_upload(pool + i * fbytes, frames[t])
 
     CH = max(args.gather_every, 1)                               # steps per contiguous run of a rank = steps per gather
+    sharded_run = (world > 1 or force_dist) and args.sharding == "frames" and args.workload == "extract"
 
     def global_batch(k):
         """Local step k -> global batch of the playback. Frame sharding deals the clip in runs of CH consecutive batches:
@@ -755,15 +746,17 @@ def main():
             block = np.stack(records[sent[0] * B:(sent[0] + n) * B])          # [n*B, stride], step-major
             sent[0] += n
             with (torch.cuda.stream(comm_stream) if comm_stream is not None else contextlib.nullcontext()):
-                t = torch.from_numpy(block).to(cdev)
-                bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-                dist.gather(t, bufs, dst=0)
+                # the product's exchange (geotrax_amd.distributed.gather_records): records packed to their real length, one
+                # all-gather of the packed sizes, one padded gather to rank 0
+                blocks, _ = gather_records(block, False, dist, torch.device(cdev), max_det, shard_gmc)
                 if rank == 0:
-                    host = np.stack([b.cpu().numpy() for b in bufs])            # [world, n*B, stride]
                     # clip order: every rank holds one contiguous run of the interval -> rank-major is clip order
-                    replay_q.put(host.reshape(world * n * B, -1))
+                    replay_q.put(np.concatenate(blocks))
+
+    replay_core = reserve_replay_core(world) if sharded_run else None   # every rank's threads stay off the core rank 0's replay thread takes
 
     def replay_worker():
+        pin_to_core(replay_core)
         while True:
             item = replay_q.get()
             if item is None:

@@ -406,9 +406,6 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     c.th = 8; c.tw = 16;
     GTX_CHECK(cin % c.kc == 0, "conv: Cin=%d is not a multiple of the K chunk %d", cin, c.kc);
     GTX_CHECK(cout % 16 == 0, "conv: Cout=%d is not a multiple of 16", cout);   // a last cout tile may be half empty (yolov8 n / m / x widths)
-    // GTX_CONV_RING=1: 3x3 stride 1 through the persistent LDS-DMA kernel (conv3x3_ring.hip). Measured slower than the
-    // one-workgroup-per-tile kernel on the network as a whole, so it is off unless asked for.
-    if (env_int("GTX_CONV_RING", 0) != 0 && ks == 3 && stride == 1 && c.kc == 16 && cin >= env_int("GTX_RING_MIN_CIN", 32)) c.variant = 3;
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -439,7 +436,7 @@ inline uint16_t f32_to_f16_bits(float f) {
 
 std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   if (acc_scale) *acc_scale = 1.f;
-  if (cfg.variant == 2 || cfg.variant == 3) {
+  if (cfg.variant == 2) {
     float sc = 1.f;
     std::vector<uint8_t> r = pack_conv_weights_split(w, cout, cin, cfg, &sc);
     if (acc_scale) *acc_scale = sc;
@@ -556,7 +553,6 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
     GTX_CHECK(p.in2 && p.c_split % cfg.kc == 0 && p.c_split < p.Cin && p.H % 2 == 0 && p.W % 2 == 0 && p.in2_cstride % 4 == 0 && p.in2_coff % 4 == 0,
               "conv: bad second source (c_split=%d, %dx%d)", p.c_split, p.W, p.H);
   }
-  if (cfg.variant == 3) return conv_ring_launch(g, cfg, stream);
   if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);
@@ -564,10 +560,6 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
 
 const char* conv_kernel_name(const ConvConfig& c) {
   static thread_local char buf[96];
-  if (c.variant == 3) {
-    snprintf(buf, sizeof buf, "conv3x3_ring_kernel<%d>", c.bn / 32);
-    return buf;
-  }
   if (c.variant == 2) {
     snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8, c.th / 8);
     return buf;

@@ -100,8 +100,7 @@ struct ConvConfig {
   int stride;  // 1 or 2
   int bn;      // cout tile: 32, 64 or 128
   int kc;      // cin elements staged per K chunk
-  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S),
-               // 3 = split-f16x3 3x3 stride 1 as a persistent LDS-DMA workgroup per CU (conv3x3_ring.hip)
+  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S)
   int th, tw;  // output pixel tile (rows x cols)
 };
 
@@ -130,9 +129,6 @@ void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t
 size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg);
 std::vector<uint8_t> pack_conv_weights_split(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale);
 std::vector<uint16_t> pack_front_weights_split(const float* w27, int c0, float* acc_scale);
-
-// conv3x3_ring.hip (variant 3; weights packed as for variant 2)
-void conv_ring_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 
 // Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
 const char* conv_kernel_name(const ConvConfig& cfg);

@@ -458,6 +458,64 @@ void Detector::fuse_stem() {
   ops_.erase(ops_.begin());
 }
 
+// The stem's output and model.1's are written by no launch of the fused forward pass (354 MB per two 1920 x 1920 frames and
+// detector): their buffers are given back here. layer_output() of one of them re-creates them and runs the stand-alone
+// launches (unfused_). Until then every reference to them holds a token that is no device address.
+namespace {
+void swap_ptr(Op& o, const void* from, void* to) {
+  if (o.in.ptr == from) o.in.ptr = to;
+  if (o.out.ptr == from) o.out.ptr = to;
+  for (int i = 0; i < o.grp.count; ++i) {
+    ConvProblem& p = o.grp.p[i];
+    if (p.in == from) p.in = to;
+    if (p.out == from) p.out = to;
+    if (p.res == from) p.res = to;
+    if (p.in2 == from) p.in2 = to;
+  }
+}
+}  // namespace
+
+void Detector::release_hidden_layers() {
+  std::vector<void*> ptrs;
+  for (size_t i = 0; i + 1 < unfused_.size() || (i < unfused_.size() && unfused_[i].kind == Op::STEM); ++i) {
+    const Op& o = unfused_[i];                       // every stand-alone op but the last conv writes a hidden tensor
+    void* out = o.kind == Op::STEM ? o.out.ptr : (o.grp.count == 1 ? o.grp.p[0].out : nullptr);
+    if (out) ptrs.push_back(out);
+  }
+  for (void* ptr : ptrs) {
+    bool live = false;                               // still written or read by a launch of the forward pass?
+    for (const Op& o : ops_) {
+      if (o.kind != Op::CONV && (o.in.ptr == ptr || o.out.ptr == ptr)) live = true;
+      for (int i = 0; i < o.grp.count; ++i) {
+        const ConvProblem& q = o.grp.p[i];
+        const bool reads_in = !q.front_img;          // a front stage computes its input patch from the image instead of loading it
+        if ((reads_in && q.in == ptr) || q.out == ptr || q.res == ptr || q.in2 == ptr) live = true;
+      }
+    }
+    if (live) continue;
+    for (size_t b = 0; b < bufs_.size(); ++b) {
+      if (bufs_[b].p != ptr) continue;
+      void* token = reinterpret_cast<void*>(static_cast<uintptr_t>(16 * (hidden_.size() + 1)));
+      hidden_.push_back({token, bufs_[b].bytes, nullptr});
+      bufs_.erase(bufs_.begin() + (long)b);
+      for (Op& o : unfused_) swap_ptr(o, ptr, token);
+      for (auto& kv : layer_views_)
+        if (kv.second.ptr == ptr) kv.second.ptr = token;
+      break;
+    }
+  }
+}
+
+void Detector::materialize_hidden_layers() {
+  for (Hidden& h : hidden_) {
+    if (h.real) continue;
+    h.real = alloc(h.bytes);
+    for (Op& o : unfused_) swap_ptr(o, h.token, h.real);
+    for (auto& kv : layer_views_)
+      if (kv.second.ptr == h.token) kv.second.ptr = h.real;
+  }
+}
+
 void Detector::set_batch(int nb) {
   if (nb == cur_nb_) return;
   for (Op& op : ops_) {
@@ -502,6 +560,7 @@ void Detector::finalize() {
   build_graph();
   fuse_front();
   fuse_stem();
+  release_hidden_layers();
   const int N = cfg_.max_batch;
   gray_h_ = cfg_.frame_h / 2;
   gray_w_ = cfg_.frame_w / 2;
@@ -525,7 +584,7 @@ void Detector::finalize() {
   nms_.out_rows = (float*)alloc(sizeof(float) * 6 * N * cfg_.max_det);
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
-  tensors_.clear();  // host copies are no longer needed
+  if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
   if (splitk_bytes_ > 0) {           // one scratch buffer for every split-K convolution (they run one after the other on the stream)
     float* scratch = (float*)alloc(splitk_bytes_);
     for (Op& op : ops_)
@@ -588,6 +647,7 @@ void Detector::run_forward(int nb, hipStream_t s, bool traced) {
 }
 
 void Detector::set_trace(int every_n) {
+  if (exact_) return exact_->set_trace(every_n);
   GTX_CHECK(finalized_ && every_n >= 0, "set_trace: detector not finalized or bad period");
   GTX_CHECK(!in_flight_, "set_trace while a batch is in flight");
   trace_every_ = every_n;
@@ -604,6 +664,7 @@ void Detector::set_trace(int every_n) {
 
 void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
                             std::vector<double>& flops, std::vector<double>& bytes) {
+  if (exact_) return exact_->trace_report(names, launches, ms, flops, bytes);
   std::map<std::string, size_t> idx;
   for (size_t i = 0; i < ops_.size() && i < trace_n_.size(); ++i) {
     if (trace_n_[i] == 0) continue;
@@ -636,11 +697,30 @@ void Detector::run_post(int nb, hipStream_t s) {
   if (sat_dev_) GTX_HIP(hipMemcpyAsync(h_sat_, sat_dev_, sizeof(int), hipMemcpyDeviceToHost, s));
 }
 
+// A split-f16x3 pass clamped an activation: from here on this object is a shell around an exact-fp32 detector built from
+// the same tensors on the same context. The split graph's device memory (activations, packed weights) is given back.
+void Detector::fall_back_to_exact() {
+  gtx_det_config c = cfg_;
+  c.fp32_split = 0;
+  std::unique_ptr<Detector> d(new Detector(ctx_, c));
+  for (const auto& kv : tensors_) d->set_tensor(kv.first, kv.second.data.data(), (int)kv.second.shape.size(), kv.second.shape.data());
+  d->finalize();
+  if (trace_every_ > 0) d->set_trace(trace_every_);
+  GTX_HIP(hipStreamSynchronize(ctx_->stream));
+  if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+  ops_.clear();
+  unfused_.clear();
+  layer_views_.clear();
+  bufs_.clear();
+  tensors_.clear();
+  exact_ = std::move(d);
+}
+
 bool Detector::saturated(bool clear) {
   const bool r = sat_seen_;
   if (clear) {
     sat_seen_ = false;
-    if (sat_dev_) {
+    if (sat_dev_ && !exact_) {
       GTX_HIP(hipSetDevice(ctx_->device));
       GTX_HIP(hipMemsetAsync(sat_dev_, 0, sizeof(int), ctx_->stream));
     }
@@ -653,6 +733,7 @@ bool Detector::saturated(bool clear) {
 // goes to the next slot of a 16-deep ring so that consumers on other streams (stabilizers) can
 // still read the images of the four batches before the newest collected one.
 void Detector::submit_dev(const void* frames, int nb, int h, int w) {
+  if (exact_) return exact_->submit_dev(frames, nb, h, w);
   GTX_CHECK(finalized_, "detector not finalized");
   GTX_CHECK(!in_flight_, "submit while a batch is in flight: call collect first");
   GTX_CHECK(nb >= 1 && nb <= cfg_.max_batch, "batch %d outside [1,%d]", nb, cfg_.max_batch);
@@ -676,12 +757,22 @@ void Detector::submit_dev(const void* frames, int nb, int h, int w) {
 }
 
 void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) {
+  if (exact_) return exact_->collect(n_out, xyxy, conf, cls, speed_ms);
   GTX_CHECK(in_flight_, "collect without a submitted batch");
   GTX_HIP(hipSetDevice(ctx_->device));
   GTX_HIP(hipEventSynchronize(ev_[3]));
   in_flight_ = false;
   collected_gray_slot_ = gray_slot_;
-  if (h_sat_ && *h_sat_) sat_seen_ = true;
+  if (h_sat_ && *h_sat_) {
+    sat_seen_ = true;
+    static const bool fallback = [] { const char* e = getenv("GTX_SAT_FALLBACK"); return !(e && e[0] == '0'); }();
+    if (fallback && conv_dtype_ == DT_F32S && !tensors_.empty()) {
+      // this batch again, at fp32's range: the frames are still where the caller put them (one batch in flight per detector)
+      flight_traced_ = false;
+      fall_back_to_exact();
+      return exact_->detect_dev(cur_frames_, flight_nb_, cfg_.frame_h, cfg_.frame_w, n_out, xyxy, conf, cls, speed_ms);
+    }
+  }
   if (flight_traced_) {
     for (size_t i = 0; i < ops_.size(); ++i) {
       float t = 0.f;
@@ -734,6 +825,7 @@ void Detector::detect_host(const uint8_t* frame, int h, int w, int* n_out, float
 }
 
 const void* Detector::gray(int b, int* gh, int* gw) const {
+  if (exact_) return exact_->gray(b, gh, gw);
   if (gh) *gh = gray_h_;
   if (gw) *gw = gray_w_;
   if (b < 0 || b >= cfg_.max_batch) return nullptr;
@@ -742,6 +834,7 @@ const void* Detector::gray(int b, int* gh, int* gw) const {
 }
 
 void Detector::raw_output(int b, float* out, int* n_anchors, bool logits) {
+  if (exact_) return exact_->raw_output(b, out, n_anchors, logits);
   GTX_CHECK(finalized_ && cur_nb_ > 0 && b >= 0 && b < cur_nb_, "raw_output: no forward pass for slot %d", b);
   const size_t per = (size_t)head_.n_anchors * (4 + head_.nc);
   if (raw_.bytes < per * cur_nb_ * sizeof(float)) raw_.alloc(per * cur_nb_ * sizeof(float));
@@ -752,6 +845,11 @@ void Detector::raw_output(int b, float* out, int* n_anchors, bool logits) {
 }
 
 void Detector::layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c) {
+  if (exact_) return exact_->layer_output(b, layer, out, h, w, c);
+  // model.0 / model.1 of a fused front launch are RECOMPUTED below by their stand-alone launches (same products, another
+  // summation order): what comes back is not what the network consumed. Not while a pass is in flight: the launches
+  // would queue behind it and overwrite the buffers it shares with them.
+  GTX_CHECK(!(out && in_flight_), "layer_output while a batch is in flight: call collect first");
   auto it = layer_views_.find(layer);
   if (it == layer_views_.end()) fail(-1, "unknown layer '%s'", layer.c_str());
   const View& v = it->second;
@@ -764,8 +862,10 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
       const bool still_written = i + 1 == unfused_.size() && unfused_[i].kind != Op::STEM;   // the fused launch's own output layer
       if (!still_written && unfused_[i].name == layer) k = (int)i;
     }
+    if (k >= 0) GTX_CHECK(cur_nb_ > 0, "layer_output('%s'): no forward pass has run yet", layer.c_str());
     if (k >= 0 && cur_nb_ > 0) {
       GTX_HIP(hipSetDevice(ctx_->device));
+      materialize_hidden_layers();
       for (int j = 0; j <= k; ++j) {
         Op o = unfused_[(size_t)j];
         if (o.kind == Op::CONV) {
@@ -782,6 +882,7 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
   if (c) *c = v.c;
   if (!out) return;
   GTX_CHECK(b >= 0 && b < cfg_.max_batch, "bad batch slot");
+  GTX_CHECK(reinterpret_cast<uintptr_t>(v.ptr) > 4096, "layer_output('%s'): the layer's buffer was not re-created", layer.c_str());
   const size_t px = (size_t)v.h * v.w;
   std::vector<uint8_t> host(px * v.cstride * es_);
   GTX_HIP(hipMemcpy(host.data(), (const uint8_t*)v.ptr + (size_t)b * px * v.cstride * es_, host.size(), hipMemcpyDeviceToHost));
@@ -804,6 +905,7 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
 
 void Detector::profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
                        std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes) {
+  if (exact_) return exact_->profile(nb, iters, names, launches, ms, flops, bytes);
   GTX_CHECK(finalized_, "detector not finalized");
   GTX_CHECK(nb >= 1 && nb <= cfg_.max_batch && iters >= 1, "bad profile arguments");
   hipStream_t s = ctx_->stream;

@@ -89,9 +89,12 @@ class Detector {
   void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
                     std::vector<double>& flops, std::vector<double>& bytes);
   int max_det() const { return cfg_.max_det; }
-  // split-f16x3 path: true when some activation of the most recently collected pass (or any pass since the last call with
-  // clear) had to be clamped to fp16's range on its way into the pair format; such a checkpoint needs fp32_split = 0.
+  // split-f16x3 path: true when some activation of a collected pass (since the last call with clear) had to be clamped to
+  // fp16's range on its way into the pair format. collect() then re-runs that batch through an exact-fp32 detector built
+  // from the same tensors and every later pass goes there (`ultralytics.half: false` promises fp32's range,
+  // default.yaml:245); GTX_SAT_FALLBACK=0 keeps the flag only.
   bool saturated(bool clear);
+  bool fell_back() const { return exact_ != nullptr; }
 
  private:
   void* alloc(size_t bytes);
@@ -112,8 +115,15 @@ class Detector {
   void run_post(int nb, hipStream_t s);
   void set_batch(int nb);
 
+  void fall_back_to_exact();
+  void release_hidden_layers();     // after the fusions: buffers only the stand-alone forms of fused layers write
+  void materialize_hidden_layers(); // ... come back on the first layer_output() that asks for one of them
+  struct Hidden { void* token; size_t bytes; void* real; };
+  std::vector<Hidden> hidden_;
+
   gtx_ctx* ctx_;
   gtx_det_config cfg_;
+  std::unique_ptr<Detector> exact_;   // the exact-fp32 detector every call is handed to once a split-f16x3 pass has saturated
   int dtype_;                // activation type in HBM (DT_F16 / DT_F32)
   int conv_dtype_;           // what the conv kernels compute in (dtype_, or DT_F32S: split-f16x3 on fp32 activations)
   size_t es_;

@@ -1,6 +1,6 @@
 // DIAGNOSTIC BUILD ONLY (`make -C geo-trax_amd stamp` -> build/libgtx_stamp.so, read by tools/clock_probe.py); force-included
-// in front of conv_igemm_split.hip / conv3x3_ring.hip, never part of libgtx.so. Shader-clock and 100 MHz wall-clock ticks
-// spent inside the K loop of the convolution, summed over workgroups (ring kernel: over tiles), to read the clock the chip
+// in front of conv_igemm_split.hip, never part of libgtx.so. Shader-clock and 100 MHz wall-clock ticks
+// spent inside the K loop of the convolution, summed over workgroups, to read the clock the chip
 // holds under the kernel (MI355X_MICROARCH.md, DVFS give-back item 6) and the cycles a K loop takes. The sums live in a buffer
 // of their own; no output value depends on them. GTX_DIAG_FN names the translation unit's read-out function.
 #pragma once

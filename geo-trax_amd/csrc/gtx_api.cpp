@@ -552,6 +552,9 @@ int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float
 int gtx_detector_saturated(gtx_detector* det, int clear, int* flag) {
   return guarded([&] { need(det, "det"); need(flag, "flag"); *flag = det->impl->saturated(clear != 0) ? 1 : 0; });
 }
+int gtx_detector_fell_back(gtx_detector* det, int* fell_back) {
+  return guarded([&] { need(det, "det"); need(fell_back, "fell_back"); *fell_back = det->impl->fell_back() ? 1 : 0; });
+}
 int gtx_detector_trace(gtx_detector* det, int every_n) {
   return guarded([&] { need(det, "det"); det->impl->set_trace(every_n); });
 }

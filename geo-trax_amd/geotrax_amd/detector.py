@@ -97,19 +97,31 @@ class Detector:
             pass
 
     def saturated(self, clear: bool = False) -> bool:
-        """fp32_split only: an activation of a collected pass lay beyond fp16's range and was clamped where the split-f16x3 path
-        stores it (include/gtx.h: gtx_detector_saturated). Such a checkpoint needs fp32_split=False."""
+        """fp32_split only: an activation of a collected pass lay beyond fp16's range where the split-f16x3 path stores it
+        (include/gtx.h: gtx_detector_saturated). The library then re-ran that batch through the exact-fp32 kernels and stays
+        there (fell_back())."""
         if not self.fp32_split:
             return False
         f = C.c_int()
         check(self.ctx.lib.gtx_detector_saturated(self.handle, int(clear), C.byref(f)))
         return bool(f.value)
 
+    def fell_back(self) -> bool:
+        """True once a saturating split-f16x3 pass has moved this detector to the exact-fp32 convolutions."""
+        f = C.c_int()
+        check(self.ctx.lib.gtx_detector_fell_back(self.handle, C.byref(f)))
+        return bool(f.value)
+
     def _collect(self, nb: int) -> list[Detections]:
         if self.fp32_split and not self._sat_warned and self.saturated():
             self._sat_warned = True
-            logger.warning("activations beyond fp16's range (|x| > 65504) were clamped by the split-f16x3 convolutions: detections differ "
-                           "from an fp32 run of this checkpoint; set fp32_split: false (GTX_FP32_SPLIT=0) for the exact-fp32 MFMA path")
+            if self.fell_back():
+                logger.warning("activations beyond fp16's range (|x| > 65504) reached the split-f16x3 convolutions: the batch was re-run with the "
+                               "exact-fp32 MFMA convolutions and the detector stays on them for the rest of the run (same results as fp32_split: "
+                               "false, at its speed); set fp32_split: false for this checkpoint to skip the detour")
+            else:
+                logger.warning("activations beyond fp16's range (|x| > 65504) were clamped by the split-f16x3 convolutions and GTX_SAT_FALLBACK=0 "
+                               "keeps them: detections differ from an fp32 run of this checkpoint")
         sp = dict(preprocess=float(self._speed[0]), inference=float(self._speed[1]), postprocess=float(self._speed[2]))
         out = []
         for b in range(nb):

@@ -9,8 +9,12 @@ over ``torch.distributed`` (RCCL on GPUs, gloo in the CPU tests), where a second
 the tracker over them in clip order and warps the tracker boxes with each frame's H while the GPUs
 work on the next round: no serial tail remains after the last frame but the last round itself.
 
-The only exchange on the data path is that gather of KB-sized records (and the all-reduce of a
-failure flag in front of it); weights are loaded by every rank from the same file. Difference from the single-GPU ("exact") order, by construction: the
+The exchanges: once per video rank 0 reads the weight file and broadcasts it as one flat fp32 buffer
+(broadcast_weights; BASELINE north star: "RCCL broadcast of weights"), the ranks agree on the source
+(agree_on_source: it opens everywhere and has the same frame count), and once per round the records go
+to rank 0 packed to their real length (wire_pack: ~3.3 KB per frame at 132 boxes instead of the 48 KB
+fixed-stride record), behind one all-gather of the packed sizes that doubles as the failure flag.
+Difference from the single-GPU ("exact") order, by construction: the
 stabilizer mask of a frame is built from the raw detections instead of the tracker-output boxes
 (extract.py:181 uses the latter), because the tracker has not run yet when a shard rank stabilizes.
 """
@@ -59,6 +63,145 @@ def unpack_frame_record(rec: np.ndarray, max_det: int):
     return body[:, :4].astype(np.float32), body[:, 4].astype(np.float32), body[:, 5].astype(np.int32), H
 
 
+# ---- wire format of a round's records. In memory a frame's record is the fixed-stride float64 row pack_frame_record() makes
+# (what gtx_tracker_replay consumes); on the wire it shrinks to what it holds:
+#   int32 n | uint8 flags (1: H valid, 2: GMC valid) | 3 pad bytes | n x 6 float32 (x1 y1 x2 y2 conf cls) | [9 f64 H] | [6 f64 warp]
+# Boxes, scores and classes are float32 / small integers at their source (detector.py), so float32 bodies lose nothing;
+# the homography and the camera-motion warp stay float64 (they are written with %.16g).
+def wire_pack(block: np.ndarray, max_det: int, with_gmc: bool = False) -> np.ndarray:
+    """[frames, stride] float64 records -> one uint8 array."""
+    parts = []
+    for rec in np.asarray(block, dtype=np.float64):
+        n = int(rec[0])
+        h_ok, g_ok = rec[-10] > 0, bool(with_gmc) and rec[-17] > 0
+        head = np.zeros(8, np.uint8)
+        head[:4] = np.frombuffer(np.int32(n).tobytes(), np.uint8)
+        head[4] = (1 if h_ok else 0) | (2 if g_ok else 0)
+        parts.append(head)
+        if n:
+            parts.append(rec[1:1 + n * 6].astype(np.float32).view(np.uint8))
+        if h_ok:
+            parts.append(np.ascontiguousarray(rec[-9:]).view(np.uint8))
+        if g_ok:
+            parts.append(np.ascontiguousarray(rec[-16:-10]).view(np.uint8))
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
+
+def wire_unpack(buf: np.ndarray, frames: int, max_det: int, with_gmc: bool = False) -> np.ndarray:
+    """Inverse of wire_pack: -> [frames, stride] float64 records."""
+    stride = 1 + max_det * 6 + (7 if with_gmc else 0) + 10
+    out = np.zeros((frames, stride), dtype=np.float64)
+    raw = np.ascontiguousarray(buf, dtype=np.uint8).tobytes()
+    o = 0
+    for f in range(frames):
+        n = int(np.frombuffer(raw, np.int32, 1, o)[0])
+        flags = raw[o + 4]
+        o += 8
+        if not 0 <= n <= max_det:
+            raise ValueError(f"wire record {f}: {n} boxes outside [0, {max_det}]")
+        out[f, 0] = n
+        if n:
+            out[f, 1:1 + n * 6] = np.frombuffer(raw, np.float32, n * 6, o)
+            o += n * 24
+        if flags & 1:
+            out[f, -10] = 1.0
+            out[f, -9:] = np.frombuffer(raw, np.float64, 9, o)
+            o += 72
+        if flags & 2:
+            out[f, -17] = 1.0
+            out[f, -16:-10] = np.frombuffer(raw, np.float64, 6, o)
+            o += 48
+    if o != len(raw):
+        raise ValueError(f"wire block holds {len(raw)} bytes, its {frames} records account for {o}")
+    return out
+
+
+def broadcast_weights(tensors: dict | None, names: dict | None, dist, device=None, error: str | None = None):
+    """Rank 0 hands in the tensors it read from the weight file (and the class names); every rank gets them back: a small
+    header through broadcast_object_list, then ONE flat fp32 buffer through dist.broadcast (44 MB for YOLOv8s; RCCL when the
+    ranks own a GPU each). `error` (rank 0): the file could not be loaded -- every rank raises RuntimeError with that text."""
+    import torch
+
+    rank = dist.get_rank()
+    head = [None]
+    order = None
+    if rank == 0:
+        if error is None:
+            order = sorted(tensors)
+            head[0] = {"keys": order, "shapes": [tuple(int(v) for v in np.asarray(tensors[k]).shape) for k in order], "names": dict(names or {})}
+        else:
+            head[0] = {"error": str(error)}
+    dist.broadcast_object_list(head, src=0)
+    meta = head[0]
+    if "error" in meta:
+        raise RuntimeError(meta["error"])
+    sizes = [int(np.prod(sh)) if len(sh) else 1 for sh in meta["shapes"]]
+    if rank == 0:
+        flat = torch.from_numpy(np.concatenate([np.asarray(tensors[k], np.float32).ravel() for k in order]))
+    else:
+        flat = torch.empty(sum(sizes), dtype=torch.float32)
+    if device is not None:
+        flat = flat.to(device)
+    dist.broadcast(flat, src=0)
+    if rank == 0:
+        return tensors, dict(names or {})
+    host, out, o = flat.cpu().numpy(), {}, 0
+    for k, sh, n in zip(meta["keys"], meta["shapes"], sizes):
+        out[k] = host[o:o + n].reshape(sh).copy()
+        o += n
+    return out, {int(k): str(v) for k, v in meta["names"].items()}
+
+
+def agree_on_source(ok: bool, n_frames: int, dist, device=None) -> tuple[bool, bool, int]:
+    """Before the first round: does the source open on EVERY rank, and with the same frame count? One all-gather of
+    (ok, frames) per rank -> (all ok, counts agree, rank 0's count). A rank that cannot open its copy (a file system that is
+    not shared, a flaky mount) must not leave the others waiting in the round's collectives."""
+    import torch
+
+    world = dist.get_world_size()
+    mine = torch.tensor([1 if ok else 0, int(n_frames)], dtype=torch.int64)
+    if device is not None:
+        mine = mine.to(device)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    rows = [[int(v) for v in g.cpu()] for g in got]
+    all_ok = all(r[0] == 1 for r in rows)
+    return all_ok, all_ok and len({r[1] for r in rows}) == 1, rows[0][1]
+
+
+def reserve_replay_core(world: int) -> int | None:
+    """At four ranks and more rank 0's tracker replay thread is busy most of the time next to 8 x 3 stage
+    threads: keep one core for it. Called by every rank's main thread before it starts its engine: the calling thread (and
+    every thread it creates afterwards) leaves the LAST core of the process's affinity mask alone; rank 0's replay thread
+    then pins itself to that core (pin_to_core). Returns the core, or None when pinning is off (fewer than four ranks, fewer
+    than four cores, GTX_PIN_REPLAY=0) -- GTX_PIN_REPLAY=1 forces it for tests."""
+    import os
+
+    mode = os.environ.get("GTX_PIN_REPLAY", "auto")
+    if mode == "0" or (mode != "1" and world < 4) or not hasattr(os, "sched_getaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 4:
+        return None
+    try:
+        os.sched_setaffinity(0, set(cores[:-1]))
+    except OSError:
+        return None
+    return cores[-1]
+
+
+def pin_to_core(core: int | None) -> bool:
+    import os
+
+    if core is None:
+        return False
+    try:
+        os.sched_setaffinity(0, {core})
+        return True
+    except OSError:
+        return False
+
+
 def init_process_group(local_device_count: int | None = None):
     """torch.distributed for a launcher-started run (RANK / WORLD_SIZE / MASTER_* in the environment). One process per
     GPU -> backend "nccl" (RCCL over xGMI) with collectives on device tensors; ranks that must share a GPU (tests on a
@@ -99,27 +242,40 @@ def shutdown_process_group() -> None:
         _created_group = False
 
 
-def gather_records(local: np.ndarray, failed: bool, dist=None, device=None):
-    """The one data-path collective of a frame-sharded video: every rank contributes its [per, stride] float64 block
-    (padded to the same `per`) and a failure flag; rank 0 gets (list of blocks by rank, any_failed), the others
-    (None, any_failed). A rank that failed on its shard still takes part (with zeros), so nobody waits for a
-    timeout; rank 0 then voids the whole video like the reference does for any exception (extract.py:198-200)."""
+def gather_records(local: np.ndarray, failed: bool, dist=None, device=None, max_det: int | None = None, with_gmc: bool = False):
+    """The data-path exchange of a round: every rank contributes its [per, stride] float64 block and a failure flag; rank 0
+    gets (list of blocks by rank, any_failed), the others (None, any_failed). On the wire a block is packed to its real
+    length (wire_pack); one all-gather of the packed sizes (-1 = this rank failed) tells every rank whether the video is
+    void and how long the padded gather has to be. A rank that failed on its shard still takes part, so nobody waits for a
+    timeout; every rank then voids the whole video like the reference does for any exception (extract.py:198-200)."""
     if dist is None:
         return [local], bool(failed)
     import torch
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    flag = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64)
-    t = torch.from_numpy(np.ascontiguousarray(local))
+    if max_det is None:                                          # from the record layout: stride = 1 + 6 max_det [+ 7] + 10
+        max_det = (local.shape[1] - 11 - (7 if with_gmc else 0)) // 6
+    wire = wire_pack(local, max_det, with_gmc) if not failed else np.zeros(0, np.uint8)
+    size = torch.tensor([-1 if failed else len(wire)], dtype=torch.int64)
     if device is not None:
-        flag, t = flag.to(device), t.to(device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)                  # every rank learns whether the video is void
-    any_failed = bool(flag.item() > 0)
+        size = size.to(device)
+    sizes = [torch.empty_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)                                 # every rank learns whether the video is void
+    sizes = [int(t.item()) for t in sizes]
+    any_failed = any(v < 0 for v in sizes)
+    pad = max(max(sizes), 8)
+    buf = np.zeros(pad, np.uint8)
+    buf[:len(wire)] = wire
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
     bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
     dist.gather(t, bufs, dst=0)
     if rank != 0:
         return None, any_failed
-    return [b.cpu().numpy() for b in bufs], any_failed
+    if any_failed:
+        return [np.zeros_like(local) for _ in range(world)], True
+    return [wire_unpack(b.cpu().numpy()[:sizes[r]], local.shape[0], max_det, with_gmc) for r, b in enumerate(bufs)], False
 
 
 def shard_runs(n_frames: int, world: int, first: int = 0, run_frames: int | None = None) -> list[list[tuple[int, int]]]:
@@ -202,7 +358,7 @@ def replay_records(blocks, n_frames: int, first: int, world: int, tracker, warp_
 
 
 def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max_det: int, dist=None, device=None, with_gmc: bool = False,
-                    run_frames: int | None = None):
+                    run_frames: int | None = None, replay_core: int | None = None):
     """One video, frames [first, n_frames) sharded over the ranks of `dist` (None: one process) as shard_runs() deals them.
     `produce(runs)` yields this rank's packed records, frame by frame, for its list of [start, stop) runs in order
     (geotrax_amd.extract drives the HIP engine there, one pipeline across the runs; the CPU tests a deterministic stand-in).
@@ -228,6 +384,7 @@ def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max
     replay_err: list = []
 
     def replay_loop():
+        pin_to_core(replay_core)                                 # reserve_replay_core(): the other threads of the job stay off it
         try:
             while True:
                 item = work.get()
@@ -253,7 +410,7 @@ def extract_sharded(n_frames: int, first: int, produce, tracker, warp_boxes, max
                         local[i] = next(gen)
                 except (Exception, SystemExit) as ex:            # this rank's shard is lost (SystemExit: initialize_streams on an unreadable
                     failed, err = True, ex                       # source): tell the others through the collective
-            blocks, any_failed = gather_records(local, failed, dist, device)
+            blocks, any_failed = gather_records(local, failed, dist, device, max_det, with_gmc)
             if any_failed:
                 raise RuntimeError(f"frame-sharded extraction failed on {'this rank: ' + repr(err) if failed else 'another rank'}")
             if rank == 0:

@@ -43,7 +43,7 @@ _INFERENCE_KEYS = {'conf', 'iou', 'imgsz', 'max_det', 'classes', 'augment', 'agn
 
 def detect_track_stabilize(args: argparse.Namespace, logger: logging.Logger) -> None:
     """Process one video (extract.py:114-131)."""
-    model = load_detector(args, logger)
+    model = load_detector_sharded(args, logger) if frame_sharding_active() else load_detector(args, logger)
     config = load_config_all(args, logger, model_names=model.names if model else None)
     proc = config['main']['processing']
     out_cfg_raw = config['main'].get('output', {})
@@ -119,7 +119,7 @@ def _engine_kwargs(config: dict) -> tuple[dict, dict | None, dict]:
     imgsz = ul.get('imgsz', 640)
     det_kw = dict(imgsz=int(max(imgsz) if isinstance(imgsz, (list, tuple)) else imgsz), conf=float(ul.get('conf') or 0.1),
                   iou=float(ul.get('iou', 0.7)), max_det=int(ul.get('max_det', 300)), classes=ul.get('classes'),
-                  agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', True)))
+                  agnostic_nms=bool(ul.get('agnostic_nms', False)), half=bool(ul.get('half', False)), rect=bool(ul.get('rect', False)))   # absent -> the reference config's value (default.yaml:300)
     eng_cfg = config['main'].get('engine') or {}
     if eng_cfg.get('fp32_split') is not None:             # `engine: {fp32_split: false}` in the config: the exact-fp32 MFMA convolutions
         det_kw['fp32_split'] = bool(eng_cfg['fp32_split'])   # instead of split-f16x3 (half: false only; default: GTX_FP32_SPLIT or on)
@@ -138,6 +138,34 @@ def frame_sharding_active() -> bool:
     if mode == "force":                                   # the sharded path with whatever world size the launcher gave, even 1 (tests:
         return "RANK" in os.environ                       # RCCL's code path on a one-GPU box)
     return int(os.environ.get("WORLD_SIZE", "1")) > 1 and mode != "0"
+
+
+def load_detector_sharded(args: argparse.Namespace, logger: logging.Logger) -> YOLO:
+    """load_detector for a launcher-started, frame-sharded run: rank 0 reads the weight file, every other rank receives the
+    tensors through one broadcast (geotrax_amd.distributed.broadcast_weights; RCCL when the ranks own a GPU each) -- the
+    weight exchange BASELINE's north star names. A model that cannot be loaded ends every rank the way load_detector ends one
+    process (error line, exit status 1)."""
+    from . import distributed as D
+
+    dist, dev, _ = D.init_process_group()
+    model, err = None, None
+    if dist.get_rank() == 0:
+        try:
+            model = load_detector(args, logger)
+        except SystemExit:                                # load_detector has logged why
+            err = "rank 0 could not load the detection model"
+    try:
+        tensors, names = D.broadcast_weights(model.tensors if model else None, model.names if model else None, dist, dev, error=err)
+    except RuntimeError as e:
+        if dist.get_rank() != 0:
+            logger.error(f"Error loading the YOLOv8 model: {e}")
+        sys.exit(1)
+    if model is None:
+        from .config_utils import load_config
+
+        model = YOLO(tensors, task=load_config(getattr(args, 'cfg', None), logger).get('ultralytics', {}).get('task', 'detect'))
+        model.names = names or model.names
+    return model
 
 
 def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray] | None:
@@ -196,16 +224,25 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
                 raise RuntimeError(f"frame {f} could not be read")
             return frame
 
-        prime = []                                           # device copies of priming frames: a ring, the engine reads them asynchronously
+        # Device copies of the priming frames: a ring, because the GMC stream reads a copy when the run's first batch has been
+        # collected, not when it is handed over. Between those two moments stage 1 can hand over at most one batch per detector
+        # stream (in flight) + the two batches of the stage-1 queue + the one stage 2 holds, and every run is at least one
+        # batch: a slot is written again n_prime runs later, so n_prime = detectors + 4 covers it with one to spare. The
+        # uploads go through a context of their own (dev_upload waits for ITS stream only, not for a detector's pass).
+        prime = []
+        n_prime = len(engine.dets) + 4
 
         def prime_ptr(frame):
-            ctx0 = engine.dets[0].ctx
-            if len(prime) < 4:
-                prime.append(ctx0.dev_alloc(frame.nbytes))   # (.nbytes of a Yuv420Frame is that of its BGR frame)
-                state.setdefault('prime', (ctx0, prime))
-            p = prime[state.get('prime_i', 0) % 4]
+            from . import _lib
+
+            if 'prime' not in state:
+                state['prime'] = (_lib.Context(local), prime)
+            pctx = state['prime'][0]
+            if len(prime) < n_prime:
+                prime.append(pctx.dev_alloc(frame.nbytes))   # (.nbytes of a Yuv420Frame is that of its BGR frame)
+            p = prime[state.get('prime_i', 0) % n_prime]
             state['prime_i'] = state.get('prime_i', 0) + 1
-            ctx0.dev_upload(p, np.ascontiguousarray(frame.bgr() if hasattr(frame, "bgr") else frame, np.uint8))
+            pctx.dev_upload(p, np.ascontiguousarray(frame.bgr() if hasattr(frame, "bgr") else frame, np.uint8))
             return p
 
         def batches():
@@ -226,10 +263,22 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         for r in engine.run(batches()):
             yield D.pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None if r.H_fallback else r.H, r.gmc, with_gmc=with_gmc)
 
+    # The source must open on EVERY rank, with the same frame count, before anybody enters a round's collectives: a rank that
+    # cannot open its copy would otherwise leave early while the others wait in the gather. The reference ends the process on an
+    # unopenable source (extract.py:250-252); here every rank does, together.
     try:
         probe = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
-        state['n_frames'] = probe.frame_count if last is None else min(probe.frame_count, last + 1)
+        n_here, ok = probe.frame_count, True
         probe.release()
+    except SystemExit:
+        n_here, ok = 0, False
+    all_ok, same, _ = D.agree_on_source(ok, n_here, dist, dev)
+    if not all_ok or not same:
+        logger.error(f"Failed to open: '{args.source}' on every rank" + ("." if not all_ok else " with the same frame count."))
+        sys.exit(1)
+    replay_core = D.reserve_replay_core(dist.get_world_size())
+    try:
+        state['n_frames'] = n_here if last is None else min(n_here, last + 1)
         # frames per rank and round: whole batches, at most the config's `engine.shard_run_frames` (16), and no more than an even
         # share of the clip so that short clips still reach every rank (0 / null: one contiguous range per rank, one gather)
         run_frames = eng_cfg.get('shard_run_frames', 16)
@@ -238,14 +287,15 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
             share = -(-max(state['n_frames'] - first, 1) // dist.get_world_size())
             run_frames = max(bsz, min(-(-int(run_frames) // bsz) * bsz, -(-share // bsz) * bsz))
         lists = D.extract_sharded(state['n_frames'], first, produce, tracker, warp_boxes, max_det, dist=dist, device=dev, with_gmc=with_gmc,
-                                  run_frames=run_frames or None)
-    except (Exception, SystemExit) as e:                     # SystemExit: initialize_streams on a missing / unopenable source
+                                  run_frames=run_frames or None, replay_core=replay_core)
+    except (Exception, SystemExit) as e:                     # SystemExit: a source that stops opening between the probe and the run
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return (np.empty((0, 12), dtype=np.float32), np.empty((0, 10))) if rank == 0 else None
     finally:
         if 'prime' in state:
             for p_ in state['prime'][1]:
                 state['prime'][0].dev_free(p_)
+            state['prime'][0].close()
         if 'reader' in state:
             state['reader'].release()
         if 'engine' in state:

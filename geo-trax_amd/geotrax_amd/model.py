@@ -145,7 +145,7 @@ class YOLO:
             self._det = Detector(self.tensors, frame_hw, imgsz=int(imgsz), conf=float(kw.get("conf") or 0.1),
                                  iou=float(kw.get("iou", 0.7)), max_det=int(kw.get("max_det", 300)), classes=kw.get("classes"),
                                  agnostic_nms=bool(kw.get("agnostic_nms", False)), half=bool(kw.get("half", False)),
-                                 rect=bool(kw.get("rect", True)), ctx=self.ctx)
+                                 rect=bool(kw.get("rect", False)), ctx=self.ctx)   # absent -> the reference config's value (default.yaml:300)
             self._det_key = key
         return self._det
 

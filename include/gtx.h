@@ -240,19 +240,26 @@ const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w
 int gtx_detector_raw_output(gtx_detector* det, int b, float* out, int* n_anchors);
 /* Same layout, class columns hold the pre-sigmoid logits (used to calibrate synthetic weights). */
 int gtx_detector_raw_logits(gtx_detector* det, int b, float* out, int* n_anchors);
-/* Activation of a named layer of the last forward ("model.4" ...), NHWC fp32, for parity. */
+/* Activation of a named layer of the last forward ("model.4" ...), NHWC fp32, for parity. Refused while a batch is in
+ * flight. On the split-f16x3 path with the fused front launch (YOLOv8 n / s) "model.0.conv" and "model.1.conv" are never
+ * stored by the forward pass: the call recomputes them with their stand-alone launches (same products, another summation
+ * order), so those two dumps are not bit for bit what the network consumed. */
 int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float* out,
                               int* h, int* w, int* c);
+/* fp32_split only. *flag = 1 when an activation of a collected pass (since the last call with clear != 0) lay beyond fp16's
+ * range and was clamped to +-65504 where the split-f16x3 path stores it as a (hi, lo) fp16 pair. `half: false` promises
+ * fp32's range (default.yaml:245), so gtx_detector_collect / _detect* of THAT pass re-run the batch through an exact-fp32
+ * detector built from the same tensors (v_mfma_f32_32x32x2_f32; the frames must still be where the caller put them, which
+ * one-batch-in-flight guarantees) and every later pass goes there; gtx_detector_fell_back reports 1 from then on. Trained,
+ * BN-folded YOLOv8 weights never get there; GTX_SAT_FALLBACK=0 in the environment keeps the flag and skips the re-run. */
+int gtx_detector_saturated(gtx_detector* det, int clear, int* flag);
+int gtx_detector_fell_back(gtx_detector* det, int* fell_back);
+
 /* Per-kernel-family profile of one forward pass: launches, total ms (HIP events around every
  * launch on the launch stream, graph disabled) and algorithmic FLOPs / bytes. `names` receives
- * up to cap entries of 96 chars. Feeds bench.py's roofline object. */
-/* fp32_split only. *flag = 1 when an activation of a collected pass (since the last call with clear != 0) lay beyond fp16's
- * range and was clamped to +-65504 where the split-f16x3 path stores it as a (hi, lo) fp16 pair: the detections then differ
- * from an fp32 run and the checkpoint needs fp32_split = 0 (exact fp32 MFMA). Trained, BN-folded YOLOv8 weights never get
- * there; the flag exists so that a fine-tuned or unfused model cannot saturate silently. */
-int gtx_detector_saturated(gtx_detector* det, int clear, int* flag);
-
-/* Live variant: after gtx_detector_trace(det, n) every n-th submitted pass carries a HIP event in
+ * up to cap entries of 96 chars. Feeds bench.py's roofline object.
+ */
+/* Live variant of the profile: after gtx_detector_trace(det, n) every n-th submitted pass carries a HIP event in
  * front of every launch of its forward graph; gtx_detector_profile(det, 0, 0, ...) then returns (and
  * clears) the per-family totals of the traced passes, i.e. kernel durations as they were inside the
  * running pipeline. n = 0 switches tracing off. */

@@ -180,6 +180,99 @@ def test_other_yolov8_scales_match_oracle(gtx_ctx, scale, gain, half, split):
     det.close()
 
 
+def test_saturation_falls_back_to_the_exact_fp32_convolutions(gtx_ctx, monkeypatch, caplog):
+    """`half: false` promises fp32's range (default.yaml:245). The seeded `l` stack at weight gain 1.7 pushes activations past
+    1e6, beyond what the split-f16x3 path's fp16 halves carry (+-65504): the pass that saturates is re-run through the
+    exact-fp32 MFMA kernels and the detector stays there -- with fp32_split=True it returns what the oracle returns, layer by
+    layer, raw head output and detections, also for the next frame and through the asynchronous pair; one warning names what
+    happened. GTX_SAT_FALLBACK=0 keeps round 3's behaviour (clamped values, flag only) so that the difference is visible."""
+    import logging
+
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import synthetic_yolov8
+    from oracle.yolov8_ref import YoloV8Ref, detect, letterbox
+
+    w = synthetic_yolov8(seed=1, nc=4, scale="l", cls_bias=-3.0, gain=1.7)
+    frames = [_frame(0), _frame(1)]
+    kw = dict(imgsz=384, half=False, rect=False, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, ctx=gtx_ctx)
+    ref = YoloV8Ref(w)
+    x, _ = letterbox(frames[0], 384, False)
+    ref_raw = ref.forward(x)[0].numpy()
+    assert max(float(ref.acts[n].abs().max()) for n in LAYERS) > 65504.0          # the case is what it claims to be
+    det = Detector(w, FRAME_HW, fp32_split=True, **kw)
+    assert det.fp32_split and not det.fell_back()
+    with caplog.at_level(logging.WARNING, logger="geotrax_amd.detector"):
+        got = det.detect(frames[0])
+    assert det.saturated() and det.fell_back()
+    assert caplog.text.count("exact-fp32") == 1 and "re-run" in caplog.text
+    for name in LAYERS:
+        a = det.layer_output(name)
+        r = ref.acts[name][0].permute(1, 2, 0).numpy()
+        assert np.isfinite(r).all(), name
+        err = np.abs(a - r).max() / (np.abs(r).max() + 1e-6)
+        assert err < 2e-4, f"{name}: rel-to-max error {err:.3e}"
+    np.testing.assert_allclose(det.raw_output()[:, 4:], ref_raw[:, 4:], atol=2e-4)
+    exact = Detector(w, FRAME_HW, fp32_split=False, **kw)
+    for f in frames:                                                               # ... and stays there: bit for bit the exact detector
+        a, b = det.detect(f), exact.detect(f)
+        np.testing.assert_array_equal(a.xyxy, b.xyxy)
+        np.testing.assert_array_equal(a.conf, b.conf)
+        xyxy, conf, cls = detect(ref, f, 384, False, 0.25, 0.7, [0, 1, 2, 3], True, 300)
+        assert len(a) == len(conf)
+        if len(conf):
+            np.testing.assert_allclose(np.sort(a.conf), np.sort(conf), atol=2e-4)
+    np.testing.assert_array_equal(got.conf, exact.detect(frames[0]).conf)
+    with caplog.at_level(logging.WARNING, logger="geotrax_amd.detector"):
+        det.detect(frames[1])
+    assert caplog.text.count("exact-fp32") == 1                                    # logged once
+    det.close()
+    # the asynchronous pair: the saturating batch is re-run inside collect() from the frames still resident in HBM
+    det = Detector(w, FRAME_HW, fp32_split=True, max_batch=2, **kw)
+    both = np.stack(frames)
+    dptr = gtx_ctx.dev_alloc(both.nbytes)
+    gtx_ctx.dev_upload(dptr, both)
+    det.submit_dev(dptr, 2)
+    pair = det.collect()
+    assert det.fell_back()
+    for d, f in zip(pair, frames):
+        np.testing.assert_array_equal(d.conf, exact.detect(f).conf)
+    g = det.gray_dptr(1)
+    assert g[0] and (g[1], g[2]) == (FRAME_HW[0] // 2, FRAME_HW[1] // 2)
+    det.submit_dev(dptr, 2)                                                        # later batches go straight to the exact kernels
+    np.testing.assert_array_equal(det.collect()[1].conf, pair[1].conf)
+    gtx_ctx.dev_free(dptr)
+    det.close()
+    exact.close()
+
+
+def test_saturation_flag_without_the_fallback(gtx_ctx):
+    """GTX_SAT_FALLBACK=0 (read once per process, hence a child process): the flag is raised, nothing is re-run, and the clamped
+    pass does NOT reproduce the exact detector -- which is why the fallback is the default."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [r'{root / 'geo-trax_amd'}', r'{root}', r'{root / 'tests'}']\n"
+        "from test_detector_gpu import _frame, FRAME_HW\n"
+        "from geotrax_amd.detector import Detector\n"
+        "from geotrax_amd.weights import synthetic_yolov8\n"
+        "w = synthetic_yolov8(seed=1, nc=4, scale='l', cls_bias=-3.0, gain=1.7)\n"
+        "kw = dict(imgsz=384, half=False, rect=False, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True)\n"
+        "a = Detector(w, FRAME_HW, fp32_split=True, **kw); b = Detector(w, FRAME_HW, fp32_split=False, **kw)\n"
+        "a.detect(_frame(0)); b.detect(_frame(0))\n"
+        "ra, rb = a.raw_output(logits=True)[:, 4:], b.raw_output(logits=True)[:, 4:]\n"
+        "print('SAT', int(a.saturated()), int(a.fell_back()), float(np.abs(ra - rb).max() / np.abs(rb).max()))\n")
+    import os
+
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**os.environ, "GTX_SAT_FALLBACK": "0"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    sat, fell, diff = [ln for ln in p.stdout.splitlines() if ln.startswith("SAT")][-1].split()[1:]
+    assert (sat, fell) == ("1", "0") and float(diff) > 1e-3
+
+
 @pytest.mark.parametrize("nc,classes", [(80, [0, 2, 5, 7, 70]), (80, None), (1, None)])
 def test_class_counts_other_than_four(gtx_ctx, nc, classes):
     """COCO-style heads (80 classes, a class filter that reaches past bit 63) and single-class heads, class-wise NMS:

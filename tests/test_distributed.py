@@ -223,3 +223,117 @@ def test_frame_record_with_gmc_block_round_trips():
     np.testing.assert_array_equal(unpack_frame_gmc(with_gmc), warp)
     none = pack_frame_record(8, xyxy[:0], conf[:0], cls[:0], None, None, with_gmc=True)
     assert unpack_frame_gmc(none) is None and unpack_frame_record(none, 8)[3] is None and len(unpack_frame_record(none, 8)[1]) == 0
+
+
+def test_wire_format_is_the_record_at_its_real_length():
+    """a frame's record travels at the length of what it holds (SURVEY 8e budgets 3.3 KB at 132 boxes), not
+    as the 48 KB fixed-stride row; unpacking gives the row back bit for bit -- boxes / scores / classes are float32 at their
+    source, H and the camera-motion warp stay float64."""
+    from geotrax_amd.distributed import pack_frame_record, wire_pack, wire_unpack
+
+    rng = np.random.default_rng(0)
+    for with_gmc in (False, True):
+        recs = []
+        for n in (0, 3, 132, 1000, 0):
+            xyxy = rng.uniform(0, 4000, (n, 4)).astype(np.float32)
+            conf, cls = rng.uniform(0, 1, n).astype(np.float32), rng.integers(0, 4, n)
+            Hm = rng.standard_normal((3, 3)) if n != 3 else None
+            warp = rng.standard_normal((2, 3)) if (with_gmc and n) else None
+            recs.append(pack_frame_record(1000, xyxy, conf, cls, Hm, warp, with_gmc=with_gmc))
+        block = np.stack(recs)
+        wire = wire_pack(block, 1000, with_gmc)
+        assert wire.dtype == np.uint8
+        np.testing.assert_array_equal(wire_unpack(wire, len(recs), 1000, with_gmc), block)
+        one = wire_pack(block[2:3], 1000, with_gmc)
+        assert len(one) == 8 + 132 * 24 + 72 + (48 if with_gmc else 0) <= 3400        # 3.3 KB at 132 boxes
+        with pytest.raises(ValueError):
+            wire_unpack(wire[:-8], len(recs), 1000, with_gmc)
+
+
+def _exchange_worker(rank, world, port, q, fail):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geotrax_amd.distributed import agree_on_source, broadcast_weights, gather_records, pack_frame_record
+
+        rng = np.random.default_rng(7)
+        tensors = {"model.0.conv.weight": rng.standard_normal((32, 3, 3, 3)).astype(np.float32), "model.0.conv.bias": rng.standard_normal(32).astype(np.float32),
+                   "model.22.cv3.0.2.weight": rng.standard_normal((4, 64, 1, 1)).astype(np.float32), "scalar": np.float32(3.5).reshape(())}
+        names = {0: "car", 1: "bus", 2: "truck", 3: "motorcycle"}
+        if fail:
+            try:
+                broadcast_weights(None, None, dist, error="no such file" if rank == 0 else None)
+            except RuntimeError as e:
+                q.put((rank, str(e)))
+            return
+        got, got_names = broadcast_weights(tensors if rank == 0 else None, names if rank == 0 else None, dist)
+        same = all(np.array_equal(got[k], tensors[k]) and got[k].shape == tensors[k].shape and got[k].dtype == np.float32 for k in tensors)
+        ok_all = agree_on_source(True, 150, dist)
+        ok_one = agree_on_source(rank != 1, 150, dist)                 # rank 1 cannot open its copy
+        ok_cnt = agree_on_source(True, 150 - rank, dist)               # the copies differ in length
+        # a round's gather: ranks hold different numbers of boxes, so their packed sizes differ
+        block = np.stack([pack_frame_record(50, rng.uniform(0, 99, (5 + 7 * rank, 4)).astype(np.float32), np.full(5 + 7 * rank, 0.5, np.float32),
+                                            np.zeros(5 + 7 * rank, np.int32), np.eye(3) * (rank + 1)) for _ in range(3)])
+        blocks, failed = gather_records(block, False, dist, None, 50, False)
+        sizes = [int(b[0, 0]) for b in blocks] if rank == 0 else None
+        q.put((rank, same and set(got) == set(tensors), got_names == names, ok_all, ok_one, ok_cnt, failed, sizes,
+               bool(rank != 0 or all(np.array_equal(blocks[r][:, -9:], np.tile((np.eye(3) * (r + 1)).ravel(), (3, 1))) for r in range(world)))))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn_exchange(world, fail):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q, fail)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_weight_broadcast_source_agreement_and_packed_gather_over_gloo():
+    """The product's exchanges of a frame-sharded run with 3 ranks (gloo here, RCCL on GPUs): rank 0's tensors arrive on every rank
+    bit for bit (north star: "broadcast of weights"), with the class names; the ranks agree on whether the source opened
+    everywhere and on its frame count before the first round; a round's records are gathered at their packed length."""
+    got = _spawn_exchange(3, fail=False)
+    for rank, same, names_ok, ok_all, ok_one, ok_cnt, failed, sizes, h_ok in got:
+        assert same and names_ok and not failed and h_ok
+        assert ok_all == (True, True, 150) and ok_one[0] is False and ok_cnt[:2] == (True, False)
+        assert sizes == ([5, 12, 19] if rank == 0 else None)
+
+
+def test_a_weight_file_rank0_cannot_load_stops_every_rank():
+    got = _spawn_exchange(2, fail=True)
+    assert [g[0] for g in got] == [0, 1] and all("no such file" in g[1] for g in got)
+
+
+def test_replay_core_is_reserved_only_for_four_ranks_and_more(monkeypatch):
+    from geotrax_amd.distributed import pin_to_core, reserve_replay_core
+
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.delenv("GTX_PIN_REPLAY", raising=False)
+        assert reserve_replay_core(2) is None and os.sched_getaffinity(0) == before
+        if len(before) >= 4:
+            core = reserve_replay_core(8)
+            assert core == max(before) and os.sched_getaffinity(0) == before - {core}       # the caller (and its later threads) stay off it
+            import threading
+
+            seen = []
+            t = threading.Thread(target=lambda: seen.append((pin_to_core(core), os.sched_getaffinity(0))))
+            t.start()
+            t.join()
+            assert seen == [(True, {core})]
+        monkeypatch.setenv("GTX_PIN_REPLAY", "0")
+        os.sched_setaffinity(0, before)
+        assert reserve_replay_core(8) is None
+        assert pin_to_core(None) is False
+    finally:
+        os.sched_setaffinity(0, before)

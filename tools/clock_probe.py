@@ -17,7 +17,7 @@ NB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 SECS = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 ctx = _lib.default_context(0)
 dbg = ctypes.CDLL(STAMP)
-for fn in (dbg.gtx_debug_conv_clock, dbg.gtx_debug_ring_clock):
+for fn in (dbg.gtx_debug_conv_clock,):
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
     fn.restype = ctypes.c_int
 
@@ -25,7 +25,7 @@ for fn in (dbg.gtx_debug_conv_clock, dbg.gtx_debug_ring_clock):
 def read():
     """Sums of the two stamped translation units (a layer runs in one of them: the other's are zero)."""
     tot = [0] * 8
-    for fn in (dbg.gtx_debug_conv_clock, dbg.gtx_debug_ring_clock):
+    for fn in (dbg.gtx_debug_conv_clock,):
         out = (ctypes.c_ulonglong * 8)()
         assert fn(out) == 0
         tot = [a + b for a, b in zip(tot, out)]
