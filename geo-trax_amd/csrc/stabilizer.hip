@@ -59,6 +59,10 @@ struct Levels {
   int n;
   int n_tiles;      // over all levels
   int tab_off[kPyrLevels];   // pyr_resize_kernel: first entry of level i's column table (its row table follows) in the table buffer
+  // pyr_group_kernel: the resizes of levels 1.. in launches of consecutive levels (group g computes levels [grp_first[g],
+  // grp_first[g] + grp_n[g])), and the LDS rectangle buffer each launch needs (largest rectangle of any of its tiles)
+  int n_groups;
+  int grp_first[kPyrLevels], grp_n[kPyrLevels], grp_buf[kPyrLevels];
 };
 
 // ------------------------------------------------------------------ gray / pyramid
@@ -117,6 +121,80 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
     *reinterpret_cast<unsigned*>(d) = out;
   } else {
     for (int k = 0; k < 4 && x + k < dw; ++k) d[k] = (uint8_t)(out >> (8 * k));
+  }
+}
+
+// Several consecutive pyramid levels in ONE launch (round 4: the eight-level pyramid is two launches, levels 1-3 and 4-7,
+// instead of seven). A workgroup owns a 64x16 tile of the group's LAST level; walking the resize tables backwards gives the
+// rectangle of every level in front of it that the tile depends on, down to the group's source level. That source rectangle
+// is staged in LDS, then level after level is computed from the rectangle before it -- the same integer bilinear expression
+// as pyr_resize_kernel on the same operands, so every byte is the per-level launches' byte -- into the other LDS buffer and
+// written to the level's image. Rectangles of neighbouring tiles overlap by the one or two pixels of bilinear support:
+// those pixels are computed and stored by both workgroups, with identical values. A tile on the right / bottom edge of its
+// level takes the rest of every level in front of it along, so that the levels are written completely.
+// Unlike the whole pyramid as one launch (185 us, see above) a group's chain is 3-4 short stages and the first group still
+// has 720 workgroups at 1920 x 1080.
+constexpr int kPyrGroupMax = 4;
+struct PyrGroup {
+  int n;                            // levels computed by this launch
+  const uint8_t* src;               // the level in front of the group
+  int sw, sh;
+  uint8_t* dst[kPyrGroupMax];
+  int w[kPyrGroupMax], h[kPyrGroupMax];
+  const unsigned* tx[kPyrGroupMax]; // column table of the level, its row table follows (pyr_src)
+  int buf_bytes;                    // one LDS rectangle buffer (two are used)
+};
+
+__global__ __launch_bounds__(256) void pyr_group_kernel(const PyrGroup G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_pyr[];
+  __shared__ int s_rect[kPyrGroupMax + 1][4];      // x0, y0, x1, y1 (inclusive); [0] = source level, [k + 1] = level k of the group
+  const int tid = threadIdx.x;
+  const int last = G.n - 1;
+  if (tid == 0) {
+    int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    int x1 = min(x0 + 63, G.w[last] - 1), y1 = min(y0 + 15, G.h[last] - 1);
+    for (int k = last; k >= 0; --k) {
+      s_rect[k + 1][0] = x0; s_rect[k + 1][1] = y0; s_rect[k + 1][2] = x1; s_rect[k + 1][3] = y1;
+      const unsigned* tabx = G.tx[k];
+      const unsigned* taby = tabx + G.w[k];
+      const int pw = k == 0 ? G.sw : G.w[k - 1], ph = k == 0 ? G.sh : G.h[k - 1];
+      const bool right = x1 == G.w[k] - 1, bottom = y1 == G.h[k] - 1;
+      const unsigned a = tabx[x0], b = tabx[x1], c = taby[y0], d = taby[y1];
+      x0 = (int)(a & 0xffff); y0 = (int)(c & 0xffff);
+      x1 = right ? pw - 1 : (int)((b & 0xffff) + (b >> 27));
+      y1 = bottom ? ph - 1 : (int)((d & 0xffff) + (d >> 27));
+    }
+    s_rect[0][0] = x0; s_rect[0][1] = y0; s_rect[0][2] = x1; s_rect[0][3] = y1;
+  }
+  __syncthreads();
+  uint8_t* bufs[2] = {s_pyr, s_pyr + G.buf_bytes};
+  {
+    const int rx = s_rect[0][0], ry = s_rect[0][1], rw = s_rect[0][2] - rx + 1, rh = s_rect[0][3] - ry + 1;
+    for (int i = tid; i < rw * rh; i += 256) bufs[0][i] = G.src[(size_t)(ry + i / rw) * G.sw + rx + i % rw];
+  }
+  __syncthreads();
+  for (int k = 0; k < G.n; ++k) {
+    const uint8_t* in = bufs[k & 1];
+    uint8_t* out = bufs[(k + 1) & 1];
+    const int sx = s_rect[k][0], sy = s_rect[k][1], sw = s_rect[k][2] - sx + 1;
+    const int dx = s_rect[k + 1][0], dy = s_rect[k + 1][1], dw = s_rect[k + 1][2] - dx + 1, dh = s_rect[k + 1][3] - dy + 1;
+    const unsigned* tabx = G.tx[k];
+    const unsigned* taby = tabx + G.w[k];
+    uint8_t* img = G.dst[k];
+    const int W = G.w[k];
+    for (int i = tid; i < dw * dh; i += 256) {
+      const int x = dx + i % dw, y = dy + i / dw;
+      const unsigned tx = tabx[x], ty = taby[y];
+      const unsigned fy = (ty >> 16) & 2047, fx = (tx >> 16) & 2047;
+      const int o0 = ((int)(ty & 0xffff) - sy) * sw - sx, o1 = o0 + ((ty >> 27) ? sw : 0);   // rows of the staged rectangle
+      const int xa = (int)(tx & 0xffff), xb = xa + (int)(tx >> 27);
+      const unsigned top = in[o0 + xa] * (2048 - fx) + in[o0 + xb] * fx;
+      const unsigned bot = in[o1 + xa] * (2048 - fx) + in[o1 + xb] * fx;
+      const uint8_t v = (uint8_t)((top * (2048 - fy) + bot * fy + (1u << 21)) >> 22);   // < 2^31: exact in 32 bits
+      out[i] = v;
+      img[(size_t)y * W + x] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -397,26 +475,17 @@ __device__ __forceinline__ unsigned long long flip_key(long k) { return (unsigne
 constexpr int kSortCap = 8192;   // eligible candidates the in-LDS sort handles (more: radix-select path)
 constexpr int kTopCap = 2048;    // keypoints per level the radix-select path keeps (level 0 takes ~22 % of max_features)
 
-// Stage 2 of the selection: the n_want best Harris keys of the eligible set, ordered by
-// (key desc, pix asc). Usual case (n <= 8192): one bitonic sort of {key, pix} pairs in LDS.
-__global__ __launch_bounds__(1024) void select_sort_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
-                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+// Stage 2 of the selection, one workgroup per level: the n_want best Harris keys of the eligible set, ordered by
+// (key desc, pix asc). Usual case (n <= 8192): one bitonic sort of {key, pix} pairs in LDS (select_by_sort). More eligible
+// candidates than that: 8-pass MSB radix select + counting rank (select_by_radix). One launch for both (round 4: they used to
+// be two launches that each returned at once for the levels of the other).
+__device__ void select_by_sort(unsigned char* s_raw, const Cand* __restrict__ c, int n, int want, const Level& lv, int li,
+                               KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_raw);        // [kSortCap]
   int* s_pix = reinterpret_cast<int*>(s_raw + sizeof(unsigned long long) * kSortCap);  // [kSortCap]
-  const int li = blockIdx.x;
-  const Level lv = L.l[li];
   const int tid = threadIdx.x;
-  const int n = min(cand_n[li], lv.cand_cap);
-  if (n > kSortCap) return;                       // select_topn_kernel takes this level
-  const int want = min(lv.n_want, n);
-  if (want == 0) {
-    if (tid == 0) kp_n[li] = 0;
-    return;
-  }
   int P = 64;
   while (P < n) P <<= 1;
-  const Cand* c = cand + lv.cand_off;
   for (int i = tid; i < P; i += blockDim.x) {
     s_key[i] = i < n ? flip_key(c[i].key) : 0ull;
     s_pix[i] = i < n ? c[i].pix : 0x7fffffff;
@@ -449,24 +518,18 @@ __global__ __launch_bounds__(1024) void select_sort_kernel(const Cand* __restric
 // (sign-flipped) 64-bit key finds the key of the n-th best candidate; candidates above it are kept,
 // ties on the boundary key are broken by the smaller pixel index; the kept set is then ordered by
 // (key desc, pix asc) with a counting rank.
-__global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
-                                                           const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
-  __shared__ int hist[256];
-  __shared__ unsigned long long s_prefix;
-  __shared__ int s_need, s_nsel;
-  __shared__ unsigned long long s_key[kTopCap];   // selected set (n_want <= kTopCap per level)
-  __shared__ int s_pix[kTopCap];
-  const int li = blockIdx.x;
-  const Level lv = L.l[li];
+__device__ void select_by_radix(unsigned char* s_raw, const Cand* __restrict__ c, int n, int want, const Level& lv, int li,
+                                KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_raw);                              // [kTopCap] selected set
+  int* s_pix = reinterpret_cast<int*>(s_raw + sizeof(unsigned long long) * kTopCap);                     // [kTopCap]
+  int* hist = s_pix + kTopCap;                                                                           // [256]
+  unsigned long long* s_prefix_p = reinterpret_cast<unsigned long long*>(hist + 256);
+  int* s_need_p = reinterpret_cast<int*>(s_prefix_p + 1);
+  int* s_nsel_p = s_need_p + 1;
+#define s_prefix (*s_prefix_p)
+#define s_need (*s_need_p)
+#define s_nsel (*s_nsel_p)
   const int tid = threadIdx.x, lane = tid & 63;
-  const int n = min(cand_n[li], lv.cand_cap);
-  if (n <= kSortCap) return;                      // select_sort_kernel did this level
-  const Cand* c = cand + lv.cand_off;
-  const int want = min(min(lv.n_want, n), kTopCap);
-  if (want == 0) {
-    if (tid == 0) kp_n[li] = 0;
-    return;
-  }
   // ---- radix select: find the key of rank `want` (1-based, descending). Harris keys share their
   // leading bytes, so in the first passes every lane of a wave hits the same bin: one LDS atomic per
   // wave when the wave agrees on the digit, per-lane atomics otherwise.
@@ -547,6 +610,26 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const Cand* __restric
     kps[lv.kp_off + r] = kp;
   }
   if (tid == 0) kp_n[li] = m;
+#undef s_prefix
+#undef s_need
+#undef s_nsel
+}
+
+__global__ __launch_bounds__(1024) void select_kernel(const Cand* __restrict__ cand, const int* __restrict__ cand_n,
+                                                      const Levels L, KeyPoint* __restrict__ kps, int* __restrict__ kp_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];            // kSortCap * 12 bytes
+  const int li = blockIdx.x;
+  const Level lv = L.l[li];
+  const int n = min(cand_n[li], lv.cand_cap);
+  const Cand* c = cand + lv.cand_off;
+  const bool by_sort = n <= kSortCap;
+  const int want = by_sort ? min(lv.n_want, n) : min(min(lv.n_want, n), kTopCap);
+  if (want == 0) {
+    if (threadIdx.x == 0) kp_n[li] = 0;
+    return;
+  }
+  if (by_sort) select_by_sort(s_raw, c, n, want, lv, li, kps, kp_n);
+  else select_by_radix(s_raw, c, n, want, lv, li, kps, kp_n);
 }
 
 // ------------------------------------------------------------------ orientation + descriptor
@@ -574,24 +657,34 @@ __device__ __forceinline__ int angle_bin(int m10, int m01) {
 // gives the orientation bin, the 35x35 interior is blurred (separable integer 7-tap Gaussian) in
 // LDS, and the 256 steered-BRIEF tests are evaluated 64 at a time: a ballot per group of 64 tests
 // is one 64-bit word of the descriptor.
+// Output goes straight to the dense per-frame lists (level by level, rank order inside a level: a slot's place is the
+// keypoint counts of the levels before it + its rank), and the pass's candidate counters / score histograms, which nobody
+// reads after the selection, are cleared here for the next frame: the former compact_kernel launch is gone (round 4).
 __global__ __launch_bounds__(256) void describe_kernel(const Levels L,
-                                                       KeyPoint* __restrict__ kps, const int* __restrict__ kp_n,
+                                                       const KeyPoint* __restrict__ kps, const int* __restrict__ kp_n,
                                                        const int8_t* __restrict__ pattern /*[bins][256][4]*/,
-                                                       unsigned long long* __restrict__ desc /*[slot][4]*/,
-                                                       float2* __restrict__ xy_full, float inv_ratio, int total_slots) {
+                                                       KeyPoint* __restrict__ okp, unsigned long long* __restrict__ odesc /*[n][4]*/,
+                                                       float2* __restrict__ oxy, int* __restrict__ total, float inv_ratio, int total_slots,
+                                                       int* __restrict__ counters, int n_counters) {
   __shared__ uint8_t s_patch[4][kPatchW * kPatchW];
   __shared__ unsigned short s_h[4][kPatchW * (kPatchW - 6)];   // horizontal pass, columns 3..37
   __shared__ uint8_t s_blur[4][(kPatchW - 6) * (kPatchW - 6)];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int slot = blockIdx.x * 4 + wv;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_counters; i += gridDim.x * blockDim.x) counters[i] = 0;
   if (slot >= total_slots) return;
-  // which level does this slot belong to?
-  int li = 0;
+  // which level does this slot belong to, and how many keypoints do the levels before it hold?
+  int li = 0, base = 0, all = 0;
 #pragma unroll
-  for (int i = 1; i < kPyrLevels; ++i)
-    if (i < L.n && slot >= L.l[i].kp_off) li = i;
+  for (int i = 0; i < kPyrLevels; ++i) {
+    const int cnt = i < L.n ? kp_n[i] : 0;
+    if (i >= 1 && i < L.n && slot >= L.l[i].kp_off) { li = i; base = all; }
+    all += cnt;
+  }
+  if (slot == 0 && lane == 0) *total = all;
   const Level lv = L.l[li];
   if (slot - lv.kp_off >= kp_n[li]) return;
+  const int dst = base + slot - lv.kp_off;
   KeyPoint kp = kps[slot];
   const uint8_t* img = lv.img;
   uint8_t* P = s_patch[wv];
@@ -641,7 +734,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const Levels L,
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int8_t* pat = pattern + (size_t)bin * 256 * 4;
-  unsigned long long* d = desc + (size_t)slot * 4;
+  unsigned long long* d = odesc + (size_t)dst * 4;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int t = g * 64 + lane;
@@ -652,102 +745,90 @@ __global__ __launch_bounds__(256) void describe_kernel(const Levels L,
   }
   if (lane == 0) {
     kp.bin = bin;
-    kps[slot] = kp;
-    xy_full[slot] = make_float2((float)kp.x * lv.scale * inv_ratio, (float)kp.y * lv.scale * inv_ratio);
+    okp[dst] = kp;
+    oxy[dst] = make_float2((float)kp.x * lv.scale * inv_ratio, (float)kp.y * lv.scale * inv_ratio);
   }
-}
-
-// Packs the per-level keypoint slots (gaps where a level found fewer than it wanted) into a dense
-// list, level by level, keeping the rank order inside a level.
-__global__ __launch_bounds__(256) void compact_kernel(const Levels L, const int* __restrict__ kp_n, const KeyPoint* __restrict__ kps,
-                                                      const unsigned long long* __restrict__ desc, const float2* __restrict__ xy,
-                                                      KeyPoint* __restrict__ okp, unsigned long long* __restrict__ odesc,
-                                                      float2* __restrict__ oxy, int* __restrict__ total,
-                                                      int* __restrict__ counters, int n_counters) {
-  // last kernel of a frame's feature pass: nobody reads the candidate counters / score histograms any more, so
-  // they are cleared here for the next frame (saves a memset launch per frame; they start out zero)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_counters; i += gridDim.x * blockDim.x) counters[i] = 0;
-  int base = 0;
-  for (int li = 0; li < L.n; ++li) {
-    const int n = kp_n[li];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-      const int s = L.l[li].kp_off + i;
-      okp[base + i] = kps[s];
-      oxy[base + i] = xy[s];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) odesc[(size_t)(base + i) * 4 + k] = desc[(size_t)s * 4 + k];
-    }
-    base += n;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *total = base;
 }
 
 // ------------------------------------------------------------------ matching
-// Brute-force Hamming 2-NN. Grid = (query tiles of 256) x (train chunks of 256): a block stages its
-// train chunk in LDS and every thread scans it for its query, leaving a partial (best, second,
-// index) per chunk; the ratio kernel below merges the chunks of a query in chunk order, which
-// preserves the "lowest index wins ties" rule.
+// Brute-force Hamming 2-NN + Lowe ratio test + ordered compaction in ONE launch (round 4; two launches before).
+// Grid = (query tiles of 256) x (train chunks of 256): a block stages its train chunk in LDS and every thread scans it for
+// its query, leaving a partial (best, second, index) per chunk. The workgroup that finishes LAST (a ticket drawn behind a
+// workgroup barrier, after every wave has waited for its stores) merges the chunks of every query in chunk order -- which
+// preserves the "lowest index wins ties" rule --, applies the ratio test and compacts the survivors in query order.
+// Cross-workgroup visibility (MI355X_MICROARCH.md, hand-off table, first row): the partials are written with write-through
+// (`sc1`) stores and read back with `sc1` loads, each storing wave drains its stores (`s_waitcnt vmcnt(0)`) before the
+// barrier, ONE lane per workgroup then adds to the device-scope ticket, and only the workgroup whose add returned the
+// last ticket reads, behind its own barrier. No cache-wide write-back or invalidate is involved.
 constexpr int kMatchChunk = 256;
+__device__ __forceinline__ void st_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void match_kernel(const unsigned long long* __restrict__ q, const int* __restrict__ nq_p,
                                                     const unsigned long long* __restrict__ t, const int* __restrict__ nt_p,
                                                     int max_q, int* __restrict__ part_idx, int* __restrict__ part_d1,
-                                                    int* __restrict__ part_d2) {
+                                                    int* __restrict__ part_d2, unsigned* __restrict__ ticket,
+                                                    float ratio, int keep_all, const float2* __restrict__ q_xy, const float2* __restrict__ t_xy,
+                                                    int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d,
+                                                    int* __restrict__ m_q, int* __restrict__ m_t, int* __restrict__ m_d,
+                                                    float4* __restrict__ m_pts, int* __restrict__ n_match) {
   __shared__ unsigned long long s_t[kMatchChunk * 4];
+  __shared__ int s_last;
   const int nq = *nq_p, nt = *nt_p;
   const int t0 = blockIdx.y * kMatchChunk;
-  if (blockIdx.x * blockDim.x >= nq || t0 >= nt) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = t0 + threadIdx.x;
-  if (j < nt) {
+  const int tid = threadIdx.x;
+  const bool active = blockIdx.x * blockDim.x < nq && t0 < nt;     // whole workgroup: uniform
+  if (active) {
+    const int i = blockIdx.x * blockDim.x + tid;
+    const int j = t0 + tid;
+    if (j < nt) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s_t[threadIdx.x * 4 + k] = t[(size_t)j * 4 + k];
+      for (int k = 0; k < 4; ++k) s_t[tid * 4 + k] = t[(size_t)j * 4 + k];
+    }
+    __syncthreads();
+    if (i < nq) {
+      const unsigned long long a0 = q[(size_t)i * 4], a1 = q[(size_t)i * 4 + 1], a2 = q[(size_t)i * 4 + 2], a3 = q[(size_t)i * 4 + 3];
+      int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
+      const int lim = min(kMatchChunk, nt - t0);
+      for (int k = 0; k < lim; ++k) {
+        const int d = __popcll(a0 ^ s_t[k * 4]) + __popcll(a1 ^ s_t[k * 4 + 1]) + __popcll(a2 ^ s_t[k * 4 + 2]) +
+                      __popcll(a3 ^ s_t[k * 4 + 3]);
+        if (d < b1) { b2 = b1; b1 = d; bi = t0 + k; }
+        else if (d < b2) b2 = d;
+      }
+      const size_t o = (size_t)blockIdx.y * max_q + i;
+      st_sc1(&part_idx[o], bi); st_sc1(&part_d1[o], b1); st_sc1(&part_d2[o], b2);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's partials have left the CU
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = drawn == gridDim.x * gridDim.y - 1 ? 1 : 0;
   }
   __syncthreads();
-  if (i >= nq) return;
-  const unsigned long long a0 = q[(size_t)i * 4], a1 = q[(size_t)i * 4 + 1], a2 = q[(size_t)i * 4 + 2], a3 = q[(size_t)i * 4 + 3];
-  int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
-  const int lim = min(kMatchChunk, nt - t0);
-  for (int k = 0; k < lim; ++k) {
-    const int d = __popcll(a0 ^ s_t[k * 4]) + __popcll(a1 ^ s_t[k * 4 + 1]) + __popcll(a2 ^ s_t[k * 4 + 2]) +
-                  __popcll(a3 ^ s_t[k * 4 + 3]);
-    if (d < b1) { b2 = b1; b1 = d; bi = t0 + k; }
-    else if (d < b2) b2 = d;
-  }
-  const size_t o = (size_t)blockIdx.y * max_q + i;
-  part_idx[o] = bi; part_d1[o] = b1; part_d2[o] = b2;
-}
-
-// Merge of the per-chunk partials + Lowe ratio test + ordered compaction (single workgroup, queries
-// in index order).
-__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ nq_p, const int* __restrict__ nt_p, int max_q,
-                                                             const int* __restrict__ part_idx, const int* __restrict__ part_d1,
-                                                             const int* __restrict__ part_d2, float ratio, int keep_all,
-                                                             const float2* __restrict__ q_xy, const float2* __restrict__ t_xy,
-                                                             int* __restrict__ best_idx, int* __restrict__ best_d, int* __restrict__ second_d,
-                                                             int* __restrict__ m_q, int* __restrict__ m_t, int* __restrict__ m_d,
-                                                             float4* __restrict__ m_pts, int* __restrict__ n_match) {
-  __shared__ int s_cnt[1024];
-  const int nq = *nq_p, nt = *nt_p;
+  if (!s_last) return;
+  // ---- the last workgroup: merge of the per-chunk partials + Lowe ratio test + ordered compaction (queries in index order)
+  int* s_cnt = reinterpret_cast<int*>(s_t);                        // [256] (+ 4 wave totals behind them)
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next pass
   const int nchunk = (nt + kMatchChunk - 1) / kMatchChunk;
-  const int tid = threadIdx.x;
   for (int i = tid; i < nq; i += blockDim.x) {
     int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
     for (int c = 0; c < nchunk; ++c) {
       const size_t o = (size_t)c * max_q + i;
-      const int d1 = part_d1[o], d2 = part_d2[o];
-      if (d1 < b1) { b2 = min(b1, d2); b1 = d1; bi = part_idx[o]; }
+      const int d1 = ld_sc1(&part_d1[o]), d2 = ld_sc1(&part_d2[o]);
+      if (d1 < b1) { b2 = min(b1, d2); b1 = d1; bi = ld_sc1(&part_idx[o]); }
       else b2 = min(b2, d1);
     }
     best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2;
   }
   __syncthreads();
-  const int per = (nq + 1023) / 1024;
+  const int per = (nq + 255) / 256;
   const int lo = tid * per, hi = min(lo + per, nq);
   int c = 0;
   for (int i = lo; i < hi; ++i)
     if (keep_all ? (nt >= 1 && best_idx[i] >= 0) : (nt >= 2 && (float)best_d[i] < ratio * (float)second_d[i])) ++c;
-  // exclusive prefix of the 1024 per-thread counts: inclusive scan inside each wave by shuffles, then the 16 wave totals
-  // (50 -> 38 us in situ against a serial walk by thread 0; what remains is the wait for a CU with 16 free wave slots)
+  // exclusive prefix of the 256 per-thread counts: inclusive scan inside each wave by shuffles, then the 4 wave totals
   {
     const int lane = tid & 63, wv = tid >> 6;
     int inc = c;
@@ -756,16 +837,15 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restri
       const int v = __shfl_up(inc, d, 64);
       if (lane >= d) inc += v;
     }
-    if (lane == 63) s_cnt[wv] = inc;
+    if (lane == 63) s_cnt[256 + wv] = inc;
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int v = s_cnt[k];
+    for (int k = 0; k < 4; ++k) {
+      const int v = s_cnt[256 + k];
       if (k < wv) base += v;
       total += v;
     }
-    __syncthreads();
     s_cnt[tid] = base + inc - c;
     if (tid == 0) *n_match = total;
   }
@@ -838,130 +918,124 @@ __device__ bool affine3(const double* px, const double* py, const double* qx, co
   return true;
 }
 
-// Hypothesis generation, one thread per hypothesis: 4 (projective) or 3 (affine) distinct matches drawn by a counter-based
-// hash of (seed, hypothesis, draw), exact minimal solve in normalised coordinates, de-normalised H.
-__global__ __launch_bounds__(256) void ransac_solve_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, unsigned seed,
-                                                           int n_hyp, double cx, double cy, double sc, int affine,
-                                                           double* __restrict__ Hout, int* __restrict__ ok_out) {
-  const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
-  if (hyp >= n_hyp) return;
-  const int n = *n_p;
+// One hypothesis: 4 (projective) or 3 (affine) distinct matches drawn by a counter-based hash of (seed, hypothesis, draw),
+// exact minimal solve in normalised coordinates, de-normalised H. Straight-line f64 code without LDS: every lane of a wave
+// runs it on the same inputs and gets the same bits, which is how the scoring wave below obtains its hypothesis.
+__device__ __attribute__((noinline)) bool make_hypothesis(const float4* __restrict__ pts, int n, unsigned seed, int hyp, double cx, double cy, double sc, int affine, double H[9]) {
   const int ns = affine ? 3 : 4;
-  int ok = 0;
-  double H[9];
-  if (n >= ns) {
-    int idx[4] = {0, 0, 0, 0};
-    unsigned ctr = 0;
-    for (int k = 0; k < ns; ++k) {
-      for (;;) {
-        const int cand = (int)(hash_u32(seed ^ hash_u32((unsigned)hyp * 977u + ctr)) % (unsigned)n);
-        ++ctr;
-        bool dup = false;
-        for (int j = 0; j < k; ++j) dup |= idx[j] == cand;
-        if (!dup) { idx[k] = cand; break; }
-      }
-    }
-    double px[4], py[4], qx[4], qy[4];
-    for (int k = 0; k < 4; ++k) {
-      const float4 p = pts[idx[k]];
-      px[k] = ((double)p.x - cx) * sc; py[k] = ((double)p.y - cy) * sc;
-      qx[k] = ((double)p.z - cx) * sc; qy[k] = ((double)p.w - cy) * sc;
-    }
-    double Hn[9];
-    ok = (affine ? affine3(px, py, qx, qy, Hn) : homography4(px, py, qx, qy, Hn)) ? 1 : 0;
-    if (ok) {
-      // de-normalise: H = T^-1 Hn T with T = [[sc,0,-sc*cx],[0,sc,-sc*cy],[0,0,1]]
-      const double is = 1.0 / sc;
-      double M[9];
-      for (int r = 0; r < 3; ++r) {   // M = Hn T
-        M[r * 3 + 0] = Hn[r * 3 + 0] * sc;
-        M[r * 3 + 1] = Hn[r * 3 + 1] * sc;
-        M[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
-      }
-      for (int k = 0; k < 3; ++k) {   // H = T^-1 M, T^-1 = [[is,0,cx],[0,is,cy],[0,0,1]]
-        H[0 + k] = is * M[0 + k] + cx * M[6 + k];
-        H[3 + k] = is * M[3 + k] + cy * M[6 + k];
-        H[6 + k] = M[6 + k];
-      }
-      if (!(fabs(H[8]) > 1e-12)) ok = 0;
+  if (n < ns) return false;
+  int idx[4] = {0, 0, 0, 0};
+  unsigned ctr = 0;
+  for (int k = 0; k < ns; ++k) {
+    for (;;) {
+      const int cand = (int)(hash_u32(seed ^ hash_u32((unsigned)hyp * 977u + ctr)) % (unsigned)n);
+      ++ctr;
+      bool dup = false;
+      for (int j = 0; j < k; ++j) dup |= idx[j] == cand;
+      if (!dup) { idx[k] = cand; break; }
     }
   }
-  ok_out[hyp] = ok;
-  if (ok)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Hout[(size_t)hyp * 9 + k] = H[k];
+  double px[4], py[4], qx[4], qy[4];
+  for (int k = 0; k < 4; ++k) {
+    const float4 p = pts[idx[k]];
+    px[k] = ((double)p.x - cx) * sc; py[k] = ((double)p.y - cy) * sc;
+    qx[k] = ((double)p.z - cx) * sc; qy[k] = ((double)p.w - cy) * sc;
+  }
+  double Hn[9];
+  if (!(affine ? affine3(px, py, qx, qy, Hn) : homography4(px, py, qx, qy, Hn))) return false;
+  // de-normalise: H = T^-1 Hn T with T = [[sc,0,-sc*cx],[0,sc,-sc*cy],[0,0,1]]
+  const double is = 1.0 / sc;
+  double M[9];
+  for (int r = 0; r < 3; ++r) {   // M = Hn T
+    M[r * 3 + 0] = Hn[r * 3 + 0] * sc;
+    M[r * 3 + 1] = Hn[r * 3 + 1] * sc;
+    M[r * 3 + 2] = Hn[r * 3 + 2] - sc * (Hn[r * 3 + 0] * cx + Hn[r * 3 + 1] * cy);
+  }
+  for (int k = 0; k < 3; ++k) {   // H = T^-1 M, T^-1 = [[is,0,cx],[0,is,cy],[0,0,1]]
+    H[0 + k] = is * M[0 + k] + cx * M[6 + k];
+    H[3 + k] = is * M[3 + k] + cy * M[6 + k];
+    H[6 + k] = M[6 + k];
+  }
+  return fabs(H[8]) > 1e-12;
 }
 
-// Scoring, one wave per hypothesis: truncated squared reprojection error (MSAC) over all matches,
-// quantised to 1/1024 px^2 so that the sum is an exact integer regardless of the reduction order.
-__global__ __launch_bounds__(256) void ransac_score_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, int n_hyp,
-                                                           float thr2, const double* __restrict__ Hin, const int* __restrict__ ok_in,
-                                                           long* __restrict__ cost) {
-  const int n = *n_p;
-  const int lane = threadIdx.x & 63;
-  const int hyp = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (hyp >= n_hyp) return;
-  if (!ok_in[hyp]) {
-    if (lane == 0) cost[hyp] = 0x7fffffffffffffffl;
-    return;
-  }
-  double H[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) H[k] = Hin[(size_t)hyp * 9 + k];
-  long acc = 0;
-  for (int i = lane; i < n; i += 64) {
-    const float4 p = pts[i];
-    const double x = p.x, y = p.y;
-    const double w = H[6] * x + H[7] * y + H[8];
-    double e = (double)thr2;
-    if (fabs(w) > 1e-12) {
-      const double iw = 1.0 / w;
-      const double dx = (H[0] * x + H[1] * y + H[2]) * iw - p.z;
-      const double dy = (H[3] * x + H[4] * y + H[5]) * iw - p.w;
-      e = fmin(dx * dx + dy * dy, (double)thr2);
-    }
-    acc += (long)(e * 1024.0 + 0.5);
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) cost[hyp] = acc;
-}
-
-// Device-side result record of one stabilize pass, fetched with a single D2H copy.
+// Device-side result record of one stabilize pass, fetched with a single D2H copy (the match points follow it in the same
+// buffer: StabOut).
 struct StabResult {
   int n_match, best, n_cur, pad;
   double H[9];
 };
 
-__global__ __launch_bounds__(1024) void argmin_kernel(const long* __restrict__ cost, int n, const double* __restrict__ Hin,
-                                                      const int* __restrict__ n_match, const int* __restrict__ n_cur,
+// Hypothesise, score and pick the winner in ONE launch (round 4; three launches before: solve, score, argmin).
+// A wave makes hypothesis `hyp` (every lane the same solve) and scores it: truncated squared reprojection error (MSAC) over
+// all matches, quantised to 1/1024 px^2 so that the sum is an exact integer regardless of the reduction order. The
+// workgroup's 8 costs are reduced in LDS to one key (cost << 16 | hyp: the lowest cost, then the lowest hypothesis index,
+// exactly the order of the former argmin) and folded into `state[0]` with one device-scope atomic minimum; `state[1]` is a
+// ticket: the workgroup that draws the last one knows every minimum has been applied (each workgroup's ticket add depends on
+// the value its minimum returned), reads the winner back with another atomic, re-derives its H from the index, writes the
+// result record and re-arms state for the next pass. Device-scope atomics are performed beyond the per-XCD L2s, so no
+// fence and no other cross-workgroup visibility is involved.
+constexpr unsigned long long kNoHyp = ~0ull;
+__global__ __launch_bounds__(512) void ransac_kernel(const float4* __restrict__ pts, const int* __restrict__ n_p, const int* __restrict__ n_cur_p,
+                                                      unsigned seed, int n_hyp, double cx, double cy, double sc, int affine, float thr2,
+                                                      unsigned long long* __restrict__ state /*[2]: best key (armed: all ones), tickets (0)*/,
                                                       StabResult* __restrict__ res) {
-  __shared__ long s_c[1024];
-  __shared__ int s_i[1024];
-  long bc = 0x7fffffffffffffffl;
-  int bi = -1;
-  for (int i = threadIdx.x; i < n; i += blockDim.x)
-    if (cost[i] < bc) { bc = cost[i]; bi = i; }
-  s_c[threadIdx.x] = bc;
-  s_i[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 512; s >= 1; s >>= 1) {
-    if (threadIdx.x < s) {
-      const long oc = s_c[threadIdx.x + s];
-      const int oi = s_i[threadIdx.x + s];
-      if (oc < s_c[threadIdx.x] || (oc == s_c[threadIdx.x] && oi >= 0 && (s_i[threadIdx.x] < 0 || oi < s_i[threadIdx.x]))) {
-        s_c[threadIdx.x] = oc;
-        s_i[threadIdx.x] = oi;
+  constexpr int kHypPerWg = 8;
+  __shared__ unsigned long long s_key[kHypPerWg];
+  __shared__ int s_last;
+  const int n = *n_p;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hyp = blockIdx.x * kHypPerWg + wv;
+  unsigned long long key = kNoHyp;
+  if (hyp < n_hyp) {
+    double H[9];
+    if (make_hypothesis(pts, n, seed, hyp, cx, cy, sc, affine, H)) {
+      long acc = 0;
+      for (int i = lane; i < n; i += 64) {
+        const float4 p = pts[i];
+        const double x = p.x, y = p.y;
+        const double w = H[6] * x + H[7] * y + H[8];
+        double e = (double)thr2;
+        if (fabs(w) > 1e-12) {
+          const double iw = 1.0 / w;
+          const double dx = (H[0] * x + H[1] * y + H[2]) * iw - p.z;
+          const double dy = (H[3] * x + H[4] * y + H[5]) * iw - p.w;
+          e = fmin(dx * dx + dy * dy, (double)thr2);
+        }
+        acc += (long)(e * 1024.0 + 0.5);
       }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      key = ((unsigned long long)acc << 16) | (unsigned long long)hyp;     // cost < 2^47 (4096 per match at most), hyp < 2^16
     }
-    __syncthreads();
   }
+  if (lane == 0) s_key[wv] = key;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const int b = s_c[0] == 0x7fffffffffffffffl ? -1 : s_i[0];
-    res->n_match = *n_match;
-    res->n_cur = *n_cur;
+    unsigned long long k = s_key[0];
+#pragma unroll
+    for (int i = 1; i < kHypPerWg; ++i) k = min(k, s_key[i]);
+    const unsigned long long before = atomicMin(&state[0], k);
+    const unsigned long long ticket = atomicAdd(&state[1], 1ull + (before & 0ull));   // ordered behind the minimum by the data dependency
+    s_last = ticket == (unsigned long long)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: every minimum has been applied
+  if (wv != 0) return;
+  unsigned long long best_key = 0;
+  if (lane == 0) best_key = atomicMin(&state[0], kNoHyp);                  // a read that cannot be served from a stale cache line
+  best_key = __shfl(best_key, 0, 64);
+  const int b = best_key == kNoHyp ? -1 : (int)(best_key & 0xffffull);
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (b >= 0) make_hypothesis(pts, n, seed, b, cx, cy, sc, affine, H);
+  if (lane == 0) {
+    res->n_match = n;
+    res->n_cur = *n_cur_p;
     res->best = b;
-    for (int k = 0; k < 9; ++k) res->H[k] = b >= 0 ? Hin[(size_t)b * 9 + k] : 0.0;
+    for (int k = 0; k < 9; ++k) res->H[k] = H[k];
+    atomicExch(&state[0], kNoHyp);                                         // re-arm for the next pass on this stream
+    atomicExch(&state[1], 0ull);
   }
 }
 
@@ -1028,15 +1102,19 @@ struct Stabilizer::Impl {
   int n_hyp = 0;
   std::vector<int8_t> pattern;   // [bins][256][4]
 
-  DevBuf d_frame, d_pyr, d_pyr_tab, d_clahe_lut, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_desc, d_xy, d_pattern;
+  DevBuf d_frame, d_pyr, d_pyr_tab, d_clahe_lut, d_rects, d_cand, d_elig, d_counters, d_kp_n, d_kps, d_pattern;
   struct Feat {
     DevBuf kps, desc, xy, n;
     int host_n = 0;
   } ref, cur;
-  DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_mpts, d_nmatch, d_H, d_cost, d_best, d_hok, d_pidx, d_pd1, d_pd2;
-  DevBuf d_res;
-  StabResult* h_res = nullptr;   // pinned
-  float4* h_pts = nullptr;       // pinned
+  DevBuf d_bidx, d_bd, d_sd, d_mq, d_mt, d_md, d_nmatch, d_best, d_pidx, d_pd1, d_pd2, d_rstate, d_mticket;
+  DevBuf d_out;                  // StabResult, then the match points (float4 x slots): one D2H copy per pass
+  uint8_t* h_out = nullptr;      // pinned image of d_out
+  StabResult* h_res = nullptr;   // = h_out
+  float4* h_pts = nullptr;       // = h_out + kOutPts
+  static constexpr size_t kOutPts = (sizeof(StabResult) + 15) / 16 * 16;
+  StabResult* d_res() const { return d_out.as<StabResult>(); }
+  float4* d_mpts() const { return reinterpret_cast<float4*>(d_out.as<uint8_t>() + kOutPts); }
   hipEvent_t done_ev = nullptr;
   hipEvent_t t0_ev = nullptr, t1_ev = nullptr;   // GPU time of the last submitted pass (timing events)
   float last_ms = 0.f;
@@ -1090,6 +1168,44 @@ void Stabilizer::Impl::plan(Levels& L, int max_features, int& slots) {
     L.tab_off[i] = t;
     if (i > 0) t += L.l[i].w + L.l[i].h;
   }
+  // Launch groups of the pyramid: 3 levels, then up to 4 at a time (8 levels: 1-3 and 4-7). GTX_PYR_GROUP=n forces groups of n
+  // (1 = a launch per level, as before round 4). A group whose largest rectangle would not fit 24 KB of LDS is split.
+  {
+    int force = 0;
+    if (const char* e = getenv("GTX_PYR_GROUP")) force = std::max(1, std::min(atoi(e), kPyrGroupMax));
+    L.n_groups = 0;
+    int first = 1;
+    while (first < L.n) {
+      int n = std::min(L.n - first, force ? force : (first == 1 && L.n - 1 > kPyrGroupMax ? 3 : kPyrGroupMax));
+      int need = 0;
+      for (;; --n) {
+        // largest rectangle over the tiles of the group's last level, by the same backward walk as the kernel
+        need = 0;
+        const Level& ll = L.l[first + n - 1];
+        for (int ty = 0; ty < cdiv(ll.h, 16); ++ty)
+          for (int tx = 0; tx < cdiv(ll.w, 64); ++tx) {
+            int x0 = tx * 64, y0 = ty * 16, x1 = std::min(x0 + 63, ll.w - 1), y1 = std::min(y0 + 15, ll.h - 1);
+            for (int k = first + n - 1; k >= first; --k) {
+              need = std::max(need, (x1 - x0 + 1) * (y1 - y0 + 1));
+              const Level &cur = L.l[k], &prev = L.l[k - 1];
+              const bool right = x1 == cur.w - 1, bottom = y1 == cur.h - 1;
+              const unsigned a = pyr_src(x0, prev.w, cur.w), b = pyr_src(x1, prev.w, cur.w), c = pyr_src(y0, prev.h, cur.h), d = pyr_src(y1, prev.h, cur.h);
+              x0 = (int)(a & 0xffff); y0 = (int)(c & 0xffff);
+              x1 = right ? prev.w - 1 : (int)((b & 0xffff) + (b >> 27));
+              y1 = bottom ? prev.h - 1 : (int)((d & 0xffff) + (d >> 27));
+            }
+            need = std::max(need, (x1 - x0 + 1) * (y1 - y0 + 1));
+          }
+        if (need <= 24 * 1024 || n == 1) break;
+      }
+      GTX_CHECK(need <= 64 * 1024, "stabilizer: scale_factor %g needs a %d-byte resize rectangle", cfg.scale_factor, need);
+      L.grp_first[L.n_groups] = first;
+      L.grp_n[L.n_groups] = n;
+      L.grp_buf[L.n_groups] = (need + 15) / 16 * 16;
+      ++L.n_groups;
+      first += n;
+    }
+  }
   GTX_CHECK(max_features * 0.25 < kTopCap, "stabilizer: at most ~8000 features per image are supported");
   pyr_bytes = off;
   cand_total = coff;
@@ -1127,8 +1243,6 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   GTX_HIP(hipMemset(S.d_counters.p, 0, sizeof(int) * (kCounterInts)));
   S.d_kp_n.alloc(sizeof(int) * kPyrLevels);
   S.d_kps.alloc(sizeof(KeyPoint) * slots);
-  S.d_desc.alloc(32 * (size_t)slots);
-  S.d_xy.alloc(sizeof(float2) * slots);
   for (Impl::Feat* f : {&S.ref, &S.cur}) {
     f->kps.alloc(sizeof(KeyPoint) * slots);
     f->desc.alloc(32 * (size_t)slots);
@@ -1138,19 +1252,23 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   }
   S.d_bidx.alloc(4 * slots); S.d_bd.alloc(4 * slots); S.d_sd.alloc(4 * slots);
   S.d_mq.alloc(4 * slots); S.d_mt.alloc(4 * slots); S.d_md.alloc(4 * slots);
-  S.d_mpts.alloc(sizeof(float4) * slots);
   S.d_nmatch.alloc(sizeof(int));
   S.n_hyp = std::max(64, std::min(cfg.ransac_max_iter, 2048));
-  S.d_H.alloc(sizeof(double) * 9 * S.n_hyp);
-  S.d_cost.alloc(sizeof(long) * S.n_hyp);
   S.d_best.alloc(sizeof(int));
-  S.d_res.alloc(sizeof(StabResult));
-  GTX_HIP(hipHostMalloc((void**)&S.h_res, sizeof(StabResult)));
-  GTX_HIP(hipHostMalloc((void**)&S.h_pts, sizeof(float4) * slots));
+  S.d_out.alloc(Impl::kOutPts + sizeof(float4) * slots);
+  GTX_HIP(hipHostMalloc((void**)&S.h_out, Impl::kOutPts + sizeof(float4) * slots));
+  S.h_res = reinterpret_cast<StabResult*>(S.h_out);
+  S.h_pts = reinterpret_cast<float4*>(S.h_out + Impl::kOutPts);
+  S.d_mticket.alloc(sizeof(unsigned));
+  GTX_HIP(hipMemset(S.d_mticket.p, 0, sizeof(unsigned)));
+  S.d_rstate.alloc(2 * sizeof(unsigned long long));
+  {
+    const unsigned long long armed[2] = {kNoHyp, 0ull};
+    GTX_HIP(hipMemcpy(S.d_rstate.p, armed, sizeof armed, hipMemcpyHostToDevice));
+  }
   GTX_HIP(hipEventCreateWithFlags(&S.done_ev, wait_event_flags(false)));
   GTX_HIP(hipEventCreate(&S.t0_ev));
   GTX_HIP(hipEventCreate(&S.t1_ev));
-  S.d_hok.alloc(sizeof(int) * S.n_hyp);
   {
     const size_t parts = (size_t)cdiv(S.slots_ref, kMatchChunk) * S.slots_cur;
     S.d_pidx.alloc(4 * parts); S.d_pd1.alloc(4 * parts); S.d_pd2.alloc(4 * parts);
@@ -1158,7 +1276,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
   stabilizer_pattern_table(S.pattern);   // rotated sampling patterns
   S.d_pattern.alloc(S.pattern.size());
   GTX_HIP(hipMemcpy(S.d_pattern.p, S.pattern.data(), S.pattern.size(), hipMemcpyHostToDevice));
-  GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 12));
+  GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 12));
   {
     const Levels& L = S.lev_cur;
     std::vector<unsigned> tab;
@@ -1176,8 +1294,7 @@ Stabilizer::Stabilizer(gtx_ctx* ctx, const gtx_stab_config& cfg) : impl_(new Imp
 
 Stabilizer::~Stabilizer() {
   if (impl_) {
-    if (impl_->h_res) (void)hipHostFree(impl_->h_res);
-    if (impl_->h_pts) (void)hipHostFree(impl_->h_pts);
+    if (impl_->h_out) (void)hipHostFree(impl_->h_out);
     if (impl_->done_ev) (void)hipEventDestroy(impl_->done_ev);
     if (impl_->t0_ev) (void)hipEventDestroy(impl_->t0_ev);
     if (impl_->t1_ev) (void)hipEventDestroy(impl_->t1_ev);
@@ -1217,10 +1334,28 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
     clahe_dev(L.l[0].img, gh, gw, d_clahe_lut.as<uint8_t>(), pyr, s);
     L.l[0].img = pyr;
   }
-  for (int i = 1; i < L.n; ++i) {
-    const unsigned* tx = d_pyr_tab.as<unsigned>() + L.tab_off[i];
-    hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[i].w, 1024), L.l[i].h), dim3(256), 0, s, L.l[i - 1].img, L.l[i - 1].w,
-                       pyr + L.l[i].off, L.l[i].w, tx, tx + L.l[i].w);
+  for (int g = 0; g < L.n_groups; ++g) {
+    const int first = L.grp_first[g], n = L.grp_n[g];
+    if (n == 1) {                                   // a single level: the plain per-level kernel (4 pixels per thread, dword stores)
+      const unsigned* tx = d_pyr_tab.as<unsigned>() + L.tab_off[first];
+      hipLaunchKernelGGL(pyr_resize_kernel, dim3(cdiv(L.l[first].w, 1024), L.l[first].h), dim3(256), 0, s, L.l[first - 1].img, L.l[first - 1].w,
+                         pyr + L.l[first].off, L.l[first].w, tx, tx + L.l[first].w);
+      continue;
+    }
+    PyrGroup G{};
+    G.n = n;
+    G.src = L.l[first - 1].img;
+    G.sw = L.l[first - 1].w;
+    G.sh = L.l[first - 1].h;
+    for (int k = 0; k < n; ++k) {
+      G.dst[k] = pyr + L.l[first + k].off;
+      G.w[k] = L.l[first + k].w;
+      G.h[k] = L.l[first + k].h;
+      G.tx[k] = d_pyr_tab.as<unsigned>() + L.tab_off[first + k];
+    }
+    G.buf_bytes = L.grp_buf[g];
+    const Level& ll = L.l[first + n - 1];
+    hipLaunchKernelGGL(pyr_group_kernel, dim3(cdiv(ll.w, 64), cdiv(ll.h, 16)), dim3(256), 2 * (size_t)G.buf_bytes, s, G);
   }
   int n_rects = 0;
   if (cfg.mask_use && boxes && n > 0) {
@@ -1231,22 +1366,18 @@ void Stabilizer::Impl::extract(const uint8_t* gray_dev, const float* boxes, int 
       n_rects = (int)rects.size();
     }
   }
-  // counters: [cand_n 8 x 16 sub-lists][elig_n 8][score histogram 8 x 256]; zero here: compact_kernel clears them at the end of every pass
+  // counters: [cand_n 8 x 16 sub-lists][elig_n 8][score histogram 8 x 256]; zero here: describe_kernel clears them at the end of every pass
   int* cand_n = d_counters.as<int>();
   int* elig_n = cand_n + kPyrLevels * kCandSub;
   int* hist = elig_n + kPyrLevels;
   hipLaunchKernelGGL(fast_detect_kernel, dim3(L.n_tiles), dim3(256), 0, s, d_rects.as<int4>(), n_rects, gw, gh, L, cfg.fast_threshold,
                      d_cand.as<Cand>(), cand_n, hist);
   hipLaunchKernelGGL(harris_kernel, dim3(512), dim3(256), 0, s, L, d_cand.as<Cand>(), cand_n, hist, d_elig.as<Cand>(), elig_n);
-  hipLaunchKernelGGL(select_sort_kernel, dim3(L.n), dim3(1024), kSortCap * 12, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
-                     d_kp_n.as<int>());
-  hipLaunchKernelGGL(select_topn_kernel, dim3(L.n), dim3(1024), 0, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
+  hipLaunchKernelGGL(select_kernel, dim3(L.n), dim3(1024), kSortCap * 12, s, d_elig.as<Cand>(), elig_n, L, d_kps.as<KeyPoint>(),
                      d_kp_n.as<int>());
   hipLaunchKernelGGL(describe_kernel, dim3(cdiv(slots, 4)), dim3(256), 0, s, L, d_kps.as<KeyPoint>(), d_kp_n.as<int>(),
-                     d_pattern.as<int8_t>(), d_desc.as<unsigned long long>(), d_xy.as<float2>(), 1.0f / cfg.downsample_ratio, slots);
-  hipLaunchKernelGGL(compact_kernel, dim3(8), dim3(256), 0, s, L, d_kp_n.as<int>(), d_kps.as<KeyPoint>(),
-                     d_desc.as<unsigned long long>(), d_xy.as<float2>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(),
-                     out.xy.as<float2>(), out.n.as<int>(), d_counters.as<int>(), kCounterInts);
+                     d_pattern.as<int8_t>(), out.kps.as<KeyPoint>(), out.desc.as<unsigned long long>(), out.xy.as<float2>(), out.n.as<int>(),
+                     1.0f / cfg.downsample_ratio, slots, d_counters.as<int>(), kCounterInts);
   GTX_HIP(hipGetLastError());
 }
 
@@ -1397,22 +1528,15 @@ void Stabilizer::Impl::submit_match() {
   const int max_q = slots_cur, n_chunks = cdiv(slots_ref, kMatchChunk);
   hipLaunchKernelGGL(match_kernel, dim3(cdiv(slots_cur, 256), n_chunks), dim3(256), 0, s, cur.desc.as<unsigned long long>(),
                      cur.n.as<int>(), ref.desc.as<unsigned long long>(), ref.n.as<int>(), max_q, d_pidx.as<int>(), d_pd1.as<int>(),
-                     d_pd2.as<int>());
-  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, cur.n.as<int>(), ref.n.as<int>(), max_q, d_pidx.as<int>(),
-                     d_pd1.as<int>(), d_pd2.as<int>(), cfg.filter_ratio, cfg.filter_type == 1 ? 1 : 0, cur.xy.as<float2>(), ref.xy.as<float2>(), d_bidx.as<int>(),
-                     d_bd.as<int>(), d_sd.as<int>(), d_mq.as<int>(), d_mt.as<int>(), d_md.as<int>(), d_mpts.as<float4>(),
+                     d_pd2.as<int>(), d_mticket.as<unsigned>(), cfg.filter_ratio, cfg.filter_type == 1 ? 1 : 0, cur.xy.as<float2>(), ref.xy.as<float2>(),
+                     d_bidx.as<int>(), d_bd.as<int>(), d_sd.as<int>(), d_mq.as<int>(), d_mt.as<int>(), d_md.as<int>(), d_mpts(),
                      d_nmatch.as<int>());
   const double cx = fw / 2.0, cy = fh / 2.0, sc = 2.0 / fw;
   const float thr2 = cfg.ransac_threshold * cfg.ransac_threshold;
-  hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), cfg.seed,
-                     n_hyp, cx, cy, sc, cfg.affine ? 1 : 0, d_H.as<double>(), d_hok.as<int>());
-  hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_mpts.as<float4>(), d_nmatch.as<int>(), n_hyp,
-                     thr2, d_H.as<double>(), d_hok.as<int>(), d_cost.as<long>());
-  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_nmatch.as<int>(),
-                     cur.n.as<int>(), d_res.as<StabResult>());
+  hipLaunchKernelGGL(ransac_kernel, dim3(cdiv(n_hyp, 8)), dim3(512), 0, s, d_mpts(), d_nmatch.as<int>(), cur.n.as<int>(), cfg.seed, n_hyp,
+                     cx, cy, sc, cfg.affine ? 1 : 0, thr2, d_rstate.as<unsigned long long>(), d_res());
   GTX_HIP(hipGetLastError());
-  GTX_HIP(hipMemcpyAsync(h_res, d_res.p, sizeof(StabResult), hipMemcpyDeviceToHost, s));
-  GTX_HIP(hipMemcpyAsync(h_pts, d_mpts.p, sizeof(float4) * slots_cur, hipMemcpyDeviceToHost, s));
+  GTX_HIP(hipMemcpyAsync(h_out, d_out.p, kOutPts + sizeof(float4) * slots_cur, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipEventRecord(t1_ev, s));
   GTX_HIP(hipEventRecord(done_ev, s));
   pending = true;
@@ -1556,16 +1680,15 @@ bool ransac_homography(int device, hipStream_t s, const float4* d_pts, int n_mat
   *n_inliers = 0;
   if (n_match < 4) return false;
   GTX_HIP(hipSetDevice(device));
-  DevBuf d_n(sizeof(int) * 2), d_H(sizeof(double) * 9 * n_hyp), d_ok(sizeof(int) * n_hyp), d_cost(sizeof(long) * n_hyp), d_res(sizeof(StabResult));
+  DevBuf d_n(sizeof(int) * 2), d_state(2 * sizeof(unsigned long long)), d_res(sizeof(StabResult));
   const int two[2] = {n_match, n_match};
+  const unsigned long long armed[2] = {kNoHyp, 0ull};
   GTX_HIP(hipMemcpyAsync(d_n.p, two, sizeof two, hipMemcpyHostToDevice, s));
+  GTX_HIP(hipMemcpyAsync(d_state.p, armed, sizeof armed, hipMemcpyHostToDevice, s));
   const double cx = frame_w / 2.0, cy = frame_h / 2.0, sc = 2.0 / frame_w;
-  hipLaunchKernelGGL(ransac_solve_kernel, dim3(cdiv(n_hyp, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), seed, n_hyp, cx, cy, sc,
-                     0, d_H.as<double>(), d_ok.as<int>());
-  hipLaunchKernelGGL(ransac_score_kernel, dim3(cdiv(n_hyp * 64, 256)), dim3(256), 0, s, d_pts, d_n.as<int>(), n_hyp, threshold * threshold,
-                     d_H.as<double>(), d_ok.as<int>(), d_cost.as<long>());
-  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, d_cost.as<long>(), n_hyp, d_H.as<double>(), d_n.as<int>(), d_n.as<int>() + 1,
-                     d_res.as<StabResult>());
+  GTX_CHECK(n_hyp <= 65536, "ransac: at most 65536 hypotheses (got %d)", n_hyp);
+  hipLaunchKernelGGL(ransac_kernel, dim3(cdiv(n_hyp, 8)), dim3(512), 0, s, d_pts, d_n.as<int>(), d_n.as<int>() + 1, seed, n_hyp, cx, cy, sc, 0,
+                     threshold * threshold, d_state.as<unsigned long long>(), d_res.as<StabResult>());
   GTX_HIP(hipGetLastError());
   StabResult R;
   std::vector<float4> pts(n_match);
