@@ -80,31 +80,6 @@ struct ConvProblem {
   int front_h, front_w_px;
 };
 
-// Chain mode (conv_igemm_split.hip, the CHAIN instantiations; DT_F32S, single-member launches): consecutive layers of one
-// stream's forward pass as launches that are NOT ordered against each other by the queue (the detector alternates two
-// streams) but by readiness counters per 8 x 16 output tile -- the next layer's workgroups are on the chip while this
-// layer's last ones run, and start as soon as the tiles under their patch are complete, instead of after the whole launch
-// has drained and the next one has been dispatched (~6 us per layer with nothing running at batch 1). Hand-off as
-// MI355X_MICROARCH.md prescribes (table "hand-offs measured with sc1 loads", first row): a producer workgroup writes its
-// output with write-through (`sc1`) 16-byte stores, every storing wave waits for its stores (`s_waitcnt vmcnt(0)`), and
-// behind a workgroup barrier ONE lane adds 1 to the tile's counter (device-scope atomic); a consumer polls the counters
-// of the tiles its input footprint touches with `sc1` loads (lanes of wave 0, one tile each) until they reach `target`,
-// joins a workgroup barrier, and loads every activation byte with `sc1` 16-byte loads. Weights and biases are not handed
-// off (plain loads). Counters are zeroed on the stream in front of the chain, so `target` = the producer's cout tiles.
-constexpr int kChainDeps = 6;
-constexpr int kChainPad = 32;   // ints between two tile counters: a counter per 128-byte line, so that the polls of one tile's waiters
-                                // and the adds to its neighbours do not queue on one line (one memory channel)
-struct ChainDep {
-  const int* ready;      // the producer launch's counters, [N][tiles_y][tiles_x] x kChainPad ints; null = unused entry
-  int tiles_x, tiles_y;
-  int target;            // a tile is complete when its counter has reached this (the producer's n_ct)
-  int kind;              // 1: tiles under this workgroup's input patch (`in`), 2: the tile of the half-resolution source (`in2`),
-};                       // 3: the same tile as the output (`res`)
-struct ConvChain {
-  int* ready_out;        // this launch's counters, [N][tiles_y][tiles_x] x kChainPad ints (null: nobody waits for this launch tile by tile)
-  ChainDep dep[kChainDeps];
-};
-
 constexpr int kMaxGroup = 8;
 struct ConvGroup {
   ConvProblem p[kMaxGroup];
@@ -148,9 +123,6 @@ double conv_flops(const ConvProblem& p, int ks);
 
 // conv_igemm_split.hip
 void conv_split_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
-// the same launch in chain mode (single member, no split-K / front / post stage); logical block = hardware block (dispatch
-// order = tile order: a waiting workgroup's producers were dispatched before it)
-void conv_split_launch_chained(const ConvGroup& g, const ConvConfig& cfg, const ConvChain& chain, hipStream_t stream);
 // second launch of a split-K convolution (ConvProblem::ksplit > 1): partial sums -> activation -> residual -> out
 void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t stream);
 // bytes of ConvProblem::partial a problem needs (0 when ksplit <= 1)

@@ -41,9 +41,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define GTXS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#ifndef GTXS_CHAIN_SLEEP
-#define GTXS_CHAIN_SLEEP 16     // x 64 clocks between two polls of a waiting workgroup (chain mode)
-#endif
 
 // Diagnostic builds (`make stamp`) force-include csrc/diag/conv_split_diag.hpp, which defines these two hooks as clock
 // stamps around the K loop; the shipped object has none.
@@ -142,27 +139,10 @@ constexpr int split_min_waves() {
   return WN == 1 ? 5 : 4;
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_rsrc(const void* base) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(p, 0, base ? 0xffffffffu : 0u, 0x00020000);   // raw buffer; a null base drops every access
-}
-constexpr int kSc1 = 16;                     // cache-policy immediate of the raw buffer builtins: sc1
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, kSc1);
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const uint4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(uint4v{v.x, v.y, v.z, v.w}, r, (int)byte_off, 0, kSc1);
-}
-
-template <int KS, int STRIDE, int WN, int CPR, int WM, int FRONT, int CHAIN = 0>
-__device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvChain* chain_p = nullptr) {
+template <int KS, int STRIDE, int WN, int CPR, int WM, int FRONT>
+__device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
   static_assert(!FRONT || (KS == 3 && STRIDE == 2 && WM == 1 && CPR == 2), "front stage: 3x3 stride 2, 16-channel chunks");
-  static_assert(!CHAIN || FRONT == 0, "chain mode: no front stage");
   constexpr int TH = Tile::TH, TW = Tile::TW, BN = Tile::BN, PW = Tile::PW, RB = Tile::RB, KC = Tile::KC;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,9 +164,8 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
   // (shared halo) meet in one L2 -- and the ranges hold equal work (ConvGroup::xcd_begin). Surplus blocks of the shorter
   // ranges leave here.
   const int xcd = blockIdx.x & 7;
-  // chain mode: logical block = hardware block, so that tiles are dispatched in tile order (a consumer's producers first)
-  const int L = CHAIN ? (int)blockIdx.x : g.xcd_begin[xcd] + (int)(blockIdx.x >> 3);
-  if (L >= (CHAIN ? g.total_blocks : g.xcd_begin[xcd + 1])) return;
+  const int L = g.xcd_begin[xcd] + (int)(blockIdx.x >> 3);
+  if (L >= g.xcd_begin[xcd + 1]) return;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
@@ -206,9 +185,6 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
   const int n = t2 / P.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;
-
-  __amdgpu_buffer_rsrc_t rs_in = chain_rsrc(nullptr), rs_in2 = chain_rsrc(nullptr), rs_res = chain_rsrc(nullptr), rs_out = chain_rsrc(nullptr);
-  if constexpr (CHAIN != 0) { rs_in = chain_rsrc(P.in); rs_in2 = chain_rsrc(P.in2); rs_res = chain_rsrc(P.res); rs_out = chain_rsrc(P.out); }
 
   const float* __restrict__ in = static_cast<const float*>(P.in);
   const float* __restrict__ in2 = static_cast<const float*>(P.in2);
@@ -246,7 +222,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
 
   uint4 pre_a[Tile::PATCH_SLOTS], pre_b[Tile::PATCH_SLOTS];
   uint4 pre_w[Tile::W_SLOTS];
-#define GTXS_PREFETCH_P(CHUNK)                                                               \
+#define GTXS_PREFETCH(CHUNK)                                                                 \
   {                                                                                          \
     const int c0__ = (CHUNK) * KC;                                                           \
     const bool up__ = KS == 1 && c0__ < P.c_split;   /* uniform: this chunk's channels come from the upsampled source */ \
@@ -254,29 +230,14 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
       uint4 va__ = make_uint4(0, 0, 0, 0), vb__ = make_uint4(0, 0, 0, 0);                    \
       if (goff[s] >= 0) {                                                                    \
-        if constexpr (CHAIN == 2) {                      /* handed-off bytes: sc1 loads only */  \
-          if (up__) {                                                                        \
-            const unsigned o__ = (unsigned)(goff2[s] + c0__) * 4u;                           \
-            va__ = ld_sc1_b128(rs_in2, o__);                                                 \
-            vb__ = ld_sc1_b128(rs_in2, o__ + 16u);                                           \
-          } else {                                                                           \
-            const unsigned o__ = (unsigned)(goff[s] + c0__) * 4u;                            \
-            va__ = ld_sc1_b128(rs_in, o__);                                                  \
-            vb__ = ld_sc1_b128(rs_in, o__ + 16u);                                            \
-          }                                                                                  \
-        } else {                                                                             \
         const uint4* src__ = reinterpret_cast<const uint4*>(up__ ? in2 + goff2[s] + c0__ : in + goff[s] + c0__); \
         va__ = src__[0];                                                                     \
         vb__ = src__[1];                                                                     \
-        }                                                                                    \
       }                                                                                      \
       pre_a[s] = va__;                                                                       \
       pre_b[s] = vb__;                                                                       \
     }                                                                                        \
     }                                                                                        \
-  }
-#define GTXS_PREFETCH_W(CHUNK)                                                               \
-  {                                                                                          \
     const uint4* w__ = wsrc + (size_t)(CHUNK) * Tile::W_CHUNKS;                              \
     _Pragma("unroll") for (int s = 0; s < Tile::W_SLOTS; ++s) {                              \
       uint4 v__ = make_uint4(0, 0, 0, 0);                                                    \
@@ -284,7 +245,6 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
       pre_w[s] = v__;                                                                        \
     }                                                                                        \
   }
-#define GTXS_PREFETCH(CHUNK) { GTXS_PREFETCH_P(CHUNK) GTXS_PREFETCH_W(CHUNK) }
 #define GTXS_COMMIT()                                                                        \
   {                                                                                          \
     if constexpr (FRONT == 0) {                                                                  \
@@ -457,54 +417,6 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
     GTXS_PREFETCH(c_begin)
     GTXS_LOAD_BIAS()
     GTXS_FRONT_TILES()
-  } else if constexpr (CHAIN != 0) {
-    // chain mode: everything that does not depend on the producers -- the first chunk's weight taps, the bias -- is requested
-    // BEFORE the wait and arrives during it; only the patch loads sit behind the hand-off
-    GTXS_PREFETCH_W(c_begin)
-    GTXS_LOAD_BIAS()
-  // ---- wait until every tile this workgroup reads is complete (see ConvChain) ----
-  if constexpr (CHAIN != 0) {
-    if (wave == 0) {
-      const ConvChain& C = *chain_p;
-      const int d = lane / 9, j = lane - 9 * d;              // lane -> (dependency, one of up to 3 x 3 tiles)
-      const int* addr = nullptr;
-      int target = 0;
-      if (d < kChainDeps && C.dep[d].ready != nullptr) {
-        const ChainDep D = C.dep[d];
-        int y_lo, y_hi, x_lo, x_hi;
-        if (D.kind == 1) {
-          y_lo = max(iy0, 0) >> 3; y_hi = min(iy0 + Tile::PH - 1, P.H - 1) >> 3;
-          x_lo = max(ix0, 0) >> 4; x_hi = min(ix0 + Tile::PW - 1, P.W - 1) >> 4;
-        } else if (D.kind == 2) {
-          y_lo = y_hi = ty >> 1; x_lo = x_hi = tx >> 1;
-        } else {
-          y_lo = y_hi = ty; x_lo = x_hi = tx;
-        }
-        const int yy = y_lo + j / 3, xx = x_lo + j % 3;
-        if (yy <= min(y_hi, D.tiles_y - 1) && xx <= min(x_hi, D.tiles_x - 1)) {
-          addr = D.ready + (((size_t)n * D.tiles_y + yy) * D.tiles_x + xx) * kChainPad;
-          target = D.target;
-        }
-      }
-      for (;;) {
-        const bool wait = addr != nullptr && __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;
-        if (__builtin_amdgcn_ballot_w64(wait) == 0) break;
-        __builtin_amdgcn_s_sleep(GTXS_CHAIN_SLEEP);
-      }
-      if constexpr (CHAIN == 1) {
-        // acquire: this CU's L1 forgets what it holds; the plain loads below are then served by L2 / memory, where the
-        // producers' write-through stores have arrived. (L2 cannot hold an older copy of a handed-off line: the lines of a
-        // tile are first read by this launch after the tile is complete -- plan_chains() admits only tensors whose pixels
-        // are whole 128-byte lines, so no line straddles two tiles -- and what earlier passes left was invalidated when this
-        // launch started.)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    __syncthreads();
-  }
-
-    GTXS_PREFETCH_P(c_begin)
   } else {
     GTXS_PREFETCH(c_begin)
     GTXS_LOAD_BIAS()
@@ -713,10 +625,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
         }
         if (res_p) {                               // uniform; the swaps below need every lane
           uint4 rc = make_uint4(0, 0, 0, 0);       // lane l: the group's hi chunk, lane l + 32: its lo chunk
-          if (res && cl < cvalid) {
-            if constexpr (CHAIN == 2) rc = ld_sc1_b128(rs_res, (unsigned)(pix * P.res_cstride + P.res_coff + ct * BN + cl) * 4u);
-            else rc = *reinterpret_cast<const uint4*>(res + cl);
-          }
+          if (res && cl < cvalid) rc = *reinterpret_cast<const uint4*>(res + cl);
           const auto sx = __builtin_amdgcn_permlane32_swap(rc.x, rc.z, false, false);   // -> (hi, lo) of this lane's channels 0, 1
           const auto sy = __builtin_amdgcn_permlane32_swap(rc.y, rc.w, false, false);   // ... and 2, 3
           const unsigned hw[2] = {sx[0], sy[0]}, lw[2] = {sx[1], sy[1]};
@@ -744,20 +653,12 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g, const ConvCh
       const int py = oy0 + 2 * (WM * wave + m) + (p >> 4), px = ox0 + (p & 15);
       const uint4 val = *reinterpret_cast<const uint4*>(stg + p * PITCH + q * 16);
       if (py < P.Ho && px < P.Wo && (q >> 1) * 8 < cvalid) {     // cvalid is a multiple of 16: whole groups
-        const size_t eo = (((size_t)n * P.Ho + py) * P.Wo + px) * o_cstride + o_coff + ct * BN + q * 4;
-        if constexpr (CHAIN != 0) st_sc1_b128(rs_out, (unsigned)eo * 4u, val);     // write-through: consumers read it before this launch ends
-        else *reinterpret_cast<uint4*>(o_base + eo) = val;
+        float* dst = o_base + (((size_t)n * P.Ho + py) * P.Wo + px) * o_cstride + o_coff + ct * BN + q * 4;
+        *reinterpret_cast<uint4*>(dst) = val;
       }
     }
   }
   if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
-  if constexpr (CHAIN != 0) {
-    // signal: every storing wave has waited for its stores, then ONE lane adds to the tile's counter
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0 && chain_p->ready_out != nullptr)
-      __hip_atomic_fetch_add(chain_p->ready_out + (((size_t)n * P.tiles_y + ty) * P.tiles_x + tx) * kChainPad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   GTXS_DIAG_EXIT()
 }
 
@@ -765,19 +666,6 @@ template <int KS, int STRIDE, int WN, int CPR, int WM>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR, WM>()))))
 void conv_igemm_split_kernel(const ConvGroup g) {
   conv_split_body<KS, STRIDE, WN, CPR, WM, 0>(g);
-}
-
-// chain mode (ConvChain): same body, readiness counters instead of the queue's launch order
-#ifndef GTXS_CHAIN_SLEEP
-#define GTXS_CHAIN_SLEEP 16     // x 64 clocks between two polls of a waiting workgroup
-#endif
-#ifndef GTXS_CHAIN_MODE
-#define GTXS_CHAIN_MODE 1      // 1: consumer = poll + agent acquire + plain (L2-served) loads; 2: poll + `sc1` loads of every byte
-#endif
-template <int KS, int STRIDE, int WN, int CPR, int WM>
-__global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu((split_min_waves<KS, STRIDE, WN, CPR, WM>()))))
-void conv_igemm_split_chain_kernel(const ConvGroup g, const ConvChain chain) {
-  conv_split_body<KS, STRIDE, WN, CPR, WM, 0, GTXS_CHAIN_MODE>(g, &chain);
 }
 
 // model.0 (the stem) + model.1 (3x3 stride 2) [+ model.2.cv1, the post stage] as one launch: see FrontTile
@@ -844,18 +732,6 @@ void launch_t(const ConvGroup& g, hipStream_t stream) {
     GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
   });
   hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), Tile::LDS_BYTES, stream, g);
-  GTX_HIP(hipGetLastError());
-}
-
-template <int KS, int STRIDE, int WN, int CPR, int WM>
-void launch_chain_t(const ConvGroup& g, const ConvChain& chain, hipStream_t stream) {
-  using Tile = SplitTile<KS, STRIDE, WN, CPR, WM>;
-  auto kern = conv_igemm_split_chain_kernel<KS, STRIDE, WN, CPR, WM>;
-  static std::once_flag once;
-  std::call_once(once, [&] {
-    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
-  });
-  hipLaunchKernelGGL(kern, dim3(g.total_blocks), dim3(256), Tile::LDS_BYTES, stream, g, chain);
   GTX_HIP(hipGetLastError());
 }
 
@@ -977,18 +853,6 @@ void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
 
 #undef GTX_CASE
   fail(-3, "conv (split-f16x3): no kernel for ks=%d stride=%d bn=%d kc=%d th=%d", c.ks, c.stride, c.bn, c.kc, c.th);
-}
-
-void conv_split_launch_chained(const ConvGroup& g, const ConvConfig& c, const ConvChain& chain, hipStream_t s) {
-  const ConvProblem& p = g.p[0];
-  GTX_CHECK(g.count == 1 && p.ksplit <= 1 && !p.post_w && !p.front_img && !p.out_plain, "conv: chain mode takes plain single-member split launches");
-  const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;
-#define GTX_CASE(KS, ST, WN, CPR, WM) \
-  if (c.ks == KS && c.stride == ST && wn == WN && cpr == CPR && wm == WM) return launch_chain_t<KS, ST, WN, CPR, WM>(g, chain, s);
-  GTX_CASE(3, 1, 1, 2, 1) GTX_CASE(3, 1, 2, 2, 1) GTX_CASE(3, 2, 1, 2, 1) GTX_CASE(3, 2, 2, 2, 1)
-  GTX_CASE(1, 1, 1, 4, 1) GTX_CASE(1, 1, 2, 4, 1) GTX_CASE(1, 1, 1, 2, 1) GTX_CASE(1, 1, 2, 2, 1)
-#undef GTX_CASE
-  fail(-3, "conv (split-f16x3, chain mode): no kernel for ks=%d stride=%d bn=%d kc=%d th=%d", c.ks, c.stride, c.bn, c.kc, c.th);
 }
 
 }  // namespace gtx

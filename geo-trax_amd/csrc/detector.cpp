@@ -22,8 +22,6 @@ Detector::Detector(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cf
   GTX_HIP(hipSetDevice(ctx->device));
   for (auto& e : ev_) GTX_HIP(hipEventCreateWithFlags(&e, wait_event_flags(true)));
   for (auto& e : ev_up_) GTX_HIP(hipEventCreate(&e));
-  chain_mode_ = cfg.chain > 0 ? 1 : (cfg.chain == 0 ? 0 : -1);
-  if (const char* e = getenv("GTX_CONV_CHAIN")) chain_mode_ = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : chain_mode_);
 }
 
 Detector::~Detector() {
@@ -36,9 +34,6 @@ Detector::~Detector() {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : trace_ev_)
     if (e) (void)hipEventDestroy(e);
-  for (auto& e : chain_ev_)
-    if (e) (void)hipEventDestroy(e);
-  if (chain_stream_) (void)hipStreamDestroy(chain_stream_);
   if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
 }
 
@@ -557,88 +552,6 @@ void Detector::set_batch(int nb) {
     }
   }
   cur_nb_ = nb;
-  plan_chains();
-}
-
-// Which launches run in chain mode at the current batch size, and what each of them waits for. A launch qualifies when it
-// is a single split-f16x3 convolution without split-K / fused stages / plain output and has at most kChainMaxBlocks
-// workgroups: two launches of a chain are in flight at a time (one per stream), the younger one's workgroups may be
-// dispatched first and wait on the chip, and the older one must always find free slots next to them (768 on the chip).
-// A chain is a run of at least two such launches; every source tensor of a launch (input, half-resolution input,
-// residual) that an earlier launch OF THE SAME CHAIN writes becomes a dependency on that launch's tile counters; sources
-// written before the chain are complete when the chain forks.
-void Detector::plan_chains() {
-  chain_segs_.clear();
-  chain_info_.assign(ops_.size(), ConvChain{});
-  const bool on = chain_mode_ == 1 || (chain_mode_ < 0 && cfg_.max_batch == 1);
-  if (!on || conv_dtype_ != DT_F32S) return;
-  constexpr int kChainMaxBlocks = 512;
-  auto eligible = [&](const Op& o) {
-    if (o.kind != Op::CONV || o.cfg.variant != 2 || o.grp.count != 1) return false;
-    const ConvProblem& p = o.grp.p[0];
-    // every handed-off tensor: pixels are whole 128-byte lines (32 channels or a multiple), so that no cache line holds
-    // bytes of two tiles (conv_igemm_split.hip, the consumer's acquire)
-    auto whole_lines = [](const void* ptr, int cstride, int coff) { return ptr == nullptr || (cstride % 32 == 0 && coff % 32 == 0); };
-    return p.ksplit <= 1 && !p.post_w && !p.front_img && !p.out_plain && o.grp.total_blocks <= kChainMaxBlocks &&
-           whole_lines(p.in, p.in_cstride, p.in_coff) && whole_lines(p.c_split > 0 ? p.in2 : nullptr, p.in2_cstride, p.in2_coff) &&
-           whole_lines(p.res, p.res_cstride, p.res_coff) && whole_lines(p.out, p.out_cstride, p.out_coff) && p.Cin % 32 == 0 && p.Cout % 32 == 0;
-  };
-  auto tiles_of = [&](const Op& o) { const ConvProblem& p = o.grp.p[0]; return (size_t)p.N * p.tiles_y * p.tiles_x * kChainPad; };
-  // dependencies of op k on the ops [first, k) of its chain; false when they do not fit a ConvChain
-  std::vector<size_t> ctr_off(ops_.size(), 0);
-  auto deps_of = [&](size_t first, size_t k, ConvChain& C) {
-    const ConvProblem& p = ops_[k].grp.p[0];
-    struct Src { const void* ptr; int c0, c1, kind; };
-    const Src srcs[3] = {{p.in, p.in_coff + p.c_split, p.in_coff + p.Cin, 1}, {p.c_split > 0 ? p.in2 : nullptr, p.in2_coff, p.in2_coff + p.c_split, 2},
-                         {p.res, p.res_coff, p.res_coff + p.Cout, 3}};
-    int nd = 0;
-    for (const Src& sr : srcs) {
-      if (!sr.ptr || sr.c1 <= sr.c0) continue;
-      for (size_t j = first; j < k; ++j) {
-        const ConvProblem& q = ops_[j].grp.p[0];
-        if (q.out != sr.ptr || q.out_coff >= sr.c1 || q.out_coff + q.Cout <= sr.c0) continue;
-        if (sr.kind == 3 && (q.tiles_x != p.tiles_x || q.tiles_y != p.tiles_y)) return false;
-        if (nd == kChainDeps) return false;
-        C.dep[nd++] = ChainDep{reinterpret_cast<const int*>(ctr_off[j]), q.tiles_x, q.tiles_y, q.n_ct, sr.kind};   // offset for now, pointer below
-      }
-    }
-    return true;
-  };
-  size_t total = 0;
-  for (size_t i = 0; i < ops_.size();) {
-    if (!eligible(ops_[i])) { ++i; continue; }
-    size_t j = i;
-    while (j < ops_.size() && eligible(ops_[j])) {
-      ConvChain C{};
-      ctr_off[j] = total;                     // tentatively
-      if (!deps_of(i, j, C)) break;
-      chain_info_[j] = C;
-      total += tiles_of(ops_[j]);
-      ++j;
-    }
-    if (j - i >= 2) chain_segs_.push_back({i, j - i});
-    else for (size_t k = i; k < j; ++k) chain_info_[k] = ConvChain{};
-    i = std::max(j, i + 1);
-  }
-  if (chain_segs_.empty()) return;
-  GTX_HIP(hipSetDevice(ctx_->device));
-  if (chain_counter_ints_ < total) {
-    chain_counters_.alloc(total * sizeof(int));
-    chain_counter_ints_ = total;
-  }
-  int* base = chain_counters_.as<int>();
-  for (const ChainSeg& sg : chain_segs_)
-    for (size_t k = sg.first; k < sg.first + sg.count; ++k) {
-      chain_info_[k].ready_out = base + ctr_off[k];
-      for (ChainDep& d : chain_info_[k].dep)
-        if (d.kind != 0) d.ready = base + reinterpret_cast<size_t>(d.ready);
-    }
-  if (!chain_stream_) GTX_HIP(hipStreamCreateWithFlags(&chain_stream_, hipStreamNonBlocking));
-  while (chain_ev_.size() < 2 * chain_segs_.size()) {
-    hipEvent_t e;
-    GTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    chain_ev_.push_back(e);
-  }
 }
 
 void Detector::finalize() {
@@ -723,24 +636,7 @@ void Detector::run_forward(int nb, hipStream_t s, bool traced) {
       GTX_HIP(hipGraphLaunch(graph_exec_, s));
       return;
     }
-    if (chain_segs_.empty()) {
-      for (const Op& op : ops_) run_op(op, nb, s);
-      return;
-    }
-    // chains: counters to zero, then per chain fork -> launches alternately on the two streams -> join
-    GTX_HIP(hipMemsetAsync(chain_counters_.p, 0, chain_counter_ints_ * sizeof(int), s));
-    size_t i = 0;
-    for (size_t c = 0; c < chain_segs_.size(); ++c) {
-      const ChainSeg& sg = chain_segs_[c];
-      for (; i < sg.first; ++i) run_op(ops_[i], nb, s);
-      GTX_HIP(hipEventRecord(chain_ev_[2 * c], s));
-      GTX_HIP(hipStreamWaitEvent(chain_stream_, chain_ev_[2 * c], 0));
-      for (size_t k = 0; k < sg.count; ++k, ++i)
-        conv_split_launch_chained(ops_[i].grp, ops_[i].cfg, chain_info_[i], (k & 1) ? chain_stream_ : s);
-      GTX_HIP(hipEventRecord(chain_ev_[2 * c + 1], chain_stream_));
-      GTX_HIP(hipStreamWaitEvent(s, chain_ev_[2 * c + 1], 0));
-    }
-    for (; i < ops_.size(); ++i) run_op(ops_[i], nb, s);
+    for (const Op& op : ops_) run_op(op, nb, s);
     return;
   }
   for (size_t i = 0; i < ops_.size(); ++i) {

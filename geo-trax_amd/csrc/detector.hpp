@@ -116,19 +116,6 @@ class Detector {
   void set_batch(int nb);
 
   void fall_back_to_exact();
-  // Chain mode (conv_igemm.hpp: ConvChain): runs of consecutive small split-f16x3 convolutions launched alternately on the
-  // context's stream and a second one, ordered tile by tile through readiness counters instead of launch by launch by the
-  // queue. Planned per batch size (set_batch); GTX_CONV_CHAIN=1 / 0 forces it on / off (default: on for single-frame
-  // passes of a detector that was created for batch 1 -- BASELINE configs[1] -- where a launch is mostly fixed cost).
-  void plan_chains();
-  struct ChainSeg { size_t first, count; };
-  std::vector<ChainSeg> chain_segs_;
-  std::vector<ConvChain> chain_info_;     // per op of ops_ (ready_out == nullptr and no deps: not chained)
-  DevBuf chain_counters_;
-  size_t chain_counter_ints_ = 0;
-  hipStream_t chain_stream_ = nullptr;
-  std::vector<hipEvent_t> chain_ev_;      // fork, join per segment
-  int chain_mode_ = -1;                   // -1 auto, 0 off, 1 on
   void release_hidden_layers();     // after the fusions: buffers only the stand-alone forms of fused layers write
   void materialize_hidden_layers(); // ... come back on the first layer_output() that asks for one of them
   struct Hidden { void* token; size_t bytes; void* real; };

@@ -32,7 +32,7 @@ class DetConfig(C.Structure):
         ("imgsz", C.c_int), ("conf", C.c_float), ("iou", C.c_float), ("max_det", C.c_int),
         ("agnostic_nms", C.c_int), ("half", C.c_int), ("rect", C.c_int), ("nc", C.c_int),
         ("n_classes", C.c_int), ("classes", C.c_int * 80), ("max_batch", C.c_int),
-        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int), ("chain", C.c_int),
+        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int),
     ]
 
 

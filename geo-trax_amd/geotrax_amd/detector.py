@@ -45,14 +45,11 @@ class Detector:
     def __init__(self, tensors: dict[str, np.ndarray], frame_hw: tuple[int, int], *, imgsz: int = 1920,
                  conf: float = 0.25, iou: float = 0.7, max_det: int = 1000, classes=None,
                  agnostic_nms: bool = True, half: bool = False, rect: bool = False, max_batch: int = 1,
-                 fp32_split: bool | None = None, chain: bool | None = None, ctx: _lib.Context | None = None):
+                 fp32_split: bool | None = None, ctx: _lib.Context | None = None):
         """half=False (the reference default, default.yaml:245) computes at fp32 grade: fp32 activations in HBM and
         either the exact-fp32 MFMA (fp32_split=False) or the split-f16x3 convolutions (fp32_split=True: hi + lo fp16
         operands, three fp16 MFMAs per product, fp32 accumulate; csrc/conv_igemm_split.hip). fp32_split=None takes
-        GTX_FP32_SPLIT from the environment (default: FP32_SPLIT_DEFAULT).
-        chain (fp32_split only; include/gtx.h: gtx_det_config.chain): runs of consecutive small convolutions ordered tile by
-        tile instead of launch by launch. None: the library decides (on for max_batch == 1). Pass False when several detectors
-        run at the same time on one device (the engine does)."""
+        GTX_FP32_SPLIT from the environment (default: FP32_SPLIT_DEFAULT)."""
         if fp32_split is None:
             fp32_split = os.environ.get("GTX_FP32_SPLIT", "1" if FP32_SPLIT_DEFAULT else "0") == "1"
         self.fp32_split = bool(fp32_split) and not half
@@ -61,8 +58,7 @@ class Detector:
         nc = int(tensors["model.22.cv3.0.2.weight"].shape[0])
         cfg = DetConfig(imgsz=imgsz, conf=conf, iou=iou, max_det=max_det, agnostic_nms=int(agnostic_nms),
                         half=int(half), rect=int(rect), nc=nc, n_classes=0, max_batch=max_batch,
-                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split),
-                        chain=-1 if chain is None else int(bool(chain)))
+                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split))
         if classes is not None:
             classes = list(classes)
             cfg.n_classes = len(classes)

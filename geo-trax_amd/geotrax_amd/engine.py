@@ -90,8 +90,6 @@ class ExtractEngine:
         # (no sharing at all) is slower for the default run (1040 vs 1230): the stabilizers then crowd the detector.
         self.dets = list(detectors or [])
         n_dets = max(int(det_streams), len(self.dets), 1)
-        if n_dets > 1:                   # chained launches (Detector(chain=...)): one chained detector per device at a time
-            det_kw = {**det_kw, "chain": False}
         n_stab = max(1, min(int(stab_streams), 4 * n_dets * self.B - 2)) if stab_kw is not None else 0   # frames in flight < gray ring lifetime
         self.tracker = tracker
         self.gmc = None

@@ -39,7 +39,7 @@ extern "C" {
  * 3: gtx_stab_config.{affine, filter_type} appended; gtx_tracker_config.type 3 (deepocsort).
  * 4: gtx_op_linear_assignment and gtx_detector_saturated added; GTX_F32S activations live in HBM as (hi, lo) fp16 pairs
  *    (host arrays handed to gtx_op_* stay plain fp32).
- * 5: gtx_feeder_* (read-ahead frame source) added; gtx_det_config.chain appended; a saturating split-f16x3 pass is
+ * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened). */
 #define GTX_ABI_VERSION 5
 
@@ -197,12 +197,6 @@ typedef struct gtx_det_config {
                      * activations in HBM, every conv operand split into hi + lo fp16 parts in LDS, three fp16
                      * MFMAs per product with fp32 accumulation (22 significand bits per operand; same
                      * detections as the exact path within the fp32 tolerance, ~3/16 of its matrix cost) */
-  int chain;        /* fp32_split only. Single-frame passes are ~46 short launches whose fixed cost (dispatch, a mostly empty last
-                     * round of workgroups) is a quarter of the pass on one stream. 1: runs of consecutive small convolutions are
-                     * launched alternately on two streams and ordered tile by tile through readiness counters (write-through
-                     * stores, `sc1` loads) instead of launch by launch -- bit-identical results; at most ONE chained detector
-                     * may run on a device at a time (its waiting workgroups and another chained detector's could fill the chip
-                     * between them). 0: off. -1: the library decides (on for max_batch == 1; GTX_CONV_CHAIN=0 / 1 overrides) */
 } gtx_det_config;
 
 int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out);

@@ -1,5 +1,5 @@
 """One detector, single-frame passes at 3840x2160 / 1920x1920 (BASELINE configs[1]), for a rocprofv3 kernel trace of the
-launch-by-launch order against chain mode (GTX_CONV_CHAIN=0 / 1):
+launch-by-launch order (and, at commit db87c7b, of chain mode: GTX_CONV_CHAIN=0 / 1 -- profiles/r04_chain_mode.txt):
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/chain_probe.py [passes]
     python tools/chain_probe.py --read DIR        -> one pass as a table: start offset, duration, gap to the previous end, queue
 """
