@@ -998,6 +998,23 @@ def main():
                                             "open file to the aggregated tables, read-ahead feeder; measured by a child process, secondary, not `value`"}
             except Exception as e:
                 out["from_file"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and dist is None and not extract and B == 1 and args.det_streams == 1 and not args.no_f16_line:
+            # BASELINE configs[1] is "batch=1": one frame per pass. With ONE pass in flight a pass is ~46 short launches and the chip
+            # idles between them (latency-bound: `value`); with two or three single-frame passes in flight on streams of their own
+            # the same kernels fill each other's gaps. Secondary key, child processes.
+            import subprocess
+
+            out["pipelined"] = {"note": "the same single-frame passes with 2 and 3 of them in flight (detector streams), frames/s; secondary, not `value`"}
+            for ns in (2, 3):
+                cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", "detect", "--batch", "1", "--det-streams", str(ns), "--steps", str(args.steps), "--warmup",
+                       str(args.warmup), "--no-cpu-baseline", "--no-profile", "--no-f16-line", "--frames", str(args.frames), "--detections", str(args.detections),
+                       "--imgsz", str(args.imgsz), "--rect", str(args.rect)] + (["--fp32", args.fp32] if args.fp32 else [])
+                try:
+                    pp = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    out["pipelined"][f"{ns}_streams"] = json.loads([ln for ln in pp.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+                except Exception as e:
+                    out["pipelined"][f"{ns}_streams"] = None
+                    out["pipelined"]["error"] = f"{type(e).__name__}: {e}"
         out["host"] = {"cores": host_cores(), "threads_per_rank": engine.host_threads + (1 if (sharded and extract and rank == 0) else 0) + 1,
                        "note": "engine stage threads (blocking waits: they sleep while the GPU works) + the main thread" +
                                (" + rank 0's tracker replay thread" if (sharded and extract) else "")}

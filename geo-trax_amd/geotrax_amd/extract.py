@@ -260,7 +260,44 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
                         yield group if opened else (group, prev_ptr)    # a run does not continue the previous batch: (re)start the GMC
                         opened, group = True, []
 
-        for r in engine.run(batches()):
+        def fed_batches():
+            """The same batches through read-ahead feeders (geotrax_amd.feeder): the rank's frames, run after run, are read and
+            uploaded beside the pipeline instead of by frame_at() on the detector stage thread; the priming frames (BoT-SORT: the
+            frame before each run) come through a second, one-frame feeder whose ring replaces the explicit one above."""
+            from .feeder import FrameFeeder
+
+            path, kind, offsets = reader.raw_layout()
+            B, n_dets = engine.B, len(engine.dets)
+            mine = [f for start, stop in runs for f in range(start, stop)]
+            primes = [start - 1 for start, stop in runs if with_gmc and start > first]
+            fd = FrameFeeder(reader.frame_hw, kind=kind, batch=B, ring=max(int(eng_cfg.get('read_ahead_batches', 3)), 1) + n_dets + 1, device=local)
+            state['feeders'] = [fd]
+            fd.open_file(path, offsets[mine], n_threads=int(eng_cfg.get('reader_threads', 3)))
+            main_it = fd.batches(n_dets)
+            prime_it = None
+            if primes:
+                pf = FrameFeeder(reader.frame_hw, kind=kind, batch=1, ring=n_prime + 1, device=local)
+                state['feeders'].append(pf)
+                pf.open_file(path, offsets[primes], n_threads=1)
+                prime_it = pf.batches(n_prime)              # a slot is written again n_prime runs later, as with the ring above
+            for start, stop in runs:
+                prev_ptr = None
+                if do_stab and not state.get('have_ref'):
+                    engine.set_reference(frame_at(first))
+                    state['have_ref'] = True
+                if with_gmc and start > first:
+                    pb = next(prime_it)
+                    pb.wait_on(None)                        # long since resident: it was requested when the feeder opened
+                    prev_ptr = pb.ptr
+                for k in range(-(-(stop - start) // B)):
+                    b = next(main_it)
+                    yield b if k else (b, prev_ptr)
+
+        layout_ok = hasattr(reader, 'raw_layout') and reader.raw_layout() is not None
+        lengths_ok = all((stop - start) % engine.B == 0 for start, stop in runs[:-1])       # batches must not span two runs
+        use_feeder = (layout_ok and lengths_ok and fail_at is None and os.environ.get("GTX_FEEDER", "1") != "0" and eng_cfg.get('read_ahead', True) is not False
+                      and (not engine.stabs or engine.use_dev_gray))
+        for r in engine.run(fed_batches() if use_feeder else batches()):
             yield D.pack_frame_record(max_det, r.xyxy, r.conf, r.cls, None if r.H_fallback else r.H, r.gmc, with_gmc=with_gmc)
 
     # The source must open on EVERY rank, with the same frame count, before anybody enters a round's collectives: a rank that
@@ -292,6 +329,8 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         logger.error(f"Error processing: '{args.source}' due to: {e}")
         return (np.empty((0, 12), dtype=np.float32), np.empty((0, 10))) if rank == 0 else None
     finally:
+        for fd_ in state.get('feeders', []):
+            fd_.close()
         if 'prime' in state:
             for p_ in state['prime'][1]:
                 state['prime'][0].dev_free(p_)

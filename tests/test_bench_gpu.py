@@ -80,14 +80,16 @@ def test_configs3_extract_then_georeference_as_one_chained_run():
 
 
 def test_configs1_detector_only_batch1_one_stream():
-    """BASELINE configs[1]: YOLOv8s HIP inference only on 3840x2160 frames, batch 1, one stream."""
+    """BASELINE configs[1]: YOLOv8s HIP inference only on 3840x2160 frames, batch 1, one stream (`value`: one pass in flight,
+    latency-bound); the same single-frame passes with two and three in flight ride along under `pipelined`."""
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "detect", "--batch", "1", "--det-streams", "1", "--steps", "60",
-                        "--warmup", "10", "--no-cpu-baseline", "--no-profile", "--no-f16-line"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--warmup", "10", "--no-cpu-baseline", "--no-profile"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = _last_json(p.stdout)
     c = d["config"]
     assert "configs[1]" in c["workload"] and c["frames_per_step"] == 1 and c["net_input"] == [1920, 1920] and c["half"] is False
     assert d["steps"] == 60 and d["value"] > 200 and c["detections_per_frame"] > 100
+    assert d["pipelined"]["2_streams"] > d["value"] and d["pipelined"]["3_streams"] > d["value"]
 
 
 def test_bench_distributed_code_path_over_rccl_with_one_rank():
