@@ -5,7 +5,10 @@
 #include "split_format.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <functional>
+#include <mutex>
 
 namespace gtx {
 
@@ -74,6 +77,34 @@ View Detector::new_view(int h, int w, int c) {
 }
 
 namespace {
+// Packed weight images are a pure function of (tensor bytes, tile configuration). An engine builds several detectors from
+// the same tensors (one per stream) and a run builds engines video after video: the image is made once per process and
+// shared (packing YOLOv8s takes ~0.15 s of host time per detector, most of what creating one costs).
+struct PackedWeights {
+  std::vector<uint8_t> bytes;
+  float acc_scale = 1.f;
+};
+std::shared_ptr<const PackedWeights> packed_weights(const HostTensor& w, int cout, int cin, const ConvConfig& cfg,
+                                                    const std::function<PackedWeights()>& make) {
+  static std::mutex mu;
+  static std::map<std::array<uint64_t, 4>, std::shared_ptr<const PackedWeights>> cache;
+  uint64_t h = 1469598103934665603ull;                       // FNV-1a over the tensor's bytes, 8 at a time
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(w.data.data());
+  for (size_t i = 0; i < w.data.size() / 2; ++i) h = (h ^ q[i]) * 1099511628211ull;
+  if (w.data.size() & 1) h = (h ^ (uint64_t)__builtin_bit_cast(uint32_t, w.data.back())) * 1099511628211ull;
+  const std::array<uint64_t, 4> key = {h, (uint64_t)w.data.size(), ((uint64_t)cout << 32) | (uint64_t)cin,
+                                       ((uint64_t)cfg.dtype << 40) | ((uint64_t)cfg.ks << 32) | ((uint64_t)cfg.bn << 16) | ((uint64_t)cfg.kc << 4) | (uint64_t)cfg.variant};
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  auto made = std::make_shared<const PackedWeights>(make());
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache.size() > 1024) cache.clear();                    // a handful of models at most; never grows without bound
+  return cache.emplace(key, std::move(made)).first->second;
+}
+
 // OIHW -> OHWI
 std::vector<float> to_ohwi(const HostTensor& t) {
   const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
@@ -110,9 +141,14 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   op.kind = Op::CONV;
   op.name = name;
   op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, force_bn_);
-  const std::vector<float> ohwi = to_ohwi(w);
-  float acc_scale = 1.f;
-  const std::vector<uint8_t> packed = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &acc_scale);
+  const auto pw = packed_weights(w, cout, cin, op.cfg, [&] {
+    PackedWeights r;
+    const std::vector<float> ohwi = to_ohwi(w);
+    r.bytes = pack_conv_weights(ohwi.data(), cout, cin, op.cfg, &r.acc_scale);
+    return r;
+  });
+  const float acc_scale = pw->acc_scale;
+  const std::vector<uint8_t>& packed = pw->bytes;
   void* dw = alloc(packed.size());
   GTX_HIP(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
   float* db = nullptr;
