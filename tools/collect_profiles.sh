@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects everything profiles/r03_* is made from into gpurun_out/final/ (run on an MI355X; then tools/pmc_summary.py
+# Collects everything profiles/rNN_* is made from into gpurun_out/final/ (run on an MI355X; then tools/pmc_summary.py
 # and plain copies turn it into the committed files; delete the local gpurun_out/final first, gpurun only ever adds files). rocprofv3 counter passes are separate runs with --kernel-trace only.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -11,6 +11,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $CM
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sq1 -- python3 $R/tools/op_profile.py 2 f32s 3 > $O/sq1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq2 -- python3 $R/tools/op_profile.py 2 f32s 3 > $O/sq2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_iso -- python3 $R/tools/op_profile.py 2 f32s 5 > $O/op_profile_under_rocprof.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_stab -- python3 $R/tools/stab_profile.py 60 > $O/stab_profile.txt 2>&1
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.log
 python bench.py --tracker botsort --no-cpu-baseline --no-f16-line > $O/bench_botsort.json 2>/dev/null
@@ -18,7 +19,9 @@ python bench.py --tracker ocsort --no-cpu-baseline --no-f16-line > $O/bench_ocso
 python bench.py --tracker deepocsort --no-cpu-baseline --no-f16-line > $O/bench_deepocsort.json 2>/dev/null
 python bench.py --fp32 exact --no-cpu-baseline --no-f16-line --steps 60 > $O/bench_fp32_exact.json 2>/dev/null
 python bench.py --half 1 --no-cpu-baseline > $O/bench_f16.json 2>/dev/null
-python bench.py --workload detect --batch 1 --det-streams 1 --no-cpu-baseline --no-f16-line > $O/bench_detect_b1.json 2>/dev/null
+python bench.py --workload detect --batch 1 --det-streams 1 --no-cpu-baseline > $O/bench_detect_b1.json 2>/dev/null     # carries `pipelined` (2 / 3 passes in flight)
+python bench.py --workload cli > $O/bench_cli.json 2>/dev/null                                                          # the product from a .y4m / .npy file
+python bench.py --host-frames --no-cpu-baseline --no-f16-line --no-profile > $O/bench_host_frames.json 2>/dev/null
 python bench.py --workload detect --no-cpu-baseline --no-f16-line > $O/bench_detect_2x2.json 2>/dev/null
 python bench.py --workload register > $O/bench_register.json 2>/dev/null
 python bench.py --workload georef > $O/bench_georef.json 2>/dev/null
