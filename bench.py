@@ -500,6 +500,7 @@ def bench_cli(args):
     det, weights, n_det, n_cand = calibrated_detector(ctx, frames[0], args, args.detections)
     dt = "f16" if args.half else ("f32s" if det.fp32_split else "f32")
     det.close()
+    ctx.close()                                                # the product loop below creates its streams in its own order, like the CLI does
     root = Path(args.cli_dir) if args.cli_dir else Path(tempfile.mkdtemp(prefix="gtx_bench_cli_"))
     root.mkdir(parents=True, exist_ok=True)
     wpath = root / "weights.safetensors"

@@ -33,6 +33,7 @@
 
 struct gtx_feeder {
   gtx_ctx ctx;                       // device + the copy stream
+  bool own_stream = true;            // false: the stream belongs to the context the feeder was created on
   int h = 0, w = 0, kind = 0;        // kind 0: BGR u8 frames, 1: I420 planes
   int B = 1, ring = 4;
   size_t src_bytes = 0, bgr_bytes = 0;
@@ -72,6 +73,7 @@ struct gtx_feeder {
     for (auto e : ev) (void)hipEventDestroy(e);
     if (pinned) (void)hipHostFree(pinned);
     if (fd >= 0) ::close(fd);
+    if (!own_stream) ctx.stream = nullptr;   // ~gtx_ctx must not destroy a borrowed stream
   }
 
   void set_error(const std::string& what) {
@@ -157,26 +159,42 @@ using gtx::guarded;
 
 extern "C" {
 
-int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, gtx_feeder** out) {
-  return guarded([&] {
-    if (!out) gtx::fail(GTX_ERR_INVALID, "out is NULL");
-    if (h <= 0 || w <= 0 || (kind != 0 && kind != 1) || batch < 1 || ring < 2)
-      gtx::fail(GTX_ERR_INVALID, "feeder: bad geometry (h %d, w %d, kind %d, batch %d, ring %d)", h, w, kind, batch, ring);
-    GTX_HIP(hipSetDevice(device));
-    std::unique_ptr<gtx_feeder> f(new gtx_feeder);
-    f->ctx.device = device;
-    f->h = h, f->w = w, f->kind = kind, f->B = batch, f->ring = ring;
-    f->bgr_bytes = (size_t)h * w * 3;
-    f->src_bytes = kind == 1 ? (size_t)h * w + 2 * (size_t)((h + 1) / 2) * ((w + 1) / 2) : f->bgr_bytes;
+namespace {
+void feeder_create(int device, hipStream_t borrowed, int h, int w, int kind, int batch, int ring, gtx_feeder** out) {
+  if (!out) gtx::fail(GTX_ERR_INVALID, "out is NULL");
+  if (h <= 0 || w <= 0 || (kind != 0 && kind != 1) || batch < 1 || ring < 2)
+    gtx::fail(GTX_ERR_INVALID, "feeder: bad geometry (h %d, w %d, kind %d, batch %d, ring %d)", h, w, kind, batch, ring);
+  GTX_HIP(hipSetDevice(device));
+  std::unique_ptr<gtx_feeder> f(new gtx_feeder);
+  f->ctx.device = device;
+  f->h = h, f->w = w, f->kind = kind, f->B = batch, f->ring = ring;
+  f->bgr_bytes = (size_t)h * w * 3;
+  f->src_bytes = kind == 1 ? (size_t)h * w + 2 * (size_t)((h + 1) / 2) * ((w + 1) / 2) : f->bgr_bytes;
+  if (borrowed) {
+    f->ctx.stream = borrowed;
+    f->own_stream = false;
+  } else {
     GTX_HIP(hipStreamCreateWithFlags(&f->ctx.stream, hipStreamNonBlocking));
-    const size_t slots = (size_t)ring * batch;
-    GTX_HIP(hipHostMalloc((void**)&f->pinned, slots * f->src_bytes, hipHostMallocDefault));
-    f->dev.alloc(slots * f->bgr_bytes);
-    if (kind == 1) f->dev_yuv.alloc(slots * f->src_bytes);
-    f->ev.resize((size_t)ring);
-    for (auto& e : f->ev) GTX_HIP(hipEventCreateWithFlags(&e, gtx::wait_event_flags(false)));
-    f->slot_frame.assign(slots, -1);
-    *out = f.release();
+  }
+  const size_t slots = (size_t)ring * batch;
+  GTX_HIP(hipHostMalloc((void**)&f->pinned, slots * f->src_bytes, hipHostMallocDefault));
+  f->dev.alloc(slots * f->bgr_bytes);
+  if (kind == 1) f->dev_yuv.alloc(slots * f->src_bytes);
+  f->ev.resize((size_t)ring);
+  for (auto& e : f->ev) GTX_HIP(hipEventCreateWithFlags(&e, gtx::wait_event_flags(false)));
+  f->slot_frame.assign(slots, -1);
+  *out = f.release();
+}
+}  // namespace
+
+int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, gtx_feeder** out) {
+  return guarded([&] { feeder_create(device, nullptr, h, w, kind, batch, ring, out); });
+}
+
+int gtx_feeder_create_on(gtx_ctx* copy_ctx, int h, int w, int kind, int batch, int ring, gtx_feeder** out) {
+  return guarded([&] {
+    if (!copy_ctx) gtx::fail(GTX_ERR_INVALID, "copy_ctx is NULL");
+    feeder_create(copy_ctx->device, copy_ctx->stream, h, w, kind, batch, ring, out);
   });
 }
 

@@ -149,6 +149,7 @@ _SIGNATURES = {
     "gtx_warp_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gtx_yuv420_to_bgr_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gtx_feeder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gtx_feeder_create_on": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_feeder_destroy": (None, [_P]),
     "gtx_feeder_open_file": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int]),
     "gtx_feeder_open_push": (C.c_int, [_P]),

@@ -77,10 +77,12 @@ def parse_prio(text: str | None) -> tuple[int, int]:
 class ExtractEngine:
     def __init__(self, weights: dict, frame_hw: tuple[int, int], det_kw: dict, tracker: Tracker | None, stab_kw: dict | None, *,
                  device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool = False,
-                 detectors: list[Detector] | None = None):
+                 detectors: list[Detector] | None = None, feeder_stream: bool = False):
         """det_kw: Detector keywords (imgsz, conf, iou, max_det, classes, agnostic_nms, half, rect). tracker None: raw
         detections pass through (ids None; the frame-sharded bench tracks later on rank 0). stab_kw None: no
-        stabilization. `detectors`: already-built Detector objects to adopt (same weights, own contexts)."""
+        stabilization. `detectors`: already-built Detector objects to adopt (same weights, own contexts). `feeder_stream`: also
+        create `self.feeder_ctx`, the context a read-ahead feeder's transfers run on (geotrax_amd.feeder.FrameFeeder(ctx=...)), at
+        its place in the stream-creation order."""
         self.device = _lib.default_device() if device is None else device
         self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
         self.B = max(int(batch), 1)
@@ -95,8 +97,14 @@ class ExtractEngine:
         self.gmc = None
         self.stabs = []
         self._spare = []                 # contexts created only to steer the stream -> hardware-queue mapping
-        # order of stream creation: d = detector, g = GMC, s = stabilizer, x = unused stream (takes a queue slot)
-        default = ["d"] + ["s"] * n_stab + ["d"] * (n_dets - 1)
+        # order of stream creation: d = detector, g = GMC, s = stabilizer, x = unused stream (takes a queue slot), f = the
+        # read-ahead feeder's copy stream
+        self.feeder_ctx = None
+        # With a feeder its copy stream is created second, right behind the first detector's: of the places swept on MI355X
+        # (profiles/r04_feeder_queue.txt) this is the one where the transfers delay the detectors least -- from a 4K .y4m
+        # 840-918 frames/s (600-frame clip, three runs) against 755-805 with the copy stream created last behind a spare stream
+        # and 838-877 with it created last; BoT-SORT: 876 against 830-836.
+        default = ["d"] + (["f"] if feeder_stream else []) + ["s"] * n_stab + ["d"] * (n_dets - 1)
         if gmc:
             # The GMC's two streams come last, behind one spare stream. The runtime hands a new stream to the least-loaded
             # hardware queue (rocprofv3's Queue_Id column shows the result); with this order the two detectors keep a queue
@@ -122,6 +130,8 @@ class ExtractEngine:
                 self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device, p_stab), **stab_kw))
             elif tok == "x":
                 self._spare.append(_lib.Context(self.device))
+            elif tok == "f" and feeder_stream and self.feeder_ctx is None:
+                self.feeder_ctx = _lib.Context(self.device)
         while len(self.dets) < n_dets:
             self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device, p_det), **det_kw))
         while len(self.stabs) < n_stab:
@@ -130,6 +140,8 @@ class ExtractEngine:
             from .gmc import GMC
 
             self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device, p_stab))
+        if feeder_stream and self.feeder_ctx is None:
+            self.feeder_ctx = _lib.Context(self.device)
         self.use_dev_gray = bool(self.stabs) and float(stab_kw.get("downsample_ratio", 0.5)) == 0.5
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
@@ -183,6 +195,9 @@ class ExtractEngine:
             self.gmc.close()
         for c in self._spare:
             c.close()
+        if self.feeder_ctx is not None:
+            self.feeder_ctx.close()
+            self.feeder_ctx = None
         self.dets, self.stabs, self.gmc, self._spare = [], [], None, []
 
     # ---- feeding

@@ -199,7 +199,8 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         n_total = reader.frame_count if last is None else min(reader.frame_count, last + 1)
         assert n_total == state['n_frames']
         engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, None, stab_kw, device=local, batch=int(eng_cfg.get('batch', 2)),
-                               det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)), gmc=with_gmc)
+                               det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)), gmc=with_gmc,
+                               feeder_stream=os.environ.get("GTX_FEEDER", "1") != "0" and eng_cfg.get('read_ahead', True) is not False)
         state['engine'] = engine
         seekable = hasattr(reader, 'seek')
         cursor = {'pos': 0, 'last': None}                    # sequential sources: next frame read() returns, and the one before it
@@ -270,7 +271,8 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
             B, n_dets = engine.B, len(engine.dets)
             mine = [f for start, stop in runs for f in range(start, stop)]
             primes = [start - 1 for start, stop in runs if with_gmc and start > first]
-            fd = FrameFeeder(reader.frame_hw, kind=kind, batch=B, ring=max(int(eng_cfg.get('read_ahead_batches', 3)), 1) + n_dets + 1, device=local)
+            fd = FrameFeeder(reader.frame_hw, kind=kind, batch=B, ring=max(int(eng_cfg.get('read_ahead_batches', 3)), 1) + n_dets + 1, device=local,
+                             ctx=engine.feeder_ctx)
             state['feeders'] = [fd]
             fd.open_file(path, offsets[mine], n_threads=int(eng_cfg.get('reader_threads', 3)))
             main_it = fd.batches(n_dets)
@@ -368,14 +370,14 @@ def _read_ahead_batches(reader, engine, eng_cfg: dict, first: int, last, frame_n
     stop = reader.frame_count if last is None else min(reader.frame_count, last + 1)
     if layout is not None:
         path, kind, offsets = layout
-        feeder = FrameFeeder(reader.frame_hw, kind=kind, batch=engine.B, ring=ring, device=engine.device)
+        feeder = FrameFeeder(reader.frame_hw, kind=kind, batch=engine.B, ring=ring, device=engine.device, ctx=engine.feeder_ctx)
         feeder.open_file(path, offsets[first:stop], n_threads=int(eng_cfg.get('reader_threads', 3)))
         frame_nums.extend(range(first, max(stop, first)))
     else:
         from .frames import Y4mReader
 
         feeder = FrameFeeder(reader.frame_hw, kind="i420" if isinstance(reader, Y4mReader) else "bgr", batch=engine.B, ring=ring,
-                             device=engine.device)
+                             device=engine.device, ctx=engine.feeder_ctx)
 
         def numbered():
             for k, f in enumerate(_frames_in_range(reader, first, last)):
@@ -407,7 +409,8 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
         tracker = model._make_tracker(ul.get('tracker', {'tracker_type': 'botsort'}))
         engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, tracker, stab_kw, batch=int(eng_cfg.get('batch', 2)),
                                det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)),
-                               gmc=model._gmc_method is not None)
+                               gmc=model._gmc_method is not None,
+                               feeder_stream=os.environ.get("GTX_FEEDER", "1") != "0" and eng_cfg.get('read_ahead', True) is not False)
         model._det = engine.dets[0]                        # introspection (names, gray) keeps working on the model object
         t_engine = time.time()
         batches, feeder = _read_ahead_batches(reader, engine, eng_cfg, first, last, frame_nums, logger)

@@ -32,15 +32,23 @@ class DeviceBatch:
 
 
 class FrameFeeder:
-    def __init__(self, frame_hw: tuple[int, int], *, kind: str = "bgr", batch: int = 2, ring: int = 6, device: int | None = None):
+    def __init__(self, frame_hw: tuple[int, int], *, kind: str = "bgr", batch: int = 2, ring: int = 6, device: int | None = None,
+                 ctx: _lib.Context | None = None):
+        """ctx: a context whose stream carries the transfers (the engine creates one at a chosen place of its stream order:
+        which hardware queue the copy stream shares decides whose launches wait behind the transfers); None: a stream of the
+        feeder's own on `device`."""
         self.lib = _lib.load()
-        self.device = _lib.default_device() if device is None else device
+        self.ctx = ctx
+        self.device = ctx.device if ctx is not None else (_lib.default_device() if device is None else device)
         self.h, self.w = int(frame_hw[0]), int(frame_hw[1])
         self.kind = {"bgr": 0, "i420": 1}[kind]
         self.batch, self.ring = int(batch), int(ring)
         self.src_bytes = self.h * self.w * 3 if self.kind == 0 else self.h * self.w + 2 * ((self.h + 1) // 2) * ((self.w + 1) // 2)
         h = C.c_void_p()
-        check(self.lib.gtx_feeder_create(self.device, self.h, self.w, self.kind, self.batch, self.ring, C.byref(h)))
+        if ctx is not None:
+            check(self.lib.gtx_feeder_create_on(ctx.handle, self.h, self.w, self.kind, self.batch, self.ring, C.byref(h)))
+        else:
+            check(self.lib.gtx_feeder_create(self.device, self.h, self.w, self.kind, self.batch, self.ring, C.byref(h)))
         self.handle = h
         self._pusher = None
         self._push_error = None

@@ -107,6 +107,11 @@ int gtx_yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv_dptr, int h, int w, void
  * Thread safety: next / wait / release from one consumer thread, push / finish from one producer thread. */
 typedef struct gtx_feeder gtx_feeder;
 int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, gtx_feeder** out);
+/* Same, the transfers and conversions run on copy_ctx's stream instead of a stream of the feeder's own (the context must
+ * outlive the feeder and be used for nothing else meanwhile). HIP deals streams to a few hardware queues in creation order and
+ * streams that share a queue run in order: a caller that creates its streams in a deliberate order (geotrax_amd.engine does)
+ * decides this way whose launches the transfers may delay. */
+int gtx_feeder_create_on(gtx_ctx* copy_ctx, int h, int w, int kind, int batch, int ring, gtx_feeder** out);
 void gtx_feeder_destroy(gtx_feeder* f);
 int gtx_feeder_open_file(gtx_feeder* f, const char* path, const int64_t* offsets, int64_t n_frames, int n_threads);
 int gtx_feeder_open_push(gtx_feeder* f);
