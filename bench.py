@@ -671,8 +671,6 @@ def main():
 
     def batch_ptr(k):
         i0 = (global_batch(k) * B) % len(order)
-        if args.host_frames and world == 1:
-            return [frames[seq[i0 + j]] for j in range(B)]       # host arrays: the engine uploads them (one staged copy per frame)
         return pool + i0 * fbytes
 
     def batch_item(k):
@@ -705,8 +703,18 @@ def main():
     shard_gmc = sharded and extract and args.tracker in GMC_TRACKERS
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
                            det_streams=args.det_streams, stab_streams=args.stab_streams,
-                           gmc=extract and args.tracker in GMC_TRACKERS, detectors=[det])
+                           gmc=extract and args.tracker in GMC_TRACKERS, detectors=[det], feeder_stream=bool(args.host_frames and world == 1))
     n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
+    host_feed = None
+    if args.host_frames and world == 1:
+        # the PCIe-inclusive measurement: the frames start as pageable host arrays and reach the engine the way the product brings
+        # any host-side source in (geotrax_amd.feeder, memory mode: three of the library's threads copy them into the pinned ring, the copy stream
+        # uploads them, the detector streams wait for the upload events) -- warm-up and timed steps from one feeder
+        from geotrax_amd.feeder import FrameFeeder
+
+        host_feed = FrameFeeder((H, W), kind="bgr", batch=B, ring=len(engine.dets) + 4, device=local, ctx=engine.feeder_ctx)
+        host_feed.open_memory([frames[seq[(i // B * B) % len(order) + i % B]] for i in range((args.warmup + args.steps) * B)], n_threads=int(os.environ.get('GTX_BENCH_COPY_THREADS', '3')))
+        host_batches = host_feed.batches(len(engine.dets))
     if extract and stab_kw is not None:
         engine.set_reference(ref_frame)                          # every rank registers against frame 0 of the clip
     records = []
@@ -714,7 +722,10 @@ def main():
     def run(k0, n_steps, sharded):
         """n_steps batches through the engine; per-frame results are identical to the frame-at-a-time order."""
         n_rows = 0
-        for r in engine.run(batch_item(k0 + k) for k in range(n_steps)):
+        import itertools
+
+        src = itertools.islice(host_batches, n_steps) if host_feed is not None else (batch_item(k0 + k) for k in range(n_steps))
+        for r in engine.run(src):
             n_rows = len(r.xyxy)
             if sharded and extract:
                 records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H, r.gmc, with_gmc=shard_gmc))
@@ -831,6 +842,8 @@ def main():
     if failure is not None:
         print(f"bench: {failure}", file=sys.stderr, flush=True)
     barrier()
+    if host_feed is not None:
+        host_feed.close()
 
     if rank == 0:
         dt = "f16" if args.half else ("f32s" if det.fp32_split else "f32")

@@ -43,6 +43,7 @@ struct gtx_feeder {
 
   int fd = -1;
   std::vector<int64_t> offsets;      // file mode: payload offset of every frame to deliver, in delivery order
+  std::vector<const uint8_t*> mem;   // memory mode: the frames as host pointers (the caller keeps them alive), in delivery order
   std::vector<std::thread> readers;
   std::thread uploader;
 
@@ -96,6 +97,10 @@ struct gtx_feeder {
       }
       uint8_t* dst = pinned + slot_of(i) * src_bytes;
       size_t got = 0;
+      if (!mem.empty()) {                       // memory mode: one copy into the pinned slot, like the page-cache copy of a pread
+        memcpy(dst, mem[(size_t)i], src_bytes);
+        got = src_bytes;
+      }
       while (got < src_bytes) {
         const ssize_t r = ::pread(fd, dst + got, src_bytes - got, (off_t)(offsets[(size_t)i] + (int64_t)got));
         if (r < 0 && errno == EINTR) continue;
@@ -213,6 +218,20 @@ int gtx_feeder_open_file(gtx_feeder* f, const char* path, const int64_t* offsets
   });
 }
 
+int gtx_feeder_open_memory(gtx_feeder* f, const void* const* frames, int64_t n_frames, int n_threads) {
+  return guarded([&] {
+    if (!f || (n_frames > 0 && !frames)) gtx::fail(GTX_ERR_INVALID, "feeder_open_memory: NULL argument");
+    if (f->fd >= 0 || f->uploader.joinable()) gtx::fail(GTX_ERR_STATE, "feeder already has a source");
+    for (int64_t i = 0; i < n_frames; ++i) {
+      if (!frames[i]) gtx::fail(GTX_ERR_INVALID, "feeder_open_memory: frame %lld is NULL", (long long)i);
+      f->mem.push_back(static_cast<const uint8_t*>(frames[i]));
+    }
+    f->n_frames = n_frames;
+    f->uploader = std::thread([f] { f->upload_loop(); });
+    for (int t = 0; t < std::max(1, std::min(n_threads, 16)); ++t) f->readers.emplace_back([f] { f->read_loop(); });
+  });
+}
+
 int gtx_feeder_open_push(gtx_feeder* f) {
   return guarded([&] {
     if (!f) gtx::fail(GTX_ERR_INVALID, "feeder is NULL");
@@ -238,6 +257,27 @@ int gtx_feeder_push(gtx_feeder* f, const void* frame, size_t bytes) {
     {
       std::lock_guard<std::mutex> lk(f->m);
       f->slot_frame[f->slot_of(i)] = i;
+    }
+    f->cv.notify_all();
+  });
+}
+
+int gtx_feeder_push_at(gtx_feeder* f, int64_t i, const void* frame, size_t bytes) {
+  return guarded([&] {
+    if (!f || !frame || i < 0) gtx::fail(GTX_ERR_INVALID, "feeder_push_at: bad argument");
+    if (bytes != f->src_bytes) gtx::fail(GTX_ERR_INVALID, "feeder_push_at: frame has %zu bytes, the feeder was built for %zu", bytes, f->src_bytes);
+    {
+      std::unique_lock<std::mutex> lk(f->m);
+      if (f->n_frames >= 0) gtx::fail(GTX_ERR_STATE, "feeder_push_at after feeder_finish");
+      f->cv.wait(lk, [&] { return f->stop || i / f->B < f->released + f->ring; });
+      if (f->stop) gtx::fail(GTX_ERR_STATE, "feeder stopped: %s", f->error.c_str());
+      if (i / f->B < f->released) gtx::fail(GTX_ERR_STATE, "feeder_push_at: frame %lld belongs to a batch that was already consumed", (long long)i);
+    }
+    memcpy(f->pinned + f->slot_of(i) * f->src_bytes, frame, bytes);
+    {
+      std::lock_guard<std::mutex> lk(f->m);
+      f->slot_frame[f->slot_of(i)] = i;
+      if (i + 1 > f->next_read) f->next_read = i + 1;
     }
     f->cv.notify_all();
   });

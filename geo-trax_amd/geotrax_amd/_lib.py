@@ -152,8 +152,10 @@ _SIGNATURES = {
     "gtx_feeder_create_on": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_feeder_destroy": (None, [_P]),
     "gtx_feeder_open_file": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int]),
+    "gtx_feeder_open_memory": (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     "gtx_feeder_open_push": (C.c_int, [_P]),
     "gtx_feeder_push": (C.c_int, [_P, _P, C.c_size_t]),
+    "gtx_feeder_push_at": (C.c_int, [_P, C.c_int64, _P, C.c_size_t]),
     "gtx_feeder_finish": (C.c_int, [_P]),
     "gtx_feeder_stop": (C.c_int, [_P]),
     "gtx_feeder_next": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),

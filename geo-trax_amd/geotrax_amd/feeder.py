@@ -58,6 +58,17 @@ class FrameFeeder:
         off = np.ascontiguousarray(offsets, dtype=np.int64)
         check(self.lib.gtx_feeder_open_file(self.handle, str(path).encode(), _lib.ptr(off), len(off), int(n_threads)))
 
+    def open_memory(self, frames, n_threads: int = 3) -> None:
+        """`frames`: a sequence of host arrays (BGR ndarrays, or the I420 `data` of Yuv420Frame objects) delivered in order; the
+        same array may appear any number of times. The library's own threads copy them into the pinned ring (no Python, no GIL
+        on that path); the arrays are kept alive by this object."""
+        self._held = [np.ascontiguousarray(f.data if hasattr(f, "data") and hasattr(f, "bgr") else f, dtype=np.uint8) for f in frames]
+        for a in self._held:
+            if a.nbytes != self.src_bytes:
+                raise ValueError(f"a frame has {a.nbytes} bytes, the feeder was built for {self.src_bytes}")
+        ptrs = (C.c_void_p * len(self._held))(*[a.ctypes.data for a in self._held])
+        check(self.lib.gtx_feeder_open_memory(self.handle, ptrs, len(self._held), int(n_threads)))
+
     def open_reader(self, frames) -> None:
         """`frames`: iterable of host frames (ndarray BGR, or frames.Yuv420Frame for an I420 feeder), drained on a thread of
         its own. An exception of the iterable ends the source and is re-raised by batches() after the frames before it."""
@@ -78,10 +89,45 @@ class FrameFeeder:
         self._pusher = threading.Thread(target=run, name="gtx-feeder-push", daemon=True)
         self._pusher.start()
 
+    def open_indexed(self, frame_at, n_frames: int, threads: int = 3) -> None:
+        """Frames 0..n_frames-1 of a random-access host source (`frame_at(i)` -> ndarray / Yuv420Frame), copied into the pinned
+        ring by `threads` host threads (gtx_feeder_push_at)."""
+        check(self.lib.gtx_feeder_open_push(self.handle))
+
+        def work(t):
+            try:
+                for i in range(t, n_frames, threads):
+                    f = frame_at(i)
+                    a = f.data if hasattr(f, "data") and hasattr(f, "bgr") else f
+                    a = np.ascontiguousarray(a, dtype=np.uint8)
+                    if self.lib.gtx_feeder_push_at(self.handle, i, _lib.ptr(a), a.nbytes) != 0:
+                        raise _lib.GtxError(-4, self.lib.gtx_last_error().decode("utf-8", "replace"))
+            except BaseException as e:                      # noqa: BLE001 (handed to the consumer)
+                if self._push_error is None:
+                    self._push_error = e
+                # a frame is missing in the middle: nothing behind it can be delivered, and the other producers and the consumer
+                # may be waiting for it (or for ring space behind it) -- end the source now
+                self.lib.gtx_feeder_stop(self.handle)
+
+        def run():
+            ts = [threading.Thread(target=work, args=(t,), name=f"gtx-feeder-push-{t}", daemon=True) for t in range(max(threads, 1))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            self.lib.gtx_feeder_finish(self.handle)
+
+        self._pusher = threading.Thread(target=run, name="gtx-feeder-push", daemon=True)
+        self._pusher.start()
+
     # ---- consumer
     def next(self) -> DeviceBatch | None:
         p, n, j = C.c_void_p(), C.c_int(), C.c_int64()
-        check(self.lib.gtx_feeder_next(self.handle, C.byref(p), C.byref(n), C.byref(j)))
+        rc = self.lib.gtx_feeder_next(self.handle, C.byref(p), C.byref(n), C.byref(j))
+        if rc != 0 and self._push_error is not None:            # the producers' own failure is the one to report
+            e, self._push_error = self._push_error, None
+            raise e
+        check(rc)
         if n.value == 0:
             if self._push_error is not None:
                 e, self._push_error = self._push_error, None

@@ -104,7 +104,7 @@ int gtx_yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv_dptr, int h, int w, void
  *   preceded it were delivered. gtx_feeder_wait: the consumer context's stream waits for batch `batch_index` to be
  *   resident (no host thread blocks); consumer NULL: the calling thread waits. gtx_feeder_release: the first n_batches
  *   batches have been consumed (the kernels reading them are complete); their slots are read into again.
- * Thread safety: next / wait / release from one consumer thread, push / finish from one producer thread. */
+ * Thread safety: next / wait / release from one consumer thread, push / finish from one producer thread (push_at: any). */
 typedef struct gtx_feeder gtx_feeder;
 int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, gtx_feeder** out);
 /* Same, the transfers and conversions run on copy_ctx's stream instead of a stream of the feeder's own (the context must
@@ -114,8 +114,16 @@ int gtx_feeder_create(int device, int h, int w, int kind, int batch, int ring, g
 int gtx_feeder_create_on(gtx_ctx* copy_ctx, int h, int w, int kind, int batch, int ring, gtx_feeder** out);
 void gtx_feeder_destroy(gtx_feeder* f);
 int gtx_feeder_open_file(gtx_feeder* f, const char* path, const int64_t* offsets, int64_t n_frames, int n_threads);
+/* The frames are host arrays (decoded footage held in memory, an ndarray [F][h][w][3]): frames[i] points at frame i's bytes,
+ * delivery order = array order; the library's reader threads copy them into the pinned ring. The arrays must stay alive and
+ * unchanged until the feeder is destroyed. */
+int gtx_feeder_open_memory(gtx_feeder* f, const void* const* frames, int64_t n_frames, int n_threads);
 int gtx_feeder_open_push(gtx_feeder* f);
 int gtx_feeder_push(gtx_feeder* f, const void* frame, size_t bytes);
+/* Push mode with several producer threads: frame number i of the source (each number exactly once, any order, any thread;
+ * a push blocks while frame i's batch is more than `ring` batches ahead of the consumer). gtx_feeder_finish after the last
+ * push has returned. */
+int gtx_feeder_push_at(gtx_feeder* f, int64_t i, const void* frame, size_t bytes);
 int gtx_feeder_finish(gtx_feeder* f);
 /* Abandons the source: worker threads end, a blocked gtx_feeder_push / gtx_feeder_next returns with an error. Call it
  * (and join the pushing thread) before gtx_feeder_destroy when the run is given up half way. */

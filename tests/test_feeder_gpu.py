@@ -72,6 +72,40 @@ def test_push_mode_and_a_failing_source(gtx_ctx):
     np.testing.assert_array_equal(np.concatenate(got), frames)
     fd.close()
 
+    # frames held in host memory, copied by the library's own threads (gtx_feeder_open_memory); the same array may repeat
+    fd = FrameFeeder((h, w), kind="bgr", batch=2, ring=3, device=gtx_ctx.device)
+    order = [0, 1, 2, 1, 0, 5, 5, 10, 3]
+    fd.open_memory([frames[k] for k in order], n_threads=3)
+    got = []
+    for b in fd.batches(in_flight=1):
+        b.wait_on(gtx_ctx)
+        gtx_ctx.synchronize()
+        got.append(_download(gtx_ctx, b.ptr, b.n, h, w))
+    np.testing.assert_array_equal(np.concatenate(got), frames[order])
+    fd.close()
+    # several producer threads, frames pushed by number (gtx_feeder_push_at): still delivered in clip order
+    fd = FrameFeeder((h, w), kind="bgr", batch=2, ring=3, device=gtx_ctx.device)
+    fd.open_indexed(lambda i: frames[i], len(frames), threads=3)
+    got = []
+    for b in fd.batches(in_flight=1):
+        b.wait_on(gtx_ctx)
+        gtx_ctx.synchronize()
+        got.append(_download(gtx_ctx, b.ptr, b.n, h, w))
+    np.testing.assert_array_equal(np.concatenate(got), frames)
+    fd.close()
+
+    def bad_at(i):
+        if i == 5:
+            raise OSError("frame 5 is gone")
+        return frames[i]
+
+    fd = FrameFeeder((h, w), kind="bgr", batch=2, ring=3, device=gtx_ctx.device)
+    fd.open_indexed(bad_at, len(frames), threads=2)
+    with pytest.raises(OSError, match="frame 5 is gone"):
+        for b in fd.batches(in_flight=1):
+            pass
+    fd.close()
+
     def broken():
         yield frames[0]
         yield frames[1]
