@@ -36,12 +36,13 @@ def test_single_gpu_line_has_the_contract_fields():
     assert 0 < d["f32_exact"]["value"] < d["value"]
     assert d["botsort"]["value"] > 100 and d["botsort"]["dtype"] == d["dtype"]
     # what the pipeline delivers when the frames do not start in HBM rides along too: `host_frames` = pageable host
-    # arrays uploaded inside the timed region, `from_file` = the product's own loop on a 150-frame .y4m on local disk. Ordered:
-    # resident >= PCIe-inclusive >= from the file (10 % slack for run-to-run noise), and each within 20 % of the one above it
+    # arrays (24.9 MB BGR each) uploaded inside the timed region, `from_file` = the product's own loop on a 150-frame .y4m (12.4 MB
+    # I420 per frame) on local disk. Ordered: neither beats the resident rate (10 % slack for run-to-run noise) and both stay within
+    # a quarter of it; between themselves they are not ordered (the file carries half the bytes per frame across PCIe)
     hf, ff = d["host_frames"]["value"], d["from_file"]["value"]
     assert hf > 100 and ff > 100 and d["from_file"]["frames"] == 150 and d["from_file"]["reference_convention_fps"] > 0
-    assert ff <= 1.1 * hf and hf <= 1.1 * d["value"], (d["value"], hf, ff)
-    assert ff >= 0.8 * hf and hf >= 0.8 * d["value"], (d["value"], hf, ff)
+    assert ff <= 1.1 * d["value"] and hf <= 1.1 * d["value"], (d["value"], hf, ff)
+    assert ff >= 0.75 * d["value"] and hf >= 0.75 * d["value"], (d["value"], hf, ff)
     # NMS sees clustered candidates: more candidates than detections in the calibration frame
     assert d["config"]["candidates_per_frame"] > 1.3 * d["config"]["detections_per_frame"]
 
