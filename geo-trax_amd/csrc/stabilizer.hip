@@ -814,11 +814,21 @@ __global__ __launch_bounds__(256) void match_kernel(const unsigned long long* __
   const int nchunk = (nt + kMatchChunk - 1) / kMatchChunk;
   for (int i = tid; i < nq; i += blockDim.x) {
     int b1 = 1 << 30, b2 = 1 << 30, bi = -1;
-    for (int c = 0; c < nchunk; ++c) {
-      const size_t o = (size_t)c * max_q + i;
-      const int d1 = ld_sc1(&part_d1[o]), d2 = ld_sc1(&part_d2[o]);
-      if (d1 < b1) { b2 = min(b1, d2); b1 = d1; bi = ld_sc1(&part_idx[o]); }
-      else b2 = min(b2, d1);
+    // eight chunks' partials are requested before the first is looked at: one round trip per eight chunks instead of
+    // two dependent ones per chunk (this single workgroup's merge was 60 of the launch's 84 us)
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {
+      int d1[8], d2[8], ix[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t o = (size_t)min(c0 + k, nchunk - 1) * max_q + i;
+        d1[k] = ld_sc1(&part_d1[o]); d2[k] = ld_sc1(&part_d2[o]); ix[k] = ld_sc1(&part_idx[o]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (c0 + k >= nchunk) break;
+        if (d1[k] < b1) { b2 = min(b1, d2[k]); b1 = d1[k]; bi = ix[k]; }
+        else b2 = min(b2, d1[k]);
+      }
     }
     best_idx[i] = bi; best_d[i] = b1; second_d[i] = b2;
   }
