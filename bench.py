@@ -551,18 +551,26 @@ def bench_cli(args):
         wall = time.perf_counter() - t0
         lr = dict(getattr(model, "last_run", {}) or {})
         assert len(tracks) and lr.get("frames") == len(seq), (len(tracks), lr)
-        return dict(frames_per_s=lr["loop_fps"], frames_per_s_incl_setup=lr["wall_fps"], engine_setup_s=lr["engine_setup_s"], reader_setup_s=lr["reader_setup_s"],
+        import zlib
+
+        digest = zlib.crc32(np.ascontiguousarray(tracks).tobytes()) ^ zlib.crc32(np.ascontiguousarray(transforms).tobytes())
+        return dict(digest=digest, frames_per_s=lr["loop_fps"], frames_per_s_incl_setup=lr["wall_fps"], engine_setup_s=lr["engine_setup_s"], reader_setup_s=lr["reader_setup_s"],
                     loop_s=lr["loop_s"], reference_convention_fps=lr["reference_convention_fps"], det_ms_per_frame=lr["det_ms"],
                     stab_ms_per_frame=lr["stab_ms"], track_with_model_s=wall, track_rows=int(len(tracks)), transforms=int(len(transforms)))
 
     res = {}
     for fmt, path in files.items():
-        one_run(path, True)                                     # warm-up: kernels, allocator, page cache
-        r = max((one_run(path, True) for _ in range(2)), key=lambda d: d["frames_per_s"])
+        warm = one_run(path, True)                              # warm-up: kernels, allocator, page cache
+        runs = [one_run(path, True) for _ in range(2)]
+        r = max(runs, key=lambda d: d["frames_per_s"])
+        # the pipeline is asynchronous end to end (reader threads, copy stream, 2 + 4 GPU streams, three host stages): its
+        # output must not depend on timing -- the three runs' tables are the same bytes
+        r["deterministic"] = len({warm["digest"], runs[0]["digest"], runs[1]["digest"]}) == 1
         r["bytes_per_frame"] = int(path.stat().st_size // len(seq))
         r["file_gbs"] = r["bytes_per_frame"] * r["frames_per_s"] / 1e9
         if args.cli_compare_sync:
             s_ = one_run(path, False)
+            r["deterministic"] = r["deterministic"] and s_["digest"] == r["digest"]      # ... and not on the reader either
             r["synchronous_reader"] = {"frames_per_s": s_["frames_per_s"], "frames_per_s_incl_setup": s_["frames_per_s_incl_setup"], "reference_convention_fps": s_["reference_convention_fps"],
                                        "note": "GTX_FEEDER=0: f.read() + pageable upload on the detector stage thread (round 3's reader)"}
         res[fmt] = r

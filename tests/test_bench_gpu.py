@@ -119,3 +119,15 @@ def test_eight_ranks_on_one_gpu_botsort():
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 8 and d["steps"] == 9 and d["value"] > 20 and "error" not in d and d["scaling"] == "weak"
     assert d["host"]["threads_per_rank"] >= 3 and d["host"]["cores"] >= 1
+
+
+def test_cli_workload_from_a_file_is_deterministic():
+    """bench.py --workload cli on a shorter clip: the product's loop on a .y4m and a .npy, read-ahead feeder and synchronous
+    reader; four runs per container produce the same tables byte for byte."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "cli", "--cli-frames", "40"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["unit"] == "frames/s" and d["value"] > 50 and set(d["from_file"]) == {"y4m", "npy"}
+    for fmt, r in d["from_file"].items():
+        assert r["deterministic"] is True, fmt
+        assert r["track_rows"] > 1000 and r["transforms"] == 39 and r["synchronous_reader"]["frames_per_s"] > 20
