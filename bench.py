@@ -93,6 +93,7 @@ def parse():
                     help="N > 1: frames = batches of ONE clip dealt to the ranks, tracks gathered to rank 0 (BASELINE north star); "
                          "videos = every rank runs the whole reference-order pipeline on its own clip, no data-path collective (SURVEY 8e best case)")
     ap.add_argument("--host-frames", action="store_true", help="N = 1: feed the engine frames from host memory instead of frames resident in HBM (the PCIe-inclusive rate: a different measurement, labelled as such in the line, never the headline)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -150,6 +151,48 @@ def pmc_traffic(kernel, batch):
         return rec["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError, IndexError):
         return None
+
+
+def live_traffic(kernel, args, B):
+    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes; the program itself
+    directly behind `--`), the counter averaged over the kernel's dispatches, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+    (gfx950 counts a 128-byte request as 64 in FETCH_SIZE). None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    sys.path.insert(0, str(ROOT / "tools"))
+    from pmc_summary import family
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(prof).exists():
+        return None
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"gtx_pmc_{counter.lower()}_")
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2",
+               "--no-cpu-baseline", "--no-profile", "--no-f16-line", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams",
+               str(args.det_streams), "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
+               "--imgsz", str(args.imgsz), "--rect", str(args.rect)] + (["--fp32", args.fp32] if args.fp32 else [])
+        try:
+            subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"})
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            n = v = 0.0
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == counter and family(r["Kernel_Name"]) == kernel:
+                    n += 1
+                    v += float(r["Counter_Value"])
+            kb[counter] = v / n if n else None
+        except Exception:
+            kb[counter] = None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if kb.get("FETCH_SIZE") is None or kb.get("WRITE_SIZE") is None:
+        return None
+    return round((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0)
 
 
 def host_cores() -> int:
@@ -1044,6 +1087,20 @@ def main():
                 except Exception as e:
                     out["pipelined"][f"{ns}_streams"] = None
                     out["pipelined"]["error"] = f"{type(e).__name__}: {e}"
+        if world == 1 and dist is None and "roofline" in out and not args.no_live_traffic and not args.no_f16_line and not args.host_frames:
+            # roofline.traffic measured in THIS run: the engine has been closed above, the children run alone
+            try:
+                engine.close()
+            except Exception:
+                pass
+            tr = live_traffic(out["roofline"]["kernel"], args, B)
+            if tr:
+                out["roofline"]["traffic_committed_summary"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate, --kernel-trace only) of "
+                                                     "this command at 6 steps; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes averaged over the kernel's dispatches; "
+                                                     "`traffic_committed_summary` = the same quantity from profiles/rNN_pmc_traffic.json")
+                out["roofline"]["traffic_over_algorithmic"] = tr / out["roofline"]["bytes_per_launch"]
         out["host"] = {"cores": host_cores(), "threads_per_rank": engine.host_threads + (1 if (sharded and extract and rank == 0) else 0) + 1,
                        "note": "engine stage threads (blocking waits: they sleep while the GPU works) + the main thread" +
                                (" + rank 0's tracker replay thread" if (sharded and extract) else "")}

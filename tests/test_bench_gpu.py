@@ -29,6 +29,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 120 and d["value"] > 100 and d["unit"] == "frames/s" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # roofline.traffic is measured by this very run (two rocprofv3 --pmc child passes) and sits near the algorithmic bytes
+    assert r["traffic_source"].startswith("measured in this run") and 0.8 < r["traffic_over_algorithmic"] < 1.6, r.get("traffic_source")
     # the default line is the reference's own precision (ultralytics.half: false, default.yaml:245); fp16 rides along
     assert d["dtype"].startswith("f32") and d["config"]["half"] is False
     assert d["f16"]["dtype"] == "f16" and d["f16"]["value"] > d["value"]
