@@ -56,6 +56,34 @@ def test_file_mode_delivers_the_files_frames_in_order_through_a_small_ring(gtx_c
     reader.release()
 
 
+def test_ring_reuse_under_an_uneven_consumer(gtx_ctx, tmp_path):
+    """400 small frames through a ring of 3 batches with a consumer that sometimes dawdles and sometimes races: every slot
+    is rewritten ~65 times while batches are still being read; every byte that arrives is the file's."""
+    import time
+
+    from geotrax_amd.feeder import FrameFeeder
+
+    h, w, n = 48, 64, 400
+    rng = np.random.default_rng(7)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    off = 128 + h * w * 3 * np.arange(n, dtype=np.int64)
+    assert np.load(path, mmap_mode="r").offset == 128
+    fd = FrameFeeder((h, w), kind="bgr", batch=2, ring=3, device=gtx_ctx.device)
+    fd.open_file(path, off, n_threads=4)
+    k = 0
+    for b in fd.batches(in_flight=2):
+        if rng.random() < 0.15:
+            time.sleep(float(rng.uniform(0, 0.004)))
+        b.wait_on(gtx_ctx)
+        got = _download(gtx_ctx, b.ptr, b.n, h, w)                 # dev_download runs on gtx_ctx's stream, behind the wait
+        np.testing.assert_array_equal(got, frames[k:k + b.n], err_msg=f"batch at frame {k}")
+        k += b.n
+    assert k == n
+    fd.close()
+
+
 def test_push_mode_and_a_failing_source(gtx_ctx):
     from geotrax_amd.feeder import FrameFeeder
 
