@@ -20,8 +20,6 @@ stabilizer mask of a frame is built from the raw detections instead of the track
 """
 from __future__ import annotations
 
-from typing import Callable
-
 import numpy as np
 
 

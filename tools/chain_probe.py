@@ -24,7 +24,6 @@ if len(sys.argv) > 2 and sys.argv[1] == "--read":
         last_end = max(last_end, e)
     sys.exit(0)
 
-import numpy as np  # noqa: E402
 from geotrax_amd import _lib  # noqa: E402
 from geotrax_amd.detector import Detector  # noqa: E402
 from geotrax_amd.synth import make_scene  # noqa: E402
