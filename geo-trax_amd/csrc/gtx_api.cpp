@@ -71,6 +71,17 @@ int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out) {
 
 void gtx_ctx_destroy(gtx_ctx* ctx) { delete ctx; }
 
+int gtx_device_open_null_stream(int device) {
+  return guarded([&] {
+    GTX_HIP(hipSetDevice(device));
+    void* p = nullptr;
+    GTX_HIP(hipMalloc(&p, 256));
+    hipError_t e = hipMemset(p, 0, 4);            // synchronous: runs on (and thereby creates) the null stream
+    (void)hipFree(p);
+    GTX_HIP(e);
+  });
+}
+
 int gtx_ctx_synchronize(gtx_ctx* ctx) {
   return guarded([&] {
     need(ctx, "ctx");

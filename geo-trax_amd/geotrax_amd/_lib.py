@@ -70,7 +70,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 5        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 6        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -80,6 +80,7 @@ _SIGNATURES = {
     "gtx_ctx_create_prio": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_ctx_destroy": (None, [_P]),
     "gtx_ctx_synchronize": (C.c_int, [_P]),
+    "gtx_device_open_null_stream": (C.c_int, [C.c_int]),
     "gtx_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "gtx_dev_free": (C.c_int, [_P, _P]),
     "gtx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),

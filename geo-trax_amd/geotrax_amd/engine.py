@@ -74,6 +74,120 @@ def parse_prio(text: str | None) -> tuple[int, int]:
     return nums[0], nums[1]
 
 
+def queue_of_streams(tokens: list[str], n_queues: int = 4) -> list[int]:
+    """Hardware queue (0-based) every stream of a creation sequence lands on, by the HIP runtime's rule as measured on MI355X
+    (tools/stream_map_probe.py, profiles/r04_stream_map.txt): a stream gets its place when it is created; the first
+    `n_queues` (GPU_MAX_HW_QUEUES, 4) streams open a queue each, a later one joins the queue that carries the fewest
+    streams, the highest-numbered one among equals; the null stream ('n') counts like any other from its first use."""
+    load, out = [], []
+    for _ in tokens:
+        if len(load) < n_queues:
+            load.append(0)
+            q = len(load) - 1
+        else:
+            q = max(range(n_queues), key=lambda i: (-load[i], i))
+        load[q] += 1
+        out.append(q)
+    return out
+
+
+def plan_stream_order(n_dets: int, n_stab: int, n_queues: int = 4) -> list[str]:
+    """The creation order of an engine's streams: d = detector, s = stabilizer, f = the read-ahead feeder's copy stream,
+    g = the GMC, n = the null stream, x = a stream that is never used.
+
+    Streams that share a hardware queue run in order, so a detector that shares one waits behind the other stream's
+    kernels and barrier packets and the two detector streams stop overlapping: with both detectors on ONE queue the
+    extract loop fed by the feeder reads 780 frames/s on MI355X, with a queue per detector 940 (profiles/r04_stream_plan.txt).
+    The order built here gives every detector a queue that it shares only with idle streams ('n', 'x') and spreads
+    stabilizers, feeder and GMC over the remaining queues; it ends so that the next two streams created (the GMC's second
+    stream, made by the library; the sharded run's priming stream) join those too. With more than two detector streams there are not enough
+    queues for that and the order is simply detectors-first."""
+    if n_dets >= n_queues - 1:
+        return ["d", "n"] + ["d"] * (n_dets - 1) + ["s"] * n_stab + ["f", "g"]
+    busy = ["s"] * n_stab + ["f", "g"]
+    order, dets_left, null_left = [], n_dets, True
+
+    def landing():
+        return queue_of_streams(order + ["?"], n_queues)[-1]
+
+    while busy or dets_left:
+        q = landing()
+        if q < n_dets:                                       # a detector's queue: the detector itself, then only idle streams
+            holds = [t for t, qq in zip(order, queue_of_streams(order, n_queues)) if qq == q]
+            if "d" not in holds and dets_left:
+                order.append("d")
+                dets_left -= 1
+            elif null_left:
+                order.append("n")
+                null_left = False
+            else:
+                order.append("x")
+        elif busy:
+            order.append(busy.pop(0))
+        else:
+            order.append("x")
+    if null_left:
+        order.append("n")
+    while any(q < n_dets for q in queue_of_streams(order + ["?", "?"], n_queues)[-2:]):   # level the queues: the next two streams
+        order.append("x")                                      # anyone creates (the GMC's second, a priming stream) join the busy ones
+    return order
+
+
+class StreamPlan:
+    """The HIP streams of the extract engine on one device: created ONCE per process, all together, in the order
+    plan_stream_order() gives, and handed out by role to every engine built afterwards.
+
+    Once, because the queue a stream lands on depends on every stream the process has created and destroyed before
+    (queue_of_streams): an engine that created its own streams got a different, usually worse, mapping for the second video
+    of a process than for the first. All together, because the library's set-up copies bring the null stream into being
+    at a moment of their own; here it is opened at its place in the order (gtx_device_open_null_stream)."""
+    _plans: dict = {}
+    _lock = threading.Lock()
+
+    def __init__(self, device: int, order: list[str], p_det: int = 0, p_stab: int = 0):
+        self.device, self.order, self.p_det, self.p_stab = device, list(order), p_det, p_stab
+        self.ctxs = []                                           # [role, Context, weakref of the holder | None]
+        for tok in self.order:
+            if tok == "n":
+                _lib.check(_lib.load().gtx_device_open_null_stream(device))
+            else:
+                self.ctxs.append([tok, _lib.Context(device, p_det if tok == "d" else p_stab if tok in ("s", "g") else 0), None])
+
+    @classmethod
+    def get(cls, device: int, n_dets: int, n_stab: int) -> "StreamPlan":
+        """The device's plan; the first call lays it out for (n_dets, n_stab) -- GTX_ENGINE_ORDER (comma-separated tokens)
+        overrides the order -- later calls reuse it and take() adds what it lacks."""
+        with cls._lock:
+            if device not in cls._plans:
+                env = os.environ.get("GTX_ENGINE_ORDER")
+                order = [t.strip() for t in env.split(",") if t.strip()] if env else plan_stream_order(n_dets, n_stab)
+                if any(t not in ("d", "s", "f", "g", "n", "x") for t in order):
+                    raise ValueError(f"GTX_ENGINE_ORDER: tokens are d, s, f, g, n, x; got {env!r}")
+                p_det, p_stab = parse_prio(os.environ.get("GTX_ENGINE_PRIO"))
+                cls._plans[device] = StreamPlan(device, order, p_det, p_stab)
+            return cls._plans[device]
+
+    def take(self, role: str, holder=None) -> _lib.Context:
+        """A context of `role` nobody holds (`holder`: the object it is for; when that object is gone the context is free
+        again without give_back). A role the plan has run out of gets a new stream, wherever the runtime puts it."""
+        import weakref
+
+        with self._lock:
+            for ent in self.ctxs:
+                if ent[0] == role and (ent[2] is None or (ent[2] is not True and ent[2]() is None)):
+                    ent[2] = weakref.ref(holder) if holder is not None else True
+                    return ent[1]
+            ctx = _lib.Context(self.device, self.p_det if role == "d" else self.p_stab if role in ("s", "g") else 0)
+            self.ctxs.append([role, ctx, weakref.ref(holder) if holder is not None else True])
+            return ctx
+
+    def give_back(self, ctx: _lib.Context) -> None:
+        with self._lock:
+            for ent in self.ctxs:
+                if ent[1] is ctx:
+                    ent[2] = None
+
+
 class ExtractEngine:
     def __init__(self, weights: dict, frame_hw: tuple[int, int], det_kw: dict, tracker: Tracker | None, stab_kw: dict | None, *,
                  device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool = False,
@@ -81,67 +195,37 @@ class ExtractEngine:
         """det_kw: Detector keywords (imgsz, conf, iou, max_det, classes, agnostic_nms, half, rect). tracker None: raw
         detections pass through (ids None; the frame-sharded bench tracks later on rank 0). stab_kw None: no
         stabilization. `detectors`: already-built Detector objects to adopt (same weights, own contexts). `feeder_stream`: also
-        create `self.feeder_ctx`, the context a read-ahead feeder's transfers run on (geotrax_amd.feeder.FrameFeeder(ctx=...)), at
-        its place in the stream-creation order."""
+        take `self.feeder_ctx`, the context a read-ahead feeder's transfers run on (geotrax_amd.feeder.FrameFeeder(ctx=...)),
+        from the stream plan."""
         self.device = _lib.default_device() if device is None else device
         self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
         self.B = max(int(batch), 1)
-        # HIP spreads streams over a few hardware queues (4 by default) in creation order, and streams that share
-        # a queue run in order. The creation orders below are the measured best on MI355X (ByteTrack: first detector,
-        # stabilizers, remaining detectors: 1390 vs 1300-1340 frames/s for detectors-first); GPU_MAX_HW_QUEUES=8
-        # (no sharing at all) is slower for the default run (1040 vs 1230): the stabilizers then crowd the detector.
         self.dets = list(detectors or [])
         n_dets = max(int(det_streams), len(self.dets), 1)
         n_stab = max(1, min(int(stab_streams), 4 * n_dets * self.B - 2)) if stab_kw is not None else 0   # frames in flight < gray ring lifetime
         self.tracker = tracker
         self.gmc = None
         self.stabs = []
-        self._spare = []                 # contexts created only to steer the stream -> hardware-queue mapping
-        # order of stream creation: d = detector, g = GMC, s = stabilizer, x = unused stream (takes a queue slot), f = the
-        # read-ahead feeder's copy stream
-        self.feeder_ctx = None
-        # With a feeder its copy stream is created second, right behind the first detector's: of the places swept on MI355X
-        # (profiles/r04_feeder_queue.txt) this is the one where the transfers delay the detectors least -- from a 4K .y4m
-        # 840-918 frames/s (600-frame clip, three runs) against 755-805 with the copy stream created last behind a spare stream
-        # and 838-877 with it created last; BoT-SORT: 876 against 830-836.
-        default = ["d"] + (["f"] if feeder_stream else []) + ["s"] * n_stab + ["d"] * (n_dets - 1)
-        if gmc:
-            # The GMC's two streams come last, behind one spare stream. The runtime hands a new stream to the least-loaded
-            # hardware queue (rocprofv3's Queue_Id column shows the result); with this order the two detectors keep a queue
-            # each and stabilizers + GMC share the other two. A detector that shares its queue with anything else waits
-            # behind that stream's barrier packets: 755 vs 712 frames/s (fp32) and 1443 vs 1354 (fp16) against the
-            # former order (d,g,s,s,d,s,s), with identical kernels.
-            default += ["x", "g"]
-        order = os.environ.get("GTX_ENGINE_ORDER") or ",".join(default)
-        # stream priorities of (detectors, stabilizers + GMC): 1 highest, 0 default, -1 lowest
-        p_det, p_stab = parse_prio(os.environ.get("GTX_ENGINE_PRIO"))
-        have_d = len(self.dets)          # adopted detectors already own their streams
-        made_d = 0
-        for tok in order.split(","):
-            if tok == "d":
-                made_d += 1
-                if made_d > have_d and len(self.dets) < n_dets:
-                    self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device, p_det), **det_kw))
-            elif tok == "g" and gmc and self.gmc is None:
-                from .gmc import GMC
+        # Every stream comes from the device's StreamPlan: which streams share a hardware queue is fixed once per process
+        # (each detector a queue of its own, stabilizers + feeder + GMC spread over the others), not by the order this
+        # constructor happens to build things in or by what the process created before.
+        self.plan = StreamPlan.get(self.device, n_dets, n_stab)
+        self._taken = []                 # the plan's contexts this engine holds (handed back by close())
 
-                self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device, p_stab))
-            elif tok == "s" and len(self.stabs) < n_stab:
-                self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device, p_stab), **stab_kw))
-            elif tok == "x":
-                self._spare.append(_lib.Context(self.device))
-            elif tok == "f" and feeder_stream and self.feeder_ctx is None:
-                self.feeder_ctx = _lib.Context(self.device)
+        def take(role):
+            ctx = self.plan.take(role, holder=self)
+            self._taken.append(ctx)
+            return ctx
+
         while len(self.dets) < n_dets:
-            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=_lib.Context(self.device, p_det), **det_kw))
+            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=take("d"), **det_kw))
         while len(self.stabs) < n_stab:
-            self.stabs.append(Stabilizer(self.frame_hw, ctx=_lib.Context(self.device, p_stab), **stab_kw))
-        if gmc and self.gmc is None:
+            self.stabs.append(Stabilizer(self.frame_hw, ctx=take("s"), **stab_kw))
+        self.feeder_ctx = take("f") if feeder_stream else None   # the context a read-ahead feeder's transfers run on
+        if gmc:
             from .gmc import GMC
 
-            self.gmc = GMC(self.frame_hw, ctx=_lib.Context(self.device, p_stab))
-        if feeder_stream and self.feeder_ctx is None:
-            self.feeder_ctx = _lib.Context(self.device)
+            self.gmc = GMC(self.frame_hw, ctx=take("g"))
         self.use_dev_gray = bool(self.stabs) and float(stab_kw.get("downsample_ratio", 0.5)) == 0.5
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
@@ -193,12 +277,10 @@ class ExtractEngine:
             s.close()
         if self.gmc is not None:
             self.gmc.close()
-        for c in self._spare:
-            c.close()
-        if self.feeder_ctx is not None:
-            self.feeder_ctx.close()
-            self.feeder_ctx = None
-        self.dets, self.stabs, self.gmc, self._spare = [], [], None, []
+        for c in self._taken:                                   # the streams stay alive for the next engine of the process
+            self.plan.give_back(c)
+        self.feeder_ctx = None
+        self.dets, self.stabs, self.gmc, self._taken = [], [], None, []
 
     # ---- feeding
     def _submit(self, det: Detector, batch) -> int:

@@ -234,10 +234,8 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         n_prime = len(engine.dets) + 4
 
         def prime_ptr(frame):
-            from . import _lib
-
             if 'prime' not in state:
-                state['prime'] = (_lib.Context(local), prime)
+                state['prime'] = (engine.plan.take("p", holder=engine), prime)   # a stream beside the plan's: it joins a stabilizer queue, not a detector's
             pctx = state['prime'][0]
             if len(prime) < n_prime:
                 prime.append(pctx.dev_alloc(frame.nbytes))   # (.nbytes of a Yuv420Frame is that of its BGR frame)
@@ -336,7 +334,7 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         if 'prime' in state:
             for p_ in state['prime'][1]:
                 state['prime'][0].dev_free(p_)
-            state['prime'][0].close()
+            state['engine'].plan.give_back(state['prime'][0])    # the stream stays for the next video of the process
         if 'reader' in state:
             state['reader'].release()
         if 'engine' in state:

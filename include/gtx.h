@@ -40,8 +40,9 @@ extern "C" {
  * 4: gtx_op_linear_assignment and gtx_detector_saturated added; GTX_F32S activations live in HBM as (hi, lo) fp16 pairs
  *    (host arrays handed to gtx_op_* stay plain fp32).
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
- *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened). */
-#define GTX_ABI_VERSION 5
+ *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
+ * 6: gtx_device_open_null_stream added. */
+#define GTX_ABI_VERSION 6
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -77,6 +78,13 @@ int gtx_ctx_create(int device, gtx_ctx** out);
 int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out);
 void gtx_ctx_destroy(gtx_ctx* ctx);
 int gtx_ctx_synchronize(gtx_ctx* ctx);
+/* Makes the device's null stream exist now (one 4-byte fill on it, waited for). The HIP runtime gives every stream its
+ * place on one of GPU_MAX_HW_QUEUES (4) hardware queues when the stream is created -- the first four open a queue each,
+ * a later one joins the queue that carries the fewest streams (ties: the highest-numbered queue) -- and the null stream
+ * takes its place the first time anything synchronous (hipMemcpy, hipMemset: the library's set-up paths) runs. A caller
+ * that lays out several contexts for concurrency (geotrax_amd/engine.py StreamPlan) calls this at a fixed point of its
+ * creation order, so that which streams share a queue does not depend on when the first set-up copy happens. Idempotent. */
+int gtx_device_open_null_stream(int device);
 /* Raw device memory for callers that keep inputs resident in HBM (bench.py). */
 int gtx_dev_alloc(gtx_ctx* ctx, size_t bytes, void** dptr);
 int gtx_dev_free(gtx_ctx* ctx, void* dptr);

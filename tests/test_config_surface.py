@@ -120,3 +120,33 @@ def test_engine_priority_variable_is_parsed_leniently_and_refused_clearly():
             assert "GTX_ENGINE_PRIO" in str(e)
         else:
             raise AssertionError(bad)
+
+
+def test_stream_to_queue_rule_reproduces_the_mappings_measured_on_mi355x():
+    """queue_of_streams restates what tools/stream_map_probe.py read from rocprofv3's Queue_Id column (profiles/r04_stream_map.txt):
+    eight streams; the same with the null stream opened after the first; and with it opened after the fifth."""
+    from geotrax_amd.engine import queue_of_streams
+
+    assert queue_of_streams(["c"] * 8) == [0, 1, 2, 3, 3, 2, 1, 0]
+    assert queue_of_streams(["c", "n"] + ["c"] * 7) == [0, 1, 2, 3, 3, 2, 1, 0, 3]
+    assert queue_of_streams(["c"] * 5 + ["n"] + ["c"] * 3) == [0, 1, 2, 3, 3, 2, 1, 0, 3]
+    assert queue_of_streams(["c", "n"] + ["c"] * 11)[2:] == [2, 3, 3, 2, 1, 0, 3, 2, 1, 0, 3]
+
+
+def test_the_stream_plan_gives_every_detector_a_queue_without_a_busy_neighbour():
+    """Streams on one hardware queue run in order: a detector must share its queue only with streams that never run anything ('x', the
+    null stream), and whatever is created next (the GMC's second stream, a priming stream) must join a queue without a detector."""
+    from geotrax_amd.engine import plan_stream_order, queue_of_streams
+
+    for n_dets, n_stab in [(2, 4), (1, 4), (1, 2), (2, 0), (1, 0), (2, 6), (2, 1)]:
+        order = plan_stream_order(n_dets, n_stab)
+        assert order.count("d") == n_dets and order.count("s") == n_stab and order.count("f") == 1 and order.count("g") == 1 and order.count("n") == 1
+        queues = queue_of_streams(order)
+        det_queues = {q for t, q in zip(order, queues) if t == "d"}
+        assert len(det_queues) == n_dets, order
+        for t, q in zip(order, queues):
+            assert t in ("d", "x", "n") or q not in det_queues, (order, queues)
+        assert queue_of_streams(order + ["next"])[-1] not in det_queues, order
+        assert queue_of_streams(order + ["next", "next"])[-1] not in det_queues, order
+    assert plan_stream_order(2, 4) == "d,d,s,s,s,s,n,x,f,g,x,x".split(",")
+    assert plan_stream_order(3, 4)[:4] == ["d", "n", "d", "d"]          # not enough queues to isolate three detectors: detectors first
