@@ -666,6 +666,9 @@ def main():
         import torch.distributed as dist
 
         if args.backend == "nccl":
+            from geotrax_amd.engine import StreamPlan
+
+            StreamPlan.get(local, max(args.det_streams, 1), max(args.stab_streams, 1) if args.workload == "extract" else 0)   # before RCCL creates its streams
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:                                                   # test mode: ranks may share a GPU, collectives on the host

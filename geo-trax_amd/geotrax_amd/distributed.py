@@ -217,6 +217,12 @@ def init_process_group(local_device_count: int | None = None):
     if not dist.is_initialized():
         _created_group = True
         if backend == "nccl":
+            # the engine's streams take their places on the hardware queues BEFORE torch / RCCL create streams of their own: the plan's
+            # layout (engine.StreamPlan: a queue per detector) assumes it starts from an empty device; laid out for the default stream
+            # counts of cfg/default.yaml, an engine configured otherwise adds what it lacks
+            from .engine import StreamPlan
+
+            StreamPlan.get(local, 2, 4)
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
