@@ -44,7 +44,9 @@ def test_single_gpu_line_has_the_contract_fields():
     hf, ff = d["host_frames"]["value"], d["from_file"]["value"]
     assert hf > 100 and ff > 100 and d["from_file"]["frames"] == 150 and d["from_file"]["reference_convention_fps"] > 0
     assert ff <= 1.1 * d["value"] and hf <= 1.1 * d["value"], (d["value"], hf, ff)
-    assert ff >= 0.75 * d["value"] and hf >= 0.75 * d["value"], (d["value"], hf, ff)
+    # with the engine's stream plan (every detector stream on a hardware queue of its own, whatever the process created before)
+    # both sit within a few per cent of the resident rate; 0.85 leaves room for box-to-box noise (VERDICT r03's bar is 0.9 x 0.9 = 0.81)
+    assert ff >= 0.85 * d["value"] and hf >= 0.85 * d["value"], (d["value"], hf, ff)
     # NMS sees clustered candidates: more candidates than detections in the calibration frame
     assert d["config"]["candidates_per_frame"] > 1.3 * d["config"]["detections_per_frame"]
 

@@ -574,6 +574,51 @@ def test_engine_frames_without_detections(gtx_ctx, tracker):
     assert all(np.isfinite(r.H).all() and abs(np.linalg.det(r.H) - 1.0) < 0.05 for r in got[1:])
 
 
+@pytest.mark.gpu
+def test_engines_of_one_process_run_on_the_same_planned_streams(gtx_ctx):
+    """engine.StreamPlan: which streams share a hardware queue depends on every stream the process has created and destroyed
+    (profiles/r04_stream_map.txt), so the engine's streams are created once, in the planned order, and every engine built afterwards
+    -- the next video of a batch -- runs on the same ones: same contexts by role, none destroyed by close(), a third engine that is
+    built while another is still open gets streams of its own."""
+    from geotrax_amd.engine import ExtractEngine, StreamPlan
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import synthetic_yolov8
+
+    scene = make_scene(seed=4, h=H, w=W)
+    frames = [scene.render(8 * k, 150) for k in range(4)]
+    kw = dict(imgsz=IMGSZ, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=1, nc=4)
+
+    def build():
+        return ExtractEngine(w, (H, W), kw, Tracker("botsort"), dict(max_features=500), batch=2, det_streams=2, stab_streams=2, gmc=True, feeder_stream=True)
+
+    def streams(e):
+        return [d.ctx for d in e.dets] + [s.ctx for s in e.stabs] + [e.gmc.ctx, e.feeder_ctx]
+
+    a = build()
+    plan = StreamPlan.get(a.device, 2, 2)
+    assert a.plan is plan and all(any(c is ent[1] for ent in plan.ctxs) for c in streams(a))
+    first, handles = streams(a), [c.handle.value for c in streams(a)]
+    assert len({id(c) for c in first}) == len(first)
+    out_a = [(r.xyxy.copy(), None if r.H is None else r.H.copy()) for r in a.run([frames[0:2], frames[2:4]])]
+    a.close()
+    assert [c.handle.value for c in first] == handles          # close() hands the streams back, it does not destroy them
+    b = build()
+    try:
+        assert all(x is y for x, y in zip(streams(b), first))    # the second engine: the very same streams, role by role
+        c = build()                                            # a second engine alive at the same time cannot share them
+        try:
+            assert not any(x is y for x in streams(c) for y in first)
+        finally:
+            c.close()
+        out_b = [(r.xyxy.copy(), None if r.H is None else r.H.copy()) for r in b.run([frames[0:2], frames[2:4]])]
+    finally:
+        b.close()
+    for (xa, ha), (xb, hb) in zip(out_a, out_b):
+        assert np.array_equal(xa, xb) and ((ha is None and hb is None) or np.array_equal(ha, hb))
+
+
 
 def _run_sharded_cli(tmp_path, cfg_path, clip, out, n_ranks, backend, port, extra_env=None):
     import os
