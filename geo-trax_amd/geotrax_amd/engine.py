@@ -160,7 +160,11 @@ class StreamPlan:
         with cls._lock:
             if device not in cls._plans:
                 env = os.environ.get("GTX_ENGINE_ORDER")
-                order = [t.strip() for t in env.split(",") if t.strip()] if env else plan_stream_order(n_dets, n_stab)
+                try:
+                    n_queues = max(int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), 1)      # the runtime's own variable; 4 is its default
+                except ValueError:
+                    n_queues = 4
+                order = [t.strip() for t in env.split(",") if t.strip()] if env else plan_stream_order(n_dets, n_stab, n_queues)
                 if any(t not in ("d", "s", "f", "g", "n", "x") for t in order):
                     raise ValueError(f"GTX_ENGINE_ORDER: tokens are d, s, f, g, n, x; got {env!r}")
                 p_det, p_stab = parse_prio(os.environ.get("GTX_ENGINE_PRIO"))
