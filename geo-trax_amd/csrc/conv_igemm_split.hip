@@ -767,22 +767,23 @@ std::vector<uint8_t> pack_conv_weights_split(const float* w, int cout, int cin, 
   const float up = std::ldexp(1.f, shift);
   *acc_scale = std::ldexp(1.f, -shift);
   std::vector<uint8_t> out((size_t)n_ct * cfg.bn * taps * cin * 4);
-  for (int ct = 0; ct < n_ct; ++ct)
-    for (int ch = 0; ch < nchunks; ++ch)
-      for (int tap = 0; tap < taps; ++tap)
-        for (int n = 0; n < cfg.bn; ++n) {
-          const int sw = (n / rpb) & (nch - 1);
-          const size_t row16 = ((((size_t)ct * nchunks + ch) * taps + tap) * cfg.bn + n) * nch;
-          for (int c = 0; c < cpr; ++c)
-            for (int e = 0; e < 8; ++e) {
-              const int ci = ch * cfg.kc + c * 8 + e;
-              const float v = ct * cfg.bn + n < cout ? w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] * up : 0.f;   // exact (power of two)
-              const _Float16 hi = (_Float16)v;
-              const _Float16 lo = (_Float16)(v - (float)hi);
-              memcpy(&out[(row16 + (size_t)(c ^ sw)) * 16 + e * 2], &hi, 2);
-              memcpy(&out[(row16 + (size_t)((cpr + c) ^ sw)) * 16 + e * 2], &lo, 2);
-            }
-        }
+  parallel_for(n_ct * nchunks, [&](int job) {                   // a (cout tile, cin chunk) pair owns a contiguous range of `out`
+    const int ct = job / nchunks, ch = job % nchunks;
+    for (int tap = 0; tap < taps; ++tap)
+      for (int n = 0; n < cfg.bn; ++n) {
+        const int sw = (n / rpb) & (nch - 1);
+        const size_t row16 = ((((size_t)ct * nchunks + ch) * taps + tap) * cfg.bn + n) * nch;
+        for (int c = 0; c < cpr; ++c)
+          for (int e = 0; e < 8; ++e) {
+            const int ci = ch * cfg.kc + c * 8 + e;
+            const float v = ct * cfg.bn + n < cout ? w[((size_t)(ct * cfg.bn + n) * taps + tap) * cin + ci] * up : 0.f;   // exact (power of two)
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            memcpy(&out[(row16 + (size_t)(c ^ sw)) * 16 + e * 2], &hi, 2);
+            memcpy(&out[(row16 + (size_t)((cpr + c) ^ sw)) * 16 + e * 2], &lo, 2);
+          }
+      }
+  });
   return out;
 }
 

@@ -109,11 +109,12 @@ std::shared_ptr<const PackedWeights> packed_weights(const HostTensor& w, int cou
 std::vector<float> to_ohwi(const HostTensor& t) {
   const int O = (int)t.shape[0], I = (int)t.shape[1], KH = (int)t.shape[2], KW = (int)t.shape[3];
   std::vector<float> r((size_t)O * I * KH * KW);
-  for (int o = 0; o < O; ++o)
+  parallel_for(O, [&](int o) {
     for (int i = 0; i < I; ++i)
       for (int y = 0; y < KH; ++y)
         for (int x = 0; x < KW; ++x)
           r[(((size_t)o * KH + y) * KW + x) * I + i] = t.data[(((size_t)o * I + i) * KH + y) * KW + x];
+  });
   return r;
 }
 }  // namespace
