@@ -479,7 +479,7 @@ void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
     p.block_begin = total;
     p.tiles_x = cdiv(p.Wo, cfg.tw);
     p.tiles_y = cdiv(p.Ho, cfg.th);
-    total += p.N * p.tiles_x * p.tiles_y * p.n_ct * (p.ksplit > 1 ? p.ksplit : 1);
+    total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
   }
   g.total_blocks = total;
   // XCD ranges of equal work. Work of a block = its K depth (members share taps, chunk and tile): with equal counts the

@@ -52,14 +52,6 @@ struct ConvProblem {
   // had to be clamped to +-65504 on its way into the pair format.
   int out_plain;
   int* sat_flag;
-  // DT_F32S, single-member launches only: deterministic split-K. ksplit > 1: the K chunks of a tile are dealt to ksplit
-  // workgroups (logical block = ((pixel tile * n_ct) + cout tile) * ksplit + s, chunks [s * nch / ksplit, (s + 1) * nch / ksplit)),
-  // each writes its raw partial sums (x acc_scale, bias in split 0, no activation) as plain fp32 into
-  // partial[s][pixel][Cout rounded up to whole cout tiles], and splitk_reduce (conv_igemm_split.hip) adds the splits in
-  // order, applies SiLU / residual and writes `out`. For launches that cannot fill the chip (60 x 60 and 120 x 120 maps at
-  // batch 1): same arithmetic per product, a fixed summation order, 2 launches instead of 1.
-  int ksplit;
-  float* partial;
   // DT_F32S, 3x3 stride-2 launches whose workgroup holds every output channel (Cout == the cout tile): a 1x1 convolution
   // fused behind the 3x3 one ("post stage": YOLOv8 model.1 -> model.2.cv1). post_w != null: the tile's SiLU(conv) values are
   // split and staged in LDS as pair rows, multiplied there by the Cout x Cout 1x1 weights (post_w: the packed LDS image of the
@@ -123,10 +115,6 @@ double conv_flops(const ConvProblem& p, int ks);
 
 // conv_igemm_split.hip
 void conv_split_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
-// second launch of a split-K convolution (ConvProblem::ksplit > 1): partial sums -> activation -> residual -> out
-void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t stream);
-// bytes of ConvProblem::partial a problem needs (0 when ksplit <= 1)
-size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg);
 std::vector<uint8_t> pack_conv_weights_split(const float* w_ohwi, int cout, int cin, const ConvConfig& cfg, float* acc_scale);
 std::vector<uint16_t> pack_front_weights_split(const float* w27, int c0, float* acc_scale);
 

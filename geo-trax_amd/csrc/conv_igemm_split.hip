@@ -172,11 +172,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
     if (i < cnt && L >= bb[i]) pi = i;
   const ConvProblem P = g.p[pi];            // by value: one burst of wide scalar loads instead of a load (and a wait) per field
 
-  // split-K (single-member launches): the innermost index of a logical block is its K split
-  const int ks_n = P.ksplit > 1 ? P.ksplit : 1;
-  const int lbs = L - P.block_begin;
-  const int ksi = lbs % ks_n;
-  const int lb = lbs / ks_n;
+  const int lb = L - P.block_begin;
   const int ct = lb % P.n_ct;
   const int pt = lb / P.n_ct;
   const int tx = pt % P.tiles_x;
@@ -189,7 +185,8 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   const float* __restrict__ in = static_cast<const float*>(P.in);
   const float* __restrict__ in2 = static_cast<const float*>(P.in2);
   const int nchunks = P.Cin / KC;
-  const int c_begin = ksi * nchunks / ks_n, c_end = (ksi + 1) * nchunks / ks_n;      // this block's K chunks
+  constexpr int c_begin = 0;
+  const int c_end = nchunks;
 
   long goff[Tile::PATCH_SLOTS];   // element offset of the unit (8 channels = 32 B: hi chunk, lo chunk), -1 = zero fill
   long goff2[Tile::PATCH_SLOTS];  // 1x1 only: the same unit in the half-resolution second source (ConvProblem::in2)
@@ -402,7 +399,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   {                                                                                          \
     _Pragma("unroll") for (int j = 0; j < WN; ++j)                                           \
       _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = make_float4(0.f, 0.f, 0.f, 0.f); \
-    if (P.bias && ksi == 0) {                 /* one uniform branch, eight independent loads (split-K: the bias enters with split 0) */ \
+    if (P.bias) {                             /* one uniform branch, eight independent loads */ \
       const float* __restrict__ bias_p = P.bias + ct * BN + 4 * (lane >> 5);                 \
       _Pragma("unroll") for (int j = 0; j < WN; ++j)                                         \
         _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) b4[j][g4] = *reinterpret_cast<const float4*>(bias_p + 32 * j + 8 * g4);   /* bias arrays are padded to whole cout tiles */ \
@@ -593,13 +590,12 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   // stores whole BN*4-byte runs per pixel. ConvProblem::out_plain keeps plain fp32 (the Detect head's last stage, read by
   // the decode kernels).
   const float sc = post ? P.post_scale : P.acc_scale;
-  const bool partial = ks_n > 1;                // split-K: raw partial sums, plain fp32, into this split's plane of P.partial
-  const int cvalid = partial ? BN : P.Cout - ct * BN;   // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
-  const bool plain = partial || P.out_plain != 0;
-  const bool act = !partial && (post ? P.post_act : P.act) != 0;
-  const void* const res_p = partial ? nullptr : P.res;
-  const int o_cstride = partial ? P.n_ct * BN : P.out_cstride, o_coff = partial ? 0 : P.out_coff;
-  float* const o_base = partial ? P.partial + (size_t)ksi * P.N * P.Ho * P.Wo * o_cstride : static_cast<float*>(P.out);
+  const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
+  const bool plain = P.out_plain != 0;
+  const bool act = (post ? P.post_act : P.act) != 0;
+  const void* const res_p = P.res;
+  const int o_cstride = P.out_cstride, o_coff = P.out_coff;
+  float* const o_base = static_cast<float*>(P.out);
   bool sat = false;
   __syncthreads();                              // every wave is done with the staging buffers
 #pragma unroll
@@ -673,54 +669,6 @@ template <int WN, int NCH>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu(2)))
 void conv_front_split_kernel(const ConvGroup g) {
   conv_split_body<3, 2, WN, 2, 1, NCH>(g);
-}
-
-// Second launch of a split-K convolution: one thread per 8-channel group of an output pixel adds the ksplit partial sums in
-// split order (fixed: the result does not depend on which workgroup finished first), applies SiLU and the residual and
-// writes the group in pair format (or plain fp32, ConvProblem::out_plain).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvProblem P, int pstride /* channels per pixel in a partial plane */) {
-  const int groups = P.Cout >> 3;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long npix = (long)P.N * P.Ho * P.Wo;
-  if (gid >= npix * groups) return;
-  const long pix = gid / groups;
-  const int c0 = (int)(gid - pix * groups) * 8;
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = 0.f;
-  for (int s = 0; s < P.ksplit; ++s) {
-    const float4* src = reinterpret_cast<const float4*>(P.partial + ((size_t)s * npix + pix) * pstride + c0);
-    const float4 a = src[0], b = src[1];
-    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-  }
-  if (P.act) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
-  }
-  if (P.res) {
-    const char* r = reinterpret_cast<const char*>(static_cast<const float*>(P.res) + pix * P.res_cstride + P.res_coff + c0);
-    const half8 rh = *reinterpret_cast<const half8*>(r), rl = *reinterpret_cast<const half8*>(r + 16);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i];
-  }
-  float* out = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + c0;
-  if (P.out_plain) {
-    reinterpret_cast<float4*>(out)[0] = make_float4(v[0], v[1], v[2], v[3]);
-    reinterpret_cast<float4*>(out)[1] = make_float4(v[4], v[5], v[6], v[7]);
-    return;
-  }
-  half8 hi, lo;
-  bool sat = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x = __builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
-    sat |= x != v[i];
-    hi[i] = (_Float16)x;
-    lo[i] = (_Float16)(x - (float)hi[i]);
-  }
-  reinterpret_cast<half8*>(out)[0] = hi;
-  reinterpret_cast<half8*>(out)[1] = lo;
-  if (sat && P.sat_flag) atomicOr(P.sat_flag, 1);
 }
 
 template <int KS, int STRIDE, int WN, int CPR, int WM>
@@ -817,30 +765,14 @@ std::vector<uint16_t> pack_front_weights_split(const float* w27 /*[27][c0], (tap
   return out;
 }
 
-size_t conv_splitk_scratch_bytes(const ConvProblem& p, const ConvConfig& cfg) {
-  if (p.ksplit <= 1) return 0;
-  const size_t pstride = (size_t)((p.Cout + cfg.bn - 1) / cfg.bn) * cfg.bn;
-  return (size_t)p.ksplit * p.N * p.Ho * p.Wo * pstride * sizeof(float);
-}
-
-void conv_splitk_reduce(const ConvProblem& p, const ConvConfig& cfg, hipStream_t s) {
-  GTX_CHECK(p.ksplit > 1 && p.partial && p.Cout % 8 == 0, "split-K reduce: not a split problem");
-  const int pstride = (p.Cout + cfg.bn - 1) / cfg.bn * cfg.bn;
-  const long work = (long)p.N * p.Ho * p.Wo * (p.Cout / 8);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, p, pstride);
-  GTX_HIP(hipGetLastError());
-}
-
 void conv_split_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t s) {
   for (int i = 0; i < g.count; ++i)
-    GTX_CHECK(g.p[i].post_w == nullptr || (c.ks == 3 && c.stride == 2 && c.th == 8 && g.p[i].Cout == c.bn && g.p[i].ksplit <= 1 && !g.p[i].res),
+    GTX_CHECK(g.p[i].post_w == nullptr || (c.ks == 3 && c.stride == 2 && c.th == 8 && g.p[i].Cout == c.bn && !g.p[i].res),
               "conv: the fused 1x1 post stage needs a 3x3 stride-2 launch whose cout tile holds every channel (Cout %d, tile %d)", g.p[i].Cout, c.bn);
-  for (int i = 0; i < g.count; ++i)
-    GTX_CHECK(g.p[i].ksplit <= 1 || (g.count == 1 && g.p[i].partial && g.p[i].ksplit <= g.p[i].Cin / c.kc), "conv: split-K needs a single-member launch, a scratch buffer and at most one split per K chunk");
   const int cpr = c.kc / 8, wn = c.bn / 32, wm = c.th / 8;
   if (g.p[0].front_img != nullptr) {
     const ConvProblem& p = g.p[0];
-    GTX_CHECK(g.count == 1 && c.ks == 3 && c.stride == 2 && cpr == 2 && wm == 1 && (wn == 1 || wn == 2) && p.Cout <= c.bn && p.ksplit <= 1 &&
+    GTX_CHECK(g.count == 1 && c.ks == 3 && c.stride == 2 && cpr == 2 && wm == 1 && (wn == 1 || wn == 2) && p.Cout <= c.bn &&
                   p.front_w && p.front_bias && p.front_h == 2 * p.H && p.front_w_px == 2 * p.W,
               "conv: the front stage needs a single 3x3 stride-2 launch with one cout tile on a stem output of half the image size");
     if (wn == 1 && p.Cin == 16) return launch_front_t<1, 1>(g, s);     // YOLOv8n: 16 -> 32 channels

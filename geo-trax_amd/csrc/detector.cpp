@@ -171,21 +171,6 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   p.acc_scale = acc_scale;
   p.out_plain = out.plain ? 1 : 0;
   p.sat_flag = conv_dtype_ == DT_F32S ? sat_dev_ : nullptr;
-  // Split-K for the launches that cannot fill the chip (GTX_SPLITK=n: up to n splits per convolution). Built for the batch-1
-  // detector of BASELINE configs[1] and measured there: 1.623 vs 1.611 ms per pass -- a 60 x 60 3x3 layer gains 10 %, a
-  // 120 x 120 one loses 20 % (the time of such a launch is ~13 us of fixed cost plus ~1.25 us per K chunk, and split-K trades
-  // chunks for a second launch) -- so it is off unless asked for. Per image: `blocks` workgroups of `nch` K chunks; the splits
-  // bring the launch to ~640 workgroups while every split keeps at least 2 chunks of a 3x3 or 8 of a 1x1.
-  static const int splitk_mode = [] { const char* e = getenv("GTX_SPLITK"); return e && *e ? atoi(e) : 0; }();   // 0 off, n: at most n splits
-  if (op.cfg.variant == 2 && splitk_mode > 1) {
-    const int blocks = cdiv(ho, op.cfg.th) * cdiv(wo, op.cfg.tw) * cdiv(cout, op.cfg.bn), nch = cin / op.cfg.kc;
-    int S = std::min(nch / (ks == 3 ? 2 : 8), 640 / std::max(blocks, 1));
-    S = std::min(S, splitk_mode);
-    if (S > 1 && force_bn_ == 0) {       // (force_bn_: the Detect head's convs, single-problem ops only until they are merged into grouped launches)
-      p.ksplit = S;
-      splitk_bytes_ = std::max(splitk_bytes_, conv_splitk_scratch_bytes(p, op.cfg));     // p.N is the detector's max_batch here
-    }
-  }
   if (up_src) {
     GTX_CHECK(ks == 1 && stride == 1 && op.cfg.variant == 2 && up_src->h * 2 == x.h && up_src->w * 2 == x.w && up_src->c < cin,
               "%s: upsampled source does not fit", name.c_str());
@@ -451,9 +436,9 @@ void Detector::fuse_front() {
     const Op &a = ops_[i], &b = ops_[i + 1];
     if (a.kind != Op::CONV || b.kind != Op::CONV || a.grp.count != 1 || b.grp.count != 1) return;
     const ConvProblem &pa = a.grp.p[0], &pb = b.grp.p[0];
-    const bool ok = a.cfg.variant == 2 && a.cfg.ks == 3 && a.cfg.stride == 2 && pa.Cout == a.cfg.bn && !pa.res && pa.ksplit <= 1 &&
+    const bool ok = a.cfg.variant == 2 && a.cfg.ks == 3 && a.cfg.stride == 2 && pa.Cout == a.cfg.bn && !pa.res &&
                     b.cfg.variant == 2 && b.cfg.ks == 1 && b.cfg.kc == 32 && b.cfg.bn == pb.Cout && pb.Cin == pa.Cout && pb.Cout == pa.Cout &&
-                    pb.in == pa.out && pb.in_cstride == pa.out_cstride && pb.in_coff == pa.out_coff && !pb.res && !pb.in2 && pb.ksplit <= 1;
+                    pb.in == pa.out && pb.in_cstride == pa.out_cstride && pb.in_coff == pa.out_coff && !pb.res && !pb.in2;
     if (!ok) return;
     unfused_ = {a, b};
     Op f = a;
@@ -480,7 +465,7 @@ void Detector::fuse_stem() {
   if (st.kind != Op::STEM || cv.kind != Op::CONV || cv.grp.count != 1 || !st.front_wpk) return;
   ConvProblem& p = cv.grp.p[0];
   const bool ok = cv.cfg.variant == 2 && cv.cfg.ks == 3 && cv.cfg.stride == 2 && cv.cfg.kc == 16 && cv.cfg.th == 8 && ((cv.cfg.bn == 32 && p.Cin == 16) || (cv.cfg.bn == 64 && p.Cin == 32)) &&
-                  p.Cout <= cv.cfg.bn && p.ksplit <= 1 && !p.res && p.in == st.out.ptr && p.in_cstride == st.out.c && p.in_coff == 0 && p.Cin == st.out.c &&
+                  p.Cout <= cv.cfg.bn && !p.res && p.in == st.out.ptr && p.in_cstride == st.out.c && p.in_coff == 0 && p.Cin == st.out.c &&
                   st.in.h == 2 * st.out.h && st.in.w == 2 * st.out.w && p.H == st.out.h && p.W == st.out.w;
   if (!ok) return;
   unfused_.insert(unfused_.begin(), st);
@@ -622,13 +607,6 @@ void Detector::finalize() {
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
   if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
-  if (splitk_bytes_ > 0) {           // one scratch buffer for every split-K convolution (they run one after the other on the stream)
-    float* scratch = (float*)alloc(splitk_bytes_);
-    for (Op& op : ops_)
-      if (op.kind == Op::CONV)
-        for (int i = 0; i < op.grp.count; ++i)
-          if (op.grp.p[i].ksplit > 1) op.grp.p[i].partial = scratch;
-  }
   set_batch(1);
   GTX_HIP(hipStreamSynchronize(ctx_->stream));
   finalized_ = true;
@@ -638,7 +616,6 @@ void Detector::run_op(const Op& op, int nb, hipStream_t s) {
   switch (op.kind) {
     case Op::CONV:
       conv_launch(op.grp, op.cfg, s);
-      if (op.grp.count == 1 && op.grp.p[0].ksplit > 1) conv_splitk_reduce(op.grp.p[0], op.cfg, s);
       break;
     case Op::STEM:
       launch_stem(dtype_ == DT_F32 ? conv_dtype_ : dtype_, op.in.ptr, nb, op.in.h, op.in.w, op.w27, op.bias, op.wpk, op.out.c, op.out.ptr, op.out.h,

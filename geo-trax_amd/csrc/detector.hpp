@@ -155,7 +155,6 @@ class Detector {
   bool sat_seen_ = false;
   bool plain_out_ = false;   // convs being built write plain fp32 (head stage 2)
   std::vector<Op> unfused_;  // the stand-alone forms of fused ops (layer_output of an intermediate runs them on demand)
-  size_t splitk_bytes_ = 0;  // scratch for the partial sums of the split-K convolutions (batch-1 detectors)
   int* h_out_n_ = nullptr;   // pinned
   float* h_out_rows_ = nullptr;
   hipEvent_t ev_[4]{};

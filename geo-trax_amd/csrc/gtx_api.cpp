@@ -126,7 +126,7 @@ int gtx_dev_download(gtx_ctx* ctx, void* host, const void* dptr, size_t bytes) {
 
 namespace {
 struct ConvOpState {
-  gtx::DevBuf x, w, b, r, y, scratch;
+  gtx::DevBuf x, w, b, r, y;
   gtx::ConvGroup g{};
   gtx::ConvConfig cfg{};
   int ho = 0, wo = 0;
@@ -212,16 +212,7 @@ void conv_setup(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const float
   p.acc_scale = acc_scale;
   p.in2 = nullptr; p.in2_cstride = p.in2_coff = p.c_split = 0;
   p.out_plain = 0; p.sat_flag = nullptr;
-  p.ksplit = 0; p.partial = nullptr;
   p.post_w = nullptr; p.post_bias = nullptr; p.post_scale = 1.f; p.post_act = 0;
-  if (const char* e = std::getenv("GTX_OP_KSPLIT")) {          // test hook: the split-K form of a split-f16x3 convolution
-    const int ks = std::atoi(e);
-    if (ks > 1 && st.cfg.variant == 2 && ks <= d->cin / st.cfg.kc) {
-      p.ksplit = ks;
-      st.scratch.alloc(conv_splitk_scratch_bytes(p, st.cfg));
-      p.partial = st.scratch.as<float>();
-    }
-  }
   st.g.count = 1;
   conv_group_finalize(st.g, st.cfg);
 }
@@ -235,7 +226,6 @@ int gtx_op_conv2d(gtx_ctx* ctx, const gtx_conv_desc* d, const void* x, const flo
     ConvOpState st;
     conv_setup(ctx, d, x, w_ohwi, bias, residual, y, st);
     gtx::conv_launch(st.g, st.cfg, ctx->stream);
-    if (st.g.p[0].ksplit > 1) gtx::conv_splitk_reduce(st.g.p[0], st.cfg, ctx->stream);
     GTX_HIP(hipStreamSynchronize(ctx->stream));
     const size_t yb = (size_t)d->n * st.ho * st.wo * d->out_cstride * gtx::dtype_size(d->dtype);
     if (d->dtype == GTX_F32S) {                       // pair format -> the caller's plain fp32 array
@@ -278,8 +268,7 @@ int gtx_op_conv2d_time(gtx_ctx* ctx, const gtx_conv_desc* d, int iters, float* m
     GTX_HIP(hipEventCreate(&e1));
     auto once = [&] {
       gtx::conv_launch(st.g, st.cfg, ctx->stream);
-      if (st.g.p[0].ksplit > 1) gtx::conv_splitk_reduce(st.g.p[0], st.cfg, ctx->stream);
-    };
+      };
     for (int i = 0; i < 3; ++i) once();
     GTX_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < iters; ++i) once();
