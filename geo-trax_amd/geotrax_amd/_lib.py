@@ -81,6 +81,9 @@ _SIGNATURES = {
     "gtx_ctx_destroy": (None, [_P]),
     "gtx_ctx_synchronize": (C.c_int, [_P]),
     "gtx_device_open_null_stream": (C.c_int, [C.c_int]),
+    "gtx_write_table_f32": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "gtx_write_table_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "gtx_write_csv": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int]),
     "gtx_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "gtx_dev_free": (C.c_int, [_P, _P]),
     "gtx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),

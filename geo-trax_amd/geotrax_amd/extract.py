@@ -31,7 +31,7 @@ from pathlib import Path
 import numpy as np
 import yaml
 
-from . import __version__
+from . import __version__, tables
 from .config_utils import backfill_args_from_config, load_config_all
 from .frames import get_video_dimensions, open_source, source_exists
 from .model import YOLO
@@ -541,7 +541,7 @@ def save_results(tracks: np.ndarray, transforms: np.ndarray, config: dict, logge
 
     try:
         if tracks.size != 0:
-            np.savetxt(tracks_txt_file, tracks, fmt='%g', delimiter=',')
+            tables.savetxt(tracks_txt_file, tracks, 6)             # np.savetxt(..., fmt='%g', delimiter=','), same bytes (tables.py)
             logger.info(f"Tracking results saved to: '{tracks_txt_file.resolve()}'")
     except Exception as e:
         logger.error(f"Failed to save the tracking results to: '{tracks_txt_file.resolve()}' due to: {e}")
@@ -554,7 +554,7 @@ def save_results(tracks: np.ndarray, transforms: np.ndarray, config: dict, logge
                 logger.warning(f"Missing frame ids found in: '{transf_txt_file}'.")
             if not np.all(np.linalg.det(matrices) > 0):
                 logger.warning(f"Invalid transforms found in: '{transf_txt_file}'.")
-            np.savetxt(transf_txt_file, transforms, fmt='%.16g', delimiter=',')
+            tables.savetxt(transf_txt_file, transforms, 16)        # fmt='%.16g'
     except Exception as e:
         logger.error(f"Failed to save the video stabilization results to: '{transf_txt_file.resolve()}' due to: {e}")
     else:

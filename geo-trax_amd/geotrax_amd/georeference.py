@@ -301,14 +301,26 @@ def create_and_format_georeferenced_df(track_id, timestamps, frame_num, x_stab_o
         "Vehicle_Speed": v_speed, "Vehicle_Acceleration": v_acceleration, "Road_Section": road_section, "Lane_Number": lane_number,
         "Visibility": visibility, "Is_Interpolated": is_interpolated,
     }
-    df = pd.DataFrame({k: v for k, v in cols.items() if v is not None})
+    # copy=False: the columns stay the arrays they are (no consolidation into per-dtype blocks: 2.7 s of the 4.9 s this function took
+    # on a 900 k-row video); every column below is replaced by a new array, never written in place
+    df = pd.DataFrame({k: v for k, v in cols.items() if v is not None}, copy=False)
     for name, digits in _ROUND.items():
         df[name] = np.round(df[name], digits)
     df["Visibility"] = df["Visibility"].astype("int")
     if "Is_Interpolated" in df.columns:
         df["Is_Interpolated"] = df["Is_Interpolated"].astype("int")
     if "Lane_Number" in df.columns:
-        df["Lane_Number"] = df["Lane_Number"].apply(lambda v: str(int(v)) if pd.notna(v) else "")
+        # str(int(v)) for a lane number, "" for a missing one (:845-846) -- through the few distinct values instead of row by row
+        lane = df["Lane_Number"]
+        if lane.dtype.kind in "fiu":
+            v = lane.to_numpy()
+            have = ~np.isnan(v) if v.dtype.kind == "f" else np.ones(len(v), bool)
+            uniq, inv = np.unique(v[have].astype(np.int64), return_inverse=True)
+            out = np.full(len(v), "", dtype=object)
+            out[have] = np.array([str(int(u)) for u in uniq], dtype=object)[inv] if len(uniq) else []
+            df["Lane_Number"] = out
+        else:
+            df["Lane_Number"] = lane.apply(lambda v: str(int(v)) if pd.notna(v) else "")
     if min_traj_length > 0:
         before = df["Vehicle_ID"].nunique()
         if "Is_Interpolated" in df.columns:
@@ -326,7 +338,10 @@ def create_and_format_georeferenced_df(track_id, timestamps, frame_num, x_stab_o
 def save_georeferenced_data(path: Path, georeferenced_df, logger: logging.Logger) -> None:
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    georeferenced_df.to_csv(path, index=False)
+    from . import tables
+
+    if not tables.dataframe_to_csv(path, georeferenced_df):     # int64 / float64 / label columns: the library's writer, same bytes
+        georeferenced_df.to_csv(path, index=False)               # anything else in the frame (free text, dates): pandas' own
     logger.info(f"Georeferenced data saved to: '{path}'.")
 
 
@@ -334,5 +349,7 @@ def save_homography(path: Path, homography: np.ndarray, logger: logging.Logger) 
     """The nine entries on one comma-separated line, 20 significant digits (georeference.py:879-889)."""
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    np.savetxt(path, np.asarray(homography, np.float64).reshape(1, -1), fmt="%.20g", delimiter=",")
+    from . import tables
+
+    tables.savetxt(path, np.asarray(homography, np.float64).reshape(1, -1), 20)     # np.savetxt(..., fmt="%.20g", delimiter=",")
     logger.info(f"Reference-to-orthophoto homography saved to: '{path}'.")

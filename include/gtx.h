@@ -41,7 +41,7 @@ extern "C" {
  *    (host arrays handed to gtx_op_* stay plain fp32).
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
- * 6: gtx_device_open_null_stream added. */
+ * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64 and gtx_write_csv added. */
 #define GTX_ABI_VERSION 6
 
 typedef enum gtx_status {
@@ -501,6 +501,22 @@ int gtx_warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const dou
 /* Same, both images resident in HBM (dptrs from gtx_dev_alloc, distinct buffers); enqueued on the
  * context's stream, returns without waiting (gtx_ctx_synchronize / a later call on the stream orders it). */
 int gtx_warp_frame_dev(gtx_ctx* ctx, const void* src_dptr, int h, int w, const double H[9], void* dst_dptr);
+
+/* ------------------------------------------------------------------ result files (host code, no GPU work)
+ *
+ * The text tables the two stages end with, byte for byte as the reference writes them, formatted on a few threads.
+ * gtx_write_table_f32 / _f64 replace np.savetxt(path, table, fmt='%.<precision>g', delimiter=',') of save_results
+ * (geotrax/extract.py:497-516: the tracks with '%g' = precision 6 on float32 rows, the transforms with '%.16g' on float64 rows;
+ * save_homography's '%.20g' line, georeference.py:879-889). data: rows x cols, row-major. n_threads <= 0: up to 8.
+ * gtx_write_csv replaces pandas.DataFrame.to_csv(path, index=False) for the georeferenced table (georeference.py:802-877):
+ * header_line = the column names joined by commas; kinds[c]: 0 = int64 column, 1 = float64 column written as repr(float)
+ * (shortest round-trip digits, NaN = empty cell), 2 = int32 codes into categories[c][0 .. n_categories[c]) (strings already
+ * quoted as a CSV cell needs; a negative code = missing = empty cell; categories / n_categories may be NULL without such columns).
+ * columns[c]: `rows` values of the column's kind. */
+int gtx_write_table_f32(const char* path, const float* data, int64_t rows, int cols, int precision, int n_threads);
+int gtx_write_table_f64(const char* path, const double* data, int64_t rows, int cols, int precision, int n_threads);
+int gtx_write_csv(const char* path, const char* header_line, int n_cols, const int* kinds, const void* const* columns,
+                  const char* const* const* categories, const int* n_categories, int64_t rows, int n_threads);
 
 #ifdef __cplusplus
 }
