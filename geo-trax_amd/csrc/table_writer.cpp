@@ -205,3 +205,42 @@ int gtx_write_csv(const char* path, const char* header_line, int n_cols, const i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// estimate_vehicle_dimensions' walk over a track (geotrax/extract.py:433-452), for every track of a table in one call.
+// Per track: an anchor point; the first later observation at least `radius` pixels away becomes the next anchor. The reference
+// does this with NumPy float32 scalars, one Python iteration per row (1.5 s of interpreter time on a 7 000-frame video); the
+// arithmetic below is the same sequence of float32 operations: x ** 2 of a float32 scalar is glibc's powf(x, 2.0f) -- which is
+// NOT x * x in 0.08 % of cases -- so powf is called through a volatile pointer (the compiler would fold it into a multiply),
+// then a float32 add, sqrtf, and the comparison against radius in float32 (a Python float is a weak scalar under NumPy 2).
+// What the walk does NOT do is the azimuth of an anchor step: NumPy's float32 arctan2 is its own SIMD routine on some CPUs and
+// libm's atan2f on others, so the caller computes it with NumPy from the (dx, dy) returned here -- the same ufunc loop the
+// reference's scalar call ends in. tests/test_postprocess.py holds the whole thing against the row-by-row form.
+namespace {
+float (*volatile powf_of_libm)(float, float) = powf;
+}
+
+extern "C" int gtx_track_anchor_walk(const float* xc, const float* yc, const int64_t* start, int n_tracks, float radius,
+                                     uint8_t* is_anchor, float* step_dx, float* step_dy) {
+  return gtx::guarded([&] {
+    if (n_tracks < 0 || (n_tracks > 0 && (!xc || !yc || !start || !is_anchor || !step_dx || !step_dy))) gtx::fail(GTX_ERR_INVALID, "anchor walk: null argument");
+    for (int t = 0; t < n_tracks; ++t) {
+      const int64_t a = start[t], b = start[t + 1];
+      if (b < a) gtx::fail(GTX_ERR_INVALID, "anchor walk: track %d has a negative length", t);
+      if (b == a) continue;
+      std::memset(is_anchor + a, 0, (size_t)(b - a));
+      float xp = xc[a], yp = yc[a];
+      for (int64_t k = a + 1; k < b; ++k) {
+        const float dx = xc[k] - xp, dy = yc[k] - yp;
+        const float d = sqrtf(powf_of_libm(dx, 2.0f) + powf_of_libm(dy, 2.0f));
+        if (d >= radius) {
+          is_anchor[k] = 1;
+          step_dx[k] = dx;
+          step_dy[k] = dy;
+          xp = xc[k];
+          yp = yc[k];
+        }
+      }
+    }
+  });
+}

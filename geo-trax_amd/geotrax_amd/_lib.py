@@ -84,6 +84,7 @@ _SIGNATURES = {
     "gtx_write_table_f32": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "gtx_write_table_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "gtx_write_csv": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int]),
+    "gtx_track_anchor_walk": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "gtx_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "gtx_dev_free": (C.c_int, [_P, _P]),
     "gtx_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),

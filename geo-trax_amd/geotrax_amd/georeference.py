@@ -188,19 +188,27 @@ def calculate_visibility(track_ids, bbox_unstab, frame_size, visibility_margin: 
 
 
 def interpolate_missing_points(frames, x, y) -> tuple:
-    """Linear fill of skipped frames (:738-766) -> (x list, y list, indices of the original samples)."""
+    """Linear fill of skipped frames (:738-766) -> (x, y with the fills in place, indices of the original samples). The reference
+    appends point by point; here the same values (x[i-1] + step * ((x[i] - x[i-1]) / gap), float64) are laid out in one pass."""
     frames = np.asarray(frames)
-    xs, ys, present = [x[0]], [y[0]], [1]
-    for i in range(1, len(frames)):
-        gap = int(frames[i] - frames[i - 1])
-        if gap > 1:
-            dx, dy = (x[i] - x[i - 1]) / gap, (y[i] - y[i - 1]) / gap
-            for step in range(1, gap):
-                xs.append(x[i - 1] + step * dx)
-                ys.append(y[i - 1] + step * dy)
-                present.append(0)
-        xs.append(x[i]); ys.append(y[i]); present.append(1)
-    return xs, ys, np.nonzero(present)[0]
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    if len(frames) < 2:
+        return x.copy(), y.copy(), np.arange(len(frames))
+    gaps = (frames[1:] - frames[:-1]).astype(np.int64)
+    per = np.where(gaps > 1, gaps, 1)                           # points an interval adds: its fills, then its sample
+    if per.sum() == len(gaps):                                  # no frame was skipped
+        return x.copy(), y.copy(), np.arange(len(frames))
+    pos = np.concatenate(([0], np.cumsum(per)))                 # where the original samples land
+    seg = np.repeat(np.arange(len(per)), per)                   # interval of every point after the first
+    step = np.arange(1, pos[-1] + 1) - pos[seg]                 # 1 .. per[seg]; == per[seg] at the interval's own sample
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dx, dy = (x[1:] - x[:-1]) / gaps, (y[1:] - y[:-1]) / gaps
+    fill = step < per[seg]
+    xs, ys = np.empty(pos[-1] + 1), np.empty(pos[-1] + 1)
+    xs[0], ys[0] = x[0], y[0]
+    xs[1:] = np.where(fill, x[seg] + step * dx[seg], x[seg + 1])
+    ys[1:] = np.where(fill, y[seg] + step * dy[seg], y[seg + 1])
+    return xs, ys, pos
 
 
 def compute_speed(x, y, fps: float) -> np.ndarray:
@@ -231,8 +239,10 @@ def compute_kinematics(track_ids, frame_num, x_local, y_local, visibility, fps: 
     speed smoothed, first speed and first two accelerations undefined."""
     n = len(track_ids)
     speed, accel = np.full(n, np.nan), np.full(n, np.nan)
-    for tid in np.unique(track_ids):
-        idx = np.where(track_ids == tid)[0]
+    track_ids = np.asarray(track_ids)
+    order = np.argsort(track_ids, kind="stable")               # per track the ascending row indices np.where(track_ids == tid)[0] gives,
+    bounds = np.flatnonzero(track_ids[order][1:] != track_ids[order][:-1]) + 1   # without a pass over the table per track
+    for idx in (np.split(order, bounds) if n else []):
         real = (np.asarray(is_interpolated)[idx] == 0) if is_interpolated is not None else np.ones(len(idx), bool)
         use = np.asarray(visibility)[idx] & real
         if use.sum() < 3:

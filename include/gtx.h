@@ -41,7 +41,7 @@ extern "C" {
  *    (host arrays handed to gtx_op_* stay plain fp32).
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
- * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64 and gtx_write_csv added. */
+ * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added. */
 #define GTX_ABI_VERSION 6
 
 typedef enum gtx_status {
@@ -517,6 +517,12 @@ int gtx_write_table_f32(const char* path, const float* data, int64_t rows, int c
 int gtx_write_table_f64(const char* path, const double* data, int64_t rows, int cols, int precision, int n_threads);
 int gtx_write_csv(const char* path, const char* header_line, int n_cols, const int* kinds, const void* const* columns,
                   const char* const* const* categories, const int* n_categories, int64_t rows, int n_threads);
+/* The per-row walk of estimate_vehicle_dimensions (geotrax/extract.py:433-452) for every track of a table in one call (host code).
+ * xc, yc: the observations' centres, float32, the rows of track t at [start[t], start[t+1]). is_anchor[row] = 1 where the reference's
+ * loop finds the observation at least `radius` pixels from the current anchor (and makes it the next one); step_dx / step_dy[row]:
+ * that step, for the caller's azimuth test. The same float32 operation sequence as the NumPy scalars of the reference (csrc/table_writer.cpp). */
+int gtx_track_anchor_walk(const float* xc, const float* yc, const int64_t* start, int n_tracks, float radius,
+                          uint8_t* is_anchor, float* step_dx, float* step_dy);
 
 #ifdef __cplusplus
 }
