@@ -6,12 +6,17 @@
 //         >1000 removed tracks so that the ring of removed ids wraps), box warps and point transforms on edge inputs.
 //   tsan: the same streams on several tracker objects from several threads at once (objects are independent; the library
 //         promises nothing shared between them).
+//   both: the result-file writers, whose worker threads format chunks and pass the file to each other in row order.
 #include <cmath>
 #include <cstdio>
 #include <random>
 #include <thread>
 #include <vector>
 
+#include <cstdint>
+#include <string>
+
+#include "../../../include/gtx.h"
 #include "../geometry.hpp"
 #include "../tracker.hpp"
 
@@ -64,9 +69,42 @@ long run_tracker(int type, unsigned seed) {
 }
 }  // namespace
 
+// The result-file writers (table_writer.cpp): several chunks per call so that their own threads hand the file to each other in
+// order, awkward values, a categorical column with missing cells; the anchor walk over ragged tracks incl. an empty one.
+bool run_writers(unsigned seed) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> U(-4000.f, 4000.f);
+  const int64_t rows = 40000;
+  std::vector<float> t((size_t)rows * 12);
+  for (float& v : t) v = U(rng);
+  t[5] = NAN; t[17] = INFINITY; t[29] = -0.0f; t[41] = 1e-38f;
+  const std::string base = "/tmp/gtx_sanitize_" + std::to_string(seed);
+  if (gtx_write_table_f32((base + ".txt").c_str(), t.data(), rows, 12, 6, 4) != GTX_OK) return false;
+  std::vector<double> d(t.begin(), t.begin() + 9 * 1000);
+  if (gtx_write_table_f64((base + "_h.txt").c_str(), d.data(), 1000, 9, 20, 3) != GTX_OK) return false;
+  std::vector<int64_t> ids((size_t)rows);
+  std::vector<double> val((size_t)rows);
+  std::vector<int32_t> code((size_t)rows);
+  for (int64_t i = 0; i < rows; ++i) { ids[i] = i / 7 - 3; val[i] = i % 11 ? (double)t[i] * 1e-3 : (double)NAN; code[i] = (int32_t)(i % 4) - 1; }
+  const char* labels[3] = {"A", "\"B,1\"", ""};
+  const int kinds[3] = {0, 1, 2};
+  const void* cols[3] = {ids.data(), val.data(), code.data()};
+  const char* const* cats[3] = {nullptr, nullptr, labels};
+  const int ncat[3] = {0, 0, 3};
+  if (gtx_write_csv((base + ".csv").c_str(), "Vehicle_ID,Value,Section", 3, kinds, cols, cats, ncat, rows, 4) != GTX_OK) return false;
+  if (gtx_write_csv("/no/such/dir/x.csv", "a,b,c", 3, kinds, cols, cats, ncat, rows, 2) == GTX_OK) return false;   // the error path closes nothing twice
+  std::vector<int64_t> start = {0, 0, 1, 300, 2000, 2001, (int64_t)rows};
+  std::vector<uint8_t> anchor((size_t)rows, 7);
+  std::vector<float> dx((size_t)rows), dy((size_t)rows);
+  if (gtx_track_anchor_walk(t.data(), t.data() + rows, start.data(), (int)start.size() - 1, 45.87156f, anchor.data(), dx.data(), dy.data()) != GTX_OK) return false;
+  std::remove((base + ".txt").c_str()); std::remove((base + "_h.txt").c_str()); std::remove((base + ".csv").c_str());
+  return anchor[0] == 0 && anchor[1] <= 1;
+}
+
 int main(int argc, char** argv) {
   const bool threads = argc > 1 && argv[1][0] == 't';
   long rows = 0;
+  if (!run_writers(threads ? 2 : 1)) { std::fprintf(stderr, "result-file writers failed\n"); return 3; }
   if (threads) {
     std::vector<long> r(6);
     std::vector<std::thread> th;
