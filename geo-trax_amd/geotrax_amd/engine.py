@@ -26,6 +26,7 @@ import ctypes as C
 import os
 import queue
 import threading
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -237,6 +238,8 @@ class ExtractEngine:
         self._last_H = None              # last valid current->reference transform, in frame order
         self._gmc_sub = self._gmc_col = 0   # frames queued on the GMC stream / warps taken (one writer thread each)
 
+    _IDLE = object()                 # drain() -> _stabilized(): no frame arrived for a few milliseconds
+
     #: host threads the engine adds to the caller's: the detector stage and the GMC + tracker stage (the stabilizer stage runs on
     #: the thread that iterates run()). All three wait on HIP events with hipEventBlockingSync, i.e. asleep while the GPU works:
     #: 8 ranks x 3 threads + rank 0's replay thread fit the 16 host cores a GPU box grants without spinning against each other.
@@ -348,9 +351,13 @@ class ExtractEngine:
         inflight = collections.deque()                          # (detector, frames in the batch)
         k = 0
 
+        paced = False                                            # the source kept this stage waiting for its last batch (a live stream)
+
         def submit_next():
-            nonlocal k
+            nonlocal k, paced
+            t0 = time.perf_counter()
             b = next(it, None)
+            paced = time.perf_counter() - t0 > 0.02              # far above a read + upload, below a frame period at 30 fps
             if b is None:
                 return
             prev = None
@@ -371,7 +378,8 @@ class ExtractEngine:
                 grays = [det.gray_dptr(b) for b in range(nb)]
                 hosts = self._host_frames.pop(id(det), None)
                 det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
-                if not host_gray:
+                late = host_gray or paced                           # paced source: the batch's results leave before the stage blocks on the next one
+                if not late:
                     submit_next()                               # keep this detector busy while the host works on the batch
                 n_skip = 0
                 if self.gmc is not None:                        # the batch queues on the GMC stream now, results in order
@@ -387,7 +395,7 @@ class ExtractEngine:
                         self.gmc.submit_gray_dev(*g)
                         self._gmc_sub += 1
                 yield det, dets, grays, hosts, det_ms, n_skip
-                if host_gray:
+                if late:
                     submit_next()
         finally:                                                # consumer stopped early or a stage failed: leave no pass in flight
             for det, *_ in inflight:
@@ -437,6 +445,7 @@ class ExtractEngine:
         q_trk = queue.Queue(maxsize=n_frames)                   # tracked frames
         stop = threading.Event()
         END = object()
+        IDLE = self._IDLE
 
         def put(q, item):
             while not stop.is_set():
@@ -459,13 +468,15 @@ class ExtractEngine:
             finally:
                 src.close()                                     # runs the source's cleanup on this thread
 
-        def drain(q):
+        def drain(q, tell_idle=False):
             while True:
                 try:
-                    item = q.get(timeout=0.05)
+                    item = q.get(timeout=0.004 if tell_idle else 0.05)
                 except queue.Empty:
                     if stop.is_set():                           # the consumer is gone and so may be the producer
                         return
+                    if tell_idle:                               # nothing for 4 ms: a paced source; the consumer may take what is pending
+                        yield IDLE
                     continue
                 if item is END:
                     return
@@ -478,7 +489,7 @@ class ExtractEngine:
         t1.start()
         t2.start()
         try:
-            yield from drain(q_trk)
+            yield from drain(q_trk, tell_idle=True)
         finally:
             stop.set()
             for q in (q_det, q_trk):                            # unblock producers stuck in put()
@@ -515,7 +526,12 @@ class ExtractEngine:
             return r
 
         try:
-            for r, det, g, host in frames:
+            for item in frames:
+                if item is self._IDLE:                              # the stages in front have nothing ready (a live stream between frames):
+                    while pending:                                  # hand out what the stabilizers hold instead of waiting for frame t + 3
+                        yield finish()
+                    continue
+                r, det, g, host = item
                 if not self.stabs:
                     yield r
                     continue
