@@ -27,6 +27,7 @@ import os
 import queue
 import threading
 import time
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -175,8 +176,6 @@ class StreamPlan:
     def take(self, role: str, holder=None) -> _lib.Context:
         """A context of `role` nobody holds (`holder`: the object it is for; when that object is gone the context is free
         again without give_back). A role the plan has run out of gets a new stream, wherever the runtime puts it."""
-        import weakref
-
         with self._lock:
             for ent in self.ctxs:
                 if ent[0] == role and (ent[2] is None or (ent[2] is not True and ent[2]() is None)):
