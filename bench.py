@@ -1068,7 +1068,8 @@ def main():
                 dh = json.loads([ln for ln in ph.stdout.splitlines() if ln.startswith("{")][-1])
                 out["host_frames"] = {"value": dh["value"], "unit": "frames/s", "steps": dh["steps"], "ms_per_step": dh["ms_per_step"],
                                       "note": "same pipeline fed 3840x2160 frames from pageable host memory (24.9 MB per frame uploaded inside the timed region): "
-                                              "the PCIe-inclusive rate; measured by a child process, secondary, not `value`"}
+                                              "the PCIe-inclusive rate; measured by a child process over its own `steps` (at least 100: with fewer timed steps than that, `value`'s region is shorter and "
+                                              "the pipeline's fill and drain -- ~3 ms -- weigh more in it than here), secondary, not `value`"}
             except Exception as e:
                 out["host_frames"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
             try:
