@@ -406,6 +406,7 @@ def bench_extract_georef(args):
 
     from geotrax_amd import _lib
     from geotrax_amd import georef_stage as gs
+    from geotrax_amd import georeference as gr
     from geotrax_amd.engine import ExtractEngine
     from geotrax_amd.postprocess import aggregate_results, postprocess_tracks
     from geotrax_amd.registration import estimate_homography
@@ -459,8 +460,8 @@ def bench_extract_georef(args):
                     due = t_start + (k * B + B - 1) / pace_fps
                     while time.perf_counter() < due:
                         time.sleep(max(min(due - time.perf_counter(), 0.002), 0))
-                for b in range(B):
-                    avail[k * B + b] = time.perf_counter()
+                for b in range(B):                              # a frame exists from its own arrival time on, not from its batch's
+                    avail[k * B + b] = min(time.perf_counter(), t_start + (k * B + b) / pace_fps) if pace_fps else time.perf_counter()
                 yield pool + ((k * B) % len(order)) * fbytes
 
         for r in engine.run(batches()):
@@ -488,8 +489,8 @@ def bench_extract_georef(args):
         df = gs.georeference_tracks(tracks[:, 1].astype(int), tracks[:, 0].astype(int), tracks[:, 2:6].astype(np.float64), tracks[:, 6].astype(np.float64),
                                     tracks[:, 7].astype(np.float64), tracks[:, 10].astype(int), tracks[:, 12:14].astype(np.float64), None, np.array([]),
                                     (H, W), 30.0, Hm, ortho_params, None, gcfg, logger, ctx=ctx)
-        df.to_csv(outdir / "synthetic.csv", index=False)
-        np.savetxt(outdir / "synthetic_geo_transf.txt", Hm.reshape(1, -1), fmt="%.20g", delimiter=",")
+        gr.save_georeferenced_data(outdir / "synthetic.csv", df, logger)                    # the product's writers (geotrax_amd/tables.py)
+        gr.save_homography(outdir / "synthetic_geo_transf.txt", Hm, logger)
         t_geo = time.perf_counter() - t0
         ys, xs = np.meshgrid(np.linspace(0, H - 1, 9), np.linspace(0, W - 1, 16), indexing="ij")
         P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
@@ -515,7 +516,7 @@ def bench_extract_georef(args):
                        "registration": {"keypoints": u["kp"], "matches": u["matches"], "inliers": u["inliers"], "max_grid_error_px_vs_known_orthophoto": u["err"]}},
             "paced": {"stream_fps": 30.0, "sustained_fps": n_fr / p["t_extract"], "frame_latency_ms": {"median": 1000 * p["lat_med"], "max": 1000 * p["lat_max"]},
                       "georeference_tail_ms": 1000 * tail_p,
-                      "note": "frames become available every 1/30 s; latency = frame available -> its tracked, stabilized result leaves the engine"}}
+                      "note": "frames become available every 1/30 s; latency = a frame's own arrival -> its tracked, stabilized result leaves the engine (the first frame of a batch of 2 waits a frame period for the second)"}}
     print(json.dumps(line), flush=True)
     engine.close()
 

@@ -351,13 +351,15 @@ class ExtractEngine:
         k = 0
 
         paced = False                                            # the source kept this stage waiting for its last batch (a live stream)
+        exhausted = False
 
         def submit_next():
-            nonlocal k, paced
+            nonlocal k, paced, exhausted
             t0 = time.perf_counter()
             b = next(it, None)
             paced = time.perf_counter() - t0 > 0.02              # far above a read + upload, below a frame period at 30 fps
             if b is None:
+                exhausted = True
                 return
             prev = None
             if isinstance(b, tuple):                            # (batch, device pointer of the frame before it | None | False)
@@ -369,8 +371,12 @@ class ExtractEngine:
 
         host_gray = bool(self.stabs) and not self.use_dev_gray
         try:
-            for _ in range(len(self.dets)):
-                submit_next()
+            def fill():                                             # a pass in flight on every detector stream -- unless the source is a stream
+                while not exhausted and not paced and len(inflight) < len(self.dets):
+                    submit_next()
+
+            submit_next()
+            fill()
             while inflight:
                 det, nb, prev = inflight.popleft()
                 dets = det.collect()
@@ -379,7 +385,7 @@ class ExtractEngine:
                 det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
                 late = host_gray or paced                           # paced source: the batch's results leave before the stage blocks on the next one
                 if not late:
-                    submit_next()                               # keep this detector busy while the host works on the batch
+                    fill()                                      # keep the detectors busy while the host works on the batch
                 n_skip = 0
                 if self.gmc is not None:                        # the batch queues on the GMC stream now, results in order
                     restart = prev is not None                  # a shard rank's batch: it does not continue the previous one
@@ -394,7 +400,9 @@ class ExtractEngine:
                         self.gmc.submit_gray_dev(*g)
                         self._gmc_sub += 1
                 yield det, dets, grays, hosts, det_ms, n_skip
-                if late:
+                if host_gray:
+                    submit_next()
+                elif late and not inflight and not exhausted:       # a stream: everything in flight has been handed on; now wait for the next batch
                     submit_next()
         finally:                                                # consumer stopped early or a stage failed: leave no pass in flight
             for det, *_ in inflight:

@@ -619,6 +619,50 @@ def test_engines_of_one_process_run_on_the_same_planned_streams(gtx_ctx):
         assert np.array_equal(xa, xb) and ((ha is None and hb is None) or np.array_equal(ha, hb))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+def test_a_paced_source_gets_the_same_results_sooner(gtx_ctx, tracker):
+    """A live stream (batches arriving slower than the pipeline works) takes the engine's other paths: stage 1 hands a batch's results on
+    before it blocks for the next batch, the stabilizer stage takes its pending frames while nothing arrives. Same frames, same order,
+    same numbers as the throughput run; and a frame's result is out before the next batch exists."""
+    import time
+
+    from geotrax_amd.engine import ExtractEngine
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.tracker import Tracker
+    from geotrax_amd.weights import synthetic_yolov8
+
+    scene = make_scene(seed=6, h=H, w=W)
+    frames = [scene.render(6 * k, 150) for k in range(12)]
+    kw = dict(imgsz=IMGSZ, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=True, rect=True)
+    w = synthetic_yolov8(seed=1, nc=4)
+    batches = [frames[i:i + 2] for i in range(0, len(frames), 2)]
+
+    def run(source):
+        eng = ExtractEngine(w, (H, W), kw, Tracker(tracker), dict(max_features=500), batch=2, det_streams=2, stab_streams=3, gmc=tracker == "botsort")
+        try:
+            return [(r.index, r.xyxy.copy(), None if r.ids is None else r.ids.copy(), None if r.H is None else r.H.copy(), time.perf_counter()) for r in eng.run(source)]
+        finally:
+            eng.close()
+
+    made = []
+
+    def paced():
+        for b in batches:
+            time.sleep(0.06)                                   # > the 20 ms that tells the engine its source is a stream
+            made.append(time.perf_counter())
+            yield b
+
+    fast, slow = run(batches), run(paced())
+    assert [r[0] for r in slow] == [r[0] for r in fast] == list(range(len(frames)))
+    for a, b in zip(fast, slow):
+        assert np.array_equal(a[1], b[1]) and ((a[2] is None and b[2] is None) or np.array_equal(a[2], b[2]))
+        assert (a[3] is None and b[3] is None) or np.array_equal(a[3], b[3])
+    # frames of batch k (k >= 2: the pipeline has been primed) left the engine before batch k + 1 was made
+    for k in range(2, len(batches) - 1):
+        assert slow[2 * k + 1][4] < made[k + 1], k
+
+
 
 def _run_sharded_cli(tmp_path, cfg_path, clip, out, n_ranks, backend, port, extra_env=None):
     import os
