@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- 4K frames/s through the MI355X extraction hot path (detect + track + stabilize).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Either spelling gives an N-rank line: without a launcher and N > 1 the script starts the N ranks itself (a child
+`torch.distributed.run`, before this process touches HIP) and forwards rank 0's line; fewer than N visible GPUs, or a launcher
+whose WORLD_SIZE is not N, is an error (exit 2) -- never a smaller run printed as if it were the one asked for.
 
 A step = one pass of the hot path over one batch of --batch consecutive 3840x2160 synthetic frames
 per rank (default 2; --batch 1 is the frame-at-a-time pass), the frames already resident in HBM when
@@ -96,7 +100,79 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, run one all_reduce over the chosen backend and print {launch_check, n_gpus, ranks_seen} -- no GPU work "
+                         "(the CPU-side test of the --gpus N self-launch)")
     return ap.parse_args()
+
+
+def visible_gpus() -> int:
+    """Devices this process could use, WITHOUT initialising HIP (torch.cuda.device_count() only counts on this image): the
+    self-launching parent must not touch the GPU, it starts other programs."""
+    import torch
+
+    return int(torch.cuda.device_count())
+
+
+def self_launch(args) -> int | None:
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`),
+    before anything in this process has touched HIP, forward the child's output (rank 0's one JSON line) and return its status.
+    Fewer than N visible devices on the RCCL backend is an error, not a smaller run. Returns None when there is nothing to
+    launch (N = 1, or already under a launcher)."""
+    if "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus and os.environ.get("GTX_BENCH_FORCE_DIST") != "1":
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    if args.workload not in ("extract", "detect"):
+        print(f"bench.py: --workload {args.workload} is a single-GPU measurement (replicas only); run it with --gpus 1", file=sys.stderr)
+        return 2
+    if args.backend == "nccl":
+        have = visible_gpus()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs for one rank per GPU over RCCL, this host shows {have} "
+                  "(--backend gloo lets ranks share a GPU: a test of the sharded path, not a measurement)", file=sys.stderr)
+            return 2
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:                              # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode          # stdout / stderr are inherited: rank 0's JSON line is the child's
+
+
+def launch_check(args) -> int:
+    """--launch-check: every rank joins the process group and adds 2**rank into one number."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    seen = 1
+    if world > 1:
+        if args.backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            t = torch.tensor([2 ** rank], dtype=torch.int64, device=f"cuda:{local}")
+        else:
+            dist.init_process_group("gloo")
+            t = torch.tensor([2 ** rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": bin(seen).count("1"), "backend": args.backend}), flush=True)
+    return 0
 
 
 def fp32_split(args):
@@ -645,6 +721,11 @@ def bench_cli(args):
 
 def main():
     args = parse()
+    rc = self_launch(args)                                  # --gpus N > 1 without a launcher: N ranks as a child process, nothing of HIP touched here
+    if rc is not None:
+        sys.exit(rc)
+    if args.launch_check:
+        sys.exit(launch_check(args))
     if args.workload == "cli":
         return bench_cli(args)
     if args.workload == "extract+georef":

@@ -167,17 +167,32 @@ def agree_on_source(ok: bool, n_frames: int, dist, device=None) -> tuple[bool, b
     return all_ok, all_ok and len({r[1] for r in rows}) == 1, rows[0][1]
 
 
+_replay_reservation: tuple[frozenset, int] | None = None   # (the mask the process started with, the core set aside): once per process
+
+
 def reserve_replay_core(world: int) -> int | None:
     """At four ranks and more rank 0's tracker replay thread is busy most of the time next to 8 x 3 stage
     threads: keep one core for it. Called by every rank's main thread before it starts its engine: the calling thread (and
     every thread it creates afterwards) leaves the LAST core of the process's affinity mask alone; rank 0's replay thread
     then pins itself to that core (pin_to_core). Returns the core, or None when pinning is off (fewer than four ranks, fewer
-    than four cores, GTX_PIN_REPLAY=0) -- GTX_PIN_REPLAY=1 forces it for tests."""
+    than four cores, GTX_PIN_REPLAY=0) -- GTX_PIN_REPLAY=1 forces it for tests.
+
+    The reservation is made ONCE per process: `geotrax_amd.batch` runs every video of a folder in one process and calls this
+    per video; a second call returns the core chosen the first time and never narrows the mask again (it used to drop one
+    more core per video). release_replay_core() gives the original mask back."""
     import os
 
+    global _replay_reservation
     mode = os.environ.get("GTX_PIN_REPLAY", "auto")
     if mode == "0" or (mode != "1" and world < 4) or not hasattr(os, "sched_getaffinity"):
         return None
+    if _replay_reservation is not None:
+        original, core = _replay_reservation
+        try:                                                 # the caller may be another thread than the first time: same mask
+            os.sched_setaffinity(0, set(original) - {core})
+        except OSError:
+            return None
+        return core
     cores = sorted(os.sched_getaffinity(0))
     if len(cores) < 4:
         return None
@@ -185,7 +200,21 @@ def reserve_replay_core(world: int) -> int | None:
         os.sched_setaffinity(0, set(cores[:-1]))
     except OSError:
         return None
+    _replay_reservation = (frozenset(cores), cores[-1])
     return cores[-1]
+
+
+def release_replay_core() -> None:
+    """Undo reserve_replay_core() for the calling thread: the affinity mask the process started with."""
+    import os
+
+    global _replay_reservation
+    if _replay_reservation is not None:
+        try:
+            os.sched_setaffinity(0, set(_replay_reservation[0]))
+        except OSError:
+            pass
+        _replay_reservation = None
 
 
 def pin_to_core(core: int | None) -> bool:

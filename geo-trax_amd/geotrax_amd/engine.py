@@ -525,7 +525,7 @@ class ExtractEngine:
         def finish():
             st, r = pending.popleft()
             st.collect()
-            r.H = st.get_cur_trans_matrix()
+            r.H = st.get_cur_trans_matrix(raw=True)
             r.stab_ms = st.last_ms()
             last_known(r)
             if r.xywh is not None:
@@ -561,7 +561,7 @@ class ExtractEngine:
                     pending.append((st, r))
                 else:                                               # other downsample ratios: the stabilizer makes its own gray
                     st.stabilize(host, r.xywh)
-                    r.H = st.get_cur_trans_matrix()
+                    r.H = st.get_cur_trans_matrix(raw=True)
                     last_known(r)
                     if r.xywh is not None:
                         r.xywh_stab = warp_boxes(r.H, r.xywh) if r.H is not None else r.xywh.copy()

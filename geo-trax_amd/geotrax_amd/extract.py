@@ -59,8 +59,10 @@ def detect_track_stabilize(args: argparse.Namespace, logger: logging.Logger) -> 
         if res is None:                                     # ranks other than 0 have handed their records over
             return
         tracks, transforms = res
-    else:
+    elif pipelined(config):
         tracks, transforms = track_with_model(model, config, logger)
+    else:
+        tracks, transforms = track_with_model_blocking(model, config, logger)
     w_h = get_video_dimensions(config['main']['args'].source)
     tracks = postprocess_tracks(tracks, config, logger, w_h)
     save_results(tracks, transforms, config, logger, out_cfg)
@@ -462,6 +464,71 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
             model._det = None
             engine.close()
     return aggregate_results(out.frame, out.ids, out.raw, out.stab, out.cls, out.conf, out.transforms, logger)
+
+
+def track_with_model_blocking(model: YOLO, config: dict, logger: logging.Logger) -> tuple[np.ndarray, np.ndarray]:
+    """The reference's loop as it stands (extract.py:134-214), one frame at a time on the calling thread through the two
+    drop-in objects of INTEGRATION.md section 1: ``model.track(frame, **config['ultralytics'], persist=True)`` and
+    ``Stabilizer(**config['stabilo'])``. This is what a maintainer gets who only swaps the two imports in the reference's
+    own extract.py; `engine: {pipelined: false}` in the config (or GTX_ENGINE=blocking) selects it here. Its tables are the
+    pipelined engine's byte for byte (tests/test_dropin_gpu.py); it is several times slower, every call waits for the GPU."""
+    from .stabilizer import Stabilizer
+
+    args = config['main']['args']
+    do_stab = config['main']['extraction']['stabilize']
+    first, last = args.cut_frame_left or 0, args.cut_frame_right
+    reader = initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
+    stabilizer = Stabilizer(**config['stabilo'])
+    eng_cfg = config['main'].get('engine') or {}
+    if eng_cfg.get('fp32_split') is not None:
+        model.fp32_split = bool(eng_cfg['fp32_split'])
+    out, frame_num, yolo_time, stab_time = _Collector(), 0, [], []
+    try:
+        while reader.isOpened():
+            success, frame = reader.read()
+            if frame_num < first:
+                frame_num += 1
+                continue
+            if not success:
+                break
+            results = model.track(frame, **config['ultralytics'], persist=True)
+            boxes = results[0].boxes
+            yolo_time.append(sum(results[0].speed.values()))
+            xywh = out.add_boxes(frame_num, boxes)                # None for a frame without boxes
+            if do_stab:
+                start_time = time.time()
+                if frame_num == first:
+                    stabilizer.set_ref_frame(frame, xywh)
+                    if xywh is not None:
+                        out.stab.append(xywh)
+                else:
+                    stabilizer.stabilize(frame, xywh)
+                    if xywh is not None:
+                        out.stab.append(stabilizer.transform_cur_boxes())
+                    out.add_transform(frame_num, stabilizer.get_cur_trans_matrix())
+                stab_time.append(1000 * (time.time() - start_time))
+            if last is not None and frame_num >= last:
+                break
+            frame_num += 1
+    except Exception as e:
+        logger.error(f"Error processing: '{args.source}' due to: {e}")
+        return np.empty((0, 12), dtype=np.float32), np.empty((0, 10))
+    else:
+        if yolo_time:
+            logger.info(f"Average YOLOv8 (preprocess + inference + postprocess) time: {sum(yolo_time) / len(yolo_time):5.1f}ms.")
+            if stab_time:
+                logger.info(f"Average stabilization time: {sum(stab_time) / len(stab_time):5.1f}ms")
+            logger.info(f"Average pipeline time: {1000 * len(yolo_time) / (sum(yolo_time) + sum(stab_time)):4.1f}fps.")
+    finally:
+        reader.release()
+        stabilizer.close()
+    return aggregate_results(out.frame, out.ids, out.raw, out.stab, out.cls, out.conf, out.transforms, logger)
+
+
+def pipelined(config: dict) -> bool:
+    """`engine: {pipelined: false}` / GTX_ENGINE=blocking: the frame-at-a-time loop instead of the engine."""
+    eng_cfg = config['main'].get('engine') or {}
+    return eng_cfg.get('pipelined', True) is not False and os.environ.get("GTX_ENGINE", "") != "blocking"
 
 
 def load_detector(args: argparse.Namespace, logger: logging.Logger) -> YOLO:

@@ -130,12 +130,13 @@ class YOLO:
         self._tracker_key = None
         self._gmc = None
         self._gmc_method = None
+        self.fp32_split: bool | None = None    # half: false only; None = the library default (split-f16x3), see Detector
 
     # ---- lazy construction, like ultralytics' predictor setup on the first call
     def _detector(self, frame_hw, kw) -> Detector:
         if kw.get("augment"):          # ultralytics.augment (default.yaml:243): test-time augmentation changes the detections
             raise NotImplementedError("augment=True (test-time augmentation) is not implemented")
-        key = (tuple(frame_hw),) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
+        key = (tuple(frame_hw), self.fp32_split) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
         if self._det is None or key != self._det_key:
             if self._det is not None:
                 self._det.close()
@@ -145,7 +146,7 @@ class YOLO:
             self._det = Detector(self.tensors, frame_hw, imgsz=int(imgsz), conf=float(kw.get("conf") or 0.1),
                                  iou=float(kw.get("iou", 0.7)), max_det=int(kw.get("max_det", 300)), classes=kw.get("classes"),
                                  agnostic_nms=bool(kw.get("agnostic_nms", False)), half=bool(kw.get("half", False)),
-                                 rect=bool(kw.get("rect", False)), ctx=self.ctx)   # absent -> the reference config's value (default.yaml:300)
+                                 rect=bool(kw.get("rect", False)), fp32_split=self.fp32_split, ctx=self.ctx)   # absent -> the reference config's value (default.yaml:300)
             self._det_key = key
         return self._det
 
@@ -200,9 +201,10 @@ class YOLO:
         kwargs = dict(kwargs)
         kwargs["conf"] = kwargs.get("conf") or 0.1      # ultralytics Model.track default
         res = self.predict(source, **kwargs)[0]
-        if len(res.boxes) == 0:
-            return [res]
         b = res.boxes
+        # ultralytics' on_predict_postprocess_end (trackers/track.py, pinned >= 8.4.80) calls tracker.update(det, img) on EVERY
+        # frame, detections or not: the frame counter advances, unmatched tracks go lost / age out and BoT-SORT's GMC moves
+        # its previous frame on. The engine follows the same rule (engine.py "Ordering rules").
         warp = None
         if self._gmc_method is not None:                    # BOTSORT.update: camera motion first, on this frame's gray image
             frame = np.asarray(source)
@@ -217,7 +219,7 @@ class YOLO:
             else:
                 warp = self._gmc.apply(frame)
         xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32), gmc=warp)
-        if len(ids) == 0:
+        if len(ids) == 0:                                   # the raw detections (or no rows) with id None (extract.py:161-165)
             return [res]
         res.boxes = Boxes(xyxy, score, cls, ids)
         return [res]

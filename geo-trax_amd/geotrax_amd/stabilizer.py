@@ -47,7 +47,9 @@ class Stabilizer:
         self.frame_hw = None
         if frame_hw is not None:
             self._create(frame_hw)
-        self._H = None
+        self._H = None                   # what get_cur_trans_matrix() returns: this frame's transform, else the last known one
+        self._H_raw = None               # this frame's own transform, None when the frame could not be registered
+        self._H_last_known = None
         self._stats = np.zeros(4, np.int32)
         self._cur_boxes = None
 
@@ -83,15 +85,22 @@ class Stabilizer:
             self._create(f.shape[:2])
         b, n = self._boxes(boxes)
         check(self.ctx.lib.gtx_stabilizer_set_ref_frame(self.handle, ptr(f), f.shape[0], f.shape[1], ptr(b), n))
-        self._H, self._cur_boxes = None, None
+        self._H = self._H_raw = self._H_last_known = None
+        self._cur_boxes = None
 
     def set_ref_gray_dev(self, gray_dptr: int, gh: int, gw: int, boxes=None) -> None:
         b, n = self._boxes(boxes)
         check(self.ctx.lib.gtx_stabilizer_set_ref_gray_dev(self.handle, C.c_void_p(gray_dptr), gh, gw, ptr(b), n))
-        self._H, self._cur_boxes = None, None
+        self._H = self._H_raw = self._H_last_known = None
+        self._cur_boxes = None
 
     def _finish(self, H, valid, boxes):
-        self._H = H.reshape(3, 3).copy() if valid.value else None
+        # stabilo keeps `trans_matrix_last_known`: a frame that cannot be registered (too few matches, no model) takes the
+        # previous valid transform for its boxes and reports it as its matrix; before the first valid one there is none.
+        self._H_raw = H.reshape(3, 3).copy() if valid.value else None
+        if self._H_raw is not None:
+            self._H_last_known = self._H_raw
+        self._H = self._H_last_known
         self._cur_boxes = boxes
         if self._stats[2] < self.min_good:
             logger.warning(f"Only {int(self._stats[2])} good matches found.")
@@ -130,9 +139,17 @@ class Stabilizer:
         check(self.ctx.lib.gtx_stabilizer_last_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
-    def get_cur_trans_matrix(self) -> np.ndarray | None:
-        """3x3 float64 mapping current-frame pixels to reference-frame pixels, or None."""
-        return None if self._H is None else self._H.copy()
+    def get_cur_trans_matrix(self, raw: bool = False) -> np.ndarray | None:
+        """3x3 float64 mapping current-frame pixels to reference-frame pixels, or None. raw=True: None also when this
+        frame itself could not be registered (the engine, whose stabilizer objects take turns, keeps the last known
+        transform in frame order itself)."""
+        H = self._H_raw if raw else self._H
+        return None if H is None else H.copy()
+
+    @property
+    def registered(self) -> bool:
+        """False when the last frame took the last known transform (or none) instead of one of its own."""
+        return self._H_raw is not None
 
     def transform_cur_boxes(self) -> np.ndarray:
         """The boxes given to the last stabilize() call, mapped into the reference frame (xywh)."""

@@ -54,9 +54,16 @@ def test_single_gpu_line_has_the_contract_fields():
 @pytest.mark.parametrize("mode,tracker", [("frames", "bytetrack"), ("frames", "botsort"), ("videos", "bytetrack")])
 def test_two_ranks_on_one_gpu(mode, tracker):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "18", "--warmup", "2", "--gather-every", "4",
-           "--no-cpu-baseline", "--no-profile", "--backend", "gloo", "--sharding", mode, "--tracker", tracker]
+    tail = ["--gpus", "2", "--steps", "18", "--warmup", "2", "--gather-every", "4",
+            "--no-cpu-baseline", "--no-profile", "--backend", "gloo", "--sharding", mode, "--tracker", tracker]
+    if tracker == "bytetrack" and mode == "frames":
+        # the driver's own spelling, no launcher: bench.py starts the two ranks itself (a child torch.distributed.run, before
+        # the parent touches HIP) and forwards rank 0's line
+        env = {k: v for k, v in env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        cmd = [sys.executable, str(ROOT / "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", str(ROOT / "bench.py")] + tail
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = _last_json(p.stdout)

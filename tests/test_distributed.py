@@ -315,7 +315,7 @@ def test_a_weight_file_rank0_cannot_load_stops_every_rank():
 
 
 def test_replay_core_is_reserved_only_for_four_ranks_and_more(monkeypatch):
-    from geotrax_amd.distributed import pin_to_core, reserve_replay_core
+    from geotrax_amd.distributed import pin_to_core, release_replay_core, reserve_replay_core
 
     before = os.sched_getaffinity(0)
     try:
@@ -324,6 +324,9 @@ def test_replay_core_is_reserved_only_for_four_ranks_and_more(monkeypatch):
         if len(before) >= 4:
             core = reserve_replay_core(8)
             assert core == max(before) and os.sched_getaffinity(0) == before - {core}       # the caller (and its later threads) stay off it
+            # once per process: a folder of videos calls it per video; the mask must not shrink by a core each time
+            for _ in range(5):
+                assert reserve_replay_core(8) == core and os.sched_getaffinity(0) == before - {core}
             import threading
 
             seen = []
@@ -331,9 +334,12 @@ def test_replay_core_is_reserved_only_for_four_ranks_and_more(monkeypatch):
             t.start()
             t.join()
             assert seen == [(True, {core})]
+            release_replay_core()
+            assert os.sched_getaffinity(0) == before
         monkeypatch.setenv("GTX_PIN_REPLAY", "0")
         os.sched_setaffinity(0, before)
         assert reserve_replay_core(8) is None
         assert pin_to_core(None) is False
     finally:
+        release_replay_core()
         os.sched_setaffinity(0, before)

@@ -1,0 +1,184 @@
+"""The advertised drop-in: the reference's loop body, unmodified, over this build's ``YOLO`` and
+``Stabilizer`` objects must give what ``python -m geotrax_amd.extract`` gives -- byte for byte.
+
+The loop in `_reference_loop` is the body of geotrax/extract.py:145-197 as it stands there (the call
+``model.track(frame, **config['ultralytics'], persist=True)``, the four ``.detach().numpy(force=True)`` reads with their
+uint16 / uint8 / float32 narrowings, ``results[0].speed``, ``set_ref_frame`` / ``stabilize`` / ``transform_cur_boxes`` /
+``get_cur_trans_matrix``); only the progress bar is left out. The clip contains frames without detections (which must still
+reach the tracker and, with BoT-SORT, the GMC: ultralytics' on_predict_postprocess_end) and frames that cannot be registered
+(which take stabilo's last known transform)."""
+import argparse
+import logging
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from test_extract_gpu import H, W, _cfg_file, _weights_file
+
+pytestmark = pytest.mark.gpu
+logger = logging.getLogger("test_dropin")
+
+
+def _reference_loop(model, Stabilizer, aggregate_results, reader, config, logger):
+    """geotrax/extract.py:134-214, body verbatim (no tqdm)."""
+    stabilizer = Stabilizer(**config['stabilo'])
+
+    frame_num, yolo_time, stab_time = 0, [], []
+    frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms = [], [], [], [], [], [], []
+    empties = 0
+
+    while reader.isOpened():
+        success, frame = reader.read()
+        if frame_num < config['main']['args'].cut_frame_left:
+            frame_num += 1
+            continue
+
+        if success:
+            results = model.track(frame, **config['ultralytics'], persist=True)
+            boxes = results[0].boxes
+            speed = results[0].speed
+            yolo_time.append(sum(speed.values()))
+
+            if len(boxes) > 0:
+                frame_arr.append(np.full((len(boxes), 1), frame_num, dtype=np.uint32))
+                if boxes.id is not None:
+                    track_ids = boxes.id.detach().numpy(force=True).astype(np.uint16).reshape(-1, 1)
+                else:
+                    track_ids = np.full((len(boxes), 1), -1)
+                track_id.append(track_ids)
+                bbox.append(boxes.xywh.detach().numpy(force=True).astype(np.float32))
+                class_id.append(boxes.cls.detach().numpy(force=True).astype(np.uint8).reshape(-1, 1))
+                conf.append(boxes.conf.detach().numpy(force=True).astype(np.float32).reshape(-1, 1))
+            else:
+                empties += 1
+
+            if config['main']['extraction']['stabilize']:
+                start_time = time.time()
+                if frame_num == config['main']['args'].cut_frame_left:
+                    stabilizer.set_ref_frame(frame, bbox[-1] if len(boxes) > 0 else None)
+                    if len(boxes) > 0:
+                        bbox_stab.append(bbox[-1])
+                else:
+                    stabilizer.stabilize(frame, bbox[-1] if len(boxes) > 0 else None)
+                    if len(boxes) > 0:
+                        bbox_stab.append(stabilizer.transform_cur_boxes())
+                    transf_matrix = stabilizer.get_cur_trans_matrix()
+                    if transf_matrix is not None:
+                        transf_matrix = transf_matrix.flatten().reshape(1, -1)
+                        transforms.append(np.hstack((np.array([[frame_num]]), transf_matrix)))
+                stab_time.append(1000 * (time.time() - start_time))
+        else:
+            break
+
+        if config['main']['args'].cut_frame_right is not None and frame_num >= config['main']['args'].cut_frame_right:
+            break
+        frame_num += 1
+    reader.release()
+    assert set(speed) == {'preprocess', 'inference', 'postprocess'} and all(v >= 0 for v in speed.values())
+    tracks, transforms = aggregate_results(frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms, logger)
+    return tracks, transforms, empties
+
+
+def _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg):
+    """Ten frames of the moving scene with three of them replaced by flat images on which the detector finds nothing (seeded
+    weights fire on texture; the candidates are tried with the detector of the test and the first empty one is taken)."""
+    from geotrax_amd.model import YOLO
+    from geotrax_amd.synth import make_scene
+
+    scene = make_scene(seed=5, h=H, w=W)
+    frames = [scene.render(10 * k, 150) for k in range(10)]
+    probe = YOLO(wpath, ctx=gtx_ctx)
+    u = {k: v for k, v in cfg["ultralytics"].items()}
+    flat = None
+    for level in (0, 114, 255, 64, 192, 32):
+        cand = np.full((H, W, 3), level, np.uint8)
+        if len(probe.predict(cand, **u)[0].boxes) == 0:
+            flat = cand
+            break
+    if probe.detector is not None:
+        probe.detector.close()
+    assert flat is not None, "no flat image is empty for the seeded detector: pick other candidates"
+    for k in (3, 4, 7):                                     # two in a row (lost-track ageing over a gap) and a single one
+        frames[k] = flat
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_path, tracker):
+    from geotrax_amd import extract as ex
+    from geotrax_amd.config_utils import load_config_all
+    from geotrax_amd.model import YOLO
+    from geotrax_amd.postprocess import aggregate_results
+    from geotrax_amd.stabilizer import Stabilizer
+    from geotrax_amd.synth import make_scene
+
+    scene = make_scene(seed=5, h=H, w=W)
+    wpath, _ = _weights_file(tmp_path, gtx_ctx, scene.render(0, 150))
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker)
+    if tracker == "botsort":
+        assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
+    frames = _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg)
+    src = tmp_path / "clip.npy"
+    np.save(src, frames)
+
+    def setup():
+        args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
+                                  class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
+        model = ex.load_detector(args, logger)
+        config = load_config_all(args, logger, model_names=model.names)
+        args.cut_frame_left, args.cut_frame_right = 0, None
+        return model, config
+
+    # (1) the product: the pipelined engine
+    model, config = setup()
+    want_tracks, want_transforms = ex.track_with_model(model, config, logger)
+    assert len(want_tracks) > 20 and want_tracks.dtype == np.float32 and want_tracks.shape[1] == 12
+    rows_on = set(np.unique(want_tracks[:, 0]).astype(int))
+    assert not rows_on & {3, 4, 7} and {0, 1, 2} <= rows_on and rows_on & {5, 6, 8, 9}   # the empty frames write no rows; tracking resumes behind them
+    # flat frames cannot be registered: they report the last known transform (stabilo's trans_matrix_last_known)
+    assert want_transforms.shape == (9, 10)
+    np.testing.assert_array_equal(want_transforms[:, 0], np.arange(1, 10))
+    np.testing.assert_array_equal(want_transforms[2, 1:], want_transforms[1, 1:])   # frame 3 <- frame 2
+    np.testing.assert_array_equal(want_transforms[3, 1:], want_transforms[1, 1:])   # frame 4 <- frame 2
+    np.testing.assert_array_equal(want_transforms[6, 1:], want_transforms[5, 1:])   # frame 7 <- frame 6
+
+    # (2) the reference's loop body over the drop-in objects, a fresh model (fresh tracker and GMC state)
+    model, config = setup()
+    assert isinstance(model, YOLO)
+    reader = ex.initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
+    tracks, transforms, empties = _reference_loop(model, Stabilizer, aggregate_results, reader, config, logger)
+    assert empties == 3
+    assert tracks.dtype == want_tracks.dtype and tracks.shape == want_tracks.shape
+    assert tracks.tobytes() == want_tracks.tobytes()
+    assert transforms.dtype == want_transforms.dtype and transforms.shape == want_transforms.shape
+    assert transforms.tobytes() == want_transforms.tobytes()
+
+    # (3) the same loop as a product path (`engine: {pipelined: false}` / GTX_ENGINE=blocking)
+    model, config = setup()
+    config['main'].setdefault('engine', {})['pipelined'] = False
+    assert not ex.pipelined(config)
+    t3, h3 = ex.track_with_model_blocking(model, config, logger)
+    assert t3.tobytes() == want_tracks.tobytes() and h3.tobytes() == want_transforms.tobytes()
+
+
+def test_track_calls_the_tracker_on_frames_without_detections(gtx_ctx, tmp_path):
+    """model.py used to return before tracker.update on an empty frame; ultralytics (and the engine) update on every frame."""
+    from geotrax_amd.model import YOLO
+    from geotrax_amd.weights import synthetic_yolov8
+
+    model = YOLO(synthetic_yolov8(seed=1, nc=4, cls_bias=-30.0), ctx=gtx_ctx)
+    frame = np.zeros((H, W, 3), np.uint8)
+    calls = []
+    kw = dict(imgsz=384, conf=0.25, iou=0.7, max_det=300, classes=[0, 1, 2, 3], agnostic_nms=True, half=False, rect=True,
+              tracker=dict(tracker_type="botsort", gmc_method="sparseOptFlow", track_high_thresh=0.25, track_low_thresh=0.1,
+                           new_track_thresh=0.25, track_buffer=30, match_thresh=0.8, fuse_score=True))
+    for k in range(3):
+        res = model.track(frame, persist=True, **kw)
+        if k == 0:
+            orig = model._tracker.update
+            model._tracker.update = lambda *a, **kws: (calls.append(kws.get("gmc")), orig(*a, **kws))[1]
+        assert len(res[0].boxes) == 0 and res[0].boxes.id is None
+    assert len(calls) == 2 and all(g is not None for g in calls)          # frames 1 and 2 (frame 0 ran before the wrapper): GMC warp handed in
+    model.detector.close()

@@ -173,9 +173,13 @@ def test_identical_frame_gives_identity_and_state_errors(gtx_ctx, seq):
     st.stabilize(fr[0], None)
     H = st.get_cur_trans_matrix()
     assert _grid_err(H, np.eye(3), HW) < 1e-6
-    flat = np.full((HW[0], HW[1], 3), 127, np.uint8)   # no texture -> no keypoints -> None (extract.py:185)
+    flat = np.full((HW[0], HW[1], 3), 127, np.uint8)   # no texture -> no keypoints -> no transform of its own
     st.stabilize(flat, None)
-    assert st.get_cur_trans_matrix() is None and st.get_cur_num_matches() == 0
+    assert st.get_cur_trans_matrix(raw=True) is None and not st.registered and st.get_cur_num_matches() == 0
+    np.testing.assert_array_equal(st.get_cur_trans_matrix(), H)      # stabilo's trans_matrix_last_known
+    st.set_ref_frame(fr[0], None)                      # a new reference frame forgets it: None (extract.py:185 skips the row)
+    st.stabilize(flat, None)
+    assert st.get_cur_trans_matrix() is None
     with pytest.raises(NotImplementedError):
         Stabilizer(HW, detector_name="sift")
 
