@@ -330,10 +330,7 @@ void Detector::build_graph() {
   // into the decode kernels (the box one only runs for anchors that pass the score gate).
   const View lvl_in[3] = {a15, a18, a21};
   const float strides[3] = {8.f, 16.f, 32.f};
-  Op st1, st2;
-  st1.kind = st2.kind = Op::CONV;
-  st1.name = "model.22.stage1";
-  st2.name = "model.22.stage2";
+  std::vector<Op> st1, st2;
   head_ = HeadParams{};
   head_.n_levels = 3;
   head_.nc = cfg_.nc;
@@ -378,20 +375,29 @@ void Detector::build_graph() {
     plain_out_ = false;
     h2.plain = conv_dtype_ == DT_F32S;
     force_kc_ = force_bn_ = 0;
-    // move the three freshly built single-problem ops into the two grouped stage ops
+    // move the three freshly built single-problem ops into the grouped stage ops: one grouped launch per stage and kernel
+    // configuration (the levels of a stage share a launch when they share the kernel; the fp32 default path runs its deep
+    // levels -- Cin >= 256 -- on the Winograd kernel and the 240 x 240 level on the direct one: two launches for a stage)
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
     ops_.resize(mark);
-    if (l == 0) { st1.cfg = o1.cfg; st2.cfg = o2.cfg; }
     auto same = [](const ConvConfig& a, const ConvConfig& b) {
       return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc &&
              a.variant == b.variant && a.th == b.th && a.tw == b.tw;
     };
-    GTX_CHECK(same(st1.cfg, o1.cfg) && same(st2.cfg, o2.cfg) && same(st2.cfg, o3.cfg),
-              "Detect level %d does not share a kernel configuration with level 0", l);
-    st1.grp.p[st1.grp.count++] = o1.grp.p[0];
-    st2.grp.p[st2.grp.count++] = o2.grp.p[0];
-    st2.grp.p[st2.grp.count++] = o3.grp.p[0];
+    auto add = [&](std::vector<Op>& stage, const char* name, const Op& o) {
+      for (Op& g : stage)
+        if (same(g.cfg, o.cfg) && g.grp.count < kMaxGroup) { g.grp.p[g.grp.count++] = o.grp.p[0]; return; }
+      Op g;
+      g.kind = Op::CONV;
+      g.name = stage.empty() ? std::string(name) : std::string(name) + "." + std::to_string(stage.size());
+      g.cfg = o.cfg;
+      g.grp.p[g.grp.count++] = o.grp.p[0];
+      stage.push_back(g);
+    };
+    add(st1, "model.22.stage1", o1);
+    add(st2, "model.22.stage2", o2);
+    add(st2, "model.22.stage2", o3);
 
     HeadLevel& L = head_.lv[l];
     L.feat = h2.ptr; L.h = h2.h; L.w = h2.w; L.cstride = h2.cstride; L.cb = cb; L.cc = cc;
@@ -419,10 +425,11 @@ void Detector::build_graph() {
     layer_views_["model.22.feat" + std::to_string(l)] = h2;
   }
   head_.n_anchors = anchor;
-  st1.family = conv_kernel_name(st1.cfg);
-  st2.family = conv_kernel_name(st2.cfg);
-  ops_.push_back(st1);
-  ops_.push_back(st2);
+  for (std::vector<Op>* stage : {&st1, &st2})
+    for (Op& g : *stage) {
+      g.family = conv_kernel_name(g.cfg);
+      ops_.push_back(g);
+    }
 }
 
 // model.1.conv (3x3 stride 2, all of its output channels in one cout tile) and model.2.cv1.conv (the 1x1 that is its only

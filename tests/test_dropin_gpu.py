@@ -136,7 +136,9 @@ def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_p
     want_tracks, want_transforms = ex.track_with_model(model, config, logger)
     assert len(want_tracks) > 20 and want_tracks.dtype == np.float32 and want_tracks.shape[1] == 12
     rows_on = set(np.unique(want_tracks[:, 0]).astype(int))
-    assert not rows_on & {3, 4, 7} and {0, 1, 2} <= rows_on and rows_on & {5, 6, 8, 9}   # the empty frames write no rows; tracking resumes behind them
+    assert not rows_on & {3, 4, 7} and {0, 1, 2} <= rows_on                   # the empty frames write no rows
+    if tracker == "bytetrack":
+        assert rows_on & {5, 6, 8, 9}                                          # tracking resumes behind them (BoT-SORT's GMC sees flat -> textured jumps: its tracks may not)
     # flat frames cannot be registered: they report the last known transform (stabilo's trans_matrix_last_known)
     assert want_transforms.shape == (9, 10)
     np.testing.assert_array_equal(want_transforms[:, 0], np.arange(1, 10))
