@@ -540,7 +540,7 @@ def bench_extract_georef(args):
                     avail[k * B + b] = min(time.perf_counter(), t_start + (k * B + b) / pace_fps) if pace_fps else time.perf_counter()
                 yield pool + ((k * B) % len(order)) * fbytes
 
-        for r in engine.run(batches()):
+        for r in engine.run(batches(), paced=bool(pace_fps)):
             lat.append(time.perf_counter() - avail[r.index])
             if r.xywh is not None:
                 n = len(r.xywh)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <deque>
 #include <functional>
 #include <mutex>
 
@@ -83,6 +84,7 @@ namespace {
 struct PackedWeights {
   std::vector<uint8_t> bytes;
   float acc_scale = 1.f;
+  std::vector<float> source;      // the tensor the image was packed from: a hit is a hit only when these floats are the caller's
 };
 std::shared_ptr<const PackedWeights> packed_weights(const HostTensor& w, int cout, int cin, const ConvConfig& cfg,
                                                     const std::function<PackedWeights()>& make) {
@@ -94,14 +96,39 @@ std::shared_ptr<const PackedWeights> packed_weights(const HostTensor& w, int cou
   if (w.data.size() & 1) h = (h ^ (uint64_t)__builtin_bit_cast(uint32_t, w.data.back())) * 1099511628211ull;
   const std::array<uint64_t, 4> key = {h, (uint64_t)w.data.size(), ((uint64_t)cout << 32) | (uint64_t)cin,
                                        ((uint64_t)cfg.dtype << 40) | ((uint64_t)cfg.ks << 32) | ((uint64_t)cfg.bn << 16) | ((uint64_t)cfg.kc << 4) | (uint64_t)cfg.variant};
+  // The key's 64-bit FNV-1a is a filter, not an identity: a hit must also hold the same floats (a collision between two layers or
+  // checkpoints of one shape would otherwise run the detector on another tensor's weights, silently). Bounded by bytes: the
+  // images + sources of a YOLOv8x are ~1 GB; past 2 GB the oldest entries go.
+  static std::deque<std::array<uint64_t, 4>> order;
+  static size_t held = 0;
   {
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
+    if (it != cache.end() && it->second->source.size() == w.data.size() &&
+        memcmp(it->second->source.data(), w.data.data(), w.data.size() * sizeof(float)) == 0)
+      return it->second;
   }
-  auto made = std::make_shared<const PackedWeights>(make());
+  PackedWeights fresh = make();
+  fresh.source = w.data;
+  auto made = std::make_shared<const PackedWeights>(std::move(fresh));
+  const size_t cost = made->bytes.size() + made->source.size() * sizeof(float);
   std::lock_guard<std::mutex> lk(mu);
-  if (cache.size() > 1024) cache.clear();                    // a handful of models at most; never grows without bound
+  auto old = cache.find(key);
+  if (old != cache.end()) {                                    // same key, other floats: the newer tensor takes the slot
+    held -= old->second->bytes.size() + old->second->source.size() * sizeof(float);
+    cache.erase(old);
+    order.erase(std::remove(order.begin(), order.end(), key), order.end());
+  }
+  while (!order.empty() && held + cost > ((size_t)2 << 30)) {
+    auto victim = cache.find(order.front());
+    if (victim != cache.end()) {
+      held -= victim->second->bytes.size() + victim->second->source.size() * sizeof(float);
+      cache.erase(victim);                                     // detectors that use the image keep it alive through their shared_ptr
+    }
+    order.pop_front();
+  }
+  held += cost;
+  order.push_back(key);
   return cache.emplace(key, std::move(made)).first->second;
 }
 

@@ -135,6 +135,21 @@ def plan_stream_order(n_dets: int, n_stab: int, n_queues: int = 4) -> list[str]:
     return order
 
 
+class PacedSource:
+    """Wraps an iterable of batches that arrive at their own pace (a live stream: frames exist when the camera delivers them).
+    ExtractEngine.run() then works for latency: a batch's results leave before stage 1 blocks on the next batch, and the
+    stabilizer stage hands out what it holds while nothing arrives. A source has to SAY so: a slow synchronous reader (an image
+    folder, a decoder, GTX_FEEDER=0) also keeps `next()` waiting, and for it the throughput schedule -- the read of batch k + 1
+    under the GPU pass of batch k -- is the right one (an earlier version guessed from one 20 ms pull and flipped on page-cache stalls)."""
+    paced = True
+
+    def __init__(self, batches):
+        self._it = batches
+
+    def __iter__(self):
+        return iter(self._it)
+
+
 class StreamPlan:
     """The HIP streams of the extract engine on one device: created ONCE per process, all together, in the order
     plan_stream_order() gives, and handed out by role to every engine built afterwards.
@@ -329,8 +344,9 @@ class ExtractEngine:
             self._host_frames[key] = [f.bgr() if isinstance(f, Yuv420Frame) else f for f in frames]
         return len(frames)
 
-    def run(self, batches):
-        """batches: iterable of device pointers (B contiguous BGR u8 frames in HBM), of feeder.DeviceBatch objects (<= B frames
+    def run(self, batches, paced: bool | None = None):
+        """paced: the source is a live stream (see PacedSource); None = what the source declares (`batches.paced`, default False).
+        batches: iterable of device pointers (B contiguous BGR u8 frames in HBM), of feeder.DeviceBatch objects (<= B frames
         on their way into HBM) or of lists of <= B host frames.
         Yields one FrameResult per frame, in feeding order. An item may also be a pair (batch, prev): the batch does not
         continue the previous one (a shard rank of the frame-sharded run) and the GMC is primed with `prev`, the
@@ -340,6 +356,7 @@ class ExtractEngine:
         queues (the C-ABI calls release the GIL): detector submit/collect -> GMC + tracker (clip order) ->
         stabilizer submit/collect + box warp (this thread, which yields). Per-frame results are the same as
         frame at a time; only the host work overlaps. GTX_ENGINE_THREADS=0 keeps everything on the calling thread."""
+        self._paced = bool(getattr(batches, "paced", False)) if paced is None else bool(paced)
         threaded = (self.tracker is not None or bool(self.stabs)) and os.environ.get("GTX_ENGINE_THREADS", "1") != "0"
         frames = self._tracked_frames_threaded(batches) if threaded else self._tracked_frames(batches)
         return self._stabilized(frames)
@@ -350,14 +367,12 @@ class ExtractEngine:
         inflight = collections.deque()                          # (detector, frames in the batch)
         k = 0
 
-        paced = False                                            # the source kept this stage waiting for its last batch (a live stream)
+        paced = self._paced                                      # a live stream (PacedSource): work for latency, not for throughput
         exhausted = False
 
         def submit_next():
-            nonlocal k, paced, exhausted
-            t0 = time.perf_counter()
+            nonlocal k, exhausted
             b = next(it, None)
-            paced = time.perf_counter() - t0 > 0.02              # far above a read + upload, below a frame period at 30 fps
             if b is None:
                 exhausted = True
                 return

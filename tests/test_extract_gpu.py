@@ -649,11 +649,13 @@ def test_a_paced_source_gets_the_same_results_sooner(gtx_ctx, tracker):
 
     def paced():
         for b in batches:
-            time.sleep(0.06)                                   # > the 20 ms that tells the engine its source is a stream
+            time.sleep(0.06)                                   # a stream: batches exist when they arrive
             made.append(time.perf_counter())
             yield b
 
-    fast, slow = run(batches), run(paced())
+    from geotrax_amd.engine import PacedSource
+
+    fast, slow = run(batches), run(PacedSource(paced()))            # the source declares itself a stream
     assert [r[0] for r in slow] == [r[0] for r in fast] == list(range(len(frames)))
     for a, b in zip(fast, slow):
         assert np.array_equal(a[1], b[1]) and ((a[2] is None and b[2] is None) or np.array_equal(a[2], b[2]))
