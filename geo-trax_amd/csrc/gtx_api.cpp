@@ -1,5 +1,6 @@
 // C ABI of libgtx.so (see include/gtx.h). Everything here is a thin try/catch shim that turns
 // gtx::Error into a status code + thread-local message.
+#include <chrono>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -70,6 +71,47 @@ int gtx_ctx_create_prio(int device, int high_priority, gtx_ctx** out) {
 }
 
 void gtx_ctx_destroy(gtx_ctx* ctx) { delete ctx; }
+
+namespace {
+// one wave that does nothing for `ticks` of the 100 MHz constant clock
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(16);
+    t = __builtin_amdgcn_s_memrealtime();
+  }
+  if (sink && threadIdx.x == 0 && ticks == ~0ull) *sink = t;
+}
+}  // namespace
+
+int gtx_streams_overlap(gtx_ctx* a, gtx_ctx* b, float spin_us, float* ms_single, float* ms_pair) {
+  return guarded([&] {
+    need(a, "a"); need(b, "b"); need(ms_single, "ms_single"); need(ms_pair, "ms_pair");
+    if (a->device != b->device) gtx::fail(GTX_ERR_INVALID, "the two contexts are on devices %d and %d", a->device, b->device);
+    GTX_HIP(hipSetDevice(a->device));
+    const unsigned long long ticks = (unsigned long long)(std::max(spin_us, 1.f) * 100.f);
+    auto timed = [&](bool both) {
+      GTX_HIP(hipStreamSynchronize(a->stream));
+      GTX_HIP(hipStreamSynchronize(b->stream));
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a->stream, ticks, (unsigned long long*)nullptr);
+      if (both) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b->stream, ticks, (unsigned long long*)nullptr);
+      GTX_HIP(hipGetLastError());
+      GTX_HIP(hipStreamSynchronize(a->stream));
+      GTX_HIP(hipStreamSynchronize(b->stream));
+      return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)timed(true);                       // the code object is loaded, both streams have run something
+    float one = 1e30f, two = 1e30f;
+    for (int i = 0; i < 3; ++i) {            // host-timed: the best of three is the one without a scheduling hiccup
+      one = std::min(one, timed(false));
+      two = std::min(two, timed(true));
+    }
+    *ms_single = one;
+    *ms_pair = two;
+  });
+}
 
 int gtx_device_open_null_stream(int device) {
   return guarded([&] {

@@ -70,7 +70,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 6        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 7        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -81,6 +81,7 @@ _SIGNATURES = {
     "gtx_ctx_destroy": (None, [_P]),
     "gtx_ctx_synchronize": (C.c_int, [_P]),
     "gtx_device_open_null_stream": (C.c_int, [C.c_int]),
+    "gtx_streams_overlap": (C.c_int, [_P, _P, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gtx_write_table_f32": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "gtx_write_table_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "gtx_write_csv": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int]),

@@ -186,7 +186,52 @@ class StreamPlan:
                     raise ValueError(f"GTX_ENGINE_ORDER: tokens are d, s, f, g, n, x; got {env!r}")
                 p_det, p_stab = parse_prio(os.environ.get("GTX_ENGINE_PRIO"))
                 cls._plans[device] = StreamPlan(device, order, p_det, p_stab)
+                cls._plans[device].verify()
             return cls._plans[device]
+
+    def overlap(self, a: _lib.Context, b: _lib.Context, spin_us: float = 150.0) -> tuple[float, float]:
+        """(ms one idle wave spins on a's stream, ms the same on both streams at once): gtx_streams_overlap."""
+        one, two = C.c_float(), C.c_float()
+        _lib.check(_lib.load().gtx_streams_overlap(a.handle, b.handle, float(spin_us), C.byref(one), C.byref(two)))
+        return float(one.value), float(two.value)
+
+    def verify(self) -> None:
+        """The layout above follows a MEASURED rule of the HIP runtime (queue_of_streams), not a documented one. Once per process
+        and device: do the detector streams really run at the same time? If two of them share a hardware queue (a runtime that
+        places streams differently), the later one is replaced by the first of up to eight fresh streams that does overlap with
+        the first detector stream, and a warning says so -- 15-20 % of the frame rate depend on it (profiles/r04_stream_plan.txt).
+        GTX_ENGINE_VERIFY=0 skips the check (0.3 ms of spinning per pair)."""
+        self.verified = None
+        if os.environ.get("GTX_ENGINE_VERIFY", "1") == "0":
+            return
+        dets = [e for e in self.ctxs if e[0] == "d"]
+        if len(dets) < 2:
+            return
+        import logging
+
+        log = logging.getLogger(__name__)
+        self.verified = True
+        for ent in dets[1:]:
+            one, two = self.overlap(dets[0][1], ent[1])
+            if two < 1.5 * one:
+                continue
+            self.verified = False
+            spares = []
+            for _ in range(8):
+                cand = _lib.Context(self.device, self.p_det)
+                o1, o2 = self.overlap(dets[0][1], cand)
+                if o2 < 1.5 * o1 and all(self.overlap(other[1], cand)[1] < 1.5 * o1 for other in dets[1:] if other is not ent):
+                    log.warning(f"stream plan: two detector streams of device {self.device} ran one after the other ({two:.2f} ms for two "
+                                f"{one:.2f} ms kernels): this HIP runtime does not place streams the way the plan assumes; "
+                                "a replacement stream that does overlap was found and is used instead")
+                    spares.append(ent[1])
+                    ent[1] = cand
+                    break
+                spares.append(cand)
+            else:
+                log.warning(f"stream plan: two detector streams of device {self.device} share a hardware queue ({two:.2f} ms for two {one:.2f} ms "
+                            "kernels) and no replacement stream overlaps: expect 15-20 % lower frame rates (GPU_MAX_HW_QUEUES, GTX_ENGINE_ORDER)")
+            self.ctxs.extend(["x", c, True] for c in spares)     # kept alive and never handed out: destroying them would move later streams
 
     def take(self, role: str, holder=None) -> _lib.Context:
         """A context of `role` nobody holds (`holder`: the object it is for; when that object is gone the context is free

@@ -41,8 +41,9 @@ extern "C" {
  *    (host arrays handed to gtx_op_* stay plain fp32).
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
- * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added. */
-#define GTX_ABI_VERSION 6
+ * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added.
+ * 7: gtx_streams_overlap added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct. */
+#define GTX_ABI_VERSION 7
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -85,6 +86,11 @@ int gtx_ctx_synchronize(gtx_ctx* ctx);
  * that lays out several contexts for concurrency (geotrax_amd/engine.py StreamPlan) calls this at a fixed point of its
  * creation order, so that which streams share a queue does not depend on when the first set-up copy happens. Idempotent. */
 int gtx_device_open_null_stream(int device);
+/* Do kernels on the two contexts' streams run at the same time? One idle wave spins for spin_us microseconds on a's stream
+ * (ms_single: host-timed, best of three) and then on both streams at once (ms_pair). Streams that share a hardware queue run
+ * in order: ms_pair ~ 2 x ms_single; streams on queues of their own: ms_pair ~ ms_single. The extract engine's stream plan
+ * (geotrax_amd/engine.py) is computed from a measured rule of the HIP runtime, not a documented one; this is its self-check. */
+int gtx_streams_overlap(gtx_ctx* a, gtx_ctx* b, float spin_us, float* ms_single, float* ms_pair);
 /* Raw device memory for callers that keep inputs resident in HBM (bench.py). */
 int gtx_dev_alloc(gtx_ctx* ctx, size_t bytes, void** dptr);
 int gtx_dev_free(gtx_ctx* ctx, void* dptr);

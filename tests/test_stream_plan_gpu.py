@@ -55,3 +55,36 @@ def test_the_planned_order_lands_on_the_hardware_queues_the_rule_predicts(tmp_pa
     det_q = {got[k] for k, (tok, _) in enumerate(streams) if tok == "d"}
     assert len(det_q) == n_dets
     assert all(tok in ("d", "x") or got[k] not in det_q for k, (tok, _) in enumerate(streams)), (order, got)
+
+
+@pytest.mark.gpu
+def test_the_plan_checks_itself_at_run_time(caplog):
+    """StreamPlan.verify(): the detector streams of the plan really run at the same time (gtx_streams_overlap: one idle wave
+    spinning on each), a stream next to itself does not; a plan whose detector streams were forced onto one hardware queue
+    (GTX_ENGINE_ORDER) finds a replacement that overlaps and says so -- in a child process, the plan is per process."""
+    sys.path[:0] = [str(ROOT / "geo-trax_amd")]
+    from geotrax_amd.engine import StreamPlan
+
+    plan = StreamPlan.get(0, 2, 4)
+    assert plan.verified is True
+    d = [e[1] for e in plan.ctxs if e[0] == "d"]
+    one, two = plan.overlap(d[0], d[1])
+    assert 0.1 < one < 0.6 and two < 1.5 * one, (one, two)          # 150 us of spinning, side by side
+    one, two = plan.overlap(d[0], d[0])
+    assert two > 1.7 * one, (one, two)                               # the same stream: one after the other
+
+    code = ("import sys, logging\n"
+            f"sys.path[:0] = [r'{ROOT / 'geo-trax_amd'}']\n"
+            "logging.basicConfig(level=logging.WARNING)\n"
+            "from geotrax_amd.engine import StreamPlan, queue_of_streams\n"
+            "order = ['d', 'x', 'x', 'x', 'x', 'x', 'x', 'd']\n"    # by the rule streams 5-8 join queues 3, 2, 1, 0: the second detector lands on the first's queue
+            "assert queue_of_streams(order)[0] == queue_of_streams(order)[-1], queue_of_streams(order)\n"
+            "import os; os.environ['GTX_ENGINE_ORDER'] = ','.join(order)\n"
+            "plan = StreamPlan.get(0, 2, 0)\n"
+            "d = [e[1] for e in plan.ctxs if e[0] == 'd']\n"
+            "one, two = plan.overlap(d[0], d[1])\n"
+            "print('VERIFIED', plan.verified, two < 1.5 * one)\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "VERIFIED False True" in p.stdout, p.stdout + p.stderr   # the plan was wrong, noticed it, and repaired itself
+    assert "replacement stream" in p.stderr
