@@ -1,15 +1,18 @@
-"""`geotrax batch` for the extract stage, mapped to one process per GPU.
+"""`geotrax batch`: the stage chain of the reference over a directory of videos, one process per GPU.
 
-Reference behaviour replaced: geotrax/batch_process.py:220-377 -- walk a directory for videos, drop the
-ones in excluded folders / matching excluded patterns, skip what already has results unless
---overwrite (asking unless --yes), run the stages per file, never let one file's failure stop the
-batch. Here the per-file stage is `geotrax_amd.extract.detect_track_stabilize` (the GPU hot path);
-georeference / visualisation / plots of the reference's batch are outside this build and are not run.
+Reference behaviour replaced: geotrax/batch_process.py:220-377 -- walk a directory for videos, drop the ones in excluded
+folders / matching excluded patterns, and per file run the stages one after the other, EACH behind its own skip-if-exists
+rule (`should_process_file`, :340-364): detection + tracking + stabilization (`geotrax_amd.extract.detect_track_stabilize`,
+skipped when the tracks file exists) and then georeferencing (`geotrax_amd.georef_stage.georeference`, needs the tracks
+file, skipped when the CSV exists); `--overwrite` re-runs a stage (asking unless `--yes`), `--no-geo` / `--geo-only` select
+stages, `--dry-run` lists them; one file's failure never stops the batch. Visualisation and plots of the reference's batch
+are not built (out of scope): `--viz-only` / `--plot-only` say so and do nothing.
 
-Multi-GPU: started under `python -m torch.distributed.run --nproc-per-node N -m geotrax_amd.batch <dir>`
-every rank scans the same sorted file list and takes the videos `i % N == rank` of the largest-first
-order (the honest best case of §8e: one video per GPU, no collective on the data path); rank 0 prints the
-summary after a barrier. Without a launcher it is a single process on GPU 0.
+Multi-GPU: started under `python -m torch.distributed.run --nproc-per-node N -m geotrax_amd.batch <dir>` every rank scans
+the same file list and the videos are handed out from a SHARED COUNTER, largest first: a rank that finishes takes the next
+video (the counter is an atomic add on the launcher's rendezvous store, which rank 0 serves) -- no rank idles for longer
+than the last video it did not get. No collective on the data path (the honest best case of 8e: one video per GPU); rank 0
+prints the summary after a barrier. Without a launcher it is a single process on GPU 0.
 """
 from __future__ import annotations
 
@@ -25,6 +28,14 @@ from .extract import add_common_args, add_processing_args, detect_track_stabiliz
 
 VIDEO_FORMATS = {'.mp4', '.mov', '.avi', '.mkv', '.npy', '.y4m'}  # constants.py:10 plus this build's array / uncompressed clips
 ACTION_EXTRACT = "Detecting, tracking, and stabilizing"
+ACTION_GEOREF = "Georeferencing"
+PROCESSING_STEPS = "detection, tracking, and stabilization"
+
+
+def _georeference(args, logger):
+    from .georef_stage import georeference
+
+    georeference(args, logger)
 
 
 def discover(input_path: Path, folders_exclude, exclude_patterns, logger: logging.Logger) -> list[Path]:
@@ -61,37 +72,99 @@ def handle_existing_results(file: Path, args, logger, exists: bool, action: str,
     return True
 
 
+def georeferenced_exist(file: Path, out_cfg: dict) -> bool:
+    """check_if_results_exist(file, 'georeferenced')."""
+    from .georef_stage import build_result_path
+
+    return build_result_path(file, "georeferenced", out_cfg).exists()
+
+
+def should_process_file(file: Path, args, logger, action: str, out_cfg: dict, ask=input) -> bool:
+    """batch_process.py:340-364: a stage runs when its own output is missing (or --overwrite allows); georeferencing also
+    needs the extraction stage's tracks file."""
+    txt_exists = results_exist(file, out_cfg)
+    if action == ACTION_EXTRACT:
+        return handle_existing_results(file, args, logger, txt_exists, PROCESSING_STEPS, ask)
+    if action == ACTION_GEOREF:
+        if not txt_exists and not getattr(args, "dry_run", False):
+            logger.error(f"'{file}' - No {PROCESSING_STEPS} results found. Skipping georeferencing.")
+            return False
+        return handle_existing_results(file, args, logger, georeferenced_exist(file, out_cfg), action, ask)
+    return False
+
+
+def order_largest_first(files: list[Path]) -> list[Path]:
+    return sorted(files, key=lambda f: (-f.stat().st_size, str(f)))
+
+
 def shard(files: list[Path], rank: int, world: int) -> list[Path]:
-    """Largest first, dealt round-robin: ranks finish close together without talking to each other."""
-    order = sorted(files, key=lambda f: (-f.stat().st_size, str(f)))
-    return [f for i, f in enumerate(order) if i % world == rank]
+    """The static deal (largest first, round-robin): what a rank gets when no shared counter is available."""
+    return [f for i, f in enumerate(order_largest_first(files)) if i % world == rank]
 
 
-def process_file(file: Path, args, logger, out_cfg: dict, run=detect_track_stabilize) -> str:
-    """-> 'done' | 'skipped' | 'failed' | 'dry'. One file's failure never stops the batch (batch_process.py:300-303)."""
+class WorkQueue:
+    """Videos handed out one at a time, largest first, from a counter every rank of the job adds to atomically (the launcher's
+    rendezvous store: `store.add` on rank 0's TCP store). A rank takes the next video when it has finished its last one, so
+    unequal videos even out by themselves; with the static deal a rank that drew the long ones finished last while the others
+    idled."""
+
+    def __init__(self, files: list[Path], store, key: str = "gtx_batch_next"):
+        self.files, self.store, self.key = order_largest_first(files), store, key
+
+    def __iter__(self):
+        while True:
+            i = int(self.store.add(self.key, 1)) - 1
+            if i >= len(self.files):
+                return
+            yield self.files[i]
+
+
+def process_file(file: Path, args, logger, out_cfg: dict, run=detect_track_stabilize, run_geo=_georeference, stats: dict | None = None) -> str:
+    """The stage chain of one file (batch_process.py:288-307). -> 'done' (a stage ran) | 'skipped' (every stage had its results)
+    | 'failed' | 'dry'. `stats` (optional) counts per stage. One file's failure never stops the batch (:300-303)."""
+    stats = stats if stats is not None else {}
+
+    def note(stage, what):
+        stats.setdefault(stage, dict(done=0, skipped=0, failed=0, dry=0))[what] += 1
+
+    geo_only, no_geo = bool(getattr(args, "geo_only", False)), bool(getattr(args, "no_geo", False))
+    if getattr(args, "viz_only", False) or getattr(args, "plot_only", False):
+        logger.warning(f"'{file}': --viz-only / --plot-only: visualisation and plots are not part of this build; nothing to do.")
+        return 'skipped'
+    stages = ([] if geo_only else [("extract", ACTION_EXTRACT, run)]) + ([] if no_geo else [("georef", ACTION_GEOREF, run_geo)])
+    ran = dry = False
+    stage = "extract"
     try:
         logger.info(f"Processing: '{file}'")
-        if not handle_existing_results(file, args, logger, results_exist(file, out_cfg), "detection, tracking, and stabilization"):
-            return 'skipped'
-        logger.info(f"{ACTION_EXTRACT}: '{file}'")
-        if args.dry_run:
-            return 'dry'
-        file_args = argparse.Namespace(**vars(args))
-        file_args.source = file
-        run(file_args, logger)
-        return 'done'
+        for stage, action, func in stages:
+            if not should_process_file(file, args, logger, action, out_cfg):
+                note(stage, 'skipped')
+                continue
+            logger.info(f"{action}: '{file}'")
+            if args.dry_run:
+                note(stage, 'dry')
+                dry = True
+                continue
+            file_args = argparse.Namespace(**vars(args))
+            file_args.source = file
+            func(file_args, logger)
+            note(stage, 'done')
+            ran = True
+        return 'done' if ran else ('dry' if dry else 'skipped')
     except Exception as e:
+        note(stage, 'failed')
         logger.error(f"Error with {file}: {e}")
         return 'failed'
     except SystemExit as e:
-        # the per-file stage exits on an unreadable video or a missing model (extract.py load_detector /
-        # initialize_streams, like the reference); inside a batch -- and above all under a launcher, where the other
-        # ranks wait in the closing all_reduce -- that is this file's failure, not the batch's
-        logger.error(f"Error with {file}: the extraction stage exited with status {e.code}")
+        # a stage exits on an unreadable video, a missing model or missing orthophotos (extract.py load_detector /
+        # initialize_streams, georef_stage, like the reference); inside a batch -- and above all under a launcher, where the
+        # other ranks wait in the closing all_reduce -- that is this file's failure, not the batch's
+        note(stage, 'failed')
+        logger.error(f"Error with {file}: the {stage} stage exited with status {e.code}")
         return 'failed'
 
 
-def process_input(args, logger: logging.Logger, run=detect_track_stabilize) -> dict:
+def process_input(args, logger: logging.Logger, run=detect_track_stabilize, run_geo=_georeference, stats: dict | None = None) -> dict:
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     input_path = Path(args.input)
     counts = dict(done=0, skipped=0, failed=0, dry=0)
@@ -113,23 +186,34 @@ def process_input(args, logger: logging.Logger, run=detect_track_stabilize) -> d
         logger.info(f"Batch processing all videos in: '{input_path}'")
         args.cut_frame_right = None
         files = discover(input_path, args.folders_exclude, args.exclude_patterns, logger)
-    mine = shard(files, rank, world) if world > 1 else files
-    if world > 1:
-        os.environ.setdefault("GTX_DEVICE", os.environ.get("LOCAL_RANK", "0"))
-        os.environ["GTX_FRAME_SHARDING"] = "0"                    # whole videos per rank here, not frames of one video (extract.py)
-        logger.info(f"rank {rank}/{world}: {len(mine)} of {len(files)} videos")
-    for f in mine:
-        counts[process_file(f, args, logger, out_cfg, run)] += 1
+    mine = files
     if world > 1:
         import torch
         import torch.distributed as dist
 
+        os.environ.setdefault("GTX_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        os.environ["GTX_FRAME_SHARDING"] = "0"                    # whole videos per rank here, not frames of one video (extract.py)
         if not dist.is_initialized():
-            dist.init_process_group("gloo")                       # control plane only: a barrier and four counters
+            dist.init_process_group("gloo")                       # control plane only: the shared counter, a barrier and four counters
+        store = None
+        if os.environ.get("GTX_BATCH_QUEUE", "1") != "0":
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:                                     # a torch without that accessor: the static deal
+                store = None
+        mine = WorkQueue(files, store) if store is not None else shard(files, rank, world)
+        logger.info(f"rank {rank}/{world}: {len(files)} videos, " + ("taken from the shared counter, largest first" if store is not None else f"{len(mine)} dealt to this rank"))
+    taken = []
+    for f in mine:
+        taken.append(f)
+        counts[process_file(f, args, logger, out_cfg, run, run_geo, stats)] += 1
+    if world > 1:
         t = torch.tensor([counts[k] for k in ('done', 'skipped', 'failed', 'dry')], dtype=torch.int64)
         dist.all_reduce(t)
         counts = dict(zip(('done', 'skipped', 'failed', 'dry'), (int(v) for v in t)))
         dist.barrier()
+    if stats is not None:
+        stats["taken"] = taken
     if rank == 0:
         logger.info(f"Batch finished: {counts['done']} processed, {counts['skipped']} skipped, {counts['failed']} failed"
                     + (f", {counts['dry']} listed (dry run)" if counts['dry'] else "") + ".")
@@ -141,12 +225,19 @@ def parse_cli_args(argv=None) -> argparse.Namespace:
     ap.add_argument("input", type=Path, help="video file or directory (searched recursively)")
     add_common_args(ap)
     add_processing_args(ap)
+    from .georef_stage import add_georeferencing_args
+
+    add_georeferencing_args(ap.add_argument_group("georeferencing"))
     g = ap.add_argument_group("batch")
     g.add_argument("--overwrite", "-o", action="store_true", help="re-process videos that already have results")
     g.add_argument("--yes", "-y", action="store_true", help="do not ask before overwriting")
-    g.add_argument("--dry-run", "-dr", action="store_true", help="list what would be processed")
-    g.add_argument("--folders-exclude", nargs="*", default=None, help="sub-folder names to skip (cfg -> batch -> folders_exclude)")
-    g.add_argument("--exclude-patterns", nargs="*", default=None, help="skip videos whose name contains any of these")
+    g.add_argument("--dry-run", "-dr", action="store_true", help="list which files and stages would be processed")
+    g.add_argument("--viz-only", "-vo", action="store_true", help="(reference flag) visualisation is not part of this build: nothing is run")
+    g.add_argument("--geo-only", "-go", action="store_true", help="only run georeferencing; skip detection, tracking, and stabilization")
+    g.add_argument("--plot-only", "-po", action="store_true", help="(reference flag) plots are not part of this build: nothing is run")
+    g.add_argument("--no-geo", "-ng", action="store_true", help="do not georeference the tracking data")
+    g.add_argument("--folders-exclude", "-fe", nargs="*", default=None, help="sub-folder names to skip (cfg -> batch -> folders_exclude)")
+    g.add_argument("--exclude-patterns", "-ep", nargs="*", default=None, help="skip videos whose name contains any of these")
     return ap.parse_args(argv)
 
 

@@ -24,7 +24,7 @@ def _tree(root: Path):
 def _args(root, **over):
     a = argparse.Namespace(input=root, cfg=None, output_folder=None, log_path=None, verbose=False, model=None, class_names=None, conf=None,
                            classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None, overwrite=False, yes=False, dry_run=False,
-                           folders_exclude=None, exclude_patterns=None)
+                           folders_exclude=None, exclude_patterns=None, no_geo=True, geo_only=False, viz_only=False, plot_only=False)
     for k, v in over.items():
         setattr(a, k, v)
     return a
@@ -102,7 +102,8 @@ def _rank_main(rank, world, root, port, q):
     q.put((rank, mine, counts, os.environ.get("GTX_DEVICE")))
 
 
-def test_two_ranks_split_the_directory(tmp_path):
+def test_two_ranks_split_the_directory(tmp_path, monkeypatch):
+    monkeypatch.setenv("GTX_BATCH_QUEUE", "0")        # the static deal (what a job without the shared counter falls back to)
     _tree(tmp_path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -117,3 +118,106 @@ def test_two_ranks_split_the_directory(tmp_path):
     assert got[0][1] == ["six.avi", "three.mov", "skipme_four.mkv"] and got[1][1] == ["one.npy", "two.mp4"]
     assert got[0][2] == got[1][2] == dict(done=5, skipped=0, failed=0, dry=0)                  # all-reduced totals on every rank
     assert got[0][3] == "0" and got[1][3] == "1"                                               # one GPU per rank
+
+
+def test_stage_chain_runs_each_stage_behind_its_own_skip_rule(tmp_path, caplog):
+    """batch_process.py:288-307, 340-377: extract then georeference per file, a stage is skipped when ITS output exists,
+    georeferencing needs the tracks file, --no-geo / --geo-only select stages, --overwrite --yes re-runs, --dry-run lists."""
+    from geotrax_amd import batch
+
+    for name in ("A1.npy", "B2.npy"):
+        (tmp_path / name).write_bytes(b"x" * 10)
+    log = []
+
+    def run(a, lg):
+        log.append(("extract", Path(a.source).name))
+        out = Path(a.source).parent / "results"
+        out.mkdir(exist_ok=True)
+        (out / f"{Path(a.source).stem}.txt").write_text("0,1\n")
+
+    def run_geo(a, lg):
+        log.append(("georef", Path(a.source).name))
+        if Path(a.source).name == "B2.npy" and not (tmp_path / "ortho_ok").exists():
+            raise SystemExit(1)                      # no orthophoto for this location: georef_stage exits like the reference
+        (Path(a.source).parent / "results" / f"{Path(a.source).stem}.csv").write_text("x\n")
+
+    def go(**over):
+        log.clear()
+        stats = {}
+        counts = batch.process_input(_args(tmp_path, **{'no_geo': False, **over}), logger, run=run, run_geo=run_geo, stats=stats)
+        return counts, stats
+
+    counts, stats = go()
+    assert log == [("extract", "A1.npy"), ("georef", "A1.npy"), ("extract", "B2.npy"), ("georef", "B2.npy")]
+    assert counts == dict(done=1, skipped=0, failed=1, dry=0)                # B2's georeference failed: the file counts as failed, the batch went on
+    assert stats["extract"] == dict(done=2, skipped=0, failed=0, dry=0) and stats["georef"] == dict(done=1, skipped=0, failed=1, dry=0)
+    (tmp_path / "ortho_ok").write_text("")
+    counts, stats = go()
+    assert log == [("georef", "B2.npy")]                                     # every other stage has its results
+    assert counts == dict(done=1, skipped=1, failed=0, dry=0) and stats["extract"]["skipped"] == 2 and stats["georef"] == dict(done=1, skipped=1, failed=0, dry=0)
+    counts, _ = go()
+    assert log == [] and counts["skipped"] == 2
+    (tmp_path / "results" / "A1.csv").unlink()
+    counts, _ = go()
+    assert log == [("georef", "A1.npy")]                                     # only the missing stage
+    (tmp_path / "results" / "A1.txt").unlink()
+    (tmp_path / "results" / "A1.csv").unlink()
+    with caplog.at_level(logging.ERROR):
+        counts, stats = go(geo_only=True)
+    assert log == [] and "No detection, tracking, and stabilization results found. Skipping georeferencing." in caplog.text
+    counts, _ = go(no_geo=True)
+    assert log == [("extract", "A1.npy")]
+    counts, stats = go(overwrite=True, yes=True)
+    assert log == [("extract", "A1.npy"), ("georef", "A1.npy"), ("extract", "B2.npy"), ("georef", "B2.npy")] and counts["done"] == 2
+    counts, stats = go(overwrite=True, yes=True, dry_run=True)
+    assert log == [] and counts["dry"] == 2 and stats["extract"]["dry"] == 2 and stats["georef"]["dry"] == 2
+    counts, _ = go(viz_only=True)
+    assert log == [] and counts["skipped"] == 2
+    # the CLI has the reference's stage flags and the georeferencing group
+    a = batch.parse_cli_args([str(tmp_path), "-go", "-y", "-orf", str(tmp_path), "-nm"])
+    assert a.geo_only and not a.no_geo and a.no_master is True and a.ortho_folder == tmp_path
+
+
+def _queue_rank(rank, world, root, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    import time
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "geo-trax_amd"))
+    from geotrax_amd import batch
+
+    mine = []
+    t0 = time.time()
+
+    def run(a, log):
+        time.sleep(Path(a.source).stat().st_size / 1000.0)       # a video takes as long as it is big
+        mine.append((Path(a.source).name, time.time() - t0))
+
+    counts = batch.process_input(_args(Path(root)), logging.getLogger(f"r{rank}"), run=run)
+    q.put((rank, mine, counts))
+
+
+def test_three_ranks_take_unequal_videos_from_the_shared_counter(tmp_path):
+    """One long video and eight short ones over three ranks: with the static deal the rank that drew the long one also drew two
+    short ones and finished 0.8 s after the others; from the shared counter it takes the long one and nothing else, and no rank
+    sits idle for longer than one short video while work is left."""
+    (tmp_path / "long.npy").write_bytes(b"x" * 900)
+    for k in range(8):
+        (tmp_path / f"short{k}.npy").write_bytes(b"x" * 100)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_queue_rank, args=(r, 3, str(tmp_path), port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    names = [[n for n, _ in g[1]] for g in got]
+    assert sorted(n for ns in names for n in ns) == sorted(f.name for f in tmp_path.glob("*.npy"))     # every video once
+    long_rank = [ns for ns in names if "long.npy" in ns]
+    assert long_rank == [["long.npy"]]                                        # whoever took the long one took nothing else
+    ends = [g[1][-1][1] for g in got]
+    assert max(ends) - min(ends) < 0.75                                       # static deal: 1.1 s against 0.3 s
+    assert all(g[2] == dict(done=9, skipped=0, failed=0, dry=0) for g in got)

@@ -353,12 +353,12 @@ def test_batch_processes_a_directory_and_skips_existing(gtx_ctx, tmp_path):
         np.save(p, np.stack([scene.render(t0 + 12 * k, 150) for k in range(3)]))
     wpath, _ = _weights_file(tmp_path, gtx_ctx, scene.render(0, 150), half=True)
     cfg_path, _ = _cfg_file(tmp_path, wpath, half=True)
-    args = batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path), "--exclude-patterns", "weights"])
+    args = batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path), "--exclude-patterns", "weights", "--no-geo"])
     counts = batch.process_input(args, logger)
     assert counts["done"] == 2 and counts["failed"] == 0
     for name in ("north/results/clip_a.txt", "south/results/clip_b.txt", "north/results/clip_a_vid_transf.txt"):
         assert (tmp_path / name).exists(), name
-    assert batch.process_input(batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path)]), logger)["skipped"] == 2
+    assert batch.process_input(batch.parse_cli_args([str(tmp_path), "--cfg", str(cfg_path), "--no-geo"]), logger)["skipped"] == 2
 
 
 @pytest.mark.parametrize("ratio", [0.5, 1.0])
