@@ -113,7 +113,7 @@ def yolov8_layer_specs(scale: str = "s", nc: int = 4) -> list[tuple[str, tuple[i
 
 def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: float = -4.0,
                      gain: float = 1.7, box_decay: float | tuple = 0.3, level_bias: tuple = (0.0, 0.0, 0.0),
-                     box_weight_scale: float = 0.3, smooth_cls: bool = False) -> dict[str, np.ndarray]:
+                     box_weight_scale: float = 0.3, smooth_cls: bool | int = False) -> dict[str, np.ndarray]:
     """Seeded random fused weights of the YOLOv8 architecture (no checkpoint is reachable here).
 
     Conv weights ~ N(0, gain^2 / fan_in) so activations keep O(1) scale through the SiLU stack;
@@ -141,7 +141,8 @@ def synthetic_yolov8(seed: int = 0, nc: int = 4, scale: str = "s", cls_bias: flo
         fan_in = shape[1] * shape[2] * shape[3]
         g = gain if has_act else 1.0
         t[name + ".weight"] = (rng.standard_normal(shape) * (g / np.sqrt(fan_in))).astype(np.float32)
-        if smooth_cls and shape[2] == 3 and (".cv3." in name or name.startswith("model.15.m.")):
+        if smooth_cls and shape[2] == 3 and (".cv3." in name or name.startswith("model.15.m.") or
+                                             (int(smooth_cls) >= 2 and name.startswith("model.12.m."))):   # 2: the stride-16 neck stage too (twice the radius at stride 8)
             mix = t[name + ".weight"][:, :, 1:2, 1:2] * np.float32(np.sqrt(shape[2] * shape[3]))   # keeps the output variance for smooth inputs
             t[name + ".weight"] = np.broadcast_to(mix / np.float32(shape[2] * shape[3]), shape).astype(np.float32).copy()
         b = rng.standard_normal(shape[0]) * 0.05

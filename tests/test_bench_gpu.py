@@ -49,6 +49,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert ff >= 0.85 * d["value"] and hf >= 0.85 * d["value"], (d["value"], hf, ff)
     # NMS sees clustered candidates: more candidates than detections in the calibration frame
     assert d["config"]["candidates_per_frame"] > 1.3 * d["config"]["detections_per_frame"]
+    # ... and the heavy end of SURVEY 8d's post-processing range rides along: 2 000 anchors above conf per frame
+    nl = d["nms_load"]
+    assert 1800 <= nl["candidates_per_frame"] <= 2200 and nl["detections_per_frame"] > 400 and nl["value"] > 0.5 * d["value"], nl
+    assert "nms_small" in nl["nms_path"] and "nms_small" in d["config"]["nms_path"]
 
 
 @pytest.mark.parametrize("mode,tracker", [("frames", "bytetrack"), ("frames", "botsort"), ("videos", "bytetrack")])
