@@ -71,6 +71,9 @@ def parse():
                          "orthophoto, row chain, kinematics, CSV), unpaced and as a 30 fps stream; "
                          "cli = the product from a file: a 150-frame 3840x2160 clip written to local disk as .y4m and .npy, then "
                          "geotrax_amd.extract.track_with_model on the file (wall-clock frames/s and the reference's own convention)")
+    ap.add_argument("--ortho", type=int, default=0,
+                    help="--workload register: register a 3840x2160 frame against a synthetic orthophoto cut-out of this width (the reference's size is "
+                         "15000, default.yaml:154, with max_features 250000) instead of a 4K frame pair")
     ap.add_argument("--cli-frames", type=int, default=150, help="--workload cli: frames of the clip (the reference's 5 s clip has 150)")
     ap.add_argument("--cli-formats", default="y4m,npy", help="--workload cli: which containers to write and measure")
     ap.add_argument("--cli-dir", default=None, help="--workload cli: where the clip is written (default: a fresh directory under the system's temp dir)")
@@ -358,6 +361,8 @@ def bench_register(args):
     from geotrax_amd.registration import register_once
     from geotrax_amd.synth import make_scene
 
+    if args.ortho:
+        return bench_register_ortho(args)
     ctx = _lib.Context(0)
     scene = make_scene(seed=0, h=H, w=W)
     a, b = scene.render(0, 150), scene.render(40, 150)
@@ -392,6 +397,88 @@ def bench_register(args):
                         "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f16"], "traffic": None,
                         "avg_launch_us": 1000.0 * ms, "flops_per_launch": flops,
                         "timing": "HIP events around 3 passes of 250000 x 250000 x 128 (gtx_op_match_2nn), incl. the exact-distance finish kernel"}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_register_ortho(args):
+    """--workload register --ortho N: K11 at the reference's size (geotrax/utils/registration.py:21-95 with cfg/default.yaml:154,158-168:
+    a 15 000-px orthophoto cut-out, max_features 250 000, ratio 0.55, 3 px, 10 000 iterations): one 3840x2160 frame registered against
+    a synthetic N x N orthophoto whose frame -> orthophoto mapping is known. Reports keypoints found, time per stage, the HBM the
+    registration holds, the 2-NN kernel's measured TFLOP/s at the keypoint counts reached, and a roofline object for the stage that
+    takes the time at this size: the SIFT pyramid (HBM-bound)."""
+    import ctypes as C
+
+    from geotrax_amd import _lib, ops
+    from geotrax_amd.registration import Sift, register_once
+    from geotrax_amd.synth import make_scene
+
+    ctx = _lib.Context(0)
+    N = int(args.ortho)
+    t0 = time.perf_counter()
+    scene = make_scene(seed=0, h=H, w=W)
+    frame = scene.render(0, 150)
+    ortho, A = scene.orthophoto_large(size=N, scale=1.3, angle=0.2)
+    t_make = time.perf_counter() - t0
+
+    def mem():
+        f, t = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().gtx_device_mem_info(0, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    free0, total = mem()
+    # the detector stage of the orthophoto on its own: GPU time by stage (HIP events), then its buffers are given back
+    sift = Sift((N, N), ctx=ctx)
+    free_sift, _ = mem()
+    sift.detect_and_compute(ortho, max_features=250000, cap=8)            # cap: rows copied back to the host (the count is what matters here)
+    k_ortho = sift.detect_and_compute(ortho, max_features=250000, cap=8)
+    st = sift.stage_ms()
+    sift.close()
+    base_px = st["base_pixels"]
+    # one write and one read of every pyramid image (6 Gaussian + 5 DoG layers of every octave: 11 x 4/3 fp32 images of the doubled
+    # base) + the BGR upload: the traffic a pyramid that keeps every layer cannot go below. The separable blurs as built move ~2 x that.
+    pyr_bytes = base_px * 4.0 * 11 * (4.0 / 3.0) * 2 + N * N * 3.0
+    kw = dict(max_features=250000, filter_ratio=0.55, ransac_epipolar_threshold=3.0, ransac_max_iter=10000, ransac_confidence=0.999999,
+              rsift_eps=1e-8, ctx=ctx)
+    Hm, stats, tm = register_once(frame, ortho, **kw)                    # first call: allocates the pyramids (kept by the library)
+    steps = max(min(args.steps, 3), 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        Hm, stats, tm = register_once(frame, ortho, **kw)
+    elapsed = time.perf_counter() - t0
+    free1, _ = mem()
+    ys, xs = np.meshgrid(np.linspace(0, H - 1, 9), np.linspace(0, W - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    err = None
+    if Hm is not None:
+        pa, pb = Hm @ P, A @ P
+        err = float(np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max())
+    nq, nt = int(stats[0]), int(stats[1])
+    rng = np.random.default_rng(0)
+    d = np.sqrt(rng.gamma(0.6, 1.0, (max(nq, nt, 2), 128)).astype(np.float32))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    *_, ms = ops.match_2nn(d[:max(nq, 1)], d[rng.permutation(max(nt, 2))], iters=3, ctx=ctx)
+    mflops = 2.0 * nq * nt * 128
+    out = {"metric": "frame-to-orthophoto registrations/sec at the reference's size (RootSIFT + 2-NN + robust homography)", "value": steps / elapsed,
+           "unit": "registrations/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": 1000.0 * elapsed / steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 keypoints/descriptors, f16 MFMA matching", "data": "synthetic",
+           "config": {"workload": f"estimate_homography GPU path: one 3840x2160 frame against a {N}x{N} synthetic orthophoto cut-out, max_features 250000 "
+                                  "(geotrax/cfg/default.yaml:154,158-168), host images in",
+                      "keypoints": {"frame": nq, "orthophoto": nt, "orthophoto_detect_pass": int(k_ortho["count"])},
+                      "good_matches": int(stats[2]), "inliers": int(stats[3]),
+                      "stage_ms": {"detect_describe_both_images": float(tm[0]), "match": float(tm[1]), "ratio": float(tm[2]), "fit": float(tm[3])},
+                      "orthophoto_sift_stage_ms": {"pyramid": st["pyramid"], "extrema_refine_orient": st["keypoints"], "describe": st["describe"]},
+                      "max_grid_error_px_vs_known_mapping": err,
+                      "hbm_gb": {"total": total / 1e9, "orthophoto_sift_buffers": (free0 - free_sift) / 1e9, "held_after_registration": (free0 - free1) / 1e9},
+                      "match_2nn": {"nq": nq, "nt": nt, "ms": float(ms), "tflops": mflops / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                    "frac_of_fp16_mfma_peak": mflops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f16"] if ms > 0 else None,
+                                    "note": "gtx_op_match_2nn on random unit descriptors of the keypoint counts reached, incl. the exact-distance finish"},
+                      "host_seconds_to_render_the_orthophoto": t_make},
+           "roofline": {"bound": "hbm", "kernel": "sift pyramid (gray, upscale, blur_h / blur_v, down, sub kernels of csrc/sift.hip)",
+                        "achieved": pyr_bytes / (st["pyramid"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": pyr_bytes / (st["pyramid"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_pass": pyr_bytes, "pass_ms": st["pyramid"],
+                        "timing": "HIP events around the pyramid stage of the orthophoto's detect pass (gtx_sift_stage_ms); algorithmic bytes = every "
+                                  "pyramid image written once and read once + the BGR upload"}}
     print(json.dumps(out), flush=True)
 
 

@@ -85,6 +85,14 @@ __global__ void spin_kernel(unsigned long long ticks, unsigned long long* sink) 
 }
 }  // namespace
 
+int gtx_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+  return guarded([&] {
+    need(free_bytes, "free_bytes"); need(total_bytes, "total_bytes");
+    GTX_HIP(hipSetDevice(device));
+    GTX_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  });
+}
+
 int gtx_streams_overlap(gtx_ctx* a, gtx_ctx* b, float spin_us, float* ms_single, float* ms_pair) {
   return guarded([&] {
     need(a, "a"); need(b, "b"); need(ms_single, "ms_single"); need(ms_pair, "ms_pair");
@@ -440,6 +448,9 @@ int gtx_sift_detect(gtx_sift* s, const uint8_t* image, int h, int w, int max_fea
     }
     if (desc && m > 0) std::memcpy(desc, d.data(), (size_t)m * 128 * sizeof(float));
   });
+}
+int gtx_sift_stage_ms(gtx_sift* s, float out[4]) {
+  return guarded([&] { need(s, "sift"); need(out, "out"); s->impl->stage_ms(out); });
 }
 int gtx_sift_pyramid(gtx_sift* s, int kind, int octave, int layer, int cap, float* out, int* h, int* w, int* n_octaves) {
   return guarded([&] {

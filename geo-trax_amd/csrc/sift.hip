@@ -430,6 +430,14 @@ struct Sift::Impl {
   size_t cand_cap = 0, kp_cap = 0;
   int n = 0;
   std::vector<SiftKeypoint> host_kps;
+  // GPU time of the stages of the last detect_and_compute (HIP events on the stream): 0 upload + gray + upscale + Gaussian / DoG pyramid,
+  // 1 extrema + refine + orientation (with their host round trips for the counters), 2 descriptors; 3 = doubled-base pixels
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float stage_ms[4] = {0, 0, 0, 0};
+  ~Impl() {
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
 
   void blur(const float* src, float* dst, int w, int h, double sigma) {
     const Taps t = make_taps(sigma);
@@ -458,6 +466,11 @@ Sift::Sift(int device, hipStream_t stream, int max_h, int max_w) : impl_(new Imp
   S.refined.alloc(S.cand_cap * sizeof(Refined));
   S.oriented.alloc(S.kp_cap * sizeof(Oriented));
   S.counters.alloc(4 * sizeof(int));
+  for (hipEvent_t& e : S.ev) GTX_HIP(hipEventCreate(&e));
+}
+
+void Sift::stage_ms(float out[4]) const {
+  for (int i = 0; i < 4; ++i) out[i] = impl_->stage_ms[i];
 }
 
 Sift::~Sift() = default;
@@ -490,6 +503,7 @@ void Sift::detect_and_compute(const uint8_t* image, int h, int w, int max_featur
   }
   T.n = n_oct;
   // ---- base image
+  GTX_HIP(hipEventRecord(S.ev[0], s));
   GTX_HIP(hipMemcpyAsync(S.frame.p, image, (size_t)h * w * 3, hipMemcpyHostToDevice, s));
   const size_t npx = (size_t)h * w;
   hipLaunchKernelGGL(gray_kernel, dim3((unsigned)cdiv((long)npx, 256L)), dim3(256), 0, s, S.frame.as<uint8_t>(), S.gray.as<float>(), npx);
@@ -516,6 +530,7 @@ void Sift::detect_and_compute(const uint8_t* image, int h, int w, int max_featur
     for (int i = 0; i < kDog; ++i)
       hipLaunchKernelGGL(sub_kernel, dim3((unsigned)cdiv((long)np, 256L)), dim3(256), 0, s, T.g[o][i + 1], T.g[o][i], T.d[o][i], np);
   }
+  GTX_HIP(hipEventRecord(S.ev[1], s));
   // ---- extrema -> refine -> orientation
   int* cnt = S.counters.as<int>();
   GTX_HIP(hipMemsetAsync(cnt, 0, 4 * sizeof(int), s));
@@ -540,6 +555,7 @@ void Sift::detect_and_compute(const uint8_t* image, int h, int w, int max_featur
                        (int)S.kp_cap);
   GTX_HIP(hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipStreamSynchronize(s));
+  GTX_HIP(hipEventRecord(S.ev[2], s));
   const int n_ori = std::min<long>(hc[2], (long)S.kp_cap);
   std::vector<Oriented> ori(n_ori);
   if (n_ori) GTX_HIP(hipMemcpy(ori.data(), S.oriented.p, sizeof(Oriented) * n_ori, hipMemcpyDeviceToHost));
@@ -593,8 +609,11 @@ void Sift::detect_and_compute(const uint8_t* image, int h, int w, int max_featur
     GTX_HIP(hipMemcpyAsync(S.xy.p, xy.data(), sizeof(float2) * n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(describe_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, T, S.finals.as<Final>(), n, S.desc.as<float>(), root ? 1 : 0, root_eps);
     GTX_HIP(hipGetLastError());
-    GTX_HIP(hipStreamSynchronize(s));   // fin / xy are stack-owned host buffers
   }
+  GTX_HIP(hipEventRecord(S.ev[3], s));
+  GTX_HIP(hipStreamSynchronize(s));     // fin / xy are stack-owned host buffers
+  for (int i = 0; i < 3; ++i) GTX_HIP(hipEventElapsedTime(&S.stage_ms[i], S.ev[i], S.ev[i + 1]));
+  S.stage_ms[3] = (float)((double)bw * bh);
 }
 
 void Sift::download(std::vector<SiftKeypoint>& kps, std::vector<float>& desc) const {

@@ -37,6 +37,9 @@ class Sift {
   // test hooks: pyramid image (kind 0 = Gaussian, 1 = DoG) of the last image
   void pyramid_image(int kind, int octave, int layer, std::vector<float>& out, int* h, int* w) const;
   int n_octaves() const;
+  // GPU ms of the last detect_and_compute: [0] upload + gray + pyramid, [1] extrema + refine + orientation, [2] descriptors; [3] = pixels
+  // of the doubled base image (the pyramid holds 11 x 4/3 fp32 images of that size)
+  void stage_ms(float out[4]) const;
 
  private:
   struct Impl;

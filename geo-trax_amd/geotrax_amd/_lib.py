@@ -81,6 +81,7 @@ _SIGNATURES = {
     "gtx_ctx_destroy": (None, [_P]),
     "gtx_ctx_synchronize": (C.c_int, [_P]),
     "gtx_device_open_null_stream": (C.c_int, [C.c_int]),
+    "gtx_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gtx_streams_overlap": (C.c_int, [_P, _P, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gtx_write_table_f32": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "gtx_write_table_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
@@ -108,6 +109,7 @@ _SIGNATURES = {
     "gtx_sift_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_sift_destroy": (None, [_P]),
     "gtx_sift_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
+    "gtx_sift_stage_ms": (C.c_int, [_P, _P]),
     "gtx_sift_pyramid": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_op_match_2nn": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "gtx_op_preprocess": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int]),

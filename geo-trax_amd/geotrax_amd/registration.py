@@ -93,7 +93,13 @@ class Sift:
                                            ptr(kp), ptr(octv), ptr(desc)))
         k = min(n.value, cap)
         return dict(xy=kp[:k, :2].copy(), size=kp[:k, 2].copy(), angle=kp[:k, 3].copy(), response=kp[:k, 4].copy(),
-                    octave=octv[:k].copy(), desc=desc[:k].copy())
+                    octave=octv[:k].copy(), desc=desc[:k].copy(), count=int(n.value))
+
+    def stage_ms(self) -> dict:
+        """GPU time of the last detect_and_compute by stage, and the pixel count of the doubled base image."""
+        out = np.zeros(4, np.float32)
+        check(self.ctx.lib.gtx_sift_stage_ms(self.handle, ptr(out)))
+        return dict(pyramid=float(out[0]), keypoints=float(out[1]), describe=float(out[2]), base_pixels=float(out[3]))
 
     def pyramid(self, kind: int, octave: int, layer: int) -> np.ndarray:
         h, w, no = C.c_int(), C.c_int(), C.c_int()

@@ -97,6 +97,57 @@ class Scene:
         img[~inside] = 60.0
         return np.clip(np.rint(img), 0, 255).astype(np.uint8), A
 
+    def orthophoto_large(self, size: int = 15000, scale: float = 1.3, angle: float = 0.2, seed: int = 7) -> tuple[np.ndarray, np.ndarray]:
+        """An orthophoto cut-out of the reference's size (`georef.transformation.cutout_width_px: 15000`, default.yaml:154): a
+        size x size textured canvas of its own (the same kind of ground as the scene: smooth noise + high-contrast structure, so
+        that the whole cut-out yields keypoints, not only the part the video sees) with the scene's static world laid in
+        through a similarity (zoom `scale`, rotation `angle`, centred) -> (BGR uint8 image, 3x3 ground truth mapping frame-0
+        pixels to orthophoto pixels). Built in row blocks: 675 MB as uint8."""
+        rng = np.random.default_rng(seed)
+        out = np.empty((size, size, 3), np.uint8)
+        cells = [(640, 22.0), (96, 10.0)]
+        grids = [rng.standard_normal((size // c + 3, size // c + 3)).astype(np.float32) for c, _ in cells]
+        tint = rng.uniform(-6, 6, 3).astype(np.float32)
+        xs = np.arange(size, dtype=np.float32)
+        step = 1000
+        for y0 in range(0, size, step):
+            y1 = min(y0 + step, size)
+            ys = np.arange(y0, y1, dtype=np.float32)
+            base = np.full((y1 - y0, size), 105.0, np.float32)
+            for (c, amp), g in zip(cells, grids):
+                gy, gx = ys / c, xs / c
+                iy, ix = gy.astype(int), gx.astype(int)
+                fy, fx = (gy - iy)[:, None], (gx - ix)[None, :]
+                a = g[iy][:, ix] * (1 - fx) + g[iy][:, ix + 1] * fx
+                b = g[iy + 1][:, ix] * (1 - fx) + g[iy + 1][:, ix + 1] * fx
+                base += amp * (a * (1 - fy) + b * fy)
+            base += rng.standard_normal(base.shape).astype(np.float32) * 3
+            out[y0:y1] = np.clip(np.rint(base[..., None] + tint), 0, 255).astype(np.uint8)
+        n_struct = int(2600 * (size / 3840.0) * (size / 2160.0))             # the scene's density of markings and roofs
+        bw, bh = rng.integers(3, 40, n_struct), rng.integers(3, 40, n_struct)
+        x, y = rng.integers(0, size - 40, n_struct), rng.integers(0, size - 40, n_struct)
+        col = np.clip(rng.uniform(30, 230, (n_struct, 1)) + rng.uniform(-8, 8, (n_struct, 3)), 0, 255).astype(np.uint8)
+        for k in range(n_struct):
+            out[y[k]:y[k] + bh[k], x[k]:x[k] + bw[k]] = col[k]
+        # the scene's world, through the similarity, inside the bounding box of its corners
+        c, s = scale * np.cos(angle), scale * np.sin(angle)
+        A = np.array([[c, -s, size / 2 - c * self.w / 2 + s * self.h / 2], [s, c, size / 2 - s * self.w / 2 - c * self.h / 2], [0, 0, 1.0]])
+        Ai = np.linalg.inv(A)
+        m = self.margin
+        corners = A @ np.array([[-m, self.w + m, self.w + m, -m], [-m, -m, self.h + m, self.h + m], [1, 1, 1, 1.0]])
+        bx0, bx1 = max(int(np.floor(corners[0].min())), 0), min(int(np.ceil(corners[0].max())) + 1, size)
+        by0, by1 = max(int(np.floor(corners[1].min())), 0), min(int(np.ceil(corners[1].max())) + 1, size)
+        for y0 in range(by0, by1, step):
+            y1 = min(y0 + step, by1)
+            yy, xx = np.mgrid[y0:y1, bx0:bx1].astype(np.float32)
+            fx = (Ai[0, 0] * xx + Ai[0, 1] * yy + Ai[0, 2]).astype(np.float32)
+            fy = (Ai[1, 0] * xx + Ai[1, 1] * yy + Ai[1, 2]).astype(np.float32)
+            inside = (fx >= -m + 1) & (fx < self.w + m - 2) & (fy >= -m + 1) & (fy < self.h + m - 2)
+            img = np.clip(np.rint(bilinear_sample(self.world, fx + m, fy + m)), 0, 255).astype(np.uint8)
+            blk = out[y0:y1, bx0:bx1]
+            blk[inside] = img[inside]
+        return out, A
+
     def render(self, t: int, n_frames: int = 150) -> np.ndarray:
         """Frame t as BGR uint8 [h,w,3]."""
         G = self.camera(t, n_frames)

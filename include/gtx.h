@@ -42,7 +42,7 @@ extern "C" {
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
  * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added.
- * 7: gtx_streams_overlap added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct. */
+ * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct. */
 #define GTX_ABI_VERSION 7
 
 typedef enum gtx_status {
@@ -86,6 +86,9 @@ int gtx_ctx_synchronize(gtx_ctx* ctx);
  * that lays out several contexts for concurrency (geotrax_amd/engine.py StreamPlan) calls this at a fixed point of its
  * creation order, so that which streams share a queue does not depend on when the first set-up copy happens. Idempotent. */
 int gtx_device_open_null_stream(int device);
+/* hipMemGetInfo of the device: what registration at the reference's size (a 15 000-px orthophoto: ~55 GB of pyramids) reports as its
+ * footprint. */
+int gtx_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* Do kernels on the two contexts' streams run at the same time? One idle wave spins for spin_us microseconds on a's stream
  * (ms_single: host-timed, best of three) and then on both streams at once (ms_pair). Streams that share a hardware queue run
  * in order: ms_pair ~ 2 x ms_single; streams on queues of their own: ms_pair ~ ms_single. The extract engine's stream plan
@@ -472,6 +475,10 @@ int gtx_sift_create(gtx_ctx* ctx, int max_h, int max_w, gtx_sift** out);
 void gtx_sift_destroy(gtx_sift* s);
 int gtx_sift_detect(gtx_sift* s, const uint8_t* image_bgr, int h, int w, int max_features, int root,
                     float root_eps, int cap, int* n, float* kp5, int* octave, float* desc);
+/* GPU milliseconds of the stages of the last detect call (HIP events on the context's stream): out[0] upload + gray + Gaussian / DoG
+ * pyramid, out[1] extrema + refinement + orientation (with the host round trips for their counters), out[2] descriptors; out[3] = the
+ * pixel count of the doubled base image (the pyramid is 11 x 4/3 fp32 images of that size: what a roofline of the stage is priced on). */
+int gtx_sift_stage_ms(gtx_sift* s, float out[4]);
 /* Gaussian (kind 0) or DoG (kind 1) image of the last detect call, [h][w] fp32. */
 int gtx_sift_pyramid(gtx_sift* s, int kind, int octave, int layer, int cap, float* out, int* h, int* w,
                      int* n_octaves);

@@ -125,3 +125,26 @@ def test_estimate_homography_recovers_a_known_warp_and_matches_the_oracle_chain(
     assert estimate_homography(flat, flat, log, max_features=20000, ctx=gtx_ctx) == (None, None, None, None)
     with pytest.raises(NotImplementedError):
         estimate_homography(src, dst, log, detector_name="orb", ctx=gtx_ctx)
+
+
+def test_registration_at_the_references_size(gtx_ctx):
+    """K11 at the size the reference runs it (geotrax/utils/registration.py:21-95 with cfg/default.yaml:154,158-168): a 3840x2160
+    frame against a 15 000 x 15 000 orthophoto cut-out, max_features 250 000, ratio 0.55, 3 px, 10 000 iterations. The synthetic
+    cut-out is textured everywhere (the detector returns its full 250 000 keypoints, the 2-NN runs ~10 k x 250 k) and contains
+    the scene through a known similarity: the estimate lands within 0.25 px of it over a 9 x 16 grid of frame points; ~65 GB of
+    pyramids for the cut-out (59 bytes per doubled pixel) fit the 288 GB of one MI355X with room for the frame's."""
+    import logging
+
+    from geotrax_amd.registration import estimate_homography
+    from geotrax_amd.synth import make_scene
+
+    H, W, N = 2160, 3840, 15000
+    sc = make_scene(seed=0, h=H, w=W)
+    frame = sc.render(0, 150)
+    ortho, A = sc.orthophoto_large(size=N, scale=1.3, angle=0.2)
+    Hm, inliers, matches, (n_src, n_dst) = estimate_homography(frame, ortho, logging.getLogger("reg15000"), ctx=gtx_ctx)
+    assert Hm is not None and n_dst == 250000 and n_src > 5000 and matches > 500 and inliers > 0.8 * matches, (n_src, n_dst, matches, inliers)
+    ys, xs = np.meshgrid(np.linspace(0, H - 1, 9), np.linspace(0, W - 1, 16), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    pa, pb = Hm @ P, A @ P
+    assert np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max() < 0.25
