@@ -81,14 +81,8 @@ void register_images(gtx_ctx* ctx, const gtx_reg_config& cfg, const uint8_t* src
     tm[1] = ms_since(t0);
     // Lowe ratio in query order (stabilo: m.distance < ratio * n.distance)
     t0 = clk::now();
-    std::vector<SiftKeypoint> kq, kt;
-    std::vector<float> unused;
+    const std::vector<SiftKeypoint>&kq = sift_src.keypoints_host(), &kt = sift_dst.keypoints_host();   // positions only: the descriptors stay in HBM
     std::vector<float4> pts;
-    {
-      std::vector<float> dq, dt;   // descriptors are not needed on the host; download() returns them anyway
-      sift_src.download(kq, dq);
-      sift_dst.download(kt, dt);
-    }
     for (int i = 0; i < nq; ++i)
       if (h1[i] >= 0 && h2[i] >= 0 && e1[i] < cfg.filter_ratio * e2[i]) pts.push_back(make_float4(kq[i].x, kq[i].y, kt[h1[i]].x, kt[h1[i]].y));
     stats[2] = (int)pts.size();

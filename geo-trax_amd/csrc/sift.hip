@@ -616,6 +616,8 @@ void Sift::detect_and_compute(const uint8_t* image, int h, int w, int max_featur
   S.stage_ms[3] = (float)((double)bw * bh);
 }
 
+const std::vector<SiftKeypoint>& Sift::keypoints_host() const { return impl_->host_kps; }
+
 void Sift::download(std::vector<SiftKeypoint>& kps, std::vector<float>& desc) const {
   const Impl& S = *impl_;
   kps = S.host_kps;

@@ -34,6 +34,7 @@ class Sift {
   const float* descriptors_dev() const;         // [n][128] fp32
   const float2* positions_dev() const;          // [n] (x, y)
   void download(std::vector<SiftKeypoint>& kps, std::vector<float>& desc) const;
+  const std::vector<SiftKeypoint>& keypoints_host() const;   // the keypoints alone: no copy of the descriptors (128 MB at 250 000 keypoints)
   // test hooks: pyramid image (kind 0 = Gaussian, 1 = DoG) of the last image
   void pyramid_image(int kind, int octave, int layer, std::vector<float>& out, int* h, int* w) const;
   int n_octaves() const;
