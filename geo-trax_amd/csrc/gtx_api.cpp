@@ -639,8 +639,8 @@ int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out) {
     need(cfg, "cfg"); need(out, "out");
     std::unique_ptr<gtx_tracker> t(new gtx_tracker);
     if (cfg->type == 2 || cfg->type == 3) t->oc.reset(new gtx::OcSortTracker(*cfg));
-    else if (cfg->type == 0 || cfg->type == 1) t->impl.reset(new gtx::ByteTracker(*cfg));
-    else gtx::fail(GTX_ERR_INVALID, "tracker type %d (0 bytetrack, 1 botsort, 2 ocsort, 3 deepocsort)", cfg->type);
+    else if (cfg->type == 0 || cfg->type == 1 || cfg->type == 4) t->impl.reset(new gtx::ByteTracker(*cfg));
+    else gtx::fail(GTX_ERR_INVALID, "tracker type %d (0 bytetrack, 1 botsort, 2 ocsort, 3 deepocsort, 4 fasttrack)", cfg->type);
     *out = t.release();
   });
 }

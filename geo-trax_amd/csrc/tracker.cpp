@@ -16,6 +16,7 @@
 #include "tracker.hpp"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -152,6 +153,10 @@ struct Track {
   int idx = 0;          // index of the detection inside the frame's detection list
   int id = 0;
   int frame_id = 0, start_frame = 0, tracklet_len = 0;
+  // FastTracker (type 4) only: the filter's recent means (newest last), occlusion state
+  std::vector<std::array<double, 8>> hist;
+  bool occluded = false, occ_lost = false;
+  int occ_frames = 0;
 };
 
 // ---- exact sparse LAP ----
@@ -546,11 +551,27 @@ struct ByteTracker::Impl {
     t.score = det.score;
     t.cls = det.cls;
     t.idx = det.idx;
+    t.occluded = false; t.occ_lost = false; t.occ_frames = 0;
+  }
+  // FastTracker: the largest fraction of t's box that one box of `others` covers
+  double covered(const Track& t, const std::vector<Track*>& others) const {
+    float a[4];
+    xyxy_of(t, kf.xywh, a);
+    const double area = std::max((double)(a[2] - a[0]) * (double)(a[3] - a[1]), 1e-12);
+    double best = 0.0;
+    for (const Track* o : others) {
+      if (o == &t) continue;
+      float b[4];
+      xyxy_of(*o, kf.xywh, b);
+      const double iw = (double)std::min(a[2], b[2]) - (double)std::max(a[0], b[0]), ih = (double)std::min(a[3], b[3]) - (double)std::max(a[1], b[1]);
+      if (iw > 0 && ih > 0) best = std::max(best, iw * ih / area);
+    }
+    return best;
   }
 };
 
 ByteTracker::ByteTracker(const gtx_tracker_config& cfg) : impl_(new Impl) {
-  GTX_CHECK(cfg.type == 0 || cfg.type == 1, "tracker type %d: only bytetrack (0) and botsort (1) are implemented", cfg.type);
+  GTX_CHECK(cfg.type == 0 || cfg.type == 1 || cfg.type == 4, "tracker type %d: bytetrack (0), botsort (1) and fasttrack (4) live here", cfg.type);
   impl_->cfg = cfg;
   impl_->kf.xywh = cfg.type == 1;
   const int fr = cfg.frame_rate > 0 ? cfg.frame_rate : 30;
@@ -639,7 +660,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
 
   PROF_MARK(predict)
   std::vector<Track> activated_new;             // tracks created this frame
-  std::vector<Track*> activated, refind, lost_now, removed_now;
+  std::vector<Track*> activated, refind, lost_now, removed_now, ft_unmatched;
   std::vector<int> x, y;
 
   // ---- first association: pool vs high-score detections ----
@@ -677,9 +698,47 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     if (x[i] >= 0) {
       if (t->state == kTracked) { S.absorb(*t, *dl[x[i]], false); activated.push_back(t); }
       else { S.absorb(*t, *dl[x[i]], true); refind.push_back(t); }
+    } else if (A.type == 4) {
+      ft_unmatched.push_back(t);                 // FastTracker: occluded or lost, decided below against the tracks that did find a detection
     } else if (t->state != kLost) {
       t->state = kLost;
       lost_now.push_back(t);
+    }
+  }
+  if (A.type == 4) {
+    // tracker.fasttrack (default.yaml:426-443; oracle/fasttrack_ref.py states the choices made where the description leaves them open): a
+    // confirmed track without a detection whose box another active track covers by occ_cover_thresh stays active on its prediction for up
+    // to active_occ_to_lost_thresh frames; at the onset its filter is rolled back (velocity of reset_velocity_offset_occ frames ago, position
+    // of reset_pos_offset_occ frames ago carried forward), the velocity dampened and the box enlarged once.
+    std::vector<Track*> seen = activated;
+    seen.insert(seen.end(), refind.begin(), refind.end());
+    const int vel_off = std::max(A.reset_velocity_offset_occ, 0), pos_off = std::max(A.reset_pos_offset_occ, 0);
+    for (Track* t : ft_unmatched) {
+      if (S.covered(*t, seen) >= (double)A.occ_cover_thresh && t->occ_frames < A.active_occ_to_lost_thresh) {
+        if (!t->occluded) {
+          t->occluded = true;
+          if (!t->hist.empty()) {
+            const int nh = (int)t->hist.size();
+            const double* pv = vel_off > 0 ? t->hist[std::max(nh - vel_off, 0)].data() : t->mean;
+            double v[4] = {pv[4], pv[5], pv[6], pv[7]};
+            const int k = std::min(pos_off, nh);
+            if (k > 0) {
+              const double* pp = t->hist[nh - k].data();
+              for (int i = 0; i < 4; ++i) t->mean[i] = pp[i] + (k + 1) * v[i];   // k stored frames back + this frame's prediction step
+            }
+            for (int i = 0; i < 4; ++i) t->mean[4 + i] = v[i];
+          }
+          for (int i = 0; i < 4; ++i) t->mean[4 + i] *= (double)A.dampen_motion_occ;
+          t->mean[3] *= (double)A.enlarge_bbox_occ;
+        }
+        t->occ_frames += 1;
+        t->idx = -1;
+        activated.push_back(t);
+      } else {
+        if (t->occluded) t->occ_lost = true;
+        t->occluded = false;
+        if (t->state != kLost) { t->state = kLost; lost_now.push_back(t); }
+      }
     }
   }
 
@@ -697,12 +756,33 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     if (y[j] >= 0) continue;
     Track t = *dleft[j];
     if (t.score < A.new_track_thresh) continue;
+    if (A.type == 4 && A.init_iou_suppress < 1.f) {     // no new track on top of an active one (tracks that found a detection this frame)
+      bool on_top = false;
+      float a[4] = {t.tlwh0[0], t.tlwh0[1], t.tlwh0[0] + t.tlwh0[2], t.tlwh0[1] + t.tlwh0[3]};
+      for (Track* o : activated) {
+        if (o->idx < 0) continue;                       // occluded tracks run on their prediction: they do not suppress
+        float b[4];
+        xyxy_of(*o, S.kf.xywh, b);
+        const float iw = std::max(std::min(a[2], b[2]) - std::max(a[0], b[0]), 0.f), ih = std::max(std::min(a[3], b[3]) - std::max(a[1], b[1]), 0.f);
+        const float inter = iw * ih, uni = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter;
+        if (1.f - (1.f - inter / (uni + 1e-7f)) >= A.init_iou_suppress) { on_top = true; break; }
+      }
+      if (!on_top)
+        for (Track* o : refind) {
+          float b[4];
+          xyxy_of(*o, S.kf.xywh, b);
+          const float iw = std::max(std::min(a[2], b[2]) - std::max(a[0], b[0]), 0.f), ih = std::max(std::min(a[3], b[3]) - std::max(a[1], b[1]), 0.f);
+          const float inter = iw * ih, uni = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter;
+          if (1.f - (1.f - inter / (uni + 1e-7f)) >= A.init_iou_suppress) { on_top = true; break; }
+        }
+      if (on_top) continue;
+    }
     S.activate(t);
     activated_new.push_back(t);
   }
   // ---- lost tracks that timed out ----
   for (Track& t : S.lost)
-    if (S.frame_id - t.frame_id > S.max_time_lost) { t.state = kRemoved; removed_now.push_back(&t); }
+    if (S.frame_id - t.frame_id > ((A.type == 4 && t.occ_lost) ? A.occ_reappear_window : S.max_time_lost)) { t.state = kRemoved; removed_now.push_back(&t); }
 
   PROF_MARK(third)
   // ---- state update (order of the lists is part of the output contract) ----
@@ -771,6 +851,15 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     S.removed_order.erase(S.removed_order.begin(), S.removed_order.begin() + drop);
   }
 
+  if (A.type == 4) {
+    const size_t keep = (size_t)std::max(std::max(A.reset_velocity_offset_occ, A.reset_pos_offset_occ), 0) + 1;
+    for (Track& t : S.tracked) {
+      std::array<double, 8> m;
+      std::memcpy(m.data(), t.mean, sizeof(double) * 8);
+      t.hist.push_back(m);
+      if (t.hist.size() > keep) t.hist.erase(t.hist.begin());
+    }
+  }
   int k = 0;
   for (const Track& t : S.tracked) {
     if (!t.activated) continue;

@@ -42,6 +42,9 @@ class TrackerConfig(C.Structure):
         ("new_track_thresh", C.c_float), ("track_buffer", C.c_int), ("match_thresh", C.c_float),
         ("fuse_score", C.c_int), ("frame_rate", C.c_int),
         ("delta_t", C.c_int), ("inertia", C.c_float), ("use_byte", C.c_int), ("min_hits", C.c_int),
+        ("reset_velocity_offset_occ", C.c_int), ("reset_pos_offset_occ", C.c_int), ("enlarge_bbox_occ", C.c_float),
+        ("dampen_motion_occ", C.c_float), ("active_occ_to_lost_thresh", C.c_int), ("occ_cover_thresh", C.c_float),
+        ("occ_reappear_window", C.c_int), ("init_iou_suppress", C.c_float),
     ]
 
 

@@ -171,6 +171,12 @@ class YOLO:
         else:
             self._gmc_method = None
         self._gmc = None
+        if ttype == "fasttrack" and not getattr(self, "_fasttrack_warned", False):
+            self._fasttrack_warned = True
+            logger.warning("tracker 'fasttrack': written from the description of its parameters in the config (occlusion test by box cover, "
+                           "Kalman roll-back at the onset, dampened velocity, one-shot box enlargement, re-find window, init-IoU suppression on "
+                           "top of ByteTrack); the pinned ultralytics' implementation may differ where that description leaves a choice open "
+                           "(oracle/fasttrack_ref.py lists the choices). Score a reference run with tools/score_run.py to pin it.")
         if ttype in ("ocsort", "deepocsort") and not getattr(self, "_ocsort_warned", False):
             self._ocsort_warned = True
             logger.warning(f"tracker '{ttype}': this build follows the authors' published OC-SORT (observation-centric re-update, momentum, "
@@ -180,7 +186,8 @@ class YOLO:
                            "tracks may differ from a geo-trax run of the same tracker. Score a reference run with tools/score_run.py to pin it.")
         return Tracker(ttype, **{k: v for k, v in params.items() if k in (
             "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score",
-            "delta_t", "inertia", "use_byte", "min_hits")})
+            "delta_t", "inertia", "use_byte", "min_hits", "reset_velocity_offset_occ", "reset_pos_offset_occ", "enlarge_bbox_occ",
+            "dampen_motion_occ", "active_occ_to_lost_thresh", "occ_cover_thresh", "occ_reappear_window", "init_iou_suppress")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:

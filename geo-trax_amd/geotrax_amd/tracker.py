@@ -4,7 +4,8 @@ Reference behaviour replaced: the tracker callback ultralytics registers for
 ``model.track(..., persist=True)`` (geotrax/extract.py:153) with the active block of
 cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time. `tracker_type: ocsort` (default.yaml:391-404) selects the OC-SORT
 implementation (csrc/ocsort.cpp), `deepocsort` (default.yaml:406-427) the same tracker with camera-motion compensation by the warp
-handed to update() (no appearance branch); fasttrack / tracktrack are not implemented and raise.
+handed to update() (no appearance branch); `fasttrack` (default.yaml:426-443) ByteTrack with occlusion handling, written from the
+config's own description of its parameters (csrc/tracker.cpp type 4, oracle/fasttrack_ref.py); tracktrack is not implemented and raises.
 """
 from __future__ import annotations
 
@@ -15,14 +16,16 @@ import numpy as np
 from . import _lib
 from ._lib import TrackerConfig, check, ptr
 
-TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2, "deepocsort": 3}
+TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2, "deepocsort": 3, "fasttrack": 4}
 
 
 class Tracker:
     def __init__(self, tracker_type: str = "bytetrack", track_high_thresh: float = 0.25, track_low_thresh: float = 0.1,
                  new_track_thresh: float = 0.25, track_buffer: int = 30, match_thresh: float = 0.8,
                  fuse_score: bool = True, frame_rate: int = 30, max_tracks: int = 4096, delta_t: int = 3, inertia: float = 0.2,
-                 use_byte: bool = False, min_hits: int = 3, **_ignored):
+                 use_byte: bool = False, min_hits: int = 3, reset_velocity_offset_occ: int = 5, reset_pos_offset_occ: int = 3,
+                 enlarge_bbox_occ: float = 1.1, dampen_motion_occ: float = 0.5, active_occ_to_lost_thresh: int = 10,
+                 occ_cover_thresh: float = 0.7, occ_reappear_window: int = 40, init_iou_suppress: float = 0.7, **_ignored):
         if tracker_type not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         self.lib = _lib.load()
@@ -30,7 +33,11 @@ class Tracker:
                             track_low_thresh=track_low_thresh, new_track_thresh=new_track_thresh,
                             track_buffer=track_buffer, match_thresh=match_thresh, fuse_score=int(fuse_score),
                             frame_rate=frame_rate, delta_t=int(delta_t), inertia=float(inertia), use_byte=int(bool(use_byte)),
-                            min_hits=int(min_hits))
+                            min_hits=int(min_hits), reset_velocity_offset_occ=int(reset_velocity_offset_occ),
+                            reset_pos_offset_occ=int(reset_pos_offset_occ), enlarge_bbox_occ=float(enlarge_bbox_occ),
+                            dampen_motion_occ=float(dampen_motion_occ), active_occ_to_lost_thresh=int(active_occ_to_lost_thresh),
+                            occ_cover_thresh=float(occ_cover_thresh), occ_reappear_window=int(occ_reappear_window),
+                            init_iou_suppress=float(init_iou_suppress))
         h = C.c_void_p()
         check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))
         self.handle = h

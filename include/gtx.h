@@ -304,7 +304,8 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
 
 typedef struct gtx_tracker_config {
   int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404), 3 = deepocsort without the
-                              appearance branch: ocsort + camera-motion compensation by gmc_affine (default.yaml:406-427) */
+                              appearance branch: ocsort + camera-motion compensation by gmc_affine (default.yaml:406-427),
+                              4 = fasttrack (default.yaml:426-443): ByteTrack + the occlusion handling of the fields at the end */
   float track_high_thresh;
   float track_low_thresh;
   float new_track_thresh;
@@ -317,6 +318,15 @@ typedef struct gtx_tracker_config {
   float inertia;
   int use_byte;
   int min_hits;
+  /* FastTracker only (type 4): tracker.fasttrack.* of the reference's config, same names and meaning (default.yaml:436-443) */
+  int reset_velocity_offset_occ;
+  int reset_pos_offset_occ;
+  float enlarge_bbox_occ;
+  float dampen_motion_occ;
+  int active_occ_to_lost_thresh;
+  float occ_cover_thresh;
+  int occ_reappear_window;
+  float init_iou_suppress;
 } gtx_tracker_config;
 
 int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);

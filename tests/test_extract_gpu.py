@@ -78,6 +78,10 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
 
         trk = OCSortRef(cmc=(active == "deepocsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer",
                                                                             "match_thresh", "delta_t", "inertia", "use_byte")})
+    elif active == "fasttrack":
+        from oracle.fasttrack_ref import FastTrackRef
+
+        trk = FastTrackRef(**{k: v for k, v in tp.items() if k != "tracker_type"})
     else:
         trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
                                                                                  "track_buffer", "match_thresh", "fuse_score")})
@@ -121,7 +125,7 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "ocsort", "deepocsort"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "ocsort", "deepocsort", "fasttrack"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
