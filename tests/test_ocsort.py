@@ -87,7 +87,7 @@ def test_ocsort_contract_details():
 
 def test_config_selects_ocsort(tmp_path):
     """tracker.active: ocsort resolves through the config surface to the C++ OC-SORT with the block's parameters; the
-    three trackers this build does not have say so."""
+    tracker this build does not have says so (FastTracker is built since round 5: tests/test_fasttrack.py)."""
     from geotrax_amd.model import YOLO
     from geotrax_amd.tracker import Tracker
 
@@ -95,9 +95,9 @@ def test_config_selects_ocsort(tmp_path):
     m._gmc_method = m._gmc = None
     t = m._make_tracker({"tracker_type": "ocsort", "track_high_thresh": 0.3, "delta_t": 2, "inertia": 0.1, "use_byte": True, "match_thresh": 0.75})
     assert isinstance(t, Tracker) and m._gmc_method is None
-    for name in ("fasttrack", "tracktrack"):
-        with pytest.raises(NotImplementedError):
-            m._make_tracker({"tracker_type": name})
+    with pytest.raises(NotImplementedError):
+        m._make_tracker({"tracker_type": "tracktrack"})
+    assert isinstance(m._make_tracker({"tracker_type": "fasttrack", "occ_cover_thresh": 0.6}), Tracker)
 
 
 @pytest.mark.parametrize("kind", ["bytetrack", "botsort", "ocsort"])
