@@ -409,10 +409,12 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     // 3x3 stride 1 with whole 64-cout tiles: the Winograd F(2x2, 3x3) form (conv_wino_split.hip) is built, bit-exactness-tested
     // and OFF: alone it is 1.05-1.35 x faster than the direct kernel on the deep K loops (Cin >= 256) and slower on the others,
     // and next to the engine's second stream it loses even there (one 512-thread workgroup takes a CU's registers: 962 vs 970
-    // frames/s; profiles/r05_winograd_probe.txt). GTX_WINO=1: every eligible layer, GTX_WINO=2: Cin >= 256 only.
+    // frames/s; profiles/r05_winograd_probe.txt). GTX_WINO=1: every eligible layer, GTX_WINO=2: Cin >= 256 only, GTX_WINO=3: the second
+    // form (16 x 16 pixels, one wave per SIMD: 1.04 x alone, its per-workgroup fixed cost is what is left).
     if (ks == 3 && stride == 1 && c.bn == 64 && c.kc == 16 && cout % 64 == 0) {
       const int mode = env_int("GTX_WINO", 0);
       if (mode == 1 || (mode == 2 && cin >= 256)) c.variant = 3;
+      if (mode == 3) { c.variant = 4; c.th = 16; }      // the 16 x 16-pixel form (one wave per SIMD)
     }
     return c;
   }
@@ -444,9 +446,9 @@ inline uint16_t f32_to_f16_bits(float f) {
 
 std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   if (acc_scale) *acc_scale = 1.f;
-  if (cfg.variant == 2 || cfg.variant == 3) {
+  if (cfg.variant == 2 || cfg.variant == 3 || cfg.variant == 4) {
     float sc = 1.f;
-    std::vector<uint8_t> r = cfg.variant == 3 ? pack_conv_weights_wino(w, cout, cin, cfg, &sc) : pack_conv_weights_split(w, cout, cin, cfg, &sc);
+    std::vector<uint8_t> r = cfg.variant >= 3 ? pack_conv_weights_wino(w, cout, cin, cfg, &sc) : pack_conv_weights_split(w, cout, cin, cfg, &sc);
     if (acc_scale) *acc_scale = sc;
     return r;
   }
@@ -561,7 +563,7 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
     GTX_CHECK(p.in2 && p.c_split % cfg.kc == 0 && p.c_split < p.Cin && p.H % 2 == 0 && p.W % 2 == 0 && p.in2_cstride % 4 == 0 && p.in2_coff % 4 == 0,
               "conv: bad second source (c_split=%d, %dx%d)", p.c_split, p.W, p.H);
   }
-  if (cfg.variant == 3) return conv_wino_launch(g, cfg, stream);
+  if (cfg.variant == 3 || cfg.variant == 4) return conv_wino_launch(g, cfg, stream);
   if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);
@@ -570,6 +572,7 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
 const char* conv_kernel_name(const ConvConfig& c) {
   static thread_local char buf[96];
   if (c.variant == 3) return "conv_wino_split_kernel";
+  if (c.variant == 4) return "conv_wino2_split_kernel";
   if (c.variant == 2) {
     snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8, c.th / 8);
     return buf;

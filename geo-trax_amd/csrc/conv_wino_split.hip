@@ -420,6 +420,378 @@ void conv_wino_split_kernel(const ConvGroup g) {
   if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Second form (ConvConfig::variant 4): 16 x 16 output pixels (8 x 8 Winograd tiles = TWO blocks of 32 MFMA columns) x 64 output
+// channels per 256-thread workgroup, ONE wave per SIMD with the whole register file (512 registers per lane: 256 accumulators).
+// What the first form's timing-only builds said it needs (profiles/r05_winograd_probe.txt): every weight fragment that comes in
+// from L2 now feeds two column blocks (half the weight stream per output: the CU's 64 B/clk vector memory path was the floor),
+// a thread transforms a WHOLE 4 x 4 tile of four channels (16 pixel reads and 320 vector instructions for 64 values: d = hi + lo is
+// put together once per pixel instead of once per row combination), and every position's V fragments are read by one wave only.
+// Wave w = transform row r: 4 positions x 2 column blocks x 2 cout blocks x 3 = 48 MFMAs per 16-channel chunk. Same packed
+// weights as the first form. V is double-buffered (2 x 64 KB), the patch single-buffered (20.7 KB) behind a second barrier.
+struct Wino2Tile {
+  static constexpr int TH = 16, TW = 16, BN = 64, KC = 16;
+  static constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;     // 18 x 18 input pixels
+  static constexpr int RAW_UNITS = NPIX * 2;                         // 648 (pixel, 8-channel unit) pieces over 256 threads: 3 slots
+  static constexpr int RAW_SLOTS = (RAW_UNITS + 255) / 256;
+  static constexpr int RAW_BYTES = (NPIX + 1) * 64;                  // + the row nobody reads
+  static constexpr int NT = 64;                                      // Winograd tiles: column blocks 0 (tile rows 0-3) and 1 (4-7)
+  static constexpr int V_BYTES = 16 * NT * 64;                       // [position][tile][hi0 hi1 lo0 lo1]: 64 KB
+  static constexpr int LOOP_BYTES = RAW_BYTES + 2 * V_BYTES;         // 151 872 B
+  static constexpr int X_BYTES = 4 * 4 * 2 * 2 * 2 * 64 * 16;        // row-stage exchange [dst r][src r][tb][j][b][lane] float4: 128 KB
+  static constexpr int LDS_BYTES = LOOP_BYTES > X_BYTES ? LOOP_BYTES : X_BYTES;
+  static __host__ __device__ constexpr int raw_row(int py, int px) { return py * PW + (px & 1) * (PW / 2) + (px >> 1); }
+  static __host__ __device__ constexpr int v_swz(int t) { return (2 * ((t >> 1) & 1)) ^ ((t >> 2) & 1); }
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void conv_wino2_split_kernel(const ConvGroup g) {
+  using T = Wino2Tile;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const lds_raw = smem;                        // [RAW_BYTES]
+  char* const lds_v = smem + T::RAW_BYTES;           // [2][V_BYTES]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave = the transform row its MFMAs work on
+
+  const int cnt = g.count;
+  int bb[kMaxGroup];
+#pragma unroll
+  for (int i = 0; i < kMaxGroup; ++i) bb[i] = g.p[i].block_begin;
+  const int xcd = blockIdx.x & 7;
+  const int L = g.xcd_begin[xcd] + (int)(blockIdx.x >> 3);
+  if (L >= g.xcd_begin[xcd + 1]) return;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < cnt && L >= bb[i]) pi = i;
+  const ConvProblem P = g.p[pi];
+
+  const int lb = L - P.block_begin;
+  const int ct = lb % P.n_ct;
+  const int pt = lb / P.n_ct;
+  const int tx0 = pt % P.tiles_x;
+  const int t2 = pt / P.tiles_x;
+  const int ty0 = t2 % P.tiles_y;
+  const int n = t2 / P.tiles_y;
+  const int oy0 = ty0 * T::TH, ox0 = tx0 * T::TW;
+  const int nchunks = P.Cin / T::KC;
+  const float* __restrict__ in = static_cast<const float*>(P.in);
+
+  // ---- raw patch: up to three (pixel, 8-channel unit) pieces per thread; buffer loads, zero padding = an offset past the tensor ----
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((size_t)P.N * P.H * P.W * P.in_cstride * 4), 0x00020000);
+  unsigned gvoff[T::RAW_SLOTS];
+  int rdst[T::RAW_SLOTS];
+#pragma unroll
+  for (int s = 0; s < T::RAW_SLOTS; ++s) {
+    const int u = tid + 256 * s;
+    gvoff[s] = 0x80000000u;
+    rdst[s] = T::NPIX * 64;
+    if (u < T::RAW_UNITS) {
+      const int pidx = u >> 1, c = u & 1;
+      const int py = pidx / T::PW, px = pidx - py * T::PW;
+      const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) gvoff[s] = (unsigned)((((size_t)(n * P.H + iy) * P.W + ix) * P.in_cstride + P.in_coff + c * 8) * 4);
+      rdst[s] = T::raw_row(py, px) * 64 + c * 32;
+    }
+  }
+  typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+  uint4v ra_[T::RAW_SLOTS], rb_[T::RAW_SLOTS];
+  const int last_chunk_off = (nchunks - 1) * (T::KC * 4);
+#define GTXW2_RAW_LOAD(CHUNK)                                                                \
+  {                                                                                          \
+    const int so__ = min((CHUNK) * (T::KC * 4), last_chunk_off);                             \
+    _Pragma("unroll") for (int s = 0; s < T::RAW_SLOTS; ++s) {                               \
+      ra_[s] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gvoff[s], so__, 0);            \
+      rb_[s] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gvoff[s], so__ + 16, 0);       \
+    }                                                                                        \
+  }
+#define GTXW2_RAW_COMMIT()                                                                   \
+  {                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < T::RAW_SLOTS; ++s) {                               \
+      char* d__ = lds_raw + rdst[s];                                                         \
+      *reinterpret_cast<uint4*>(d__) = make_uint4(ra_[s].x, ra_[s].y, rb_[s].x, rb_[s].y);   \
+      *reinterpret_cast<uint4*>(d__ + 16) = make_uint4(ra_[s].z, ra_[s].w, rb_[s].z, rb_[s].w); \
+    }                                                                                        \
+  }
+
+  // ---- weights: this wave's row r of a chunk = [j][c][hi | lo] = 16 fragments of 16 bytes per lane; reloaded position by position ----
+  const uint4* __restrict__ usrc = reinterpret_cast<const uint4*>(P.wpack) + ((((size_t)ct * nchunks) * 4 + r) * 2) * (8 * 64) + lane;
+  constexpr size_t U_CHUNK = 4 * 2 * 8 * 64;
+  uint4 u[2][8];                                      // [j][2 c + hl]
+#define GTXW2_U_LOAD(C, CHUNK)                                                               \
+  {                                                                                          \
+    const uint4* s__ = usrc + (size_t)(CHUNK) * U_CHUNK;                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+      u[j][2 * (C)] = s__[(j * 8 + 2 * (C)) * 64];                                           \
+      u[j][2 * (C) + 1] = s__[(j * 8 + 2 * (C) + 1) * 64];                                   \
+    }                                                                                        \
+  }
+
+  // ---- transform job of this thread: tile tt (0..63), channel quad q: the whole 4 x 4 tile ----
+  const int tt = tid >> 2, q = tid & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const float one = P.acc_scale * __builtin_amdgcn_rcpf(P.acc_scale);   // 1.0 the compiler cannot fold (keeps the fp16 -> fp32 fmas as v_fma_mix_f32)
+  const int t_base = ((2 * tty) * T::PW + ttx) * 64 + q * 16;
+  const int vsw_t = T::v_swz(tt & 31);
+  const int vw_hi = tt * 64 + (((q >> 1) ^ vsw_t) << 4) + (q & 1) * 8;
+  const int vw_lo = tt * 64 + (((2 + (q >> 1)) ^ vsw_t) << 4) + (q & 1) * 8;
+  uint4 D__[4][4];                                    // the tile's 16 pixels (4 hi halves | 4 lo halves each), read behind the second barrier
+  float2v Y__[4][2][4];                               // [input row][channel pair][position column]: the tile after its column stage
+#define GTXW2_T_READ()                                                                       \
+  {                                                                                          \
+    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                         \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c)                                          \
+        D__[rr][c] = *reinterpret_cast<const uint4*>(lds_raw + t_base + (rr * T::PW + (c & 1) * (T::PW / 2) + (c >> 1)) * 64); \
+  }
+  // Phase A, input rows RR0 and RR0 + 1: d = hi + lo for the row's four pixels and four channels, then the column stage
+  // (d B: d0 - d2, d1 + d2, d2 - d1, d1 - d3). 32 v_fma_mix_f32 + 32 adds per call.
+#define GTXW2_T_ROWS(RR0)                                                                    \
+  {                                                                                          \
+    _Pragma("unroll") for (int rr = (RR0); rr < (RR0) + 2; ++rr)                             \
+      _Pragma("unroll") for (int cp = 0; cp < 2; ++cp) {                                     \
+        float2v d__[4];                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                      \
+          const half2v h__ = __builtin_bit_cast(half2v, cp == 0 ? D__[rr][c].x : D__[rr][c].y); \
+          const half2v l__ = __builtin_bit_cast(half2v, cp == 0 ? D__[rr][c].z : D__[rr][c].w); \
+          d__[c] = float2v{__builtin_fmaf((float)l__[0], one, (float)h__[0]), __builtin_fmaf((float)l__[1], one, (float)h__[1])}; \
+        }                                                                                    \
+        Y__[rr][cp][0] = d__[0] - d__[2]; Y__[rr][cp][1] = d__[1] + d__[2];                  \
+        Y__[rr][cp][2] = d__[2] - d__[1]; Y__[rr][cp][3] = d__[1] - d__[3];                  \
+      }                                                                                      \
+  }
+  // Phase B, output rows R0 and R0 + 1 of the transformed tile: the row stage (Bt: y0 - y2, y1 + y2, y2 - y1, y1 - y3), the
+  // split into hi + lo, and the 8-byte stores of the quad's halves to the row's four positions. 32 adds + 64 split instructions.
+#define GTXW2_T_OUT(R0, VBUF)                                                                \
+  {                                                                                          \
+    _Pragma("unroll") for (int ro = (R0); ro < (R0) + 2; ++ro)                               \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                        \
+        uint2 hi__, lo__;                                                                    \
+        const float2v v0__ = ro == 0 ? Y__[0][0][c] - Y__[2][0][c] : (ro == 1 ? Y__[1][0][c] + Y__[2][0][c] : (ro == 2 ? Y__[2][0][c] - Y__[1][0][c] : Y__[1][0][c] - Y__[3][0][c])); \
+        const float2v v1__ = ro == 0 ? Y__[0][1][c] - Y__[2][1][c] : (ro == 1 ? Y__[1][1][c] + Y__[2][1][c] : (ro == 2 ? Y__[2][1][c] - Y__[1][1][c] : Y__[1][1][c] - Y__[3][1][c])); \
+        split2_mix(v0__, hi__.x, lo__.x, -one);                                              \
+        split2_mix(v1__, hi__.y, lo__.y, -one);                                              \
+        char* vp__ = lds_v + (VBUF) * T::V_BYTES + (4 * ro + c) * (T::NT * 64);              \
+        *reinterpret_cast<uint2*>(vp__ + vw_hi) = hi__;                                      \
+        *reinterpret_cast<uint2*>(vp__ + vw_lo) = lo__;                                      \
+      }                                                                                      \
+  }
+
+  // ---- MFMA operand addresses: column block tb, column = lane & 31, k half h ----
+  const int mt = lane & 31, h = lane >> 5;
+  const int vsw_m = T::v_swz(mt);
+  const int vr_hi = ((4 * r) * T::NT + mt) * 64 + ((h ^ vsw_m) << 4);
+  const int vr_lo = ((4 * r) * T::NT + mt) * 64 + (((2 + h) ^ vsw_m) << 4);
+
+  floatx16 acc[4][2][2];                              // [position c][column block][cout block]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][tb][j][i] = 0.f;
+
+  // ---- prologue ----
+  GTXW2_RAW_LOAD(0)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) GTXW2_U_LOAD(c, 0)
+  const float4 bias4[2] = {P.bias ? *reinterpret_cast<const float4*>(P.bias + ct * T::BN + 8 * r + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f),
+                           P.bias ? *reinterpret_cast<const float4*>(P.bias + ct * T::BN + 32 + 8 * r + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f)};
+  GTXW2_RAW_COMMIT()
+  GTXW2_RAW_LOAD(1)
+  __syncthreads();
+  GTXW2_T_READ()
+  GTXW2_T_ROWS(0) GTXW2_T_ROWS(2)
+  GTXW2_T_OUT(0, 0) GTXW2_T_OUT(2, 0)
+  __syncthreads();                                    // V(0) written, every read of the patch done
+  GTXW2_RAW_COMMIT()
+  GTXW2_RAW_LOAD(2)
+  __syncthreads();
+  if (nchunks > 1) GTXW2_T_READ()
+
+  // One chunk as straight-line code: the MFMAs of chunk i (V buffer i & 1) position by position, behind each position's twelve the
+  // reload of its weights for chunk i + 1 and a quarter of the transform of chunk i + 1 (its 16 pixels are in registers since the
+  // end of the last chunk); then a barrier, the patch of chunk i + 2 from its registers into the (single) raw buffer, a barrier,
+  // the next tile's 16 pixel reads. HAS_T: a chunk i + 1 exists; HAS_R: a chunk i + 2 exists.
+// One transform unit per step: steps 0-7 = phase A for (input row, channel pair), steps 8-23 = phase B for (output row, column).
+#define GTXW2_T_UNIT(S, VBUF)                                                                \
+  {                                                                                          \
+    if (GTXW_PROBE & 1) {                            /* timing only: the LDS traffic of the transform without its arithmetic */ \
+      if ((S) >= 8) {                                                                        \
+        const int ro = ((S) - 8) >> 2, c = ((S) - 8) & 3;                                    \
+        char* vp__ = lds_v + (VBUF) * T::V_BYTES + (4 * ro + c) * (T::NT * 64);              \
+        *reinterpret_cast<uint2*>(vp__ + vw_hi) = make_uint2(D__[ro][c].x, D__[ro][c].y);    \
+        *reinterpret_cast<uint2*>(vp__ + vw_lo) = make_uint2(D__[ro][c].z, D__[ro][c].w);    \
+      }                                                                                      \
+    } else if ((S) < 8) {                                                                           \
+      const int rr = (S) >> 1, cp = (S) & 1;                                                 \
+      float2v d__[4];                                                                        \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                        \
+        const half2v h__ = __builtin_bit_cast(half2v, cp == 0 ? D__[rr][c].x : D__[rr][c].y); \
+        const half2v l__ = __builtin_bit_cast(half2v, cp == 0 ? D__[rr][c].z : D__[rr][c].w); \
+        d__[c] = float2v{__builtin_fmaf((float)l__[0], one, (float)h__[0]), __builtin_fmaf((float)l__[1], one, (float)h__[1])}; \
+      }                                                                                      \
+      Y__[rr][cp][0] = d__[0] - d__[2]; Y__[rr][cp][1] = d__[1] + d__[2];                    \
+      Y__[rr][cp][2] = d__[2] - d__[1]; Y__[rr][cp][3] = d__[1] - d__[3];                    \
+    } else {                                                                                 \
+      const int ro = ((S) - 8) >> 2, c = ((S) - 8) & 3;                                      \
+      uint2 hi__, lo__;                                                                      \
+      const float2v v0__ = ro == 0 ? Y__[0][0][c] - Y__[2][0][c] : (ro == 1 ? Y__[1][0][c] + Y__[2][0][c] : (ro == 2 ? Y__[2][0][c] - Y__[1][0][c] : Y__[1][0][c] - Y__[3][0][c])); \
+      const float2v v1__ = ro == 0 ? Y__[0][1][c] - Y__[2][1][c] : (ro == 1 ? Y__[1][1][c] + Y__[2][1][c] : (ro == 2 ? Y__[2][1][c] - Y__[1][1][c] : Y__[1][1][c] - Y__[3][1][c])); \
+      split2_mix(v0__, hi__.x, lo__.x, -one);                                                \
+      split2_mix(v1__, hi__.y, lo__.y, -one);                                                \
+      char* vp__ = lds_v + (VBUF) * T::V_BYTES + (4 * ro + c) * (T::NT * 64);                \
+      *reinterpret_cast<uint2*>(vp__ + vw_hi) = hi__;                                        \
+      *reinterpret_cast<uint2*>(vp__ + vw_lo) = lo__;                                        \
+    }                                                                                        \
+  }
+  // MFMA number M of a chunk (0..47): position c = M / 12, cout block j, column block tb, term (lo x hi, hi x lo, hi x hi)
+#define GTXW2_MFMA(M)                                                                        \
+  {                                                                                          \
+    const int c = (M) / 12, j = ((M) % 12) / 6, tb = (((M) % 12) % 6) / 3, term = (M) % 3;   \
+    const half8 uh__ = *reinterpret_cast<const half8*>(&u[j][2 * c]);                        \
+    const half8 ul__ = *reinterpret_cast<const half8*>(&u[j][2 * c + 1]);                    \
+    if (!(GTXW_PROBE & 2)) acc[c][tb][j] = GTXW_MFMA(term == 0 ? ul__ : uh__, term == 1 ? bl__[c & 1][tb] : bh__[c & 1][tb], acc[c][tb][j]); \
+    else if (term == 2) acc[c][tb][j][0] += (float)ul__[0] + (float)uh__[0] + (float)bl__[c & 1][tb][0] + (float)bh__[c & 1][tb][0]; \
+  }
+#define GTXW2_FRAGS(C)                                                                       \
+  {                                                                                          \
+    _Pragma("unroll") for (int tb = 0; tb < 2; ++tb) {                                       \
+      bh__[(C) & 1][tb] = *reinterpret_cast<const half8*>(vh__ + (C) * (T::NT * 64) + tb * (32 * 64)); \
+      bl__[(C) & 1][tb] = *reinterpret_cast<const half8*>(vl__ + (C) * (T::NT * 64) + tb * (32 * 64)); \
+    }                                                                                        \
+  }
+  // One chunk in 24 pinned steps of two MFMAs and one transform unit each (one wave per SIMD: an MFMA holds the vector issue port
+  // for 8 of its 32 cycles, so ~7 vector instructions of the transform of chunk i + 1 go into every gap instead of behind the
+  // MFMAs; the scheduler only orders inside a step). Position c's V fragments are read three steps ahead of its first MFMA,
+  // its weights for chunk i + 1 reloaded behind its last. Then a barrier, the patch of chunk i + 2 from its registers into the
+  // (single) raw buffer, a barrier, the next tile's 16 pixel reads. HAS_T: a chunk i + 1 exists; HAS_R: a chunk i + 2 exists.
+#define GTXW2_CHUNK(I, HAS_T, HAS_R)                                                         \
+  {                                                                                          \
+    const int b__ = (I) & 1;                                                                 \
+    const char* vh__ = lds_v + b__ * T::V_BYTES + vr_hi;                                     \
+    const char* vl__ = lds_v + b__ * T::V_BYTES + vr_lo;                                     \
+    half8 bh__[2][2], bl__[2][2];                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    GTXW2_FRAGS(0)                                                                           \
+    _Pragma("unroll") for (int st__ = 0; st__ < 24; ++st__) {                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (st__ % 6 == 3 && st__ / 6 < 3) GTXW2_FRAGS(st__ / 6 + 1)                              \
+      GTXW2_MFMA(2 * st__)                                                                    \
+      GTXW2_MFMA(2 * st__ + 1)                                                                \
+      if (HAS_T) {                                                                           \
+        if (!(GTXW_PROBE & 4)) GTXW2_T_UNIT(st__, b__ ^ 1)                                    \
+        if (st__ % 6 == 5 && !(GTXW_PROBE & 8)) GTXW2_U_LOAD(st__ / 6, (I) + 1)               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+      }                                                                                      \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    __syncthreads();                                  /* V(i + 1) is written; nobody reads the patch any more */ \
+    if (HAS_R && !(GTXW_PROBE & 16)) {                                                       \
+      GTXW2_RAW_COMMIT()                                                                     \
+      GTXW2_RAW_LOAD((I) + 3)                                                                \
+    }                                                                                        \
+    if (HAS_R && !(GTXW_PROBE & 64)) __syncthreads();                                        \
+    if (HAS_R) GTXW2_T_READ()                                                                \
+  }
+  int i = 0;
+  for (; i + 2 < nchunks; ++i) GTXW2_CHUNK(i, true, true)
+  if (i + 1 < nchunks) { GTXW2_CHUNK(i, true, false) ++i; }
+  GTXW2_CHUNK(i, false, false)
+#undef GTXW2_CHUNK
+#undef GTXW2_FRAGS
+#undef GTXW2_MFMA
+#undef GTXW2_T_UNIT
+#undef GTXW2_T_OUT
+#undef GTXW2_T_ROWS
+#undef GTXW2_T_READ
+#undef GTXW2_U_LOAD
+#undef GTXW2_RAW_COMMIT
+#undef GTXW2_RAW_LOAD
+
+  // ---- output transform: column stage in registers, row stage through LDS, every wave finishes the channel group g4 = its r ----
+  {
+    float4* xw = reinterpret_cast<float4*>(smem) + (size_t)r * (2 * 2 * 2 * 64) + lane;     // [dst][src = r][tb][j][b][lane]
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float4 t0, t1;
+#define GTXW2_COL(K, F) \
+          t0.F = acc[0][tb][j][4 * rd + K] + acc[1][tb][j][4 * rd + K] + acc[2][tb][j][4 * rd + K]; \
+          t1.F = acc[1][tb][j][4 * rd + K] - acc[2][tb][j][4 * rd + K] - acc[3][tb][j][4 * rd + K];
+          GTXW2_COL(0, x) GTXW2_COL(1, y) GTXW2_COL(2, z) GTXW2_COL(3, w)
+#undef GTXW2_COL
+          float4* dst = xw + (size_t)rd * (4 * 2 * 2 * 2 * 64) + ((tb * 2 + j) * 2) * 64;
+          dst[0] = t0;
+          dst[64] = t1;
+        }
+  }
+  __syncthreads();
+  const float sc = P.acc_scale;
+  const bool plain = P.out_plain != 0, act = P.act != 0;
+  const void* const res_p = P.res;
+  bool sat = false;
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 y[2][2];
+      const float4* xr = reinterpret_cast<const float4*>(smem) + (size_t)r * (4 * 2 * 2 * 2 * 64) + ((tb * 2 + j) * 2) * 64 + lane;   // [dst = r][src][tb][j][b][lane]
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        const float4 s0 = xr[0 * (2 * 2 * 2 * 64) + bq * 64], s1 = xr[1 * (2 * 2 * 2 * 64) + bq * 64], s2 = xr[2 * (2 * 2 * 2 * 64) + bq * 64],
+                     s3 = xr[3 * (2 * 2 * 2 * 64) + bq * 64];
+        y[0][bq] = make_float4(s0.x + s1.x + s2.x, s0.y + s1.y + s2.y, s0.z + s1.z + s2.z, s0.w + s1.w + s2.w);
+        y[1][bq] = make_float4(s1.x - s2.x - s3.x, s1.y - s2.y - s3.y, s1.z - s2.z - s3.z, s1.w - s2.w - s3.w);
+      }
+      const int cg = ct * T::BN + 32 * j + 8 * r;     // first channel of the lane pair's 8-channel group
+      const int tile = tb * 32 + mt, mty = tile >> 3, mtx = tile & 7;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq) {
+          const int oy = oy0 + 2 * mty + a, ox = ox0 + 2 * mtx + bq;
+          const bool inside = oy < P.Ho && ox < P.Wo;
+          const size_t pix = inside ? ((size_t)n * P.Ho + oy) * P.Wo + ox : 0;
+          float2v v[2] = {__builtin_elementwise_fma(float2v{y[a][bq].x, y[a][bq].y}, float2v{sc, sc}, float2v{bias4[j].x, bias4[j].y}),
+                          __builtin_elementwise_fma(float2v{y[a][bq].z, y[a][bq].w}, float2v{sc, sc}, float2v{bias4[j].z, bias4[j].w})};
+          if (act) { v[0] = silu2(v[0]); v[1] = silu2(v[1]); }
+          if (res_p) {
+            uint4 rc = make_uint4(0, 0, 0, 0);
+            if (inside) rc = *reinterpret_cast<const uint4*>(static_cast<const float*>(res_p) + pix * P.res_cstride + P.res_coff + cg + 4 * h);
+            const auto sx = __builtin_amdgcn_permlane32_swap(rc.x, rc.z, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(rc.y, rc.w, false, false);
+            const unsigned hw[2] = {sx[0], sy[0]}, lw[2] = {sx[1], sy[1]};
+            const half4 rh = *reinterpret_cast<const half4*>(hw), rl = *reinterpret_cast<const half4*>(lw);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              v[k] += float2v{(float)rh[2 * k], (float)rh[2 * k + 1]} + float2v{(float)rl[2 * k], (float)rl[2 * k + 1]};
+          }
+          float* dst = static_cast<float*>(P.out) + pix * P.out_cstride + P.out_coff + cg + 4 * h;
+          if (plain) {
+            if (inside) *reinterpret_cast<float4*>(dst) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+          } else {
+            uint2 hi, lo;
+            split2(v[0], hi.x, lo.x, sat);
+            split2(v[1], hi.y, lo.y, sat);
+            const auto sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+            if (inside) *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        }
+    }
+  if (P.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(P.sat_flag, 1);
+}
+
 }  // namespace
 
 // Packed image: [cout tile 64][cin chunk 16][row r][cout block j][position c][hi | lo][lane 64][8 halves] -- the A operand of
@@ -482,6 +854,16 @@ void conv_wino_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t strea
     GTX_CHECK(c.ks == 3 && c.stride == 1 && c.bn == 64 && c.kc == 16 && p.Cout % 64 == 0 && p.Cin % 16 == 0 && p.Ho == p.H && p.Wo == p.W &&
                   !p.post_w && !p.front_img && p.c_split == 0,
               "conv (Winograd): 3x3 stride 1, pad 1, Cout %% 64 == 0, Cin %% 16 == 0 only (Cin %d, Cout %d)", p.Cin, p.Cout);
+  }
+  if (c.th == 16) {                                   // variant 4: 16 x 16 pixels, 4 waves, one per SIMD
+    auto kern2 = conv_wino2_split_kernel;
+    static std::once_flag once2;
+    std::call_once(once2, [&] {
+      GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Tile::LDS_BYTES));
+    });
+    hipLaunchKernelGGL(kern2, dim3(g.grid_blocks), dim3(256), Wino2Tile::LDS_BYTES, stream, g);
+    GTX_HIP(hipGetLastError());
+    return;
   }
   auto kern = conv_wino_split_kernel;
   static std::once_flag once;

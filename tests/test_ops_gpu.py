@@ -85,7 +85,8 @@ def test_conv2d_split_f16x3_meets_the_fp32_bar(gtx_ctx, case):
 
 @pytest.mark.parametrize("shape", [(1, 8, 16, 16, 64, False), (2, 20, 30, 64, 64, True), (1, 60, 60, 32, 128, False), (2, 37, 53, 128, 192, True),
                                    (1, 16, 32, 256, 64, False)])
-def test_conv2d_winograd_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_conv2d_winograd_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape, mode):
     """The Winograd F(2x2, 3x3) form of the split-f16x3 3x3 convolution (csrc/conv_wino_split.hip; opt-in, GTX_WINO=1): same
     bar as the direct kernel against a float64 convolution of the values the pair format holds, on partial tiles, several
     cout tiles, with residual and SiLU; and within 2e-6 of the direct kernel."""
@@ -110,7 +111,7 @@ def test_conv2d_winograd_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
         y = y + pairs(res)
     monkeypatch.setenv("GTX_WINO", "0")
     direct = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
-    monkeypatch.setenv("GTX_WINO", "1")
+    monkeypatch.setenv("GTX_WINO", mode)              # 1: 8 x 16 pixels, 8 waves; 3: 16 x 16 pixels, one wave per SIMD
     wino = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
     scale = np.abs(y).max()
     assert not np.array_equal(wino, direct)           # the other kernel did run

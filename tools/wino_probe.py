@@ -46,7 +46,7 @@ for (n, h, wd, cin, cout, act, use_res) in [(1, 8, 16, 16, 64, False, False), (1
     want = ref_conv(pairs(x), w, b.astype(np.float64), act, None if res is None else pairs(res))
     os.environ["GTX_WINO"] = "0"
     y0 = ops.conv2d(x, w, b, act=act, residual=res, split=True, ctx=ctx)
-    os.environ["GTX_WINO"] = "1"
+    os.environ["GTX_WINO"] = os.environ.get("WINO_MODE", "1")          # 1: 8 x 16-pixel form, 3: 16 x 16-pixel form
     y1 = ops.conv2d(x, w, b, act=act, residual=res, split=True, ctx=ctx)
     os.environ["GTX_WINO"] = "0"
     scale = np.abs(want).max()
