@@ -24,6 +24,7 @@ python bench.py --workload cli > $O/bench_cli.json 2>/dev/null                  
 python bench.py --host-frames --no-cpu-baseline --no-f16-line --no-profile > $O/bench_host_frames.json 2>/dev/null
 python bench.py --workload detect --no-cpu-baseline --no-f16-line > $O/bench_detect_2x2.json 2>/dev/null
 python bench.py --workload register > $O/bench_register.json 2>/dev/null
+python bench.py --workload register --ortho 15000 --steps 3 > $O/bench_register_ortho15000.json 2>/dev/null   # K11 at the reference's size
 python bench.py --workload georef > $O/bench_georef.json 2>/dev/null
 python bench.py --workload warp > $O/bench_warp.json 2>/dev/null
 python bench.py --workload extract+georef > $O/bench_extract_georef.json 2>/dev/null

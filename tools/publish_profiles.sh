@@ -4,7 +4,7 @@
 set -e
 T=${1:?tag}; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/final; P=$R/profiles
 python $R/tools/pmc_summary.py --stats $O/stats --fetch $O/fetch --write $O/write --sq $O/sq1,$O/sq2 --batch 2 --tag $T
-for f in default botsort ocsort deepocsort fp32_exact f16 detect_b1 detect_2x2 register georef warp extract_georef cli host_frames; do
+for f in default botsort ocsort deepocsort fp32_exact f16 detect_b1 detect_2x2 register register_ortho15000 georef warp extract_georef cli host_frames; do
   [ -s $O/bench_$f.json ] && cp $O/bench_$f.json $P/${T}_bench_$f.json
 done
 [ -s $O/bench_under_rocprof.json ] && cp $O/bench_under_rocprof.json $P/${T}_bench_under_rocprof.json
