@@ -389,7 +389,7 @@ int env_int(const char* name, int dflt) {
 }
 }  // namespace
 
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc, int force_bn) {
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc, int force_bn, long out_pixels) {
   ConvConfig c{};
   c.dtype = dtype;
   c.ks = ks;
@@ -415,6 +415,9 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
       const int mode = env_int("GTX_WINO", 0);
       if (mode == 1 || (mode == 2 && cin >= 256)) c.variant = 3;
       if (mode == 3) { c.variant = 4; c.th = 16; }      // the 16 x 16-pixel form (one wave per SIMD)
+      // 4: the second form only where it used less CU-time than the direct kernel alone: launches that fill the chip for several
+      // rounds of its workgroups (>= 1024 of them: 240 x 240 maps at batch 2) with at least 8 chunks of K
+      if (mode == 4 && cin >= 128 && out_pixels * (cout / 64) >= 1024L * 256) { c.variant = 4; c.th = 16; }
     }
     return c;
   }

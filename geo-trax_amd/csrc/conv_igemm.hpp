@@ -98,7 +98,8 @@ struct ConvConfig {
 
 // Picks the tile configuration used for a layer shape.
 // force_kc / force_bn > 0 pin the K chunk / cout tile (grouped launches: every member must use the same kernel instantiation).
-ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0, int force_bn = 0);
+// out_pixels (N x Ho x Wo at the layer's largest batch, 0 = unknown): only read by the GTX_WINO=4 experiment.
+ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, int force_kc = 0, int force_bn = 0, long out_pixels = 0);
 
 // Host-side weight packing: w is [Cout][KS][KS][Cin] fp32 (OHWI). Returns the packed
 // byte image for `cfg` (element type per cfg.dtype). acc_scale (may be null) receives ConvProblem::acc_scale.

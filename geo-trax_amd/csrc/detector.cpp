@@ -168,7 +168,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   Op op;
   op.kind = Op::CONV;
   op.name = name;
-  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, force_bn_);
+  op.cfg = conv_pick_config(conv_dtype_, ks, stride, cin, cout, force_kc_, force_bn_, (long)x.n * ho * wo);
   const auto pw = packed_weights(w, cout, cin, op.cfg, [&] {
     PackedWeights r;
     const std::vector<float> ohwi = to_ohwi(w);
