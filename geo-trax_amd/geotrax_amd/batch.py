@@ -102,6 +102,9 @@ def shard(files: list[Path], rank: int, world: int) -> list[Path]:
     return [f for i, f in enumerate(order_largest_first(files)) if i % world == rank]
 
 
+_queue_calls = 0
+
+
 class WorkQueue:
     """Videos handed out one at a time, largest first, from a counter every rank of the job adds to atomically (the launcher's
     rendezvous store: `store.add` on rank 0's TCP store). A rank takes the next video when it has finished its last one, so
@@ -201,7 +204,9 @@ def process_input(args, logger: logging.Logger, run=detect_track_stabilize, run_
                 store = dist.distributed_c10d._get_default_store()
             except Exception:                                     # a torch without that accessor: the static deal
                 store = None
-        mine = WorkQueue(files, store) if store is not None else shard(files, rank, world)
+        global _queue_calls                                       # one counter per call: every rank calls process_input the same number of times
+        _queue_calls += 1
+        mine = WorkQueue(files, store, key=f"gtx_batch_next_{_queue_calls}") if store is not None else shard(files, rank, world)
         logger.info(f"rank {rank}/{world}: {len(files)} videos, " + ("taken from the shared counter, largest first" if store is not None else f"{len(mine)} dealt to this rank"))
     taken = []
     for f in mine:
