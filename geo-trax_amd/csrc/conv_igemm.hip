@@ -419,6 +419,11 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
       // rounds of its workgroups (>= 1024 of them: 240 x 240 maps at batch 2) with at least 8 chunks of K
       if (mode == 4 && cin >= 128 && out_pixels * (cout / 64) >= 1024L * 256) { c.variant = 4; c.th = 16; }
     }
+    // 3x3 stride 1, 64-cout tiles, Cin a multiple of 32: the v_mfma_f32_16x16x32_f16 form (conv_k32_split.hip). GTX_K32=0: off
+    if (ks == 3 && stride == 1 && c.bn == 64 && c.variant == 2 && c.kc == 16 && cin % 32 == 0 && env_int("GTX_K32", 1) != 0) {
+      c.variant = 5;
+      c.kc = 32;
+    }
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -449,9 +454,9 @@ inline uint16_t f32_to_f16_bits(float f) {
 
 std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   if (acc_scale) *acc_scale = 1.f;
-  if (cfg.variant == 2 || cfg.variant == 3 || cfg.variant == 4) {
+  if (cfg.variant >= 2 && cfg.variant <= 5) {
     float sc = 1.f;
-    std::vector<uint8_t> r = cfg.variant >= 3 ? pack_conv_weights_wino(w, cout, cin, cfg, &sc) : pack_conv_weights_split(w, cout, cin, cfg, &sc);
+    std::vector<uint8_t> r = (cfg.variant == 3 || cfg.variant == 4) ? pack_conv_weights_wino(w, cout, cin, cfg, &sc) : pack_conv_weights_split(w, cout, cin, cfg, &sc);
     if (acc_scale) *acc_scale = sc;
     return r;
   }
@@ -567,6 +572,7 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
               "conv: bad second source (c_split=%d, %dx%d)", p.c_split, p.W, p.H);
   }
   if (cfg.variant == 3 || cfg.variant == 4) return conv_wino_launch(g, cfg, stream);
+  if (cfg.variant == 5) return conv_k32_launch(g, cfg, stream);
   if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);
@@ -576,6 +582,7 @@ const char* conv_kernel_name(const ConvConfig& c) {
   static thread_local char buf[96];
   if (c.variant == 3) return "conv_wino_split_kernel";
   if (c.variant == 4) return "conv_wino2_split_kernel";
+  if (c.variant == 5) return "conv_k32_split_kernel";
   if (c.variant == 2) {
     snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8, c.th / 8);
     return buf;
