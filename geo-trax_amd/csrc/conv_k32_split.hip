@@ -29,7 +29,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 // Timing-only builds (`make k32probe`, wrong results): GTXK_PROBE bit 0 = no barriers inside a chunk (rows 1, 2), bit 1 = no weight
-// commits (LDS stores) for rows 1, 2, bit 2 = no MFMAs, bit 3 = no weight loads from global for rows 1, 2, bit 4 = no epilogue
+// commits (LDS stores) for rows 1, 2, bit 2 = no MFMAs, bit 3 = no weight loads from global for rows 1, 2, bit 5 = no weight fragment reads from LDS (the first tap's stay in registers),
+// bit 6 = no pixel fragment reads from LDS after a chunk's first tap
 #ifndef GTXK_PROBE
 #define GTXK_PROBE 0
 #endif
@@ -209,8 +210,9 @@ void conv_k32_split_kernel(const ConvGroup g) {
       constexpr int kx__ = (U) / 4, a__ = (U) % 4;                                             \
       constexpr int bs__ = ((KY) * 3 + kx__) & 1;                                              \
       __builtin_amdgcn_sched_barrier(0);                                                       \
-      if ((U) + 1 < 12) GTXK_LOAD_A(((U) + 1) / 4, ((U) + 1) % 4, ((U) + 1) & 1)               \
-      if (kx__ < 2) GTXK_LOAD_B(KY, kx__ + 1, bs__ ^ 1, a__)                                   \
+      if ((U) + 1 < 12 && !(GTXK_PROBE & 32)) GTXK_LOAD_A(((U) + 1) / 4, ((U) + 1) % 4, ((U) + 1) & 1) \
+      if (GTXK_PROBE & 64) {}                                                                  \
+      else if (kx__ < 2) GTXK_LOAD_B(KY, kx__ + 1, bs__ ^ 1, a__)                              \
       else if (!(LAST_ROW)) GTXK_LOAD_B((KY) + 1, 0, bs__ ^ 1, a__)                            \
       acc[a__][0] = GTXK_MFMA(al[(U) & 1], bh[bs__][0], acc[a__][0]);                          \
       acc[a__][1] = GTXK_MFMA(al[(U) & 1], bh[bs__][1], acc[a__][1]);                          \
@@ -226,7 +228,7 @@ void conv_k32_split_kernel(const ConvGroup g) {
       __builtin_amdgcn_sched_barrier(0);                                                       \
     }
 #define GTXK_ROW(KY, LAST_ROW)                                                                 \
-    GTXK_LOAD_A(0, 0, 0)                                                                       \
+    GTXK_LOAD_A(0, 0, 0) if (GTXK_PROBE & 32) GTXK_LOAD_A(0, 1, 1) if (GTXK_PROBE & 64) { bh[1][0] = bh[0][0]; bh[1][1] = bh[0][1]; bl[1][0] = bl[0][0]; bl[1][1] = bl[0][1]; }                                                                      \
     GTXK_UNIT(KY, 0, LAST_ROW) GTXK_UNIT(KY, 1, LAST_ROW) GTXK_UNIT(KY, 2, LAST_ROW) GTXK_UNIT(KY, 3, LAST_ROW)   \
     GTXK_UNIT(KY, 4, LAST_ROW) GTXK_UNIT(KY, 5, LAST_ROW) GTXK_UNIT(KY, 6, LAST_ROW) GTXK_UNIT(KY, 7, LAST_ROW)   \
     GTXK_UNIT(KY, 8, LAST_ROW) GTXK_UNIT(KY, 9, LAST_ROW) GTXK_UNIT(KY, 10, LAST_ROW) GTXK_UNIT(KY, 11, LAST_ROW)
