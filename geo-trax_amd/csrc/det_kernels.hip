@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const NmsBuffers nb, int 
     reinterpret_cast<float4*>(nb.s_box)[so] = b;
     nb.s_score[so] = si;
     nb.s_cls[so] = c;
+    if (nb.s_anchor) nb.s_anchor[so] = ai;
     (void)cls_offset;
   }
 }
@@ -1232,6 +1233,7 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const NmsBuffers nb, 
     r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
     r[4] = nb.s_score[(size_t)n * nb.nms_cap + i];
     r[5] = (float)nb.s_cls[(size_t)n * nb.nms_cap + i];
+    if (nb.out_anchor) nb.out_anchor[(size_t)n * nb.max_det + slot] = nb.s_anchor[(size_t)n * nb.nms_cap + i];
   }
 }
 
@@ -1347,6 +1349,7 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsBuffers nb, fl
       r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = o.w;
       r[4] = nb.cand_score[base + slot];
       r[5] = (float)nb.cand_cls[base + slot];
+      if (nb.out_anchor) nb.out_anchor[(size_t)n * nb.max_det + my_slot] = nb.cand_anchor[base + slot];
     }
     __threadfence_block();
     if (lane == 0) {
@@ -1359,6 +1362,44 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsBuffers nb, fl
   }
   __syncthreads();
   if (tid == 0) nb.out_n[n] = s_nkeep;
+}
+
+// One workgroup of `dim` threads per output row: thread k averages the c / dim consecutive channels of group k at the row's anchor
+__global__ void obj_feats_kernel(const FeatLevels fl, int dtype, const NmsBuffers nb, float* __restrict__ out) {
+  const int n = blockIdx.y, slot = blockIdx.x;
+  if (slot >= min(nb.out_n[n], nb.max_det)) return;
+  const int a = nb.out_anchor[(size_t)n * nb.max_det + slot];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; ++i)
+    if (i < fl.n_levels && a >= fl.anchor_begin[i]) l = i;
+  const int la = a - fl.anchor_begin[l];
+  const int g = fl.c[l] / fl.dim;
+  const size_t e0 = ((size_t)n * fl.h[l] * fl.w[l] + la) * fl.cstride[l] + fl.coff[l];
+  for (int k = threadIdx.x; k < fl.dim; k += blockDim.x) {
+    float sum = 0.f;
+    for (int j = 0; j < g; ++j) {
+      const size_t e = e0 + (size_t)k * g + j;
+      float v;
+      if (dtype == DT_F16) {
+        v = (float)static_cast<const _Float16*>(fl.feat[l])[e];
+      } else if (dtype == DT_F32S) {                     // pair format (split_format.hpp): hi + lo is exact in fp32
+        const char* b = static_cast<const char*>(fl.feat[l]) + (e & ~(size_t)7) * 4;
+        v = (float)*reinterpret_cast<const _Float16*>(b + 2 * (e & 7)) + (float)*reinterpret_cast<const _Float16*>(b + 16 + 2 * (e & 7));
+      } else {
+        v = static_cast<const float*>(fl.feat[l])[e];
+      }
+      sum += v;
+    }
+    out[((size_t)n * nb.max_det + slot) * fl.dim + k] = sum / (float)g;
+  }
+}
+
+void launch_obj_feats(int dtype, const FeatLevels& fl, int n, const NmsBuffers& nb, float* out, hipStream_t s) {
+  GTX_CHECK(nb.out_anchor != nullptr && fl.dim > 0, "obj_feats: the NMS buffers keep no anchors");
+  for (int l = 0; l < fl.n_levels; ++l) GTX_CHECK(fl.c[l] % fl.dim == 0, "obj_feats: level %d has %d channels, not a multiple of %d", l, fl.c[l], fl.dim);
+  hipLaunchKernelGGL(obj_feats_kernel, dim3(nb.max_det, n), dim3(128), 0, s, fl, dtype, nb, out);
+  GTX_HIP(hipGetLastError());
 }
 
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,

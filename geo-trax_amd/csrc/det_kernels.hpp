@@ -75,12 +75,27 @@ struct NmsBuffers {
   float* s_box;         // [N][nms_cap][4]
   float* s_score;       // [N][nms_cap]
   int* s_cls;           // [N][nms_cap]
+  int* s_anchor;        // [N][nms_cap] (may be null: anchors of the kept boxes not wanted)
   unsigned long long* mask;  // [N][nms_cap][nms_cap/64]
   // final
   int max_det;
   int* out_n;           // [N]
   float* out_rows;      // [N][max_det][6] x1 y1 x2 y2 conf cls (frame pixels)
+  int* out_anchor;      // [N][max_det] anchor index of every output row (may be null)
 };
+
+// Per-object appearance vectors "from the detector" (ultralytics BoT-SORT `with_reid: true, model: auto`,
+// default.yaml:376-379): the Detect layer's three input maps, every level's channels averaged in consecutive groups down to
+// the narrowest level's width (`dim`), read at the anchor each kept box came from (predictor.get_obj_feats).
+struct FeatLevels {
+  const void* feat[kMaxLevels];   // [N][h][w][cstride] activations of the detector's dtype (pair format for DT_F32S)
+  int h[kMaxLevels], w[kMaxLevels], cstride[kMaxLevels], coff[kMaxLevels], c[kMaxLevels];
+  int anchor_begin[kMaxLevels];
+  int n_levels;
+  int dim;                        // min over levels of c
+};
+// out: [N][max_det][dim] fp32, rows [0, out_n[n]) of image n written
+void launch_obj_feats(int dtype, const FeatLevels& fl, int n, const NmsBuffers& nb, float* out, hipStream_t s);
 
 void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
 // Decode every anchor (debug / parity): out [N][A][4+nc] fp32 = xywh (network px) + class scores

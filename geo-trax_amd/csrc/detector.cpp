@@ -32,6 +32,7 @@ Detector::~Detector() {
   if (h_out_n_) (void)hipHostFree(h_out_n_);
   if (h_sat_) (void)hipHostFree(h_sat_);
   if (h_out_rows_) (void)hipHostFree(h_out_rows_);
+  if (h_feats_) (void)hipHostFree(h_feats_);
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_up_)
@@ -452,6 +453,17 @@ void Detector::build_graph() {
     layer_views_["model.22.feat" + std::to_string(l)] = h2;
   }
   head_.n_anchors = anchor;
+  feat_levels_ = FeatLevels{};
+  if (cfg_.obj_feats) {                           // `with_reid: true, model: auto`: the Detect layer's inputs, read after NMS
+    feat_levels_.n_levels = 3;
+    feat_levels_.dim = std::min(lvl_in[0].c, std::min(lvl_in[1].c, lvl_in[2].c));
+    for (int l = 0; l < 3; ++l) {
+      feat_levels_.feat[l] = lvl_in[l].ptr; feat_levels_.h[l] = lvl_in[l].h; feat_levels_.w[l] = lvl_in[l].w;
+      feat_levels_.cstride[l] = lvl_in[l].cstride; feat_levels_.coff[l] = lvl_in[l].coff; feat_levels_.c[l] = lvl_in[l].c;
+      feat_levels_.anchor_begin[l] = head_.lv[l].anchor_begin;
+      GTX_CHECK(lvl_in[l].c % feat_levels_.dim == 0, "obj_feats: Detect input %d has %d channels, not a multiple of %d", l, lvl_in[l].c, feat_levels_.dim);
+    }
+  }
   for (std::vector<Op>* stage : {&st1, &st2})
     for (Op& g : *stage) {
       g.family = conv_kernel_name(g.cfg);
@@ -638,6 +650,13 @@ void Detector::finalize() {
   nms_.mask = (unsigned long long*)alloc(sizeof(unsigned long long) * N * (size_t)nms_.nms_cap * (nms_.nms_cap / 64));
   nms_.out_n = (int*)alloc(sizeof(int) * N);
   nms_.out_rows = (float*)alloc(sizeof(float) * 6 * N * cfg_.max_det);
+  nms_.s_anchor = nms_.out_anchor = nullptr;
+  if (cfg_.obj_feats) {
+    nms_.s_anchor = (int*)alloc(sizeof(int) * N * nms_.nms_cap);
+    nms_.out_anchor = (int*)alloc(sizeof(int) * N * cfg_.max_det);
+    d_feats_ = (float*)alloc(sizeof(float) * N * cfg_.max_det * feat_levels_.dim);
+    GTX_HIP(hipHostMalloc((void**)&h_feats_, sizeof(float) * N * cfg_.max_det * feat_levels_.dim));
+  }
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
   if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
@@ -743,6 +762,20 @@ void Detector::run_post(int nb, hipStream_t s) {
   GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
   if (sat_dev_) GTX_HIP(hipMemcpyAsync(h_sat_, sat_dev_, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (cfg_.obj_feats) {
+    launch_obj_feats(conv_dtype_, feat_levels_, nb, nms_, d_feats_, s);
+    GTX_HIP(hipMemcpyAsync(h_feats_, d_feats_, sizeof(float) * nb * cfg_.max_det * feat_levels_.dim, hipMemcpyDeviceToHost, s));
+  }
+}
+
+void Detector::features(int b, float* out, int cap, int* n, int* dim) const {
+  if (exact_) return exact_->features(b, out, cap, n, dim);
+  GTX_CHECK(cfg_.obj_feats && h_feats_, "features: the detector was created without gtx_det_config.obj_feats");
+  GTX_CHECK(b >= 0 && b < cfg_.max_batch, "features: image %d of %d", b, cfg_.max_batch);
+  const int cnt = std::min(b < (int)c_feat_n_.size() ? c_feat_n_[b] : 0, cap);
+  if (n) *n = cnt;
+  if (dim) *dim = feat_levels_.dim;
+  if (out && cnt > 0) memcpy(out, c_feats_.data() + (size_t)b * cfg_.max_det * feat_levels_.dim, sizeof(float) * cnt * feat_levels_.dim);
 }
 
 // A split-f16x3 pass clamped an activation: from here on this object is a shell around an exact-fp32 detector built from
@@ -833,6 +866,15 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
     flight_traced_ = false;
   }
   const int nb = flight_nb_;
+  if (cfg_.obj_feats) {                              // out of the pinned buffer before the next pass of this detector lands in it
+    c_feat_n_.assign(cfg_.max_batch, 0);
+    c_feats_.resize((size_t)cfg_.max_batch * cfg_.max_det * feat_levels_.dim);
+    for (int b = 0; b < nb; ++b) {
+      c_feat_n_[b] = h_out_n_[b];
+      const size_t o = (size_t)b * cfg_.max_det * feat_levels_.dim;
+      memcpy(c_feats_.data() + o, h_feats_ + o, sizeof(float) * h_out_n_[b] * feat_levels_.dim);
+    }
+  }
   for (int b = 0; b < nb; ++b) {
     const int n = h_out_n_[b];
     n_out[b] = n;

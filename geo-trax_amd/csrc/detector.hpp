@@ -89,6 +89,9 @@ class Detector {
   void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
                     std::vector<double>& flops, std::vector<double>& bytes);
   int max_det() const { return cfg_.max_det; }
+  // gtx_det_config::obj_feats: appearance vectors of image b's boxes of the most recently collected batch, [n][dim] (n = its box count)
+  int feat_dim() const { return exact_ ? exact_->feat_dim() : feat_levels_.dim; }
+  void features(int b, float* out, int cap, int* n, int* dim) const;
   // split-f16x3 path: true when some activation of a collected pass (since the last call with clear) had to be clamped to
   // fp16's range on its way into the pair format. collect() then re-runs that batch through an exact-fp32 detector built
   // from the same tensors and every later pass goes there (`ultralytics.half: false` promises fp32's range,
@@ -156,6 +159,11 @@ class Detector {
   bool plain_out_ = false;   // convs being built write plain fp32 (head stage 2)
   std::vector<Op> unfused_;  // the stand-alone forms of fused ops (layer_output of an intermediate runs them on demand)
   int* h_out_n_ = nullptr;   // pinned
+  FeatLevels feat_levels_{};
+  float* d_feats_ = nullptr;  // [max_batch][max_det][dim]
+  float* h_feats_ = nullptr;  // pinned
+  std::vector<float> c_feats_;   // the collected batch's vectors
+  std::vector<int> c_feat_n_;
   float* h_out_rows_ = nullptr;
   hipEvent_t ev_[4]{};
   hipGraphExec_t graph_exec_ = nullptr;   // captured forward graph for batch size graph_nb_

@@ -608,6 +608,9 @@ int gtx_detector_saturated(gtx_detector* det, int clear, int* flag) {
 int gtx_detector_fell_back(gtx_detector* det, int* fell_back) {
   return guarded([&] { need(det, "det"); need(fell_back, "fell_back"); *fell_back = det->impl->fell_back() ? 1 : 0; });
 }
+int gtx_detector_features(gtx_detector* det, int b, float* out, int cap, int* n, int* dim) {
+  return guarded([&] { need(det, "det"); det->impl->features(b, out, cap, n, dim); });
+}
 int gtx_detector_trace(gtx_detector* det, int every_n) {
   return guarded([&] { need(det, "det"); det->impl->set_trace(every_n); });
 }
@@ -656,6 +659,17 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
     if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
     if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
     else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+  });
+}
+
+int gtx_tracker_update_feats(gtx_tracker* trk, int n, const float* xyxy, const float* conf, const int* cls, const double* gmc_affine,
+                             const float* feats, int feat_dim, int cap, int* n_out, float* out_xyxy, int* out_id, float* out_score,
+                             int* out_cls, int* out_det_idx) {
+  return guarded([&] {
+    need(trk, "trk"); need(n_out, "n_out");
+    if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
+    if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);   // no appearance branch there
+    else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx, feats, feat_dim);
   });
 }
 

@@ -157,6 +157,17 @@ struct Track {
   std::vector<std::array<double, 8>> hist;
   bool occluded = false, occ_lost = false;
   int occ_frames = 0;
+  // BoT-SORT with_reid only (BOTrack): the detection's normalised appearance vector and the track's 0.9-EMA of them (float32)
+  std::vector<float> curr_feat, smooth_feat;
+  void update_features(const std::vector<float>& f) {   // BOTrack.update_features (feat arrives normalised: it is a curr_feat)
+    curr_feat = f;
+    if (smooth_feat.empty()) { smooth_feat = f; }
+    else for (size_t i = 0; i < f.size(); ++i) smooth_feat[i] = 0.9f * smooth_feat[i] + (1.f - 0.9f) * f[i];
+    float ss = 0.f;
+    for (float v : smooth_feat) ss += v * v;
+    const float nrm = std::sqrt(ss);
+    for (float& v : smooth_feat) v /= nrm;
+  }
 };
 
 // ---- exact sparse LAP ----
@@ -526,6 +537,35 @@ struct ByteTracker::Impl {
     return P;
   }
 
+  // BOTSORT.get_dists with the appearance branch: IoU cost, its proximity mask, score fusion, then min with cosine distance / 2
+  // where the latter is accepted (<= 1 - appearance_thresh) and the boxes are proximate. Dense: the branch is opt-in.
+  SparseCost reid_costs(const std::vector<Track*>& a, const std::vector<Track*>& b, bool fuse, double limit) const {
+    SparseCost P;
+    const int na = (int)a.size(), nb = (int)b.size();
+    P.rows = na; P.cols = nb;
+    P.start.assign(na + 1, 0);
+    if (na == 0 || nb == 0) return P;
+    const std::vector<float> d0 = dists(a, b, false), df = fuse ? dists(a, b, true) : d0;
+    const float far = 1.f - cfg.proximity_thresh;
+    const double reject = 1.0 - (double)cfg.appearance_thresh;
+    for (int r = 0; r < na; ++r) {
+      for (int c = 0; c < nb; ++c) {
+        double v = (double)df[(size_t)r * nb + c];
+        const std::vector<float>&u = a[r]->smooth_feat, &w = b[c]->curr_feat;
+        if (!(d0[(size_t)r * nb + c] > far) && !u.empty() && u.size() == w.size()) {
+          double uw = 0, uu = 0, ww = 0;                       // scipy cdist(..., 'cosine') on float32 rows, in double
+          for (size_t k = 0; k < u.size(); ++k) { uw += (double)u[k] * w[k]; uu += (double)u[k] * u[k]; ww += (double)w[k] * w[k]; }
+          double e = std::max(0.0, 1.0 - uw / (std::sqrt(uu) * std::sqrt(ww))) / 2.0;
+          if (e > reject) e = 1.0;
+          v = std::min(v, e);
+        }
+        if (v < limit) { P.adj.push_back(c); P.w.push_back(v - limit); }
+      }
+      P.start[r + 1] = (int)P.adj.size();
+    }
+    return P;
+  }
+
   void activate(Track& t) {
     t.id = new_id();
     double z[4];
@@ -552,6 +592,7 @@ struct ByteTracker::Impl {
     t.cls = det.cls;
     t.idx = det.idx;
     t.occluded = false; t.occ_lost = false; t.occ_frames = 0;
+    if (!det.curr_feat.empty()) t.update_features(det.curr_feat);   // BOTrack.update / re_activate
   }
   // FastTracker: the largest fraction of t's box that one box of `others` covers
   double covered(const Track& t, const std::vector<Track*>& others) const {
@@ -589,9 +630,12 @@ void ByteTracker::reset() {
 }
 
 void ByteTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap,
-                         int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
+                         int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx,
+                         const float* feats, int feat_dim) {
   Impl& S = *impl_;
   const gtx_tracker_config& A = S.cfg;
+  const bool reid = A.type == 1 && A.with_reid != 0;
+  GTX_CHECK(!reid || n == 0 || (feats != nullptr && feat_dim > 0), "tracker: with_reid needs an appearance vector per detection (gtx_tracker_update_feats)");
   S.frame_id += 1;
   PROF_T0
 
@@ -605,6 +649,14 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
     t.score = conf[i];
     t.cls = cls[i];
     t.idx = i;
+    if (reid) {                                     // BOTrack.__init__ -> update_features: feat /= ||feat|| in float32
+      t.curr_feat.assign(feats + (size_t)i * feat_dim, feats + (size_t)(i + 1) * feat_dim);
+      float ss = 0.f;
+      for (float v : t.curr_feat) ss += v * v;
+      const float nrm = std::sqrt(ss);
+      for (float& v : t.curr_feat) v /= nrm;
+      t.smooth_feat = t.curr_feat;
+    }
     if (conf[i] >= A.track_high_thresh) det_hi.push_back(t);
     else if (conf[i] > A.track_low_thresh) det_lo.push_back(t);
   }
@@ -667,7 +719,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   std::vector<Track*> dh;
   for (Track& d : det_hi) dh.push_back(&d);
   {
-    const SparseCost c1 = S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh);
+    const SparseCost c1 = reid ? S.reid_costs(pool, dh, A.fuse_score != 0, A.match_thresh) : S.sparse_costs(pool, dh, A.fuse_score != 0, A.match_thresh);
 #ifdef GTX_TRK_PROF
     g_prof.cnt[0] += pool.size(); g_prof.cnt[1] += dh.size(); g_prof.cnt[2] += c1.adj.size(); g_prof.cnt[3] += S.lost.size();
 #endif
@@ -746,7 +798,7 @@ void ByteTracker::update(int n, const float* xyxy, const float* conf, const int*
   // ---- unconfirmed tracks vs leftover high-score detections (0.7) ----
   std::vector<Track*> dleft;
   for (int j : u_det) dleft.push_back(dh[j]);
-  linear_assignment_sparse(S.sparse_costs(unconfirmed, dleft, A.fuse_score != 0, 0.7), x, y);
+  linear_assignment_sparse(reid ? S.reid_costs(unconfirmed, dleft, A.fuse_score != 0, 0.7) : S.sparse_costs(unconfirmed, dleft, A.fuse_score != 0, 0.7), x, y);
   for (size_t i = 0; i < unconfirmed.size(); ++i) {
     if (x[i] >= 0) { S.absorb(*unconfirmed[i], *dleft[x[i]], false); activated.push_back(unconfirmed[i]); }
     else { unconfirmed[i]->state = kRemoved; removed_now.push_back(unconfirmed[i]); }

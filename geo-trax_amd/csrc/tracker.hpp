@@ -12,8 +12,10 @@ class ByteTracker {
   explicit ByteTracker(const gtx_tracker_config& cfg);
   ~ByteTracker();
   void reset();
+  // feats (may be null): [n][feat_dim] appearance vectors, used when gtx_tracker_config.with_reid is set (BoT-SORT)
   void update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
-              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
+              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx,
+              const float* feats = nullptr, int feat_dim = 0);
 
  private:
   struct Impl;

@@ -32,7 +32,7 @@ class DetConfig(C.Structure):
         ("imgsz", C.c_int), ("conf", C.c_float), ("iou", C.c_float), ("max_det", C.c_int),
         ("agnostic_nms", C.c_int), ("half", C.c_int), ("rect", C.c_int), ("nc", C.c_int),
         ("n_classes", C.c_int), ("classes", C.c_int * 80), ("max_batch", C.c_int),
-        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int),
+        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int), ("obj_feats", C.c_int),
     ]
 
 
@@ -45,6 +45,7 @@ class TrackerConfig(C.Structure):
         ("reset_velocity_offset_occ", C.c_int), ("reset_pos_offset_occ", C.c_int), ("enlarge_bbox_occ", C.c_float),
         ("dampen_motion_occ", C.c_float), ("active_occ_to_lost_thresh", C.c_int), ("occ_cover_thresh", C.c_float),
         ("occ_reappear_window", C.c_int), ("init_iou_suppress", C.c_float),
+        ("with_reid", C.c_int), ("proximity_thresh", C.c_float), ("appearance_thresh", C.c_float),
     ]
 
 
@@ -73,7 +74,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 7        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 8        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -132,12 +133,14 @@ _SIGNATURES = {
     "gtx_detector_layer_output": (C.c_int, [_P, C.c_int, C.c_char_p, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_saturated": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "gtx_detector_fell_back": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "gtx_detector_features": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_trace": (C.c_int, [_P, C.c_int]),
     "gtx_detector_profile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "gtx_tracker_create": (C.c_int, [C.POINTER(TrackerConfig), C.POINTER(_P)]),
     "gtx_tracker_destroy": (None, [_P]),
     "gtx_tracker_reset": (C.c_int, [_P]),
     "gtx_tracker_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
+    "gtx_tracker_update_feats": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "gtx_tracker_replay": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gtx_op_linear_assignment": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P]),
     "gtx_stabilizer_create": (C.c_int, [_P, C.POINTER(StabConfig), C.POINTER(_P)]),

@@ -30,6 +30,7 @@ class Detections:
     conf: np.ndarray   # [n] float32
     cls: np.ndarray    # [n] int32
     speed: dict        # {'preprocess','inference','postprocess'} ms, like results[0].speed
+    feats: np.ndarray | None = None   # [n, dim] float32 appearance vectors (Detector(obj_feats=True)), what BoT-SORT's `model: auto` ReID reads
 
     def __len__(self):
         return len(self.conf)
@@ -45,8 +46,9 @@ class Detector:
     def __init__(self, tensors: dict[str, np.ndarray], frame_hw: tuple[int, int], *, imgsz: int = 1920,
                  conf: float = 0.25, iou: float = 0.7, max_det: int = 1000, classes=None,
                  agnostic_nms: bool = True, half: bool = False, rect: bool = False, max_batch: int = 1,
-                 fp32_split: bool | None = None, ctx: _lib.Context | None = None):
-        """half=False (the reference default, default.yaml:245) computes at fp32 grade: fp32 activations in HBM and
+                 fp32_split: bool | None = None, obj_feats: bool = False, ctx: _lib.Context | None = None):
+        """obj_feats: keep one appearance vector per box (Detections.feats; include/gtx.h gtx_det_config.obj_feats).
+        half=False (the reference default, default.yaml:245) computes at fp32 grade: fp32 activations in HBM and
         either the exact-fp32 MFMA (fp32_split=False) or the split-f16x3 convolutions (fp32_split=True: hi + lo fp16
         operands, three fp16 MFMAs per product, fp32 accumulate; csrc/conv_igemm_split.hip). fp32_split=None takes
         GTX_FP32_SPLIT from the environment (default: FP32_SPLIT_DEFAULT)."""
@@ -58,7 +60,8 @@ class Detector:
         nc = int(tensors["model.22.cv3.0.2.weight"].shape[0])
         cfg = DetConfig(imgsz=imgsz, conf=conf, iou=iou, max_det=max_det, agnostic_nms=int(agnostic_nms),
                         half=int(half), rect=int(rect), nc=nc, n_classes=0, max_batch=max_batch,
-                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split))
+                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split), obj_feats=int(bool(obj_feats)))
+        self.obj_feats = bool(obj_feats)
         if classes is not None:
             classes = list(classes)
             cfg.n_classes = len(classes)
@@ -126,7 +129,18 @@ class Detector:
         out = []
         for b in range(nb):
             n = int(self._n[b])
-            out.append(Detections(self._xyxy[b, :n].copy(), self._conf[b, :n].copy(), self._cls[b, :n].copy(), sp))
+            out.append(Detections(self._xyxy[b, :n].copy(), self._conf[b, :n].copy(), self._cls[b, :n].copy(), sp,
+                                  self.features(b, n) if self.obj_feats else None))
+        return out
+
+    def features(self, b: int = 0, n: int | None = None) -> np.ndarray:
+        """[n, dim] appearance vectors of image b of the batch collected last (gtx_detector_features)."""
+        cnt, dim = C.c_int(), C.c_int()
+        check(self.ctx.lib.gtx_detector_features(self.handle, b, None, self.max_det, C.byref(cnt), C.byref(dim)))
+        n = cnt.value if n is None else min(n, cnt.value)
+        out = np.zeros((n, dim.value), np.float32)
+        if n:
+            check(self.ctx.lib.gtx_detector_features(self.handle, b, ptr(out), n, C.byref(cnt), C.byref(dim)))
         return out
 
     def detect(self, frame_bgr: np.ndarray) -> Detections:

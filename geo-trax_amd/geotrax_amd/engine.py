@@ -268,6 +268,10 @@ class ExtractEngine:
         n_dets = max(int(det_streams), len(self.dets), 1)
         n_stab = max(1, min(int(stab_streams), 4 * n_dets * self.B - 2)) if stab_kw is not None else 0   # frames in flight < gray ring lifetime
         self.tracker = tracker
+        if tracker is not None and getattr(tracker, "with_reid", False):   # BoT-SORT `with_reid: true, model: auto`: a vector per box
+            det_kw = dict(det_kw, obj_feats=True)
+            if any(not getattr(d, "obj_feats", False) for d in self.dets):
+                raise ValueError("the tracker associates on appearance vectors (with_reid): adopted detectors must be built with obj_feats=True")
         self.gmc = None
         self.stabs = []
         # Every stream comes from the device's StreamPlan: which streams share a hardware queue is fixed once per process
@@ -282,7 +286,7 @@ class ExtractEngine:
             return ctx
 
         while len(self.dets) < n_dets:
-            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=take("d"), **det_kw))
+            self.dets.append(Detector(weights, self.frame_hw, max_batch=self.B, ctx=take("d"), **det_kw))   # det_kw carries obj_feats when the tracker asks
         while len(self.stabs) < n_stab:
             self.stabs.append(Stabilizer(self.frame_hw, ctx=take("s"), **stab_kw))
         self.feeder_ctx = take("f") if feeder_stream else None   # the context a read-ahead feeder's transfers run on
@@ -482,7 +486,7 @@ class ExtractEngine:
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
             warp = self._gmc_collect() if self.gmc is not None else None
             if self.tracker is not None:                        # also on frames without detections (frame counter, lost/removed ageing)
-                t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp)
+                t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp, feats=d.feats)
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
             r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms, warp)

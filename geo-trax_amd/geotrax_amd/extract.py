@@ -189,6 +189,9 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
     rank = dist.get_rank()
     first, last = args.cut_frame_left or 0, args.cut_frame_right
     tracker = model._make_tracker(config['ultralytics'].get('tracker', {'tracker_type': 'botsort'}))   # also decides whether a GMC runs
+    if getattr(tracker, 'with_reid', False):
+        raise NotImplementedError("the frame-sharded run carries boxes and warps between ranks, not appearance vectors: "
+                                  "`with_reid: true` needs the single-process run (one GPU per video)")
     with_gmc = model._gmc_method is not None
     max_det = det_kw['max_det']
     state = {}

@@ -136,7 +136,7 @@ class YOLO:
     def _detector(self, frame_hw, kw) -> Detector:
         if kw.get("augment"):          # ultralytics.augment (default.yaml:243): test-time augmentation changes the detections
             raise NotImplementedError("augment=True (test-time augmentation) is not implemented")
-        key = (tuple(frame_hw), self.fp32_split) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
+        key = (tuple(frame_hw), self.fp32_split, bool(getattr(self, "_obj_feats", False))) + tuple(repr(kw.get(k)) for k in _PREDICT_KEYS)
         if self._det is None or key != self._det_key:
             if self._det is not None:
                 self._det.close()
@@ -146,7 +146,7 @@ class YOLO:
             self._det = Detector(self.tensors, frame_hw, imgsz=int(imgsz), conf=float(kw.get("conf") or 0.1),
                                  iou=float(kw.get("iou", 0.7)), max_det=int(kw.get("max_det", 300)), classes=kw.get("classes"),
                                  agnostic_nms=bool(kw.get("agnostic_nms", False)), half=bool(kw.get("half", False)),
-                                 rect=bool(kw.get("rect", False)), fp32_split=self.fp32_split, ctx=self.ctx)   # absent -> the reference config's value (default.yaml:300)
+                                 rect=bool(kw.get("rect", False)), fp32_split=self.fp32_split, obj_feats=bool(getattr(self, "_obj_feats", False)), ctx=self.ctx)   # absent -> the reference config's value (default.yaml:300)
             self._det_key = key
         return self._det
 
@@ -160,7 +160,12 @@ class YOLO:
             raise NotImplementedError(f"tracker_type '{ttype}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         if ttype in ("botsort", "deepocsort"):                # the two trackers that take a camera-motion warp per frame
             if params.get("with_reid"):
-                raise NotImplementedError(f"{ttype}: the appearance (ReID) branch is not implemented")
+                # botsort + `model: auto` (default.yaml:376-379): appearance vectors from the detector's own feature maps
+                # (Detector(obj_feats=True) -> Tracker.update(feats=)); a separate ReID network's weights cannot be read here
+                if ttype != "botsort":
+                    raise NotImplementedError(f"{ttype}: the appearance (ReID) branch is not implemented")
+                if str(params.get("model", "auto")) != "auto":
+                    raise NotImplementedError(f"botsort with_reid: only `model: auto` (detector-derived features) is implemented, not '{params.get('model')}'")
             gm = params.get("gmc_method", "none")
             if gm in ("none", None):
                 self._gmc_method = None
@@ -187,7 +192,8 @@ class YOLO:
         return Tracker(ttype, **{k: v for k, v in params.items() if k in (
             "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score",
             "delta_t", "inertia", "use_byte", "min_hits", "reset_velocity_offset_occ", "reset_pos_offset_occ", "enlarge_bbox_occ",
-            "dampen_motion_occ", "active_occ_to_lost_thresh", "occ_cover_thresh", "occ_reappear_window", "init_iou_suppress")})
+            "dampen_motion_occ", "active_occ_to_lost_thresh", "occ_cover_thresh", "occ_reappear_window", "init_iou_suppress",
+            "with_reid", "proximity_thresh", "appearance_thresh")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:
@@ -207,7 +213,10 @@ class YOLO:
                 self._gmc.reset_params()
         kwargs = dict(kwargs)
         kwargs["conf"] = kwargs.get("conf") or 0.1      # ultralytics Model.track default
-        res = self.predict(source, **kwargs)[0]
+        self._obj_feats = bool(getattr(self._tracker, "with_reid", False))   # `with_reid: true, model: auto`: the detector keeps a vector per box
+        frame = np.ascontiguousarray(source, dtype=np.uint8)
+        d = self._detector(frame.shape[:2], kwargs).detect(frame)
+        res = Results(Boxes(d.xyxy, d.conf, d.cls, None), d.speed, frame.shape[:2], self.names)
         b = res.boxes
         # ultralytics' on_predict_postprocess_end (trackers/track.py, pinned >= 8.4.80) calls tracker.update(det, img) on EVERY
         # frame, detections or not: the frame counter advances, unmatched tracks go lost / age out and BoT-SORT's GMC moves
@@ -225,7 +234,7 @@ class YOLO:
                 warp = self._gmc.collect()
             else:
                 warp = self._gmc.apply(frame)
-        xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32), gmc=warp)
+        xyxy, ids, score, cls, _idx = self._tracker.update(b._xyxy, b._conf, b._cls.astype(np.int32), gmc=warp, feats=d.feats)
         if len(ids) == 0:                                   # the raw detections (or no rows) with id None (extract.py:161-165)
             return [res]
         res.boxes = Boxes(xyxy, score, cls, ids)

@@ -4,7 +4,8 @@ Reference behaviour replaced: the tracker callback ultralytics registers for
 ``model.track(..., persist=True)`` (geotrax/extract.py:153) with the active block of
 cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one frame at a time. `tracker_type: ocsort` (default.yaml:391-404) selects the OC-SORT
 implementation (csrc/ocsort.cpp), `deepocsort` (default.yaml:406-427) the same tracker with camera-motion compensation by the warp
-handed to update() (no appearance branch); `fasttrack` (default.yaml:426-443) ByteTrack with occlusion handling, written from the
+handed to update() (no appearance branch there); `botsort` with `with_reid: true, model: auto` associates on the detector's own appearance
+vectors as well (update(..., feats=), csrc/tracker.cpp reid_costs); `fasttrack` (default.yaml:426-443) ByteTrack with occlusion handling, written from the
 config's own description of its parameters (csrc/tracker.cpp type 4, oracle/fasttrack_ref.py); tracktrack is not implemented and raises.
 """
 from __future__ import annotations
@@ -25,7 +26,8 @@ class Tracker:
                  fuse_score: bool = True, frame_rate: int = 30, max_tracks: int = 4096, delta_t: int = 3, inertia: float = 0.2,
                  use_byte: bool = False, min_hits: int = 3, reset_velocity_offset_occ: int = 5, reset_pos_offset_occ: int = 3,
                  enlarge_bbox_occ: float = 1.1, dampen_motion_occ: float = 0.5, active_occ_to_lost_thresh: int = 10,
-                 occ_cover_thresh: float = 0.7, occ_reappear_window: int = 40, init_iou_suppress: float = 0.7, **_ignored):
+                 occ_cover_thresh: float = 0.7, occ_reappear_window: int = 40, init_iou_suppress: float = 0.7,
+                 with_reid: bool = False, proximity_thresh: float = 0.5, appearance_thresh: float = 0.8, **_ignored):
         if tracker_type not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         self.lib = _lib.load()
@@ -37,7 +39,9 @@ class Tracker:
                             reset_pos_offset_occ=int(reset_pos_offset_occ), enlarge_bbox_occ=float(enlarge_bbox_occ),
                             dampen_motion_occ=float(dampen_motion_occ), active_occ_to_lost_thresh=int(active_occ_to_lost_thresh),
                             occ_cover_thresh=float(occ_cover_thresh), occ_reappear_window=int(occ_reappear_window),
-                            init_iou_suppress=float(init_iou_suppress))
+                            init_iou_suppress=float(init_iou_suppress), with_reid=int(bool(with_reid) and tracker_type == "botsort"),
+                            proximity_thresh=float(proximity_thresh), appearance_thresh=float(appearance_thresh))
+        self.with_reid = bool(cfg.with_reid)
         h = C.c_void_p()
         check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -66,12 +70,23 @@ class Tracker:
     def reset(self):
         check(self.lib.gtx_tracker_reset(self.handle))
 
-    def update(self, xyxy: np.ndarray, conf: np.ndarray, cls: np.ndarray, gmc: np.ndarray | None = None):
-        """-> (xyxy [k,4] f32, id [k] i32, score [k] f32, cls [k] i32, det_idx [k] i32)."""
+    def update(self, xyxy: np.ndarray, conf: np.ndarray, cls: np.ndarray, gmc: np.ndarray | None = None, feats: np.ndarray | None = None):
+        """-> (xyxy [k,4] f32, id [k] i32, score [k] f32, cls [k] i32, det_idx [k] i32). feats: [n, dim] float32 appearance vectors,
+        one per detection (required when the tracker was made with with_reid)."""
         xyxy = np.ascontiguousarray(xyxy, dtype=np.float32).reshape(-1, 4)
         conf = np.ascontiguousarray(conf, dtype=np.float32)
         cls = np.ascontiguousarray(cls, dtype=np.int32)
         g = None if gmc is None else np.ascontiguousarray(gmc, dtype=np.float64).reshape(6)
+        if self.with_reid:
+            if feats is None or len(feats) != len(conf):
+                raise ValueError("with_reid: update() needs one appearance vector per detection (feats [n, dim])")
+            f = np.ascontiguousarray(feats, dtype=np.float32)
+            f = f.reshape(len(conf), -1) if len(conf) else f.reshape(0, 0)
+            check(self.lib.gtx_tracker_update_feats(self.handle, len(conf), xyxy.ctypes.data, conf.ctypes.data, cls.ctypes.data,
+                                                    None if g is None else g.ctypes.data, f.ctypes.data if len(conf) else None,
+                                                    f.shape[1] if len(conf) else 0, self.cap, self._n_ref, *self._out_ptrs))
+            k = self._n.value
+            return (self._xyxy[:k].copy(), self._id[:k].copy(), self._score[:k].copy(), self._cls[:k].copy(), self._idx[:k].copy())
         check(self.lib.gtx_tracker_update(self.handle, len(conf), xyxy.ctypes.data, conf.ctypes.data, cls.ctypes.data,
                                           None if g is None else g.ctypes.data, self.cap, self._n_ref, *self._out_ptrs))
         k = self._n.value

@@ -42,8 +42,10 @@ extern "C" {
  * 5: gtx_feeder_* (read-ahead frame source) added; a saturating split-f16x3 pass is
  *    re-run by the detector through the exact-fp32 kernels (gtx_detector_saturated reports that it happened).
  * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added.
- * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct. */
-#define GTX_ABI_VERSION 7
+ * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct.
+ * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
+ *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added. */
+#define GTX_ABI_VERSION 8
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -227,6 +229,10 @@ typedef struct gtx_det_config {
                      * activations in HBM, every conv operand split into hi + lo fp16 parts in LDS, three fp16
                      * MFMAs per product with fp32 accumulation (22 significand bits per operand; same
                      * detections as the exact path within the fp32 tolerance, ~3/16 of its matrix cost) */
+  int obj_feats;    /* 1: keep an appearance vector per output box (gtx_detector_features) -- what ultralytics hands BoT-SORT under
+                     * `with_reid: true, model: auto` (default.yaml:376-379; engine/predictor.py get_obj_feats): the Detect layer's
+                     * three input maps, each level's channels averaged in consecutive groups down to the narrowest level's width
+                     * (128 for YOLOv8s), read at the anchor the box came from */
 } gtx_det_config;
 
 int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out);
@@ -284,6 +290,9 @@ int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float
  * BN-folded YOLOv8 weights never get there; GTX_SAT_FALLBACK=0 in the environment keeps the flag and skips the re-run. */
 int gtx_detector_saturated(gtx_detector* det, int clear, int* flag);
 int gtx_detector_fell_back(gtx_detector* det, int* fell_back);
+/* gtx_det_config.obj_feats: the appearance vectors of image b of the most recently collected batch, out [n][dim] fp32 in the
+ * order of its boxes (n = min(box count, cap); out may be NULL to ask for n and dim). */
+int gtx_detector_features(gtx_detector* det, int b, float* out, int cap, int* n, int* dim);
 
 /* Per-kernel-family profile of one forward pass: launches, total ms (HIP events around every
  * launch on the launch stream, graph disabled) and algorithmic FLOPs / bytes. `names` receives
@@ -327,6 +336,12 @@ typedef struct gtx_tracker_config {
   float occ_cover_thresh;
   int occ_reappear_window;
   float init_iou_suppress;
+  /* BoT-SORT only (type 1): tracker.botsort.{with_reid, proximity_thresh, appearance_thresh} (default.yaml:376-378). with_reid = 1:
+   * gtx_tracker_update_feats must be used; the cost of a pair whose boxes overlap by at least proximity_thresh becomes
+   * min(IoU cost, cosine distance / 2) when the latter is <= 1 - appearance_thresh (BOTSORT.get_dists) */
+  int with_reid;
+  float proximity_thresh;
+  float appearance_thresh;
 } gtx_tracker_config;
 
 int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);
@@ -341,6 +356,13 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
                        const int* cls, const double* gmc_affine, int cap, int* n_out,
                        float* out_xyxy, int* out_id, float* out_score, int* out_cls,
                        int* out_det_idx);
+
+/* gtx_tracker_update with one appearance vector per detection (feats [n][feat_dim] fp32, e.g. gtx_detector_features): BOTrack's
+ * normalised current vector and its 0.9-EMA, used by the first association and the unconfirmed one when
+ * gtx_tracker_config.with_reid is set (ultralytics/trackers/bot_sort.py). feats == NULL behaves like gtx_tracker_update. */
+int gtx_tracker_update_feats(gtx_tracker* trk, int n, const float* xyxy, const float* conf, const int* cls,
+                             const double* gmc_affine, const float* feats, int feat_dim, int cap, int* n_out,
+                             float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
 
 /* The sequential half of a frame-sharded run (rank 0): n_recs per-frame records in clip order, each `stride`
  * doubles laid out as geotrax_amd/distributed.py::pack_frame_record writes them -- n, max_det x (x1, y1, x2, y2, conf, cls),

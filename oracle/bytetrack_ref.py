@@ -18,6 +18,9 @@ mock the model). What pins it indirectly: the golden track file
 data/results-pixel/U_video_cut.txt shows ids 1..N assigned in detection (confidence) order on
 the first frame and Kalman-posterior boxes afterwards, which is what this procedure produces.
 
+The appearance branch (`with_reid: true, model: auto`: BOTrack.update_features, BOTSORT.get_dists, matching.embedding_distance) is
+restated the same way; the vectors themselves are oracle/yolov8_ref.py obj_feats_table (engine/predictor.py get_obj_feats).
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 from __future__ import annotations
@@ -66,7 +69,7 @@ class KalmanXYAH:
 
 
 class Track:
-    def __init__(self, xywh, score, cls, idx):
+    def __init__(self, xywh, score, cls, idx, feat=None):
         x, y, w, h = (np.float32(v) for v in xywh)
         self._tlwh = np.array([x - w / np.float32(2), y - h / np.float32(2), w, h], dtype=np.float32)
         self.mean = self.cov = None
@@ -75,16 +78,32 @@ class Track:
         self.score, self.cls, self.idx = float(score), int(cls), int(idx)
         self.id = 0
         self.frame_id = self.start_frame = self.tracklet_len = 0
+        # bot_sort.py BOTrack (with_reid): the detection's normalised appearance vector and the track's 0.9-EMA of them
+        self.curr_feat = self.smooth_feat = None
+        if feat is not None:
+            self.update_features(np.array(feat, dtype=np.float32))
+
+    def update_features(self, feat):
+        feat = feat / np.linalg.norm(feat)
+        self.curr_feat = feat
+        if self.smooth_feat is None:
+            self.smooth_feat = feat
+        else:
+            self.smooth_feat = np.float32(0.9) * self.smooth_feat + np.float32(1 - 0.9) * feat
+        self.smooth_feat = self.smooth_feat / np.linalg.norm(self.smooth_feat)
 
 
 class ByteTrackRef:
     def __init__(self, track_high_thresh=0.25, track_low_thresh=0.1, new_track_thresh=0.25, track_buffer=30,
-                 match_thresh=0.8, fuse_score=True, frame_rate=30, botsort=False):
+                 match_thresh=0.8, fuse_score=True, frame_rate=30, botsort=False, with_reid=False, proximity_thresh=0.5,
+                 appearance_thresh=0.8):
         self.hi, self.lo, self.new_thr = track_high_thresh, track_low_thresh, new_track_thresh
         self.match_thresh, self.fuse = match_thresh, fuse_score
         self.max_time_lost = int(frame_rate / 30.0 * track_buffer)
         self.kf = KalmanXYAH(xywh=botsort)
         self.botsort = botsort
+        # bot_sort.py BOTSORT.get_dists, `with_reid: true, model: auto` (default.yaml:376-379): appearance vectors come with the detections
+        self.reid, self.proximity, self.appearance = bool(with_reid) and botsort, proximity_thresh, appearance_thresh
         self.tracked, self.lost, self.removed = [], [], []
         self.frame_id = 0
         self._count = 0
@@ -127,6 +146,26 @@ class ByteTrackRef:
             cost = np.float32(1) - (np.float32(1) - cost) * s
         return cost.astype(np.float32)
 
+    def _get_dists(self, a, b):
+        """BOTSORT.get_dists: IoU cost, score fusion, and -- with_reid -- the minimum with half the cosine distance between the
+        track's smoothed vector and the detection's, where that is at most 1 - appearance_thresh and the boxes overlap by at
+        least proximity_thresh."""
+        d = self._dists(a, b, False)
+        if not a or not b:
+            return d
+        mask = d > np.float32(1 - self.proximity)
+        if self.fuse:
+            d = self._dists(a, b, True)
+        if self.reid:
+            from scipy.spatial.distance import cdist
+            tf = np.asarray([t.smooth_feat for t in a], dtype=np.float32)
+            df = np.asarray([t.curr_feat for t in b], dtype=np.float32)
+            emb = np.maximum(0.0, cdist(tf, df, "cosine")) / 2.0
+            emb[emb > (1 - self.appearance)] = 1.0
+            emb[mask] = 1.0
+            d = np.minimum(d, emb)
+        return d
+
     @staticmethod
     def _assign(cost, thresh):
         """lap.lapjv(cost, extend_cost=True, cost_limit=thresh) -> matches, unmatched rows/cols."""
@@ -150,16 +189,19 @@ class ByteTrackRef:
         t.tracklet_len = 0 if reactivate else t.tracklet_len + 1
         t.state, t.activated, t.frame_id = TRACKED, True, self.frame_id
         t.score, t.cls, t.idx = det.score, det.cls, det.idx
+        if det.curr_feat is not None:
+            t.update_features(det.curr_feat)
 
-    def update(self, xyxy, conf, cls, gmc=None):
+    def update(self, xyxy, conf, cls, gmc=None, feats=None):
         """One frame. Returns rows [x1,y1,x2,y2,id,score,cls,idx] of active tracks (float32)."""
         self.frame_id += 1
         xyxy = np.asarray(xyxy, dtype=np.float32).reshape(-1, 4)
         xywh = np.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2, (xyxy[:, 1] + xyxy[:, 3]) / 2,
                          xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]], 1).astype(np.float32)
         conf = np.asarray(conf, dtype=np.float32)
-        det_hi = [Track(xywh[i], conf[i], cls[i], i) for i in range(len(conf)) if conf[i] >= np.float32(self.hi)]
-        det_lo = [Track(xywh[i], conf[i], cls[i], i) for i in range(len(conf))
+        ft = (lambda i: feats[i]) if (self.reid and feats is not None) else (lambda i: None)
+        det_hi = [Track(xywh[i], conf[i], cls[i], i, ft(i)) for i in range(len(conf)) if conf[i] >= np.float32(self.hi)]
+        det_lo = [Track(xywh[i], conf[i], cls[i], i, ft(i)) for i in range(len(conf))
                   if np.float32(self.lo) < conf[i] < np.float32(self.hi)]
         unconfirmed = [t for t in self.tracked if not t.activated]
         confirmed = [t for t in self.tracked if t.activated]
@@ -182,7 +224,7 @@ class ByteTrackRef:
                 t.cov = R8 @ t.cov @ R8.T
 
         activated, refind, lost_now, removed_now = [], [], [], []
-        matches, u_track, u_det = self._assign(self._dists(pool, det_hi, self.fuse), self.match_thresh)
+        matches, u_track, u_det = self._assign(self._get_dists(pool, det_hi) if self.reid else self._dists(pool, det_hi, self.fuse), self.match_thresh)
         for i, j in matches:
             t = pool[i]
             if t.state == TRACKED:
@@ -207,7 +249,7 @@ class ByteTrackRef:
                 t.state = LOST
                 lost_now.append(t)
         left = [det_hi[j] for j in u_det]
-        matches, u_unc, u_left = self._assign(self._dists(unconfirmed, left, self.fuse), 0.7)
+        matches, u_unc, u_left = self._assign(self._get_dists(unconfirmed, left) if self.reid else self._dists(unconfirmed, left, self.fuse), 0.7)
         for i, j in matches:
             self._absorb(unconfirmed[i], left[j], False)
             activated.append(unconfirmed[i])

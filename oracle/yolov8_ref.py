@@ -193,6 +193,7 @@ class YoloV8Ref:
         a["model.19.conv"] = x19 = self._conv("model.19.conv", x18, 2)
         x21 = self._c2f("model.21", torch.cat([x19, x9], 1), False)
 
+        self.detect_inputs = (x15, x18, x21)        # what ultralytics' `with_reid, model: auto` hook keeps (the Detect layer's inputs)
         outs = []
         for l, (f, stride) in enumerate(zip((x15, x18, x21), (8.0, 16.0, 32.0))):
             b = self._conv(f"model.22.cv2.{l}.1.conv", self._conv(f"model.22.cv2.{l}.0.conv", f))
@@ -212,6 +213,14 @@ class YoloV8Ref:
             xywh = torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], 1) * stride
             outs.append(torch.cat([xywh, cls.view(B, self.nc, H * W).sigmoid()], 1))
         return torch.cat(outs, 2).transpose(1, 2).contiguous()
+
+
+    def obj_feats_table(self) -> np.ndarray:
+        """ultralytics engine/predictor.py get_obj_feats on the last forward: [A, s] with s = the narrowest level's channel count --
+        every level's channels averaged in consecutive groups of C / s, levels concatenated in anchor order."""
+        maps = self.detect_inputs
+        s = min(int(x.shape[1]) for x in maps)
+        return torch.cat([x.permute(0, 2, 3, 1).reshape(x.shape[0], -1, s, x.shape[1] // s).float().mean(dim=-1) for x in maps], dim=1)[0].numpy()
 
 
 # --------------------------------------------------------------------------- post-processing
@@ -240,26 +249,31 @@ def nms_torchvision(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.nda
 
 
 def non_max_suppression(pred: np.ndarray, conf: float, iou: float, classes=None, agnostic: bool = False,
-                        max_det: int = 300, max_nms: int = 30000, max_wh: int = 7680) -> np.ndarray:
-    """pred: [A, 4+nc] (xywh + scores) of one image -> [n, 6] xyxy, conf, cls (network pixels)."""
+                        max_det: int = 300, max_nms: int = 30000, max_wh: int = 7680, return_idx: bool = False):
+    """pred: [A, 4+nc] (xywh + scores) of one image -> [n, 6] xyxy, conf, cls (network pixels); return_idx: also the anchor
+    index of every kept row (ultralytics non_max_suppression(return_idxs=True))."""
     pred = pred.astype(np.float32)
     xy, wh = pred[:, :2], pred[:, 2:4] / np.float32(2)
     box = np.concatenate([xy - wh, xy + wh], 1)
     cls = pred[:, 4:]
     keep0 = cls.max(1) > np.float32(conf)
+    anchors = np.flatnonzero(keep0)
     box, cls = box[keep0], cls[keep0]
     j = cls.argmax(1)
     cf = cls[np.arange(len(j)), j]
-    x = np.concatenate([box, cf[:, None], j[:, None].astype(np.float32)], 1)[cf > np.float32(conf)]
+    sel = cf > np.float32(conf)
+    x, anchors = np.concatenate([box, cf[:, None], j[:, None].astype(np.float32)], 1)[sel], anchors[sel]
     if classes is not None:
-        x = x[np.isin(x[:, 5].astype(int), np.asarray(classes))]
+        sel = np.isin(x[:, 5].astype(int), np.asarray(classes))
+        x, anchors = x[sel], anchors[sel]
     if len(x) == 0:
-        return np.zeros((0, 6), np.float32)
+        return (np.zeros((0, 6), np.float32), np.zeros(0, np.int64)) if return_idx else np.zeros((0, 6), np.float32)
     if len(x) > max_nms:
-        x = x[np.argsort(-x[:, 4], kind="stable")[:max_nms]]
+        sel = np.argsort(-x[:, 4], kind="stable")[:max_nms]
+        x, anchors = x[sel], anchors[sel]
     c = x[:, 5:6] * np.float32(0 if agnostic else max_wh)
     i = nms_torchvision(x[:, :4] + c, x[:, 4], iou)[:max_det]
-    return x[i]
+    return (x[i], anchors[i]) if return_idx else x[i]
 
 
 def scale_boxes(boxes_xyxy: np.ndarray, net_hw: tuple[int, int], src_hw: tuple[int, int]) -> np.ndarray:
@@ -277,12 +291,15 @@ def scale_boxes(boxes_xyxy: np.ndarray, net_hw: tuple[int, int], src_hw: tuple[i
 
 
 def detect(model: YoloV8Ref, frame_bgr: np.ndarray, imgsz: int, rect: bool, conf: float, iou: float,
-           classes=None, agnostic: bool = False, max_det: int = 300):
-    """Whole detector chain on one frame -> (xyxy [n,4] frame pixels, conf [n], cls [n])."""
+           classes=None, agnostic: bool = False, max_det: int = 300, return_feats: bool = False):
+    """Whole detector chain on one frame -> (xyxy [n,4] frame pixels, conf [n], cls [n]); return_feats: also the [n, s]
+    appearance vectors BoT-SORT's `model: auto` ReID reads (obj_feats_table at the kept anchors)."""
     x, g = letterbox(frame_bgr, imgsz, rect, half=model.half)
     pred = model.forward(x)[0].numpy()
-    det = non_max_suppression(pred, conf, iou, classes, agnostic, max_det)
+    det, idx = non_max_suppression(pred, conf, iou, classes, agnostic, max_det, return_idx=True)
     xyxy = scale_boxes(det[:, :4], (g["net_h"], g["net_w"]), frame_bgr.shape[:2])
+    if return_feats:
+        return xyxy, det[:, 4], det[:, 5].astype(np.int32), model.obj_feats_table()[idx]
     return xyxy, det[:, 4], det[:, 5].astype(np.int32)
 
 

@@ -362,3 +362,40 @@ def test_fused_stem_matches_the_stem_launch(gtx_ctx, weights, monkeypatch, imgsz
     finally:
         sep.close()
         one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "exact", "half"])
+@pytest.mark.parametrize("conf", [0.25, 0.02])
+def test_object_features_are_the_detect_inputs_at_the_boxes_anchors(gtx_ctx, weights, mode, conf):
+    """`with_reid: true, model: auto` (default.yaml:376-379): the vector BoT-SORT gets per box is what ultralytics'
+    predictor.get_obj_feats makes -- the Detect layer's three input maps, each level's channels averaged in consecutive groups
+    down to the narrowest level's width, read at the anchor the kept box came from. Checked against the same reduction in numpy
+    on gtx_detector_layer_output, with the anchor found from the full decode (conf 0.02: > 4096 candidates, the general NMS path)."""
+    from geotrax_amd.detector import Detector
+
+    hw = (640, 640)
+    frame = _frame(1, hw)
+    det = Detector(weights, hw, imgsz=640, half=(mode == "half"), fp32_split=(mode == "split"), obj_feats=True, ctx=gtx_ctx,
+                   conf=conf, iou=0.7, max_det=300, agnostic_nms=False)
+    plain = Detector(weights, hw, imgsz=640, half=(mode == "half"), fp32_split=(mode == "split"), ctx=gtx_ctx,
+                     conf=conf, iou=0.7, max_det=300, agnostic_nms=False)
+    d, p = det.detect(frame), plain.detect(frame)
+    np.testing.assert_array_equal(d.xyxy, p.xyxy)                    # keeping the vectors changes no box
+    np.testing.assert_array_equal(d.conf, p.conf)
+    assert p.feats is None and d.feats is not None and d.feats.shape == (len(d), 128) and len(d) > 20
+    maps = [det.layer_output(n) for n in ("model.15", "model.18", "model.21")]      # [h, w, c]
+    s = min(m.shape[-1] for m in maps)
+    table = np.concatenate([m.reshape(-1, s, m.shape[-1] // s).astype(np.float32).mean(-1) for m in maps], 0)   # [anchors, 128]
+    raw = det.raw_output(0)                                          # [anchors, 4 + nc]: xywh in network pixels, class scores
+    assert len(raw) == len(table)
+    for j in range(len(d)):
+        k = int(d.cls[j])
+        cand = np.flatnonzero(np.abs(raw[:, 4 + k] - d.conf[j]) < 1e-6)
+        r = raw[cand, :4]                                            # 640 x 640 frame at imgsz 640: network pixels == frame pixels
+        boxes = np.clip(np.stack([r[:, 0] - r[:, 2] / 2, r[:, 1] - r[:, 3] / 2, r[:, 0] + r[:, 2] / 2, r[:, 1] + r[:, 3] / 2], 1), 0, 640)
+        hit = cand[np.abs(boxes - d.xyxy[j]).max(1) < 2e-3]          # the anchor(s) this box can have come from
+        assert len(hit), j
+        err = min(np.abs(table[a] - d.feats[j]).max() for a in hit)
+        assert err <= 1e-6 * max(1.0, np.abs(d.feats[j]).max()), (j, err)
+    det.close(); plain.close()

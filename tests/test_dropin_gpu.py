@@ -105,8 +105,10 @@ def _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg):
     return np.stack(frames)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid"])
 def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_path, tracker):
+    reid = tracker.endswith("+reid")         # `with_reid: true, model: auto`: the detector hands BoT-SORT a vector per box on both routes
+    tracker = tracker.split("+")[0]
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.model import YOLO
@@ -116,7 +118,7 @@ def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_p
 
     scene = make_scene(seed=5, h=H, w=W)
     wpath, _ = _weights_file(tmp_path, gtx_ctx, scene.render(0, 150))
-    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker)
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, **({"with_reid": True} if reid else {}))
     if tracker == "botsort":
         assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     frames = _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg)

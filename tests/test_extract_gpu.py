@@ -39,7 +39,7 @@ def _weights_file(tmp_path, gtx_ctx, probe_frame, half=False):
     return path, w
 
 
-def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=None):
+def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=None, with_reid=False):
     import yaml
     from geotrax_amd.config_utils import DEFAULT_CFG
 
@@ -53,6 +53,8 @@ def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=
         cfg["tracker"][tracker]["gmc_method"] = gmc_method
         # the seeded weights are calibrated so that the detections sit just above conf = 0.25: below deepocsort's own 0.3
         cfg["tracker"][tracker].update(track_high_thresh=0.25, new_track_thresh=0.25)
+    if with_reid:
+        cfg["tracker"][tracker]["with_reid"] = True            # `model: auto` is the config's default (default.yaml:379)
     cfg["extraction"]["model"] = str(model_path)
     cfg["extraction"]["min_track_length"] = 2
     p = tmp_path / "cfg.yaml"
@@ -84,16 +86,19 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
         trk = FastTrackRef(**{k: v for k, v in tp.items() if k != "tracker_type"})
     else:
         trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
-                                                                                 "track_buffer", "match_thresh", "fuse_score")})
+                                                                                 "track_buffer", "match_thresh", "fuse_score")},
+                           **({k: tp[k] for k in ("with_reid", "proximity_thresh", "appearance_thresh")} if active == "botsort" else {}))
+    reid = active == "botsort" and bool(tp.get("with_reid"))
     gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort") and tp.get("gmc_method") == "sparseOptFlow" else None
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
     rows, transforms = [], []
     for f, frame in enumerate(frames):
-        xyxy, conf, cls = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"])
+        xyxy, conf, cls, *feats = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"],
+                                         return_feats=reid)
         warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
-        t = trk.update(xyxy, conf, cls, gmc=warp)           # every frame, with or without detections (ultralytics track.py)
+        t = trk.update(xyxy, conf, cls, gmc=warp, **({"feats": feats[0]} if reid else {}))   # every frame, with or without detections (ultralytics track.py)
         if len(conf):
             if len(t):
                 bx, ids, sc, cl = t[:, :4], t[:, 4], t[:, 5], t[:, 6]
@@ -125,8 +130,10 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "ocsort", "deepocsort", "fasttrack"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
+    reid = tracker == "botsort+reid"        # BoT-SORT's appearance branch on detector-derived vectors (`with_reid: true, model: auto`)
+    tracker = tracker.split("+")[0]
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.stabilizer import Stabilizer
@@ -137,7 +144,7 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     src = tmp_path / "clip.npy"
     np.save(src, frames)
     wpath, weights = _weights_file(tmp_path, gtx_ctx, frames[0])
-    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="sparseOptFlow" if tracker == "deepocsort" else None)
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="sparseOptFlow" if tracker == "deepocsort" else None, with_reid=reid)
     if tracker == "botsort":
         assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,

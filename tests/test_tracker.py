@@ -142,3 +142,51 @@ def test_tracker_rejects_unknown_type():
 
     with pytest.raises(NotImplementedError):
         Tracker("tracktrack")
+
+
+def _stream_with_feats(seed, dim=128, **kw):
+    """_stream plus an appearance vector per detection: the object's own direction + noise (false positives: random ones)."""
+    rng = np.random.default_rng(seed + 500)
+    protos = {}
+    for xyxy, conf, cls in _stream(seed, **kw):
+        feats = np.zeros((len(conf), dim), np.float32)
+        for j in range(len(conf)):
+            key = (int(cls[j]), round(float(xyxy[j, 2] - xyxy[j, 0]) / 8))          # size bucket + class: a stable stand-in for identity
+            if key not in protos:
+                protos[key] = rng.standard_normal(dim)
+            feats[j] = (protos[key] + 0.35 * rng.standard_normal(dim)) * rng.uniform(0.5, 20.0)   # un-normalised, like pooled activations
+        yield xyxy, conf, cls, feats
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_botsort_with_reid_matches_oracle(seed):
+    """BoT-SORT's appearance branch on detector-derived vectors (`with_reid: true, model: auto`, default.yaml:376-379;
+    csrc/tracker.cpp reid_costs) against oracle/bytetrack_ref.py's restatement of BOTSORT.get_dists / BOTrack.update_features."""
+    from geotrax_amd.tracker import Tracker
+    from oracle.bytetrack_ref import ByteTrackRef
+
+    trk = Tracker("botsort", with_reid=True, proximity_thresh=0.5, appearance_thresh=0.8)
+    ref = ByteTrackRef(botsort=True, with_reid=True, proximity_thresh=0.5, appearance_thresh=0.8)
+    plain = ByteTrackRef(botsort=True)
+    n_rows, differs = 0, False
+    for t, (xyxy, conf, cls, feats) in enumerate(_stream_with_feats(seed, n_obj=60, jitter=4.0, p_miss=0.15)):
+        b, i, s, c, d = trk.update(xyxy, conf, cls, None, feats=feats)
+        r = ref.update(xyxy, conf, cls, None, feats=feats)
+        p = plain.update(xyxy, conf, cls, None)
+        np.testing.assert_array_equal(i, r[:, 4].astype(np.int32), err_msg=f"frame {t} ids")
+        np.testing.assert_array_equal(d, r[:, 7].astype(np.int32), err_msg=f"frame {t} detection index")
+        np.testing.assert_allclose(b, r[:, :4], rtol=0, atol=2e-3)
+        differs |= len(p) != len(r) or not np.array_equal(p[:, [4, 7]], r[:, [4, 7]])
+        n_rows += len(i)
+    assert n_rows > 1000
+    assert differs                                        # the appearance term did change associations on this stream
+
+
+def test_with_reid_needs_a_vector_per_detection():
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("botsort", with_reid=True)
+    xyxy = np.array([[10, 10, 50, 40]], np.float32)
+    with pytest.raises(ValueError):
+        trk.update(xyxy, np.array([0.9], np.float32), np.array([0], np.int32))
+    assert Tracker("bytetrack", with_reid=True).with_reid is False      # only BoT-SORT has the branch
