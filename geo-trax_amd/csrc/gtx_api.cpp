@@ -643,13 +643,14 @@ int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out) {
     std::unique_ptr<gtx_tracker> t(new gtx_tracker);
     if (cfg->type == 2 || cfg->type == 3) t->oc.reset(new gtx::OcSortTracker(*cfg));
     else if (cfg->type == 0 || cfg->type == 1 || cfg->type == 4) t->impl.reset(new gtx::ByteTracker(*cfg));
-    else gtx::fail(GTX_ERR_INVALID, "tracker type %d (0 bytetrack, 1 botsort, 2 ocsort, 3 deepocsort, 4 fasttrack)", cfg->type);
+    else if (cfg->type == 5) t->tt.reset(new gtx::TrackTrackTracker(*cfg));
+    else gtx::fail(GTX_ERR_INVALID, "tracker type %d (0 bytetrack, 1 botsort, 2 ocsort, 3 deepocsort, 4 fasttrack, 5 tracktrack)", cfg->type);
     *out = t.release();
   });
 }
 void gtx_tracker_destroy(gtx_tracker* trk) { delete trk; }
 int gtx_tracker_reset(gtx_tracker* trk) {
-  return guarded([&] { need(trk, "trk"); if (trk->oc) trk->oc->reset(); else trk->impl->reset(); });
+  return guarded([&] { need(trk, "trk"); if (trk->oc) trk->oc->reset(); else if (trk->tt) trk->tt->reset(); else trk->impl->reset(); });
 }
 int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* conf, const int* cls,
                        const double* gmc_affine, int cap, int* n_out, float* out_xyxy, int* out_id, float* out_score,
@@ -658,6 +659,7 @@ int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* 
     need(trk, "trk"); need(n_out, "n_out");
     if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
     if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+    else if (trk->tt) trk->tt->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
     else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
   });
 }
@@ -669,6 +671,7 @@ int gtx_tracker_update_feats(gtx_tracker* trk, int n, const float* xyxy, const f
     need(trk, "trk"); need(n_out, "n_out");
     if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
     if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);   // no appearance branch there
+    else if (trk->tt) trk->tt->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
     else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx, feats, feat_dim);
   });
 }
@@ -703,6 +706,8 @@ int gtx_tracker_replay(gtx_tracker* trk, const double* recs, int n_recs, int str
       if (room <= 0 && n > 0) gtx::fail(GTX_ERR_INVALID, "replay: more than %d track rows", row_cap);
       if (trk->oc)
         trk->oc->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
+      else if (trk->tt)
+        trk->tt->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
       else
         trk->impl->update(n, xyxy.data(), conf.data(), cls.data(), gmc, room, &k, ox, row_id + used, row_score + used, row_cls + used, row_det_idx + used);
       rows_per_frame[f] = k;

@@ -35,6 +35,20 @@ class OcSortTracker {
   std::unique_ptr<Impl> impl_;
 };
 
+// TrackTrack (tracker.tracktrack, default.yaml:445-470): tracktrack.cpp. Same update() contract.
+class TrackTrackTracker {
+ public:
+  explicit TrackTrackTracker(const gtx_tracker_config& cfg);
+  ~TrackTrackTracker();
+  void reset();
+  void update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
+              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+
 // Minimum-cost assignment of a dense rows x cols matrix that matches min(rows, cols) pairs (what
 // scipy.optimize.linear_sum_assignment / lap.lapjv(extend_cost=True) return). x[r] = column of row r or -1.
 void lap_full(const std::vector<double>& cost, int rows, int cols, std::vector<int>& x);
@@ -46,4 +60,5 @@ void lap_limited(const float* cost, int rows, int cols, double limit, std::vecto
 struct gtx_tracker {
   std::unique_ptr<gtx::ByteTracker> impl;
   std::unique_ptr<gtx::OcSortTracker> oc;
+  std::unique_ptr<gtx::TrackTrackTracker> tt;
 };

@@ -46,6 +46,9 @@ class TrackerConfig(C.Structure):
         ("dampen_motion_occ", C.c_float), ("active_occ_to_lost_thresh", C.c_int), ("occ_cover_thresh", C.c_float),
         ("occ_reappear_window", C.c_int), ("init_iou_suppress", C.c_float),
         ("with_reid", C.c_int), ("proximity_thresh", C.c_float), ("appearance_thresh", C.c_float),
+        ("lost_match_thr", C.c_float), ("iou_weight", C.c_float), ("reid_weight", C.c_float), ("conf_weight", C.c_float),
+        ("angle_weight", C.c_float), ("penalty_p", C.c_float), ("penalty_q", C.c_float), ("reduce_step", C.c_float),
+        ("tai_thr", C.c_float), ("min_track_len", C.c_int),
     ]
 
 

@@ -158,7 +158,7 @@ class YOLO:
         ttype = params.get("tracker_type", "botsort")
         if ttype not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker_type '{ttype}' is not implemented (available: {sorted(TRACKER_TYPES)})")
-        if ttype in ("botsort", "deepocsort"):                # the two trackers that take a camera-motion warp per frame
+        if ttype in ("botsort", "deepocsort", "tracktrack"):  # the trackers that take a camera-motion warp per frame
             if params.get("with_reid"):
                 # botsort + `model: auto` (default.yaml:376-379): appearance vectors from the detector's own feature maps
                 # (Detector(obj_feats=True) -> Tracker.update(feats=)); a separate ReID network's weights cannot be read here
@@ -176,6 +176,13 @@ class YOLO:
         else:
             self._gmc_method = None
         self._gmc = None
+        if ttype == "tracktrack" and not getattr(self, "_tracktrack_warned", False):
+            self._tracktrack_warned = True
+            logger.warning("tracker 'tracktrack': written from the description of its parameters in the config and the published method (height-modulated "
+                           "IoU + confidence + corner-angle cost, iterative mutual-minimum assignment under a shrinking threshold, track-aware "
+                           "initialisation); no appearance model (reid_weight falls back to the HMIoU distance), penalty_q has nothing to act on; the "
+                           "pinned ultralytics' implementation may differ where that description leaves a choice open (oracle/tracktrack_ref.py lists "
+                           "the choices). Score a reference run with tools/score_run.py to pin it.")
         if ttype == "fasttrack" and not getattr(self, "_fasttrack_warned", False):
             self._fasttrack_warned = True
             logger.warning("tracker 'fasttrack': written from the description of its parameters in the config (occlusion test by box cover, "
@@ -193,7 +200,8 @@ class YOLO:
             "track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer", "match_thresh", "fuse_score",
             "delta_t", "inertia", "use_byte", "min_hits", "reset_velocity_offset_occ", "reset_pos_offset_occ", "enlarge_bbox_occ",
             "dampen_motion_occ", "active_occ_to_lost_thresh", "occ_cover_thresh", "occ_reappear_window", "init_iou_suppress",
-            "with_reid", "proximity_thresh", "appearance_thresh")})
+            "with_reid", "proximity_thresh", "appearance_thresh", "lost_match_thr", "iou_weight", "reid_weight", "conf_weight", "angle_weight",
+            "penalty_p", "penalty_q", "reduce_step", "tai_thr", "min_track_len")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:

@@ -6,7 +6,8 @@ cfg -> tracker (geotrax/cfg/default.yaml:361-389). Runs on the host (C++), one f
 implementation (csrc/ocsort.cpp), `deepocsort` (default.yaml:406-427) the same tracker with camera-motion compensation by the warp
 handed to update() (no appearance branch there); `botsort` with `with_reid: true, model: auto` associates on the detector's own appearance
 vectors as well (update(..., feats=), csrc/tracker.cpp reid_costs); `fasttrack` (default.yaml:426-443) ByteTrack with occlusion handling, written from the
-config's own description of its parameters (csrc/tracker.cpp type 4, oracle/fasttrack_ref.py); tracktrack is not implemented and raises.
+config's own description of its parameters (csrc/tracker.cpp type 4, oracle/fasttrack_ref.py); `tracktrack` (default.yaml:445-470) the
+multi-cue cost + iterative assignment + track-aware initialisation tracker, written the same way (csrc/tracktrack.cpp, oracle/tracktrack_ref.py).
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import numpy as np
 from . import _lib
 from ._lib import TrackerConfig, check, ptr
 
-TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2, "deepocsort": 3, "fasttrack": 4}
+TRACKER_TYPES = {"bytetrack": 0, "botsort": 1, "ocsort": 2, "deepocsort": 3, "fasttrack": 4, "tracktrack": 5}
 
 
 class Tracker:
@@ -27,7 +28,9 @@ class Tracker:
                  use_byte: bool = False, min_hits: int = 3, reset_velocity_offset_occ: int = 5, reset_pos_offset_occ: int = 3,
                  enlarge_bbox_occ: float = 1.1, dampen_motion_occ: float = 0.5, active_occ_to_lost_thresh: int = 10,
                  occ_cover_thresh: float = 0.7, occ_reappear_window: int = 40, init_iou_suppress: float = 0.7,
-                 with_reid: bool = False, proximity_thresh: float = 0.5, appearance_thresh: float = 0.8, **_ignored):
+                 with_reid: bool = False, proximity_thresh: float = 0.5, appearance_thresh: float = 0.8,
+                 lost_match_thr: float = 0.0, iou_weight: float = 0.5, reid_weight: float = 0.5, conf_weight: float = 0.1, angle_weight: float = 0.05,
+                 penalty_p: float = 0.2, penalty_q: float = 0.4, reduce_step: float = 0.05, tai_thr: float = 0.55, min_track_len: int = 3, **_ignored):
         if tracker_type not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         self.lib = _lib.load()
@@ -40,7 +43,10 @@ class Tracker:
                             dampen_motion_occ=float(dampen_motion_occ), active_occ_to_lost_thresh=int(active_occ_to_lost_thresh),
                             occ_cover_thresh=float(occ_cover_thresh), occ_reappear_window=int(occ_reappear_window),
                             init_iou_suppress=float(init_iou_suppress), with_reid=int(bool(with_reid) and tracker_type == "botsort"),
-                            proximity_thresh=float(proximity_thresh), appearance_thresh=float(appearance_thresh))
+                            proximity_thresh=float(proximity_thresh), appearance_thresh=float(appearance_thresh),
+                            lost_match_thr=float(lost_match_thr), iou_weight=float(iou_weight), reid_weight=float(reid_weight),
+                            conf_weight=float(conf_weight), angle_weight=float(angle_weight), penalty_p=float(penalty_p), penalty_q=float(penalty_q),
+                            reduce_step=float(reduce_step), tai_thr=float(tai_thr), min_track_len=int(min_track_len))
         self.with_reid = bool(cfg.with_reid)
         h = C.c_void_p()
         check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))

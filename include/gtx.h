@@ -44,7 +44,8 @@ extern "C" {
  * 6: gtx_device_open_null_stream, gtx_write_table_f32 / _f64, gtx_write_csv and gtx_track_anchor_walk added.
  * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct.
  * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
- *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added. */
+ *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added;
+ *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended. */
 #define GTX_ABI_VERSION 8
 
 typedef enum gtx_status {
@@ -314,7 +315,8 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
 typedef struct gtx_tracker_config {
   int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404), 3 = deepocsort without the
                               appearance branch: ocsort + camera-motion compensation by gmc_affine (default.yaml:406-427),
-                              4 = fasttrack (default.yaml:426-443): ByteTrack + the occlusion handling of the fields at the end */
+                              4 = fasttrack (default.yaml:426-443): ByteTrack + the occlusion handling of the fields at the end,
+                              5 = tracktrack (default.yaml:445-470): multi-cue cost + iterative assignment + track-aware initialisation */
   float track_high_thresh;
   float track_low_thresh;
   float new_track_thresh;
@@ -342,6 +344,13 @@ typedef struct gtx_tracker_config {
   int with_reid;
   float proximity_thresh;
   float appearance_thresh;
+  /* TrackTrack only (type 5): tracker.tracktrack.* of the reference's config, same names and meaning (default.yaml:453-468);
+   * penalty_q is accepted and has nothing to act on (the tracker sees the detector's NMS output only) */
+  float lost_match_thr;
+  float iou_weight, reid_weight, conf_weight, angle_weight;
+  float penalty_p, penalty_q, reduce_step;
+  float tai_thr;
+  int min_track_len;
 } gtx_tracker_config;
 
 int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);

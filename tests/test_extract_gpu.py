@@ -49,6 +49,8 @@ def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=
     cfg["ultralytics"].update(imgsz=IMGSZ, half=half, max_det=300, rect=True)
     cfg["stabilo"].update(STAB)
     cfg["tracker"]["active"] = tracker
+    if tracker == "tracktrack":                                # the seeded weights' detections sit just above conf = 0.25: far below tracktrack's 0.6 / 0.7
+        cfg["tracker"][tracker].update(track_high_thresh=0.25, new_track_thresh=0.25, track_low_thresh=0.1, min_track_len=2)
     if gmc_method is not None:                                 # deepocsort ships with gmc_method: none (default.yaml:421)
         cfg["tracker"][tracker]["gmc_method"] = gmc_method
         # the seeded weights are calibrated so that the detections sit just above conf = 0.25: below deepocsort's own 0.3
@@ -84,12 +86,16 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
         from oracle.fasttrack_ref import FastTrackRef
 
         trk = FastTrackRef(**{k: v for k, v in tp.items() if k != "tracker_type"})
+    elif active == "tracktrack":
+        from oracle.tracktrack_ref import TrackTrackRef
+
+        trk = TrackTrackRef(**{k: v for k, v in tp.items() if k not in ("tracker_type", "gmc_method", "with_reid", "model")})
     else:
         trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
                                                                                  "track_buffer", "match_thresh", "fuse_score")},
                            **({k: tp[k] for k in ("with_reid", "proximity_thresh", "appearance_thresh")} if active == "botsort" else {}))
     reid = active == "botsort" and bool(tp.get("with_reid"))
-    gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort") and tp.get("gmc_method") == "sparseOptFlow" else None
+    gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort", "tracktrack") and tp.get("gmc_method") == "sparseOptFlow" else None
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
@@ -130,7 +136,7 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack", "tracktrack"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     reid = tracker == "botsort+reid"        # BoT-SORT's appearance branch on detector-derived vectors (`with_reid: true, model: auto`)
     tracker = tracker.split("+")[0]

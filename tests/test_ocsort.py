@@ -87,7 +87,7 @@ def test_ocsort_contract_details():
 
 def test_config_selects_ocsort(tmp_path):
     """tracker.active: ocsort resolves through the config surface to the C++ OC-SORT with the block's parameters; the
-    tracker this build does not have says so (FastTracker is built since round 5: tests/test_fasttrack.py)."""
+    tracker this build does not have says so (FastTracker and TrackTrack are built since round 5: tests/test_fasttrack.py, test_tracktrack.py)."""
     from geotrax_amd.model import YOLO
     from geotrax_amd.tracker import Tracker
 
@@ -96,8 +96,12 @@ def test_config_selects_ocsort(tmp_path):
     t = m._make_tracker({"tracker_type": "ocsort", "track_high_thresh": 0.3, "delta_t": 2, "inertia": 0.1, "use_byte": True, "match_thresh": 0.75})
     assert isinstance(t, Tracker) and m._gmc_method is None
     with pytest.raises(NotImplementedError):
-        m._make_tracker({"tracker_type": "tracktrack"})
+        m._make_tracker({"tracker_type": "strongsort"})
     assert isinstance(m._make_tracker({"tracker_type": "fasttrack", "occ_cover_thresh": 0.6}), Tracker)
+    t = m._make_tracker({"tracker_type": "tracktrack", "gmc_method": "sparseOptFlow", "tai_thr": 0.5})   # round 5: tests/test_tracktrack.py
+    assert isinstance(t, Tracker) and m._gmc_method == "sparseOptFlow"
+    with pytest.raises(NotImplementedError):
+        m._make_tracker({"tracker_type": "tracktrack", "with_reid": True})
 
 
 @pytest.mark.parametrize("kind", ["bytetrack", "botsort", "ocsort"])

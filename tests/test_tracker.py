@@ -141,7 +141,7 @@ def test_tracker_rejects_unknown_type():
     from geotrax_amd.tracker import Tracker
 
     with pytest.raises(NotImplementedError):
-        Tracker("tracktrack")
+        Tracker("strongsort")
 
 
 def _stream_with_feats(seed, dim=128, **kw):

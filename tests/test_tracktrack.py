@@ -1,0 +1,109 @@
+"""TrackTrack (tracker.tracktrack, default.yaml:445-470; csrc/tracktrack.cpp behind gtx_tracker_*, type 5) against
+oracle/tracktrack_ref.py on seeded streams, plus the behaviours its parameters describe. CPU only."""
+import numpy as np
+import pytest
+
+from test_tracker import _stream
+
+
+def _run(kw, stream, gmc_seed=None):
+    from geotrax_amd.tracker import Tracker
+    from oracle.tracktrack_ref import TrackTrackRef
+
+    trk, ref = Tracker("tracktrack", **kw), TrackTrackRef(**kw)
+    rng = np.random.default_rng(gmc_seed or 0)
+    rows = 0
+    for t, (xyxy, conf, cls) in enumerate(stream):
+        gmc = None
+        if gmc_seed is not None:
+            gmc = np.array([[1 + 1e-4 * rng.normal(), 1e-4 * rng.normal(), 0.3 * rng.normal()],
+                            [1e-4 * rng.normal(), 1 + 1e-4 * rng.normal(), 0.3 * rng.normal()]])
+        b, i, s, c, d = trk.update(xyxy, conf, cls, gmc)
+        r = ref.update(xyxy, conf, cls, gmc)
+        assert len(i) == len(r), f"frame {t}: {len(i)} tracks vs {len(r)}"
+        np.testing.assert_array_equal(i, r[:, 4].astype(np.int32), err_msg=f"frame {t} ids")
+        np.testing.assert_array_equal(d, r[:, 7].astype(np.int32), err_msg=f"frame {t} detection index")
+        np.testing.assert_array_equal(c, r[:, 6].astype(np.int32))
+        np.testing.assert_allclose(b, r[:, :4], rtol=0, atol=2e-3)
+        rows += len(i)
+    return rows
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("with_gmc", [False, True])
+def test_tracktrack_matches_oracle(seed, with_gmc):
+    kw = dict(track_high_thresh=0.6, track_low_thresh=0.25, new_track_thresh=0.7, match_thresh=0.7, min_track_len=3)
+    assert _run(kw, _stream(seed, n_obj=60, jitter=3.0, p_miss=0.12), gmc_seed=seed + 7 if with_gmc else None) > 800
+
+
+def test_tracktrack_lost_rebinding_and_other_knobs_match_oracle():
+    kw = dict(track_high_thresh=0.5, track_low_thresh=0.2, new_track_thresh=0.55, match_thresh=0.8, lost_match_thr=0.9, reduce_step=0.1,
+              penalty_p=0.1, tai_thr=0.4, min_track_len=2, angle_weight=0.2, conf_weight=0.2, track_buffer=10)
+    assert _run(kw, _stream(5, n_obj=80, jitter=5.0, p_miss=0.25, p_low=0.2)) > 800
+
+
+def _box(cx, cy, w=60.0, h=40.0):
+    return [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2]
+
+
+def test_tracks_are_reported_from_their_third_observation_and_keep_their_identity():
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("tracktrack")
+    seen = []
+    for t in range(8):
+        boxes = np.array([_box(100 + 4 * t, 100), _box(400, 300 + 3 * t)], np.float32)
+        if t == 2:                                                  # a third object appears on the third frame
+            pass
+        if t >= 2:
+            boxes = np.vstack([boxes, _box(700 - 5 * t, 500)]).astype(np.float32)
+        _, ids, *_ = trk.update(boxes, np.full(len(boxes), 0.9, np.float32), np.zeros(len(boxes), np.int32))
+        seen.append(sorted(ids.tolist()))
+    assert seen[0] == [1, 2] and seen[1] == [1, 2]                  # the clip's first frame reports at once (like ByteTrack)
+    assert seen[2] == [1, 2] and seen[3] == [1, 2]                  # the newcomer has one, then two observations
+    assert seen[4] == [1, 2, 3] and seen[7] == [1, 2, 3]            # min_track_len = 3 observations: reported, same ids throughout
+
+
+def test_track_aware_initialisation_drops_a_detection_on_top_of_a_matched_track():
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("tracktrack", min_track_len=1)
+    one = np.array([_box(200, 200)], np.float32)
+    for _ in range(3):
+        _, ids, *_ = trk.update(one, np.array([0.9], np.float32), np.zeros(1, np.int32))
+    assert ids.tolist() == [1]
+    two = np.array([_box(200, 200), _box(206, 203)], np.float32)    # IoU 0.76 with the tracked box: above tai_thr 0.55
+    _, ids, *_ = trk.update(two, np.array([0.9, 0.85], np.float32), np.zeros(2, np.int32))
+    assert ids.tolist() == [1]
+    far = np.array([_box(200, 200), _box(260, 200)], np.float32)    # IoU 0: a new object
+    _, ids, *_ = trk.update(far, np.array([0.9, 0.85], np.float32), np.zeros(2, np.int32))
+    assert sorted(ids.tolist()) == [1, 2]
+
+
+def test_low_confidence_detections_keep_a_track_but_start_none():
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("tracktrack", min_track_len=1, track_high_thresh=0.6, track_low_thresh=0.25, new_track_thresh=0.7)   # the config's values
+    b = np.array([_box(300, 300)], np.float32)
+    trk.update(b, np.array([0.9], np.float32), np.zeros(1, np.int32))
+    _, ids, score, *_ = trk.update(b, np.array([0.4], np.float32), np.zeros(1, np.int32))     # between low (0.25) and high (0.6): cost + penalty_p
+    assert ids.tolist() == [1] and abs(float(score[0]) - 0.4) < 1e-6
+    other = np.array([_box(300, 300), _box(900, 900)], np.float32)
+    _, ids, *_ = trk.update(other, np.array([0.9, 0.65], np.float32), np.zeros(2, np.int32))   # 0.65 < new_track_thresh 0.7
+    assert ids.tolist() == [1]
+
+
+def test_mutual_minimum_assignment_prefers_the_closer_pair():
+    """Two tracks, one detection overlapping both: the detection goes to the track whose cost is lower (row and column minimum),
+    the other track goes lost and comes back when its own detection returns."""
+    from geotrax_amd.tracker import Tracker
+
+    trk = Tracker("tracktrack", min_track_len=1)
+    two = np.array([_box(300, 300), _box(330, 300)], np.float32)
+    for _ in range(3):
+        _, ids, *_ = trk.update(two, np.array([0.9, 0.9], np.float32), np.zeros(2, np.int32))
+    assert sorted(ids.tolist()) == [1, 2]
+    _, ids, _, _, didx = trk.update(np.array([_box(304, 300)], np.float32), np.array([0.9], np.float32), np.zeros(1, np.int32))
+    assert ids.tolist() == [1]
+    _, ids, *_ = trk.update(two, np.array([0.9, 0.9], np.float32), np.zeros(2, np.int32))
+    assert sorted(ids.tolist()) == [1, 2]
