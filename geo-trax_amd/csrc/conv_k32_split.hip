@@ -30,7 +30,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 // Timing-only builds (`make k32probe`, wrong results): GTXK_PROBE bit 0 = no barriers inside a chunk (rows 1, 2), bit 1 = no weight
 // commits (LDS stores) for rows 1, 2, bit 2 = no MFMAs, bit 3 = no weight loads from global for rows 1, 2, bit 5 = no weight fragment reads from LDS (the first tap's stay in registers),
-// bit 6 = no pixel fragment reads from LDS after a chunk's first tap
+// bit 6 = no pixel fragment reads from LDS after a chunk's first tap, bit 7 = the first chunk's global loads skipped (what a workgroup
+// that had requested them under the previous tile's epilogue would see), bit 8 = no epilogue (one store per lane)
 #ifndef GTXK_PROBE
 #define GTXK_PROBE 0
 #endif
@@ -169,8 +170,14 @@ void conv_k32_split_kernel(const ConvGroup g) {
     d__[0] = pw0; d__[256] = pw1; d__[512] = pw2; d__[768] = pw3; d__[1024] = pw4; d__[1280] = pw5; \
   }
 
-  GTXK_PREFETCH_PATCH(0)
-  GTXK_PREFETCH_W(0)
+  if (GTXK_PROBE & 128) {                          // timing-only: the first chunk's loads cost nothing
+#pragma unroll
+    for (int s = 0; s < Tile::PATCH_SLOTS; ++s) pre_a[s] = pre_b[s] = make_uint4(tid, s, 0, 0);
+    pw0 = pw1 = pw2 = pw3 = pw4 = pw5 = make_uint4(tid, 1, 2, 3);
+  } else {
+    GTXK_PREFETCH_PATCH(0)
+    GTXK_PREFETCH_W(0)
+  }
 
   // accumulators start at bias / acc_scale (conv_igemm_split.hip): lane (col, kg) of block a holds couts 16 a + 4 kg + 0..3
   floatx4 acc[4][2];
@@ -267,6 +274,14 @@ void conv_k32_split_kernel(const ConvGroup g) {
   // Lane (col, kg) of block (a, m) holds couts 16 a + 4 kg + 0..3 of pixel (row 2 wave + m, col): lanes kg = 2 q and 2 q + 1 hold
   // the two halves of the 8-channel group 2 a + q, and two v_permlane16_swap turn them into the group's 16-byte hi chunk (even kg)
   // and lo chunk (odd kg) -- byte 64 a + 16 kg of the pixel's 256-byte run. Staged per wave in LDS, stored as whole runs.
+  if (GTXK_PROBE & 256) {
+    floatx4 t = acc[0][0];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { t += acc[a][0]; t += acc[a][1]; }
+    const int oy = oy0 + 2 * wave, ox = ox0 + col;
+    if (oy < P.Ho && ox < P.Wo) *reinterpret_cast<floatx4*>(static_cast<float*>(P.out) + (((size_t)n * P.Ho + oy) * P.Wo + ox) * P.out_cstride + P.out_coff + ct * BN + 4 * kg) = t;
+    return;
+  }
   const float sc = P.acc_scale;
   const int cvalid = P.Cout - ct * BN;
   const bool plain = P.out_plain != 0;
