@@ -49,8 +49,9 @@ HBM_PEAK_GBS = 8000.0
 # fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is the dense fp16 peak / 3
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0 / 3.0}
 DTYPE_NAME = {"f16": "f16", "f32": "f32", "f32s": "f32 (split-f16x3 MFMA)"}
-TRACKER_LABEL = {"bytetrack": "ByteTrack", "botsort": "BoT-SORT (GPU GMC)", "ocsort": "OC-SORT", "deepocsort": "Deep OC-SORT motion half (GPU GMC)"}
-GMC_TRACKERS = ("botsort", "deepocsort")   # trackers that take a camera-motion warp per frame (bench runs them with gmc_method: sparseOptFlow)
+TRACKER_LABEL = {"bytetrack": "ByteTrack", "botsort": "BoT-SORT (GPU GMC)", "ocsort": "OC-SORT", "deepocsort": "Deep OC-SORT motion half (GPU GMC)",
+                 "fasttrack": "FastTracker", "tracktrack": "TrackTrack (GPU GMC; association thresholds of the other trackers: the seeded boxes sit just above conf 0.25)"}
+GMC_TRACKERS = ("botsort", "deepocsort", "tracktrack")   # trackers that take a camera-motion warp per frame (bench runs them with gmc_method: sparseOptFlow)
 H, W = 2160, 3840
 # seeded weights of the bench: only the stride-8 head fires, DFL biases give ~120 x 60 px boxes in 4K, and the class
 # branch is spatially smooth so that candidates come in clusters and NMS suppresses about half of them
@@ -85,7 +86,7 @@ def parse():
                          "fp32 accumulate). Default: the library's default (geotrax_amd.detector.FP32_SPLIT_DEFAULT)")
     ap.add_argument("--rect", type=int, default=0, help="ultralytics.rect (reference config: false -> 1920x1920 input)")
     ap.add_argument("--imgsz", type=int, default=1920)
-    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort", "deepocsort"],
+    ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort", "deepocsort", "fasttrack", "tracktrack"],
                     help="default: bytetrack at N = 1 (BASELINE configs[2]), botsort at N > 1 (configs[4]; the reference's own default, default.yaml:362)")
     ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
     ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")
