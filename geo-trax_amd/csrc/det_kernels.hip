@@ -989,8 +989,9 @@ __global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, co
     const HeadLevel& L = hp.lv[l];
     const int la = a - L.anchor_begin;
     const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
-    const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
+    float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
     const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
+    if (nb.sparse_feat) f0 = i < nb.sparse_cap ? nb.sparse_feat[((size_t)n * nb.sparse_cap + i) * 64 + lane] : 0.f;   // cb == 64 (head_sparse.hip)
     float acc = L.bb[lane];
     const float* wr = s_wb + l * cbmax * 64 + lane;
     const int k0 = min(L.cb, 64);
@@ -1027,12 +1028,20 @@ __global__ __launch_bounds__(256) void head_raw_kernel(const HeadParams hp, floa
 }
 
 void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
+  launch_head_gate(dtype, hp, n, nb, s);
+  launch_head_boxes(dtype, hp, n, nb, s);
+}
+
+void launch_head_gate(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
   GTX_HIP(hipMemsetAsync(nb.count, 0, sizeof(int) * n, s));
   dim3 grid(cdiv(hp.n_anchors, 16), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(head_candidates_kernel<_Float16>, grid, block, 0, s, hp, nb);
   else hipLaunchKernelGGL(head_candidates_kernel<float>, grid, block, 0, s, hp, nb);
   GTX_HIP(hipGetLastError());
-  dim3 grid2(64, n);
+}
+
+void launch_head_boxes(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
+  dim3 grid2(64, n), block(256);
   const size_t lds = (size_t)hp.n_levels * hp.lv[0].cb * 64 * sizeof(float);
   static std::once_flag once;     // detectors run on several host threads (engine stage 1, set_reference)
   std::call_once(once, [] {

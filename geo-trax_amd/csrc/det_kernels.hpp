@@ -82,6 +82,9 @@ struct NmsBuffers {
   int* out_n;           // [N]
   float* out_rows;      // [N][max_det][6] x1 y1 x2 y2 conf cls (frame pixels)
   int* out_anchor;      // [N][max_det] anchor index of every output row (may be null)
+  // box features of the candidates from the sparse box branch ([N][sparse_cap][cb] fp32; null: the decode reads HeadLevel::feat)
+  const float* sparse_feat;
+  int sparse_cap;
 };
 
 // Per-object appearance vectors "from the detector" (ultralytics BoT-SORT `with_reid: true, model: auto`,
@@ -97,7 +100,30 @@ struct FeatLevels {
 // out: [N][max_det][dim] fp32, rows [0, out_n[n]) of image n written
 void launch_obj_feats(int dtype, const FeatLevels& fl, int n, const NmsBuffers& nb, float* out, hipStream_t s);
 
+// launch_head_candidates = the score gate (class branch, compaction) followed by the box decode of the candidates; the two halves
+// are also available on their own so that the sparse box branch (head_sparse.hip) can run between them.
 void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
+void launch_head_gate(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
+void launch_head_boxes(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s);
+
+// The Detect box branch (cv2[l][0]: Cin -> 64 and cv2[l][1]: 64 -> 64, both 3x3 + SiLU) evaluated at the candidate anchors only
+// (head_sparse.hip; split-f16x3 path). Per level: the Detect input (pair format), the packed weight image of the first layer's
+// 64-cout tile and of the second layer (pack_conv_weights_split with 32-channel chunks), their biases and power-of-two scales.
+struct SparseBoxLevel {
+  const void* in;
+  int H, W, cstride, coff, cin;
+  const void* w1; const float* b1; float sc1;
+  const void* w2; const float* b2; float sc2;
+  int anchor_begin;
+};
+struct SparseBox {
+  SparseBoxLevel lv[kMaxLevels];
+  int n_levels;
+  int cap;              // candidates per image the buffer holds (more: the caller runs the dense layers)
+  float* feat;          // [N][cap][64] fp32: the box features of candidate i, read by the decode when NmsBuffers::sparse_feat is set
+  int* sat_flag;
+};
+void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s);
 // Decode every anchor (debug / parity): out [N][A][4+nc] fp32 = xywh (network px) + class scores
 // (or class logits).
 void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, bool logits, hipStream_t s);

@@ -33,6 +33,7 @@ Detector::~Detector() {
   if (h_sat_) (void)hipHostFree(h_sat_);
   if (h_out_rows_) (void)hipHostFree(h_out_rows_);
   if (h_feats_) (void)hipHostFree(h_feats_);
+  if (h_count_) (void)hipHostFree(h_count_);
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_up_)
@@ -79,6 +80,11 @@ View Detector::new_view(int h, int w, int c) {
 }
 
 namespace {
+bool env_flag(const char* name, bool dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? e[0] != '0' : dflt;
+}
+
 // Packed weight images are a pure function of (tensor bytes, tile configuration). An engine builds several detectors from
 // the same tensors (one per stream) and a run builds engines video after video: the image is made once per process and
 // shared (packing YOLOv8s takes ~0.15 s of host time per detector, most of what creating one costs).
@@ -409,23 +415,16 @@ void Detector::build_graph() {
     GTX_CHECK(ops_.size() == mark + 3, "internal: head op count");
     Op o1 = ops_[mark], o2 = ops_[mark + 1], o3 = ops_[mark + 2];
     ops_.resize(mark);
-    auto same = [](const ConvConfig& a, const ConvConfig& b) {
-      return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc &&
-             a.variant == b.variant && a.th == b.th && a.tw == b.tw;
-    };
-    auto add = [&](std::vector<Op>& stage, const char* name, const Op& o) {
-      for (Op& g : stage)
-        if (same(g.cfg, o.cfg) && g.grp.count < kMaxGroup) { g.grp.p[g.grp.count++] = o.grp.p[0]; return; }
-      Op g;
-      g.kind = Op::CONV;
-      g.name = stage.empty() ? std::string(name) : std::string(name) + "." + std::to_string(stage.size());
-      g.cfg = o.cfg;
-      g.grp.p[g.grp.count++] = o.grp.p[0];
-      stage.push_back(g);
-    };
-    add(st1, "model.22.stage1", o1);
-    add(st2, "model.22.stage2", o2);
-    add(st2, "model.22.stage2", o3);
+    // Sparse box branch (head_sparse.hip): the box half of stage 1 (cout tile 0 of the stacked image) and cv2[l][1] are evaluated
+    // at the candidate anchors only, after the score gate; stage 1 keeps its class half (cout tiles 1..), same packed image,
+    // same scale. Needs the 16x16x32 kernel's image (32-channel chunks, one 64-cout box tile); decided for all levels at once.
+    if (l == 0) {
+      sparse_on_ = conv_dtype_ == DT_F32S && env_flag("GTX_SPARSE_BOX", true);
+      sparse_ = SparseBox{};
+      dense_box_ops_.clear();
+    }
+    sparse_on_ = sparse_on_ && cb == 64 && o1.cfg.variant == 5 && o1.cfg.bn == 64 && o2.cfg.variant == 5 && cin % 32 == 0;
+    head_ops_[l][0] = o1; head_ops_[l][1] = o2; head_ops_[l][2] = o3;
 
     HeadLevel& L = head_.lv[l];
     L.feat = h2.ptr; L.h = h2.h; L.w = h2.w; L.cstride = h2.cstride; L.cb = cb; L.cc = cc;
@@ -453,6 +452,58 @@ void Detector::build_graph() {
     layer_views_["model.22.feat" + std::to_string(l)] = h2;
   }
   head_.n_anchors = anchor;
+  {
+    auto same = [](const ConvConfig& a, const ConvConfig& b) {
+      return a.dtype == b.dtype && a.ks == b.ks && a.stride == b.stride && a.bn == b.bn && a.kc == b.kc &&
+             a.variant == b.variant && a.th == b.th && a.tw == b.tw;
+    };
+    auto add = [&](std::vector<Op>& stage, const char* name, const Op& o) {
+      for (Op& g : stage)
+        if (same(g.cfg, o.cfg) && g.grp.count < kMaxGroup) { g.grp.p[g.grp.count++] = o.grp.p[0]; return; }
+      Op g;
+      g.kind = Op::CONV;
+      g.name = stage.empty() ? std::string(name) : std::string(name) + "." + std::to_string(stage.size());
+      g.cfg = o.cfg;
+      g.grp.p[g.grp.count++] = o.grp.p[0];
+      stage.push_back(g);
+    };
+    std::vector<Op> d1, d2;                          // the dense box layers, kept for the debug read-backs and the overflow case
+    for (int l = 0; l < 3; ++l) {
+      Op o1 = head_ops_[l][0];
+      const Op &o2 = head_ops_[l][1], &o3 = head_ops_[l][2];
+      if (sparse_on_) {
+        const ConvProblem full = o1.grp.p[0];
+        const int cb = head_.lv[l].cb, cc = head_.lv[l].cc;
+        const size_t tile_bytes = (size_t)(full.Cin / o1.cfg.kc) * 9 * 64 * 128;   // one 64-cout tile of the packed image
+        SparseBoxLevel& S = sparse_.lv[l];
+        S.in = full.in; S.H = full.H; S.W = full.W; S.cstride = full.in_cstride; S.coff = full.in_coff; S.cin = full.Cin;
+        S.w1 = full.wpack; S.b1 = full.bias; S.sc1 = full.acc_scale;
+        S.w2 = o2.grp.p[0].wpack; S.b2 = o2.grp.p[0].bias; S.sc2 = o2.grp.p[0].acc_scale;
+        S.anchor_begin = head_.lv[l].anchor_begin;
+        GTX_CHECK(full.bias && o2.grp.p[0].bias && o2.grp.p[0].Cin == 64 && o2.grp.p[0].Cout == 64, "sparse box branch: unexpected Detect box layers");
+        Op box1 = o1;                                // the box tile alone
+        box1.grp.p[0].Cout = cb;
+        add(d1, "model.22.box1", box1);
+        add(d2, "model.22.box2", o2);
+        ConvProblem& p = o1.grp.p[0];                // the class tiles alone
+        p.wpack = static_cast<const char*>(full.wpack) + tile_bytes;
+        p.bias = full.bias + 64;
+        p.Cout = cc;
+        p.out_coff = full.out_coff + cb;
+        add(st1, "model.22.stage1", o1);
+        add(st2, "model.22.stage2", o3);
+      } else {
+        add(st1, "model.22.stage1", o1);
+        add(st2, "model.22.stage2", o2);
+        add(st2, "model.22.stage2", o3);
+      }
+    }
+    if (sparse_on_) {
+      sparse_.n_levels = 3;
+      for (std::vector<Op>* stage : {&d1, &d2})
+        for (Op& g : *stage) { g.family = conv_kernel_name(g.cfg); dense_box_ops_.push_back(g); }
+    }
+  }
   feat_levels_ = FeatLevels{};
   if (cfg_.obj_feats) {                           // `with_reid: true, model: auto`: the Detect layer's inputs, read after NMS
     feat_levels_.n_levels = 3;
@@ -657,6 +708,14 @@ void Detector::finalize() {
     d_feats_ = (float*)alloc(sizeof(float) * N * cfg_.max_det * feat_levels_.dim);
     GTX_HIP(hipHostMalloc((void**)&h_feats_, sizeof(float) * N * cfg_.max_det * feat_levels_.dim));
   }
+  if (sparse_on_) {
+    sparse_.cap = kSparseCap;
+    sparse_.feat = (float*)alloc(sizeof(float) * N * kSparseCap * 64);
+    sparse_.sat_flag = sat_dev_;
+    nms_.sparse_feat = sparse_.feat;
+    nms_.sparse_cap = kSparseCap;
+    GTX_HIP(hipHostMalloc((void**)&h_count_, sizeof(int) * N));
+  }
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
   if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
@@ -757,7 +816,16 @@ void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& l
 }
 
 void Detector::run_post(int nb, hipStream_t s) {
-  launch_head_candidates(dtype_, head_, nb, nms_, s);
+  if (sparse_on_) {                                // score gate -> the box branch at the candidates -> their boxes
+    NmsBuffers nbuf = nms_;
+    launch_head_gate(dtype_, head_, nb, nbuf, s);
+    launch_head_sparse_box(sparse_, nb, nbuf, s);
+    launch_head_boxes(dtype_, head_, nb, nbuf, s);
+    GTX_HIP(hipMemcpyAsync(h_count_, nms_.count, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+    dense_head_valid_ = false;
+  } else {
+    launch_head_candidates(dtype_, head_, nb, nms_, s);
+  }
   launch_nms(nms_, nb, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
   GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
@@ -766,6 +834,19 @@ void Detector::run_post(int nb, hipStream_t s) {
     launch_obj_feats(conv_dtype_, feat_levels_, nb, nms_, d_feats_, s);
     GTX_HIP(hipMemcpyAsync(h_feats_, d_feats_, sizeof(float) * nb * cfg_.max_det * feat_levels_.dim, hipMemcpyDeviceToHost, s));
   }
+}
+
+// The dense box layers of the Detect head on the activations of the pass that ran last (sparse mode leaves them out of the
+// forward): for the debug read-backs and for a batch with more candidates than the sparse buffer holds.
+void Detector::run_dense_box(hipStream_t s) {
+  if (!sparse_on_ || dense_head_valid_) return;
+  GTX_CHECK(cur_nb_ > 0, "no forward pass has run yet");
+  for (Op o : dense_box_ops_) {
+    for (int i = 0; i < o.grp.count; ++i) o.grp.p[i].N = cur_nb_;
+    conv_group_finalize(o.grp, o.cfg);
+    run_op(o, cur_nb_, s);
+  }
+  dense_head_valid_ = true;
 }
 
 void Detector::features(int b, float* out, int cap, int* n, int* dim) const {
@@ -865,6 +946,26 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
     }
     flight_traced_ = false;
   }
+  if (sparse_on_) {                                  // more candidates than the sparse buffer holds: the dense layers, then the tail again
+    bool over = false;
+    for (int b = 0; b < flight_nb_; ++b) over = over || h_count_[b] > kSparseCap;
+    if (over) {
+      hipStream_t s = ctx_->stream;
+      run_dense_box(s);
+      NmsBuffers dense = nms_;
+      dense.sparse_feat = nullptr;
+      launch_head_boxes(dtype_, head_, flight_nb_, dense, s);
+      launch_nms(dense, flight_nb_, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
+      GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * flight_nb_, hipMemcpyDeviceToHost, s));
+      GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * flight_nb_ * cfg_.max_det, hipMemcpyDeviceToHost, s));
+      if (cfg_.obj_feats) {
+        launch_obj_feats(conv_dtype_, feat_levels_, flight_nb_, nms_, d_feats_, s);
+        GTX_HIP(hipMemcpyAsync(h_feats_, d_feats_, sizeof(float) * flight_nb_ * cfg_.max_det * feat_levels_.dim, hipMemcpyDeviceToHost, s));
+      }
+      GTX_HIP(hipStreamSynchronize(s));
+      ++sparse_overflows_;
+    }
+  }
   const int nb = flight_nb_;
   if (cfg_.obj_feats) {                              // out of the pinned buffer before the next pass of this detector lands in it
     c_feat_n_.assign(cfg_.max_batch, 0);
@@ -928,6 +1029,8 @@ void Detector::raw_output(int b, float* out, int* n_anchors, bool logits) {
   GTX_CHECK(finalized_ && cur_nb_ > 0 && b >= 0 && b < cur_nb_, "raw_output: no forward pass for slot %d", b);
   const size_t per = (size_t)head_.n_anchors * (4 + head_.nc);
   if (raw_.bytes < per * cur_nb_ * sizeof(float)) raw_.alloc(per * cur_nb_ * sizeof(float));
+  GTX_CHECK(!in_flight_, "raw_output while a batch is in flight: call collect first");
+  run_dense_box(ctx_->stream);                     // the full decode reads every anchor's box features
   launch_head_raw(dtype_, head_, cur_nb_, raw_.as<float>(), logits, ctx_->stream);
   GTX_HIP(hipMemcpyAsync(out, raw_.as<float>() + per * b, per * sizeof(float), hipMemcpyDeviceToHost, ctx_->stream));
   GTX_HIP(hipStreamSynchronize(ctx_->stream));
@@ -943,6 +1046,11 @@ void Detector::layer_output(int b, const std::string& layer, float* out, int* h,
   auto it = layer_views_.find(layer);
   if (it == layer_views_.end()) fail(-1, "unknown layer '%s'", layer.c_str());
   const View& v = it->second;
+  if (out && sparse_on_ && cur_nb_ > 0 && (layer.rfind("model.22.", 0) == 0 || layer.rfind("__head", 0) == 0)) {
+    GTX_HIP(hipSetDevice(ctx_->device));
+    run_dense_box(ctx_->stream);                   // the head's box layers are not part of the forward in sparse mode
+    GTX_HIP(hipStreamSynchronize(ctx_->stream));
+  }
   if (out) {
     // an intermediate the fused launches no longer write (the stem's output, model.1's): run the stand-alone launches up to
     // it now -- the network input of the last pass is still in HBM. The last entry of unfused_ is a layer the fused launch

@@ -98,6 +98,10 @@ class Detector {
   // default.yaml:245); GTX_SAT_FALLBACK=0 keeps the flag only.
   bool saturated(bool clear);
   bool fell_back() const { return exact_ != nullptr; }
+  void sparse_box(int* on, int* overflows) const {
+    if (on) *on = (!exact_ && sparse_on_) ? 1 : 0;
+    if (overflows) *overflows = sparse_overflows_;
+  }
 
  private:
   void* alloc(size_t bytes);
@@ -160,6 +164,16 @@ class Detector {
   std::vector<Op> unfused_;  // the stand-alone forms of fused ops (layer_output of an intermediate runs them on demand)
   int* h_out_n_ = nullptr;   // pinned
   FeatLevels feat_levels_{};
+  // sparse box branch (head_sparse.hip): on for the split-f16x3 path when the head's layers have the 16x16x32 kernel's weight images
+  static constexpr int kSparseCap = 8192;   // candidates per image its buffer holds
+  bool sparse_on_ = false;
+  SparseBox sparse_{};
+  Op head_ops_[3][3];
+  std::vector<Op> dense_box_ops_;
+  bool dense_head_valid_ = false;
+  int* h_count_ = nullptr;   // pinned: candidates per image of the pass in flight
+  int sparse_overflows_ = 0;
+  void run_dense_box(hipStream_t s);
   float* d_feats_ = nullptr;  // [max_batch][max_det][dim]
   float* h_feats_ = nullptr;  // pinned
   std::vector<float> c_feats_;   // the collected batch's vectors

@@ -608,6 +608,9 @@ int gtx_detector_saturated(gtx_detector* det, int clear, int* flag) {
 int gtx_detector_fell_back(gtx_detector* det, int* fell_back) {
   return guarded([&] { need(det, "det"); need(fell_back, "fell_back"); *fell_back = det->impl->fell_back() ? 1 : 0; });
 }
+int gtx_detector_sparse_box(gtx_detector* det, int* on, int* overflows) {
+  return guarded([&] { need(det, "det"); det->impl->sparse_box(on, overflows); });
+}
 int gtx_detector_features(gtx_detector* det, int b, float* out, int cap, int* n, int* dim) {
   return guarded([&] { need(det, "det"); det->impl->features(b, out, cap, n, dim); });
 }

@@ -1,0 +1,183 @@
+// The Detect box branch at candidate anchors only (default fp32 path, split-f16x3). gfx950.
+//
+// Detect's box branch is two 3x3 convolutions (cv2[l][0]: Cin -> 64, cv2[l][1]: 64 -> 64) whose output is read by the decode at
+// the anchors that pass the score gate and nowhere else: a few hundred to a few thousand of the 75 600 anchors of a 1920 x 1920
+// input. This kernel evaluates the two layers for those anchors alone -- one wave per candidate: the 3 x 3 neighbourhood of
+// cv2[l][0] outputs the second layer needs (nine MFMA columns), then cv2[l][1] at the anchor -- with the arithmetic of the dense
+// kernels it replaces (conv_k32_split.hip: same packed weight images and power-of-two scales, same v_mfma_f32_16x16x32_f16
+// sequence per output pixel -- chunk, kernel row, kernel column, small terms first -- same bias start, SiLU and hi / lo split,
+// zero padding at the image border for both layers), so a candidate's 64 box features are the dense path's bit for bit.
+// The dense convolutions stay available (Detector: GTX_SPARSE_BOX=0, the debug read-backs, more candidates than the buffer holds).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "det_kernels.hpp"
+
+namespace gtx {
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#define GTXH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+// conv_k32_split.hip's epilogue arithmetic (same operations in the same order)
+__device__ __forceinline__ float2v silu2(const float2v v) {
+  const float2v t = v * -1.44269504088896341f;
+  const float2v d = float2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
+  return v * float2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ void split2(const float2v v, unsigned& hi, unsigned& lo, bool& sat) {
+  const float2v x = {__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f)};
+  sat |= x.x != v.x || x.y != v.y;
+  const half2v h = __builtin_convertvector(x, half2v);
+  const half2v l = __builtin_convertvector(x - __builtin_convertvector(h, float2v), half2v);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+constexpr int kRowBytes = 256;                    // 64 channels in pair format
+constexpr int kWaveLds = 16 * kRowBytes;          // the nine first-layer pixels of a candidate (rows 9..15: the idle MFMA columns)
+
+// packed weight image of a 64-cout tile with 32-channel chunks (pack_conv_weights_split): [chunk][tap][n 64][8 swizzled 16-B chunks]
+__device__ __forceinline__ const char* wrow(const void* w, int step /* chunk * 9 + tap */, int row) {
+  return static_cast<const char*>(w) + ((size_t)step * 64 + row) * 128;
+}
+
+__global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb, const NmsBuffers nb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ci = blockIdx.x * 4 + wave;
+  const int cnt = min(min(nb.count[n], nb.cap), sb.cap);
+  if (ci >= cnt) return;                          // wave-uniform; no workgroup barrier below
+  const int a = __builtin_amdgcn_readfirstlane(nb.cand_anchor[(size_t)n * nb.cap + ci]);
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxLevels; ++i)
+    if (i < sb.n_levels && a >= sb.lv[i].anchor_begin) l = i;
+  const SparseBoxLevel& L = sb.lv[l];
+  const int la = a - L.anchor_begin;
+  const int ay = la / L.W, ax = la - ay * L.W;
+  const int col = lane & 15, kg = lane >> 4;
+  const int pos = min(col, 8);                    // first-layer pixel of this MFMA column (columns 9..15 repeat the last one)
+  const int y1 = ay + pos / 3 - 1, x1 = ax + pos % 3 - 1;
+  const bool valid1 = y1 >= 0 && y1 < L.H && x1 >= 0 && x1 < L.W;   // outside the map: the second layer's zero padding
+  const float* __restrict__ in = static_cast<const float*>(L.in) + (size_t)n * L.H * L.W * L.cstride + L.coff + kg * 8;
+  char* lds = smem + wave * kWaveLds;
+
+  // ---- first layer: nine pixels x 64 channels, K = Cin x 9 ----
+  floatx4 acc[4];
+  {
+    const float inv_sc = __builtin_amdgcn_rcpf(L.sc1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(L.b1 + 16 * q + 4 * kg);
+      acc[q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
+    }
+  }
+  const int nsteps = (L.cin / 32) * 9;
+  half8 bh, bl, ah[4], al[4];
+  half8 nbh, nbl, nah[4], nal[4];
+#define GTXH_LOAD1(STEP, BH, BL, AH, AL)                                                        \
+  {                                                                                             \
+    const int ch__ = (STEP) / 9, tap__ = (STEP) - ch__ * 9;                                     \
+    const int y__ = y1 + tap__ / 3 - 1, x__ = x1 + tap__ % 3 - 1;                               \
+    uint4 h__ = make_uint4(0, 0, 0, 0), l__ = make_uint4(0, 0, 0, 0);                           \
+    if (y__ >= 0 && y__ < L.H && x__ >= 0 && x__ < L.W) {                                       \
+      const uint4* s__ = reinterpret_cast<const uint4*>(in + ((size_t)y__ * L.W + x__) * L.cstride + ch__ * 32); \
+      h__ = s__[0];                                                                             \
+      l__ = s__[1];                                                                             \
+    }                                                                                           \
+    BH = __builtin_bit_cast(half8, h__);                                                        \
+    BL = __builtin_bit_cast(half8, l__);                                                        \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+      const int row__ = 16 * q + col;                                                           \
+      const char* w__ = wrow(L.w1, STEP, row__);                                                \
+      AH[q] = *reinterpret_cast<const half8*>(w__ + ((kg ^ ((row__ >> 1) & 7)) << 4));          \
+      AL[q] = *reinterpret_cast<const half8*>(w__ + (((4 + kg) ^ ((row__ >> 1) & 7)) << 4));    \
+    }                                                                                           \
+  }
+  GTXH_LOAD1(0, bh, bl, ah, al)
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) GTXH_LOAD1(s + 1, nbh, nbl, nah, nal)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = GTXH_MFMA(al[q], bh, acc[q]);
+      acc[q] = GTXH_MFMA(ah[q], bl, acc[q]);
+      acc[q] = GTXH_MFMA(ah[q], bh, acc[q]);
+    }
+    bh = nbh; bl = nbl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ah[q] = nah[q]; al[q] = nal[q]; }
+  }
+#undef GTXH_LOAD1
+  // SiLU, hi / lo split, pair rows in LDS: lane (col, kg) of block q holds channels 16 q + 4 kg + 0..3 of pixel col; two
+  // v_permlane16_swap make the 8-channel group's hi chunk (even kg) and lo chunk (odd kg): byte 64 q + 16 kg of the row
+  bool sat = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float2v v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      v[e] = silu2(float2v{acc[q][2 * e], acc[q][2 * e + 1]} * L.sc1);
+      if (!valid1) v[e] = float2v{0.f, 0.f};
+    }
+    uint2 hi, lo;
+    bool s1 = false;
+    split2(v[0], hi.x, lo.x, s1);
+    split2(v[1], hi.y, lo.y, s1);
+    sat |= s1 && col < 9;
+    const auto sx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+    const auto sy = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+    *reinterpret_cast<uint4*>(lds + col * kRowBytes + 64 * q + 16 * kg) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+  }
+
+  // ---- second layer at the anchor: K = 64 x 9 over the nine staged pixels (every column computes the same pixel) ----
+  {
+    const float inv_sc = __builtin_amdgcn_rcpf(L.sc2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(L.b2 + 16 * q + 4 * kg);
+      acc[q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
+    }
+  }
+#pragma unroll 1
+  for (int s = 0; s < 18; ++s) {
+    const int ch = s / 9, tap = s - ch * 9;
+    const char* r = lds + tap * kRowBytes + (4 * ch + kg) * 32;      // the tap's pixel, 8-channel group 4 ch + kg: hi chunk, lo chunk
+    const half8 xh = *reinterpret_cast<const half8*>(r), xl = *reinterpret_cast<const half8*>(r + 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * q + col;
+      const char* w = wrow(L.w2, s, row);
+      const half8 wh = *reinterpret_cast<const half8*>(w + ((kg ^ ((row >> 1) & 7)) << 4));
+      const half8 wl = *reinterpret_cast<const half8*>(w + (((4 + kg) ^ ((row >> 1) & 7)) << 4));
+      acc[q] = GTXH_MFMA(wl, xh, acc[q]);
+      acc[q] = GTXH_MFMA(wh, xl, acc[q]);
+      acc[q] = GTXH_MFMA(wh, xh, acc[q]);
+    }
+  }
+  if (col == 0) {                                  // plain fp32, what the decode reads (ConvProblem::out_plain of the dense layer)
+    float* o = sb.feat + ((size_t)n * sb.cap + ci) * 64 + 4 * kg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float2v v0 = silu2(float2v{acc[q][0], acc[q][1]} * L.sc2), v1 = silu2(float2v{acc[q][2], acc[q][3]} * L.sc2);
+      *reinterpret_cast<float4*>(o + 16 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+  }
+  if (sb.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(sb.sat_flag, 1);
+}
+
+}  // namespace
+
+void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s) {
+  GTX_CHECK(sb.cap > 0 && sb.feat != nullptr, "sparse box branch: no buffer");
+  hipLaunchKernelGGL(head_sparse_box_kernel, dim3((sb.cap + 3) / 4, n), dim3(256), 4 * kWaveLds, s, sb, nb);
+  GTX_HIP(hipGetLastError());
+}
+
+}  // namespace gtx

@@ -109,6 +109,14 @@ class Detector:
         check(self.ctx.lib.gtx_detector_saturated(self.handle, int(clear), C.byref(f)))
         return bool(f.value)
 
+    def sparse_box(self) -> tuple[bool, int]:
+        """(on, overflows): whether this detector evaluates the Detect box branch at the candidate anchors only (the default fp32
+        path; GTX_SPARSE_BOX=0 at construction: off) and how many collected batches had more candidates than its buffer holds and
+        were finished by the dense layers (include/gtx.h: gtx_detector_sparse_box)."""
+        on, over = C.c_int(), C.c_int()
+        check(self.ctx.lib.gtx_detector_sparse_box(self.handle, C.byref(on), C.byref(over)))
+        return bool(on.value), int(over.value)
+
     def fell_back(self) -> bool:
         """True once a saturating split-f16x3 pass has moved this detector to the exact-fp32 convolutions."""
         f = C.c_int()

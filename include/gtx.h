@@ -45,7 +45,7 @@ extern "C" {
  * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct.
  * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
  *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added;
- *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended. */
+ *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box added. */
 #define GTX_ABI_VERSION 8
 
 typedef enum gtx_status {
@@ -291,6 +291,11 @@ int gtx_detector_layer_output(gtx_detector* det, int b, const char* layer, float
  * BN-folded YOLOv8 weights never get there; GTX_SAT_FALLBACK=0 in the environment keeps the flag and skips the re-run. */
 int gtx_detector_saturated(gtx_detector* det, int clear, int* flag);
 int gtx_detector_fell_back(gtx_detector* det, int* fell_back);
+/* Default fp32 path: the Detect box branch (cv2[l][0], cv2[l][1]) is evaluated at the anchors that pass the score gate only, bit
+ * for bit what the dense layers give there (csrc/head_sparse.hip; GTX_SPARSE_BOX=0 builds detectors without it). on = 1 when this
+ * detector does so; overflows = collected batches with more candidates per image than its buffer holds (8192), which were
+ * finished by the dense layers instead. */
+int gtx_detector_sparse_box(gtx_detector* det, int* on, int* overflows);
 /* gtx_det_config.obj_feats: the appearance vectors of image b of the most recently collected batch, out [n][dim] fp32 in the
  * order of its boxes (n = min(box count, cap); out may be NULL to ask for n and dim). */
 int gtx_detector_features(gtx_detector* det, int b, float* out, int cap, int* n, int* dim);

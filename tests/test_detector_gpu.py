@@ -399,3 +399,60 @@ def test_object_features_are_the_detect_inputs_at_the_boxes_anchors(gtx_ctx, wei
         err = min(np.abs(table[a] - d.feats[j]).max() for a in hit)
         assert err <= 1e-6 * max(1.0, np.abs(d.feats[j]).max()), (j, err)
     det.close(); plain.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("imgsz,conf", [(640, 0.25), (1920, 0.25)])
+def test_sparse_box_branch_is_the_dense_one_bit_for_bit(gtx_ctx, weights, monkeypatch, imgsz, conf):
+    """The default fp32 path evaluates Detect's box branch (cv2[l][0], cv2[l][1]) at the anchors that pass the score gate only
+    (csrc/head_sparse.hip): same boxes, scores and order as the dense layers, bit for bit -- at the image border too (zero padding
+    of both layers) -- and the debug read-backs (full decode, the head's feature maps) still return the dense layers' values."""
+    from geotrax_amd.detector import Detector
+
+    from geotrax_amd.weights import calibrate_cls_bias
+
+    hw = (2160, 3840) if imgsz == 1920 else (640, 640)
+    frame = _frame(3, hw)
+    kw = dict(imgsz=imgsz, conf=conf, iou=0.7, max_det=1000, agnostic_nms=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_SPARSE_BOX", "0")
+    if imgsz == 1920:                                # the seeded class bias fires nowhere on this frame: set it for ~400 candidates
+        probe = Detector(weights, hw, **kw)
+        probe.detect(frame)
+        weights = calibrate_cls_bias(weights, probe.raw_output(logits=True)[:, 4:], conf, 400)
+        probe.close()
+    dense = Detector(weights, hw, **kw)
+    monkeypatch.setenv("GTX_SPARSE_BOX", "1")
+    sparse = Detector(weights, hw, **kw)
+    assert dense.sparse_box() == (False, 0) and sparse.sparse_box() == (True, 0)
+    a, b = dense.detect(frame), sparse.detect(frame)
+    assert len(a) > 30
+    np.testing.assert_array_equal(b.xyxy, a.xyxy)
+    np.testing.assert_array_equal(b.conf, a.conf)
+    np.testing.assert_array_equal(b.cls, a.cls)
+    assert a.xyxy[:, :2].min() < 1.0 or imgsz == 1920                # boxes that touch the border: anchors in the first rows / columns
+    if imgsz == 640:
+        np.testing.assert_array_equal(sparse.raw_output(0), dense.raw_output(0))
+        for name in ("model.22.feat0", "model.22.feat1", "model.22.feat2"):
+            np.testing.assert_array_equal(sparse.layer_output(name), dense.layer_output(name), err_msg=name)
+        c = sparse.detect(frame)                                     # and the read-backs left the next pass alone
+        np.testing.assert_array_equal(c.xyxy, a.xyxy)
+    assert sparse.sparse_box() == (True, 0)
+    dense.close(); sparse.close()
+
+
+@pytest.mark.gpu
+def test_more_candidates_than_the_sparse_buffer_holds_go_through_the_dense_layers(gtx_ctx, weights, monkeypatch):
+    from geotrax_amd.detector import Detector
+
+    hw = (1080, 1920)
+    frame = _frame(4, hw)
+    kw = dict(imgsz=1920, conf=0.002, iou=0.7, max_det=300, agnostic_nms=False, rect=True, ctx=gtx_ctx)   # nearly every anchor passes
+    monkeypatch.setenv("GTX_SPARSE_BOX", "0")
+    dense = Detector(weights, hw, **kw)
+    monkeypatch.setenv("GTX_SPARSE_BOX", "1")
+    sparse = Detector(weights, hw, **kw)
+    a, b = dense.detect(frame), sparse.detect(frame)
+    assert sparse.sparse_box() == (True, 1)                          # one batch over the buffer
+    np.testing.assert_array_equal(b.xyxy, a.xyxy)
+    np.testing.assert_array_equal(b.conf, a.conf)
+    dense.close(); sparse.close()
