@@ -1109,6 +1109,9 @@ def main():
                                "f32": "fp32 activations, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                "f32s": "fp32 activations in HBM; conv operands split into hi+lo fp16 parts, three fp16 MFMAs per product, fp32 accumulate "
                                        "(22 significand bits per operand; passes the fp32 parity assertions of tests/test_detector_gpu.py unchanged)"}[dt],
+                "detect_head": (("box branch (cv2[l][0], cv2[l][1]) evaluated at the score gate's candidates only, the dense layers' values bit for bit "
+                                 "(csrc/head_sparse.hip; every other layer dense); batches over 8192 candidates per image finish on the dense layers: "
+                                 f"{det.sparse_box()[1]} such in this run") if det.sparse_box()[0] else "dense"),
                 "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
