@@ -145,7 +145,7 @@ void conv_igemm_kernel(const ConvGroup g) {
   const int pt = lb / P.n_ct;
   const int tx = pt % P.tiles_x;
   const int t2 = pt / P.tiles_x;
-  const int ty = t2 % P.tiles_y;
+  const int ty = t2 % P.tiles_y + P.ty_first;
   const int n = t2 / P.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;
@@ -497,6 +497,12 @@ void conv_group_finalize(ConvGroup& g, const ConvConfig& cfg) {
     p.block_begin = total;
     p.tiles_x = cdiv(p.Wo, cfg.tw);
     p.tiles_y = cdiv(p.Ho, cfg.th);
+    if (p.ty_count > 0) {
+      GTX_CHECK(p.ty_first >= 0 && p.ty_first + p.ty_count <= p.tiles_y, "conv: tile rows [%d, %d) of %d", p.ty_first, p.ty_first + p.ty_count, p.tiles_y);
+      p.tiles_y = p.ty_count;
+    } else {
+      p.ty_first = 0;
+    }
     total += p.N * p.tiles_x * p.tiles_y * p.n_ct;
   }
   g.total_blocks = total;

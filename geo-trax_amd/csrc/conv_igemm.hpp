@@ -37,7 +37,9 @@ struct ConvProblem {
   int out_cstride, out_coff;
   int res_cstride, res_coff;
   int act;              // 1 = SiLU, 0 = identity
-  int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8)
+  int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8); tiles_y counts the tile rows the launch computes
+  int ty_first, ty_count; // ty_count > 0: only tile rows [ty_first, ty_first + ty_count) are computed (the others keep what the
+                        // buffer holds: Detector's letterbox-padding rows, whose values do not depend on the frame); 0 = all
   int n_ct;             // cout tiles (Cout / BN)
   // Optional second source (split-f16x3 1x1 kernels only): input channels [0, c_split) are the nearest-neighbour 2x
   // upsampling of `in2` ([N][H/2][W/2][in2_cstride], slice at in2_coff) and are read from there at (y/2, x/2); channels

@@ -177,7 +177,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   const int pt = lb / P.n_ct;
   const int tx = pt % P.tiles_x;
   const int t2 = pt / P.tiles_x;
-  const int ty = t2 % P.tiles_y;
+  const int ty = t2 % P.tiles_y + P.ty_first;
   const int n = t2 / P.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - Tile::PAD, ix0 = ox0 * STRIDE - Tile::PAD;

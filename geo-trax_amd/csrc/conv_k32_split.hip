@@ -105,7 +105,7 @@ void conv_k32_split_kernel(const ConvGroup g) {
   const int pt = lb / P.n_ct;
   const int tx = pt % P.tiles_x;
   const int t2 = pt / P.tiles_x;
-  const int ty = t2 % P.tiles_y;
+  const int ty = t2 % P.tiles_y + P.ty_first;
   const int n = t2 / P.tiles_y;
   const int oy0 = ty * Tile::TH, ox0 = tx * Tile::TW;
   const int iy0 = oy0 - 1, ix0 = ox0 - 1;

@@ -140,7 +140,7 @@ void conv_wino_split_kernel(const ConvGroup g) {
   const int pt = lb / P.n_ct;
   const int tx0 = pt % P.tiles_x;
   const int t2 = pt / P.tiles_x;
-  const int ty0 = t2 % P.tiles_y;
+  const int ty0 = t2 % P.tiles_y + P.ty_first;
   const int n = t2 / P.tiles_y;
   const int oy0 = ty0 * T::TH, ox0 = tx0 * T::TW;
   const int nchunks = P.Cin / T::KC;
@@ -474,7 +474,7 @@ void conv_wino2_split_kernel(const ConvGroup g) {
   const int pt = lb / P.n_ct;
   const int tx0 = pt % P.tiles_x;
   const int t2 = pt / P.tiles_x;
-  const int ty0 = t2 % P.tiles_y;
+  const int ty0 = t2 % P.tiles_y + P.ty_first;
   const int n = t2 / P.tiles_y;
   const int oy0 = ty0 * T::TH, ox0 = tx0 * T::TW;
   const int nchunks = P.Cin / T::KC;

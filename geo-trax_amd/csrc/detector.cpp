@@ -639,22 +639,28 @@ void Detector::set_batch(int nb) {
   if (nb == cur_nb_) return;
   for (Op& op : ops_) {
     if (op.kind != Op::CONV) continue;
-    for (int i = 0; i < op.grp.count; ++i) op.grp.p[i].N = nb;
+    for (int i = 0; i < op.grp.count; ++i) {
+      op.grp.p[i].N = nb;
+      op.grp.p[i].ty_first = pad_skip_on_ ? op.ty_first[i] : 0;
+      op.grp.p[i].ty_count = pad_skip_on_ ? op.ty_count[i] : 0;
+    }
     conv_group_finalize(op.grp, op.cfg);
     op.flops = 0;
     op.bytes = 0;
     for (int i = 0; i < op.grp.count; ++i) {
       const ConvProblem& p = op.grp.p[i];
-      op.flops += conv_flops(p, op.cfg.ks);
-      op.bytes += ((double)p.N * p.H * p.W * (p.Cin - 0.75 * p.c_split) + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
+      // the share of the output rows this launch computes (letterbox-padding rows are skipped: plan_pad_skip)
+      const double part = std::min(1.0, (double)p.tiles_y * op.cfg.th / p.Ho);
+      op.flops += part * conv_flops(p, op.cfg.ks);
+      op.bytes += part * ((double)p.N * p.H * p.W * (p.Cin - 0.75 * p.c_split) + (double)p.N * p.Ho * p.Wo * p.Cout) * es_ +
                   (double)p.Cout * p.Cin * op.cfg.ks * op.cfg.ks * es_;
       if (p.post_w) {                     // the fused 1x1 layer: its FLOPs and weights; its output replaces the 3x3 layer's (same size)
-        op.flops += 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * p.Cout;
+        op.flops += part * 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * p.Cout;
         op.bytes += (double)p.Cout * p.Cout * es_;
       }
       if (p.front_img) {                  // the fused stem: its FLOPs; RGB0 bytes are read instead of the stem's output
-        op.flops += 2.0 * p.N * p.H * p.W * (double)p.Cin * 27;
-        op.bytes += (double)p.N * p.front_h * p.front_w_px * 4 - (double)p.N * p.H * p.W * p.Cin * es_;
+        op.flops += part * 2.0 * p.N * p.H * p.W * (double)p.Cin * 27;
+        op.bytes += part * ((double)p.N * p.front_h * p.front_w_px * 4 - (double)p.N * p.H * p.W * p.Cin * es_);
       }
     }
   }
@@ -671,6 +677,98 @@ void Detector::set_batch(int nb) {
     }
   }
   cur_nb_ = nb;
+}
+
+// Rows of every activation tensor that can depend on the frame. The letterbox puts the resized frame in rows [top, top + new_h)
+// of the network input and a constant colour everywhere else (ultralytics LetterBox, default.yaml `rect: false`: 420 + 420 of
+// 1920 rows for a 16:9 frame); a convolution's output row outside the reach of those rows sees the same inputs for every
+// frame, so its value is a constant of the checkpoint. Those rows are computed once (prime_pad_skip, at finalize) and the
+// launches of every later pass cover the other tile rows only -- the buffers keep the constants, the results are the full
+// launches' bit for bit. The interval grows with every 3x3 layer and covers the whole map from the SPPF on; the gain is in the
+// backbone's large maps. GTX_PAD_SKIP=0: off.
+void Detector::plan_pad_skip() {
+  pad_skip_rows_ = pad_skip_total_ = 0;
+  struct Rows { int lo, hi; };
+  std::map<const void*, Rows> dep;                   // buffer -> frame-dependent rows; a buffer that is not here depends on the frame everywhere
+  std::set<const void*> full;                        // ... and these stay that way whatever is written to them later
+  dep[img_.ptr] = Rows{lb_.top, lb_.top + lb_.new_h};
+  auto through = [](Rows r, int k, int s, int h_out) {   // rows of a k x k / stride s / pad k/2 layer's output that see input rows [lo, hi)
+    const int p = k / 2;
+    const int num = r.lo + p - k + 1;                      // y >= num / s
+    const int lo = num <= 0 ? 0 : (num + s - 1) / s;
+    const int hi = (r.hi - 1 + p) / s + 1;
+    return Rows{lo, std::min(h_out, hi)};
+  };
+  auto unite = [](Rows a, Rows b) { return Rows{std::min(a.lo, b.lo), std::max(a.hi, b.hi)}; };
+  auto get = [&](const void* p, Rows& r) {
+    auto it = dep.find(p);
+    if (it == dep.end()) return false;
+    r = it->second;
+    return true;
+  };
+  auto put = [&](const void* p, bool known, Rows r) {
+    if (!known) { dep.erase(p); full.insert(p); return; }
+    if (full.count(p)) return;
+    auto it = dep.find(p);
+    if (it == dep.end()) dep[p] = r; else it->second = unite(it->second, r);   // another slice of a concat buffer may reach further
+  };
+  for (Op& op : ops_) {
+    if (op.kind == Op::STEM) {
+      Rows in{0, 0};
+      const bool known = get(op.in.ptr, in);
+      put(op.out.ptr, known, through(in, 3, 2, op.out.h));
+      continue;
+    }
+    if (op.kind != Op::CONV) { put(op.out.ptr, false, Rows{0, 0}); continue; }   // pools / upsampling: deep in the network
+    for (int i = 0; i < op.grp.count; ++i) {
+      const ConvProblem& p = op.grp.p[i];
+      op.ty_first[i] = op.ty_count[i] = 0;
+      Rows in{0, p.H};
+      bool known;
+      if (p.front_img) {
+        Rows img{0, 0};
+        known = get(p.front_img, img);
+        if (known) in = through(img, 3, 2, p.H);
+      } else {
+        known = get(p.in, in) && p.c_split == 0;       // a second, upsampled source: neck layers, all rows
+      }
+      Rows out = through(in, op.cfg.ks, op.cfg.stride, p.Ho);
+      if (known && p.res) {
+        Rows r{0, 0};
+        known = get(p.res, r);
+        if (known) out = unite(out, r);
+      }
+      const int tiles = (p.Ho + op.cfg.th - 1) / op.cfg.th;
+      pad_skip_total_ += tiles;
+      put(p.out, known, out);
+      if (!known) continue;
+      const int t0 = out.lo / op.cfg.th, t1 = std::min(tiles, (out.hi + op.cfg.th - 1) / op.cfg.th);
+      if (t1 - t0 < tiles && t1 > t0) {
+        op.ty_first[i] = t0;
+        op.ty_count[i] = t1 - t0;
+        pad_skip_rows_ += tiles - (t1 - t0);
+      }
+    }
+  }
+}
+
+// One full pass over every batch slot on a blank frame: the rows the later launches skip now hold their constants.
+void Detector::prime_pad_skip() {
+  if (pad_skip_rows_ == 0) return;
+  const int N = cfg_.max_batch;
+  hipStream_t s = ctx_->stream;
+  DevBuf blank;
+  blank.alloc((size_t)N * cfg_.frame_h * cfg_.frame_w * 3);
+  GTX_HIP(hipMemsetAsync(blank.p, 0, blank.bytes, s));
+  pad_skip_on_ = false;
+  cur_nb_ = 0;
+  set_batch(N);
+  launch_preprocess(dtype_, (const uint8_t*)blank.p, N, lb_, img_.ptr, nullptr, gray_h_, gray_w_, s);
+  for (const Op& op : ops_) run_op(op, N, s);
+  GTX_HIP(hipStreamSynchronize(s));
+  if (sat_dev_) GTX_HIP(hipMemsetAsync(sat_dev_, 0, sizeof(int), s));
+  pad_skip_on_ = true;
+  cur_nb_ = 0;
 }
 
 void Detector::finalize() {
@@ -719,6 +817,10 @@ void Detector::finalize() {
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
   if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
+  if (env_flag("GTX_PAD_SKIP", true)) {
+    plan_pad_skip();
+    prime_pad_skip();
+  }
   set_batch(1);
   GTX_HIP(hipStreamSynchronize(ctx_->stream));
   finalized_ = true;

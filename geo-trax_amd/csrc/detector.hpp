@@ -5,6 +5,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,8 @@ struct Op {
   float stem_scale = 1.f;      // split-f16x3 stem: inverse of the weights' power-of-two scaling
   const void* front_wpk = nullptr;   // the same weights packed for the front stage of model.1 (ConvProblem::front_w)
   float front_scale = 1.f;
+  // rows of the output that depend on the frame (Detector::plan_pad_skip), as tile rows per group member; count 0 = all
+  int ty_first[kMaxGroup] = {0}, ty_count[kMaxGroup] = {0};
   double flops = 0;      // algorithmic 2*MAC
   double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
 };
@@ -98,6 +101,11 @@ class Detector {
   // default.yaml:245); GTX_SAT_FALLBACK=0 keeps the flag only.
   bool saturated(bool clear);
   bool fell_back() const { return exact_ != nullptr; }
+  void pad_skip(int* on, int* skipped, int* total) const {
+    if (on) *on = (!exact_ && pad_skip_on_) ? 1 : 0;
+    if (skipped) *skipped = pad_skip_rows_;
+    if (total) *total = pad_skip_total_;
+  }
   void sparse_box(int* on, int* overflows) const {
     if (on) *on = (!exact_ && sparse_on_) ? 1 : 0;
     if (overflows) *overflows = sparse_overflows_;
@@ -174,6 +182,11 @@ class Detector {
   int* h_count_ = nullptr;   // pinned: candidates per image of the pass in flight
   int sparse_overflows_ = 0;
   void run_dense_box(hipStream_t s);
+  // letterbox-padding rows: activations there do not depend on the frame; computed once (finalize), skipped afterwards
+  bool pad_skip_on_ = false;
+  int pad_skip_rows_ = 0, pad_skip_total_ = 0;   // tile rows skipped / planned over all convolution launches (for the report)
+  void plan_pad_skip();
+  void prime_pad_skip();
   float* d_feats_ = nullptr;  // [max_batch][max_det][dim]
   float* h_feats_ = nullptr;  // pinned
   std::vector<float> c_feats_;   // the collected batch's vectors
