@@ -225,8 +225,9 @@ View Detector::c2f(const std::string& pfx, const View& x, bool shortcut, const V
   View cat = new_view(x.h, x.w, (2 + n) * c);
   View first = cat.slice(0, 2 * c);
   conv(pfx + ".cv1.conv", x, 1, true, &first, nullptr, up_src);
-  View tmp = new_view(x.h, x.w, c);
   for (int k = 0; k < n; ++k) {
+    // a buffer of its own per bottleneck: rows that no launch rewrites (plan_pad_skip) must keep ONE producer's values
+    View tmp = new_view(x.h, x.w, c);
     const std::string m = pfx + ".m." + std::to_string(k);
     View src = cat.slice((1 + k) * c, c);
     View dst = cat.slice((2 + k) * c, c);
@@ -691,6 +692,24 @@ void Detector::plan_pad_skip() {
   struct Rows { int lo, hi; };
   std::map<const void*, Rows> dep;                   // buffer -> frame-dependent rows; a buffer that is not here depends on the frame everywhere
   std::set<const void*> full;                        // ... and these stay that way whatever is written to them later
+  // A region two different launches write (a scratch buffer reused by two layers) cannot keep either's constants: whoever
+  // writes it computes every row. Writers per buffer as channel ranges.
+  struct Writer { int c0, c1; Op* op; int member; };
+  std::map<const void*, std::vector<Writer>> writers;
+  auto second_writer = [&](const void* p, int c0, int c1, Op* op, int member) {
+    bool hit = false;
+    for (Writer& w : writers[p])
+      if (c0 < w.c1 && w.c0 < c1) {
+        hit = true;
+        if (w.op->ty_count[w.member] > 0) {            // the earlier writer had been given a row range: take it back
+          const ConvProblem& q = w.op->grp.p[w.member];
+          pad_skip_rows_ -= (q.Ho + w.op->cfg.th - 1) / w.op->cfg.th - w.op->ty_count[w.member];
+          w.op->ty_first[w.member] = w.op->ty_count[w.member] = 0;
+        }
+      }
+    writers[p].push_back(Writer{c0, c1, op, member});
+    return hit;
+  };
   dep[img_.ptr] = Rows{lb_.top, lb_.top + lb_.new_h};
   auto through = [](Rows r, int k, int s, int h_out) {   // rows of a k x k / stride s / pad k/2 layer's output that see input rows [lo, hi)
     const int p = k / 2;
@@ -740,6 +759,7 @@ void Detector::plan_pad_skip() {
       }
       const int tiles = (p.Ho + op.cfg.th - 1) / op.cfg.th;
       pad_skip_total_ += tiles;
+      if (second_writer(p.out, p.out_coff, p.out_coff + p.Cout, &op, i)) known = false;
       put(p.out, known, out);
       if (!known) continue;
       const int t0 = out.lo / op.cfg.th, t1 = std::min(tiles, (out.hi + op.cfg.th - 1) / op.cfg.th);

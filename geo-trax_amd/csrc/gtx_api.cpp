@@ -608,6 +608,9 @@ int gtx_detector_saturated(gtx_detector* det, int clear, int* flag) {
 int gtx_detector_fell_back(gtx_detector* det, int* fell_back) {
   return guarded([&] { need(det, "det"); need(fell_back, "fell_back"); *fell_back = det->impl->fell_back() ? 1 : 0; });
 }
+int gtx_detector_pad_skip(gtx_detector* det, int* on, int* skipped, int* total) {
+  return guarded([&] { need(det, "det"); det->impl->pad_skip(on, skipped, total); });
+}
 int gtx_detector_sparse_box(gtx_detector* det, int* on, int* overflows) {
   return guarded([&] { need(det, "det"); det->impl->sparse_box(on, overflows); });
 }

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "gtx_detector_layer_output": (C.c_int, [_P, C.c_int, C.c_char_p, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_saturated": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "gtx_detector_fell_back": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "gtx_detector_pad_skip": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_sparse_box": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_features": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gtx_detector_trace": (C.c_int, [_P, C.c_int]),

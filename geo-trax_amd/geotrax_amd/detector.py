@@ -109,6 +109,14 @@ class Detector:
         check(self.ctx.lib.gtx_detector_saturated(self.handle, int(clear), C.byref(f)))
         return bool(f.value)
 
+    def pad_skip(self) -> tuple[bool, int, int]:
+        """(on, skipped, total): whether this detector leaves the frame-independent rows of the letterbox padding out of its
+        launches (computed once at creation; GTX_PAD_SKIP=0: off), and how many 8-row tile rows per image and pass that is, of how
+        many (include/gtx.h: gtx_detector_pad_skip)."""
+        on, sk, tot = C.c_int(), C.c_int(), C.c_int()
+        check(self.ctx.lib.gtx_detector_pad_skip(self.handle, C.byref(on), C.byref(sk), C.byref(tot)))
+        return bool(on.value), int(sk.value), int(tot.value)
+
     def sparse_box(self) -> tuple[bool, int]:
         """(on, overflows): whether this detector evaluates the Detect box branch at the candidate anchors only (the default fp32
         path; GTX_SPARSE_BOX=0 at construction: off) and how many collected batches had more candidates than its buffer holds and

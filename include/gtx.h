@@ -45,7 +45,7 @@ extern "C" {
  * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct.
  * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
  *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added;
- *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box added. */
+ *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box and gtx_detector_pad_skip added. */
 #define GTX_ABI_VERSION 8
 
 typedef enum gtx_status {
@@ -296,6 +296,13 @@ int gtx_detector_fell_back(gtx_detector* det, int* fell_back);
  * detector does so; overflows = collected batches with more candidates per image than its buffer holds (8192), which were
  * finished by the dense layers instead. */
 int gtx_detector_sparse_box(gtx_detector* det, int* on, int* overflows);
+/* Letterbox-padding rows (ultralytics LetterBox with `rect: false`: 420 + 420 of 1920 input rows for a 16:9 frame): an activation row
+ * out of reach of the frame's rows sees the same inputs for every frame, so its value is a constant of the checkpoint. The detector
+ * computes those rows once when it is created (one full pass on a blank frame over every batch slot) and its later launches
+ * cover the other tile rows only; the buffers keep the constants and every result is the full launches' bit for bit
+ * (csrc/detector.cpp plan_pad_skip; GTX_PAD_SKIP=0 builds detectors without it). on = 1 when rows are being skipped; skipped /
+ * total = 8-row tile rows left out / launched per image and pass, summed over the convolution launches. */
+int gtx_detector_pad_skip(gtx_detector* det, int* on, int* skipped, int* total);
 /* gtx_det_config.obj_feats: the appearance vectors of image b of the most recently collected batch, out [n][dim] fp32 in the
  * order of its boxes (n = min(box count, cap); out may be NULL to ask for n and dim). */
 int gtx_detector_features(gtx_detector* det, int b, float* out, int cap, int* n, int* dim);

@@ -456,3 +456,56 @@ def test_more_candidates_than_the_sparse_buffer_holds_go_through_the_dense_layer
     np.testing.assert_array_equal(b.xyxy, a.xyxy)
     np.testing.assert_array_equal(b.conf, a.conf)
     dense.close(); sparse.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "exact", "half"])
+@pytest.mark.parametrize("hw,imgsz", [((1080, 1920), 960), ((720, 960), 640)])
+def test_padding_rows_are_computed_once_and_every_result_stays_bit_identical(gtx_ctx, weights, monkeypatch, mode, hw, imgsz):
+    """`rect: false` letterboxes a 16:9 frame into a square input: 44 % of its rows are a constant colour, and an activation row out
+    of reach of the frame's rows is the same for every frame. The detector computes those rows when it is created and leaves them
+    out of its launches afterwards (csrc/detector.cpp plan_pad_skip). Over a sequence of different frames, with two batch slots,
+    every detection AND every layer the tests can read back must equal a detector built with GTX_PAD_SKIP=0 bit for bit."""
+    from geotrax_amd.detector import Detector
+
+    kw = dict(imgsz=imgsz, conf=0.25, iou=0.7, max_det=300, agnostic_nms=True, half=(mode == "half"), fp32_split=(mode == "split"),
+              max_batch=2, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_PAD_SKIP", "0")
+    full = Detector(weights, hw, **kw)
+    monkeypatch.setenv("GTX_PAD_SKIP", "1")
+    skip = Detector(weights, hw, **kw)
+    on, skipped, total = skip.pad_skip()
+    assert on and 0 < skipped < 0.5 * total and full.pad_skip()[0] is False
+    assert skipped > 0.1 * total or hw != (1080, 1920)                 # 16:9 into a square: a tenth of all tile rows and more
+    frames = np.stack([_frame(s, hw) for s in range(4)])
+    frames[1] = 255 - frames[1]                                      # unlike its neighbours everywhere
+    frames[2, : hw[0] // 2] = 0
+    dptr = gtx_ctx.dev_alloc(frames[:2].nbytes)
+    try:
+        for k in (0, 2, 1):                                          # pairs (0,1), (2,3), (1,2): every slot sees different frames
+            pair = np.ascontiguousarray(frames[k:k + 2])
+            gtx_ctx.dev_upload(dptr, pair)
+            a, b = full.detect_dev(dptr, 2), skip.detect_dev(dptr, 2)
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(y.xyxy, x.xyxy)
+                np.testing.assert_array_equal(y.conf, x.conf)
+                np.testing.assert_array_equal(y.cls, x.cls)
+            for name in LAYERS:
+                for slot in (0, 1):
+                    np.testing.assert_array_equal(skip.layer_output(name, slot), full.layer_output(name, slot), err_msg=f"{name} slot {slot} pair {k}")
+        one = skip.detect(frames[3])                                 # a single frame after the pairs
+        ref = full.detect(frames[3])
+        np.testing.assert_array_equal(one.xyxy, ref.xyxy)
+    finally:
+        gtx_ctx.dev_free(dptr)
+    full.close(); skip.close()
+
+
+@pytest.mark.gpu
+def test_nothing_is_skipped_without_padding_rows(gtx_ctx, weights):
+    from geotrax_amd.detector import Detector
+
+    sq = Detector(weights, (640, 640), imgsz=640, ctx=gtx_ctx)                     # square frame: no padding
+    rc = Detector(weights, (1080, 1920), imgsz=960, rect=True, ctx=gtx_ctx)        # rect: 544 x 960, 2 + 2 padding rows
+    assert sq.pad_skip()[1] == 0 and rc.pad_skip()[1] == 0
+    sq.close(); rc.close()
