@@ -1112,6 +1112,10 @@ def main():
                 "detect_head": (("box branch (cv2[l][0], cv2[l][1]) evaluated at the score gate's candidates only, the dense layers' values bit for bit "
                                  "(csrc/head_sparse.hip; every other layer dense); batches over 8192 candidates per image finish on the dense layers: "
                                  f"{det.sparse_box()[1]} such in this run") if det.sparse_box()[0] else "dense"),
+                "letterbox_padding": ((lambda ps: (f"rect = false puts the 16:9 frame in {round(H * min(args.imgsz / H, args.imgsz / W))} of {det.net_hw[0]} input rows; activation rows out of reach "
+                                                    f"of them are constants of the checkpoint, computed once when the detector is created and left out of the launches afterwards: "
+                                                    f"{ps[1]} of {ps[2]} tile rows per image and pass (results bit-identical to computing them every pass; the `every_row_every_pass` "
+                                                    f"key is this line without it)") if ps[0] else "every row computed in every pass")(det.pad_skip())),
                 "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)",
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
@@ -1238,6 +1242,24 @@ def main():
                                            "tracker and box warp at ~8 x the golden clip's box count; measured by a child process, secondary, not `value`"}
             except Exception as e:
                 out["nms_load"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
+                and os.environ.get("GTX_PAD_SKIP", "1") != "0":
+            # secondary key: the same line with every row of every layer and every pixel of the Detect box branch computed in every pass
+            import subprocess
+
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(max(args.steps, 100)), "--warmup", str(args.warmup), "--no-cpu-baseline",
+                   "--no-profile", "--no-f16-line", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams", str(args.det_streams),
+                   "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
+                   "--imgsz", str(args.imgsz), "--rect", str(args.rect)]
+            try:
+                pe = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "GTX_PAD_SKIP": "0", "GTX_SPARSE_BOX": "0"})
+                de = json.loads([ln for ln in pe.stdout.splitlines() if ln.startswith("{")][-1])
+                out["every_row_every_pass"] = {"value": de["value"], "unit": "frames/s", "steps": de["steps"], "ms_per_step": de["ms_per_step"],
+                                               "note": "GTX_PAD_SKIP=0 GTX_SPARSE_BOX=0: the letterbox-padding rows recomputed in every pass and the Detect box "
+                                                       "branch evaluated at every anchor, as before round 5's last two changes; same detections bit for bit "
+                                                       "(tests/test_detector_gpu.py); measured by a child process, secondary, not `value`"}
+            except Exception as e:
+                out["every_row_every_pass"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line:
             # secondary key: the N > 1 default workload (BoT-SORT + GPU GMC, BASELINE configs[4]) on this one GPU, so that a scaling
             # series started from this line has its like-for-like single-GPU base in it (the primary line here is configs[2], ByteTrack)

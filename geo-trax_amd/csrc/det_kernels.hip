@@ -925,6 +925,10 @@ __global__ __launch_bounds__(256) void head_candidates_kernel(const HeadParams h
       nb.cand_score[o] = best;
       nb.cand_anchor[o] = a;
       nb.cand_cls[o] = best_c;
+      if (nb.lvl_count && idx < nb.lvl_cap) {      // filed under its level for the sparse box branch (head_sparse.hip)
+        const int k = atomicAdd(&nb.lvl_count[n * kMaxLevels + l], 1);
+        nb.lvl_list[((size_t)n * kMaxLevels + l) * nb.lvl_cap + k] = idx;   // k <= idx < lvl_cap
+      }
     }
   }
 }
@@ -1034,6 +1038,7 @@ void launch_head_candidates(int dtype, const HeadParams& hp, int n, const NmsBuf
 
 void launch_head_gate(int dtype, const HeadParams& hp, int n, const NmsBuffers& nb, hipStream_t s) {
   GTX_HIP(hipMemsetAsync(nb.count, 0, sizeof(int) * n, s));
+  if (nb.lvl_count) GTX_HIP(hipMemsetAsync(nb.lvl_count, 0, sizeof(int) * n * kMaxLevels, s));
   dim3 grid(cdiv(hp.n_anchors, 16), n), block(256);
   if (dtype == DT_F16) hipLaunchKernelGGL(head_candidates_kernel<_Float16>, grid, block, 0, s, hp, nb);
   else hipLaunchKernelGGL(head_candidates_kernel<float>, grid, block, 0, s, hp, nb);

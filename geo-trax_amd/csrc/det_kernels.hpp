@@ -85,6 +85,11 @@ struct NmsBuffers {
   // box features of the candidates from the sparse box branch ([N][sparse_cap][cb] fp32; null: the decode reads HeadLevel::feat)
   const float* sparse_feat;
   int sparse_cap;
+  // ... and the candidates filed by level for it (indices into the candidate arrays): lvl_count [N][kMaxLevels],
+  // lvl_list [N][kMaxLevels][lvl_cap]; null: not kept
+  int* lvl_count;
+  int* lvl_list;
+  int lvl_cap;
 };
 
 // Per-object appearance vectors "from the detector" (ultralytics BoT-SORT `with_reid: true, model: auto`,

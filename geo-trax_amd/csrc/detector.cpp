@@ -832,6 +832,9 @@ void Detector::finalize() {
     sparse_.sat_flag = sat_dev_;
     nms_.sparse_feat = sparse_.feat;
     nms_.sparse_cap = kSparseCap;
+    nms_.lvl_cap = kSparseCap;
+    nms_.lvl_count = (int*)alloc(sizeof(int) * N * kMaxLevels);
+    nms_.lvl_list = (int*)alloc(sizeof(int) * N * kMaxLevels * kSparseCap);
     GTX_HIP(hipHostMalloc((void**)&h_count_, sizeof(int) * N));
   }
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));

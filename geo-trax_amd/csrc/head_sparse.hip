@@ -2,8 +2,9 @@
 //
 // Detect's box branch is two 3x3 convolutions (cv2[l][0]: Cin -> 64, cv2[l][1]: 64 -> 64) whose output is read by the decode at
 // the anchors that pass the score gate and nowhere else: a few hundred to a few thousand of the 75 600 anchors of a 1920 x 1920
-// input. This kernel evaluates the two layers for those anchors alone -- one wave per candidate: the 3 x 3 neighbourhood of
-// cv2[l][0] outputs the second layer needs (nine MFMA columns), then cv2[l][1] at the anchor -- with the arithmetic of the dense
+// input. This kernel evaluates the two layers for those anchors alone -- a wave takes four candidates of one level: the 3 x 3
+// neighbourhood of cv2[l][0] outputs the second layer needs (nine MFMA columns per candidate), then cv2[l][1] at the anchors --
+// with the arithmetic of the dense
 // kernels it replaces (conv_k32_split.hip: same packed weight images and power-of-two scales, same v_mfma_f32_16x16x32_f16
 // sequence per output pixel -- chunk, kernel row, kernel column, small terms first -- same bias start, SiLU and hi / lo split,
 // zero padding at the image border for both layers), so a candidate's 64 box features are the dense path's bit for bit.
@@ -39,61 +40,73 @@ __device__ __forceinline__ void split2(const float2v v, unsigned& hi, unsigned& 
 }
 
 constexpr int kRowBytes = 256;                    // 64 channels in pair format
-constexpr int kWaveLds = 16 * kRowBytes;          // the nine first-layer pixels of a candidate (rows 9..15: the idle MFMA columns)
+constexpr int kCandPerWave = 4;                   // candidates of one level a wave works on: they share every weight fragment
+constexpr int kWaveLds = kCandPerWave * 9 * kRowBytes;   // their first-layer pixels (3 x 3 each)
 
 // packed weight image of a 64-cout tile with 32-channel chunks (pack_conv_weights_split): [chunk][tap][n 64][8 swizzled 16-B chunks]
 __device__ __forceinline__ const char* wrow(const void* w, int step /* chunk * 9 + tap */, int row) {
   return static_cast<const char*>(w) + ((size_t)step * 64 + row) * 128;
 }
 
-__global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb, const NmsBuffers nb) {
+// grid.x = levels x groups: workgroup g of level l takes candidates [16 g, 16 g + 16) of the level's list (head_candidates_kernel
+// files every candidate under its level), four per wave. A wave's candidates share the weights: 8 fragment loads per K step feed
+// 48 MFMAs, and the four independent accumulator sets hide the loads' latency.
+__global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb, const NmsBuffers nb, int groups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = blockIdx.y;
+  const int l = blockIdx.x / groups, g = blockIdx.x - l * groups;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ci = blockIdx.x * 4 + wave;
-  const int cnt = min(min(nb.count[n], nb.cap), sb.cap);
-  if (ci >= cnt) return;                          // wave-uniform; no workgroup barrier below
-  const int a = __builtin_amdgcn_readfirstlane(nb.cand_anchor[(size_t)n * nb.cap + ci]);
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxLevels; ++i)
-    if (i < sb.n_levels && a >= sb.lv[i].anchor_begin) l = i;
+  const int cnt = min(nb.lvl_count[n * kMaxLevels + l], nb.lvl_cap);
+  const int first = (g * 4 + wave) * kCandPerWave;
+  if (first >= cnt) return;                       // wave-uniform; no workgroup barrier below
   const SparseBoxLevel& L = sb.lv[l];
-  const int la = a - L.anchor_begin;
-  const int ay = la / L.W, ax = la - ay * L.W;
   const int col = lane & 15, kg = lane >> 4;
   const int pos = min(col, 8);                    // first-layer pixel of this MFMA column (columns 9..15 repeat the last one)
-  const int y1 = ay + pos / 3 - 1, x1 = ax + pos % 3 - 1;
-  const bool valid1 = y1 >= 0 && y1 < L.H && x1 >= 0 && x1 < L.W;   // outside the map: the second layer's zero padding
+  int ci[kCandPerWave], y1[kCandPerWave], x1[kCandPerWave];
+  bool valid1[kCandPerWave];
+#pragma unroll
+  for (int c = 0; c < kCandPerWave; ++c) {
+    const int k = min(first + c, cnt - 1);        // a short last group repeats its last candidate (not stored twice)
+    ci[c] = __builtin_amdgcn_readfirstlane(nb.lvl_list[((size_t)n * kMaxLevels + l) * nb.lvl_cap + k]);
+    const int a = __builtin_amdgcn_readfirstlane(nb.cand_anchor[(size_t)n * nb.cap + ci[c]]);
+    const int la = a - L.anchor_begin;
+    const int ay = la / L.W, ax = la - ay * L.W;
+    y1[c] = ay + pos / 3 - 1;
+    x1[c] = ax + pos % 3 - 1;
+    valid1[c] = y1[c] >= 0 && y1[c] < L.H && x1[c] >= 0 && x1[c] < L.W;   // outside the map: the second layer's zero padding
+  }
   const float* __restrict__ in = static_cast<const float*>(L.in) + (size_t)n * L.H * L.W * L.cstride + L.coff + kg * 8;
   char* lds = smem + wave * kWaveLds;
 
-  // ---- first layer: nine pixels x 64 channels, K = Cin x 9 ----
-  floatx4 acc[4];
+  // ---- first layer: nine pixels x 64 channels per candidate, K = Cin x 9 ----
+  floatx4 acc[kCandPerWave][4];
   {
     const float inv_sc = __builtin_amdgcn_rcpf(L.sc1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 b = *reinterpret_cast<const float4*>(L.b1 + 16 * q + 4 * kg);
-      acc[q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
+#pragma unroll
+      for (int c = 0; c < kCandPerWave; ++c) acc[c][q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
     }
   }
   const int nsteps = (L.cin / 32) * 9;
-  half8 bh, bl, ah[4], al[4];
-  half8 nbh, nbl, nah[4], nal[4];
+  half8 bh[kCandPerWave], bl[kCandPerWave], ah[4], al[4];
+  half8 nbh[kCandPerWave], nbl[kCandPerWave], nah[4], nal[4];
 #define GTXH_LOAD1(STEP, BH, BL, AH, AL)                                                        \
   {                                                                                             \
     const int ch__ = (STEP) / 9, tap__ = (STEP) - ch__ * 9;                                     \
-    const int y__ = y1 + tap__ / 3 - 1, x__ = x1 + tap__ % 3 - 1;                               \
-    uint4 h__ = make_uint4(0, 0, 0, 0), l__ = make_uint4(0, 0, 0, 0);                           \
-    if (y__ >= 0 && y__ < L.H && x__ >= 0 && x__ < L.W) {                                       \
-      const uint4* s__ = reinterpret_cast<const uint4*>(in + ((size_t)y__ * L.W + x__) * L.cstride + ch__ * 32); \
-      h__ = s__[0];                                                                             \
-      l__ = s__[1];                                                                             \
+    _Pragma("unroll") for (int c = 0; c < kCandPerWave; ++c) {                                  \
+      const int y__ = y1[c] + tap__ / 3 - 1, x__ = x1[c] + tap__ % 3 - 1;                       \
+      uint4 h__ = make_uint4(0, 0, 0, 0), l__ = make_uint4(0, 0, 0, 0);                         \
+      if (y__ >= 0 && y__ < L.H && x__ >= 0 && x__ < L.W) {                                     \
+        const uint4* s__ = reinterpret_cast<const uint4*>(in + ((size_t)y__ * L.W + x__) * L.cstride + ch__ * 32); \
+        h__ = s__[0];                                                                           \
+        l__ = s__[1];                                                                           \
+      }                                                                                         \
+      BH[c] = __builtin_bit_cast(half8, h__);                                                   \
+      BL[c] = __builtin_bit_cast(half8, l__);                                                   \
     }                                                                                           \
-    BH = __builtin_bit_cast(half8, h__);                                                        \
-    BL = __builtin_bit_cast(half8, l__);                                                        \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
       const int row__ = 16 * q + col;                                                           \
       const char* w__ = wrow(L.w1, STEP, row__);                                                \
@@ -105,12 +118,15 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) GTXH_LOAD1(s + 1, nbh, nbl, nah, nal)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[q] = GTXH_MFMA(al[q], bh, acc[q]);
-      acc[q] = GTXH_MFMA(ah[q], bl, acc[q]);
-      acc[q] = GTXH_MFMA(ah[q], bh, acc[q]);
-    }
-    bh = nbh; bl = nbl;
+    for (int c = 0; c < kCandPerWave; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[c][q] = GTXH_MFMA(al[q], bh[c], acc[c][q]);
+        acc[c][q] = GTXH_MFMA(ah[q], bl[c], acc[c][q]);
+        acc[c][q] = GTXH_MFMA(ah[q], bh[c], acc[c][q]);
+      }
+#pragma unroll
+    for (int c = 0; c < kCandPerWave; ++c) { bh[c] = nbh[c]; bl[c] = nbl[c]; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { ah[q] = nah[q]; al[q] = nal[q]; }
   }
@@ -119,36 +135,40 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
   // v_permlane16_swap make the 8-channel group's hi chunk (even kg) and lo chunk (odd kg): byte 64 q + 16 kg of the row
   bool sat = false;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float2v v[2];
+  for (int c = 0; c < kCandPerWave; ++c)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      v[e] = silu2(float2v{acc[q][2 * e], acc[q][2 * e + 1]} * L.sc1);
-      if (!valid1) v[e] = float2v{0.f, 0.f};
+    for (int q = 0; q < 4; ++q) {
+      float2v v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v[e] = silu2(float2v{acc[c][q][2 * e], acc[c][q][2 * e + 1]} * L.sc1);
+        if (!valid1[c]) v[e] = float2v{0.f, 0.f};
+      }
+      uint2 hi, lo;
+      bool s1 = false;
+      split2(v[0], hi.x, lo.x, s1);
+      split2(v[1], hi.y, lo.y, s1);
+      sat |= s1 && col < 9;
+      const auto sx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+      if (col < 9) *reinterpret_cast<uint4*>(lds + (c * 9 + col) * kRowBytes + 64 * q + 16 * kg) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
-    uint2 hi, lo;
-    bool s1 = false;
-    split2(v[0], hi.x, lo.x, s1);
-    split2(v[1], hi.y, lo.y, s1);
-    sat |= s1 && col < 9;
-    const auto sx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
-    const auto sy = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
-    *reinterpret_cast<uint4*>(lds + col * kRowBytes + 64 * q + 16 * kg) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-  }
 
-  // ---- second layer at the anchor: K = 64 x 9 over the nine staged pixels (every column computes the same pixel) ----
+  // ---- second layer at the anchors: K = 64 x 9 over each candidate's nine staged pixels; MFMA column j works for candidate j & 3 ----
+  floatx4 acc2[4];
   {
     const float inv_sc = __builtin_amdgcn_rcpf(L.sc2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 b = *reinterpret_cast<const float4*>(L.b2 + 16 * q + 4 * kg);
-      acc[q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
+      acc2[q] = floatx4{b.x * inv_sc, b.y * inv_sc, b.z * inv_sc, b.w * inv_sc};
     }
   }
-#pragma unroll 1
+  const char* mine = lds + (col & 3) * 9 * kRowBytes;
+#pragma unroll 2
   for (int s = 0; s < 18; ++s) {
     const int ch = s / 9, tap = s - ch * 9;
-    const char* r = lds + tap * kRowBytes + (4 * ch + kg) * 32;      // the tap's pixel, 8-channel group 4 ch + kg: hi chunk, lo chunk
+    const char* r = mine + tap * kRowBytes + (4 * ch + kg) * 32;     // the tap's pixel, 8-channel group 4 ch + kg: hi chunk, lo chunk
     const half8 xh = *reinterpret_cast<const half8*>(r), xl = *reinterpret_cast<const half8*>(r + 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -156,16 +176,19 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
       const char* w = wrow(L.w2, s, row);
       const half8 wh = *reinterpret_cast<const half8*>(w + ((kg ^ ((row >> 1) & 7)) << 4));
       const half8 wl = *reinterpret_cast<const half8*>(w + (((4 + kg) ^ ((row >> 1) & 7)) << 4));
-      acc[q] = GTXH_MFMA(wl, xh, acc[q]);
-      acc[q] = GTXH_MFMA(wh, xl, acc[q]);
-      acc[q] = GTXH_MFMA(wh, xh, acc[q]);
+      acc2[q] = GTXH_MFMA(wl, xh, acc2[q]);
+      acc2[q] = GTXH_MFMA(wh, xl, acc2[q]);
+      acc2[q] = GTXH_MFMA(wh, xh, acc2[q]);
     }
   }
-  if (col == 0) {                                  // plain fp32, what the decode reads (ConvProblem::out_plain of the dense layer)
-    float* o = sb.feat + ((size_t)n * sb.cap + ci) * 64 + 4 * kg;
+  if (col < kCandPerWave && first + col < cnt) {   // plain fp32, what the decode reads (ConvProblem::out_plain of the dense layer)
+    int mine_ci = ci[0];
+#pragma unroll
+    for (int c = 1; c < kCandPerWave; ++c) mine_ci = col == c ? ci[c] : mine_ci;
+    float* o = sb.feat + ((size_t)n * sb.cap + mine_ci) * 64 + 4 * kg;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float2v v0 = silu2(float2v{acc[q][0], acc[q][1]} * L.sc2), v1 = silu2(float2v{acc[q][2], acc[q][3]} * L.sc2);
+      const float2v v0 = silu2(float2v{acc2[q][0], acc2[q][1]} * L.sc2), v1 = silu2(float2v{acc2[q][2], acc2[q][3]} * L.sc2);
       *reinterpret_cast<float4*>(o + 16 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
   }
@@ -175,8 +198,9 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
 }  // namespace
 
 void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s) {
-  GTX_CHECK(sb.cap > 0 && sb.feat != nullptr, "sparse box branch: no buffer");
-  hipLaunchKernelGGL(head_sparse_box_kernel, dim3((sb.cap + 3) / 4, n), dim3(256), 4 * kWaveLds, s, sb, nb);
+  GTX_CHECK(sb.cap > 0 && sb.feat != nullptr && nb.lvl_count != nullptr && nb.lvl_list != nullptr && nb.lvl_cap == sb.cap, "sparse box branch: no buffers");
+  const int groups = (nb.lvl_cap + 4 * kCandPerWave - 1) / (4 * kCandPerWave);
+  hipLaunchKernelGGL(head_sparse_box_kernel, dim3(sb.n_levels * groups, n), dim3(256), 4 * kWaveLds, s, sb, nb, groups);
   GTX_HIP(hipGetLastError());
 }
 
