@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
     }
   }
   const int nsteps = (L.cin / 32) * 9;
-  half8 bh[kCandPerWave], bl[kCandPerWave], ah[4], al[4];
-  half8 nbh[kCandPerWave], nbl[kCandPerWave], nah[4], nal[4];
-#define GTXH_LOAD1(STEP, BH, BL, AH, AL)                                                        \
+  // three register sets in rotation: the loads of steps s + 1 and s + 2 are in flight while step s multiplies (a step's loads are
+  // L2 round trips; nine taps per chunk: the step count is a multiple of three)
+  half8 bh[3][kCandPerWave], bl[3][kCandPerWave], ah[3][4], al[3][4];
+#define GTXH_LOAD1(STEP, R)                                                                     \
   {                                                                                             \
     const int ch__ = (STEP) / 9, tap__ = (STEP) - ch__ * 9;                                     \
     _Pragma("unroll") for (int c = 0; c < kCandPerWave; ++c) {                                  \
@@ -104,32 +105,34 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
         h__ = s__[0];                                                                           \
         l__ = s__[1];                                                                           \
       }                                                                                         \
-      BH[c] = __builtin_bit_cast(half8, h__);                                                   \
-      BL[c] = __builtin_bit_cast(half8, l__);                                                   \
+      bh[R][c] = __builtin_bit_cast(half8, h__);                                                \
+      bl[R][c] = __builtin_bit_cast(half8, l__);                                                \
     }                                                                                           \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
       const int row__ = 16 * q + col;                                                           \
       const char* w__ = wrow(L.w1, STEP, row__);                                                \
-      AH[q] = *reinterpret_cast<const half8*>(w__ + ((kg ^ ((row__ >> 1) & 7)) << 4));          \
-      AL[q] = *reinterpret_cast<const half8*>(w__ + (((4 + kg) ^ ((row__ >> 1) & 7)) << 4));    \
+      ah[R][q] = *reinterpret_cast<const half8*>(w__ + ((kg ^ ((row__ >> 1) & 7)) << 4));       \
+      al[R][q] = *reinterpret_cast<const half8*>(w__ + (((4 + kg) ^ ((row__ >> 1) & 7)) << 4)); \
     }                                                                                           \
   }
-  GTXH_LOAD1(0, bh, bl, ah, al)
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) GTXH_LOAD1(s + 1, nbh, nbl, nah, nal)
-#pragma unroll
-    for (int c = 0; c < kCandPerWave; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[c][q] = GTXH_MFMA(al[q], bh[c], acc[c][q]);
-        acc[c][q] = GTXH_MFMA(ah[q], bl[c], acc[c][q]);
-        acc[c][q] = GTXH_MFMA(ah[q], bh[c], acc[c][q]);
-      }
-#pragma unroll
-    for (int c = 0; c < kCandPerWave; ++c) { bh[c] = nbh[c]; bl[c] = nbl[c]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { ah[q] = nah[q]; al[q] = nal[q]; }
+#define GTXH_STEP1(S, R)                                                                        \
+  {                                                                                             \
+    if ((S) + 2 < nsteps) GTXH_LOAD1((S) + 2, ((R) + 2) % 3)                                    \
+    _Pragma("unroll") for (int c = 0; c < kCandPerWave; ++c)                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                           \
+        acc[c][q] = GTXH_MFMA(al[R][q], bh[R][c], acc[c][q]);                                   \
+        acc[c][q] = GTXH_MFMA(ah[R][q], bl[R][c], acc[c][q]);                                   \
+        acc[c][q] = GTXH_MFMA(ah[R][q], bh[R][c], acc[c][q]);                                   \
+      }                                                                                         \
   }
+  GTXH_LOAD1(0, 0)
+  GTXH_LOAD1(1, 1)
+  for (int s = 0; s < nsteps; s += 3) {
+    GTXH_STEP1(s, 0)
+    GTXH_STEP1(s + 1, 1)
+    GTXH_STEP1(s + 2, 2)
+  }
+#undef GTXH_STEP1
 #undef GTXH_LOAD1
   // SiLU, hi / lo split, pair rows in LDS: lane (col, kg) of block q holds channels 16 q + 4 kg + 0..3 of pixel col; two
   // v_permlane16_swap make the 8-channel group's hi chunk (even kg) and lo chunk (odd kg): byte 64 q + 16 kg of the row
@@ -165,22 +168,36 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
     }
   }
   const char* mine = lds + (col & 3) * 9 * kRowBytes;
-#pragma unroll 2
-  for (int s = 0; s < 18; ++s) {
-    const int ch = s / 9, tap = s - ch * 9;
-    const char* r = mine + tap * kRowBytes + (4 * ch + kg) * 32;     // the tap's pixel, 8-channel group 4 ch + kg: hi chunk, lo chunk
-    const half8 xh = *reinterpret_cast<const half8*>(r), xl = *reinterpret_cast<const half8*>(r + 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = 16 * q + col;
-      const char* w = wrow(L.w2, s, row);
-      const half8 wh = *reinterpret_cast<const half8*>(w + ((kg ^ ((row >> 1) & 7)) << 4));
-      const half8 wl = *reinterpret_cast<const half8*>(w + (((4 + kg) ^ ((row >> 1) & 7)) << 4));
-      acc2[q] = GTXH_MFMA(wl, xh, acc2[q]);
-      acc2[q] = GTXH_MFMA(wh, xl, acc2[q]);
-      acc2[q] = GTXH_MFMA(wh, xh, acc2[q]);
-    }
+  half8 wh[3][4], wl[3][4];
+#define GTXH_LOAD2(STEP, R)                                                                     \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+    const int row__ = 16 * q + col;                                                             \
+    const char* w__ = wrow(L.w2, STEP, row__);                                                  \
+    wh[R][q] = *reinterpret_cast<const half8*>(w__ + ((kg ^ ((row__ >> 1) & 7)) << 4));         \
+    wl[R][q] = *reinterpret_cast<const half8*>(w__ + (((4 + kg) ^ ((row__ >> 1) & 7)) << 4));   \
   }
+#define GTXH_STEP2(S, R)                                                                        \
+  {                                                                                             \
+    if ((S) + 2 < 18) GTXH_LOAD2((S) + 2, ((R) + 2) % 3)                                        \
+    const int ch__ = (S) / 9, tap__ = (S) - ch__ * 9;                                           \
+    const char* r__ = mine + tap__ * kRowBytes + (4 * ch__ + kg) * 32;   /* the tap's pixel, 8-channel group 4 ch + kg: hi chunk, lo chunk */ \
+    const half8 xh__ = *reinterpret_cast<const half8*>(r__), xl__ = *reinterpret_cast<const half8*>(r__ + 16); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+      acc2[q] = GTXH_MFMA(wl[R][q], xh__, acc2[q]);                                             \
+      acc2[q] = GTXH_MFMA(wh[R][q], xl__, acc2[q]);                                             \
+      acc2[q] = GTXH_MFMA(wh[R][q], xh__, acc2[q]);                                             \
+    }                                                                                           \
+  }
+  GTXH_LOAD2(0, 0)
+  GTXH_LOAD2(1, 1)
+#pragma unroll 1
+  for (int s = 0; s < 18; s += 3) {
+    GTXH_STEP2(s, 0)
+    GTXH_STEP2(s + 1, 1)
+    GTXH_STEP2(s + 2, 2)
+  }
+#undef GTXH_STEP2
+#undef GTXH_LOAD2
   if (col < kCandPerWave && first + col < cnt) {   // plain fp32, what the decode reads (ConvProblem::out_plain of the dense layer)
     int mine_ci = ci[0];
 #pragma unroll
