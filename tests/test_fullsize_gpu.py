@@ -479,3 +479,49 @@ def test_extract_from_a_4k_y4m_through_the_feeder_equals_the_synchronous_reader(
         Hm, Ht = row[1:].reshape(3, 3), np.linalg.inv(sc.camera(t, 150))
         pa, pb = Hm @ g, Ht @ g
         assert np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max() < 1.0, t
+
+
+@pytest.mark.gpu
+def test_4k_default_detector_equals_one_that_computes_every_row_and_every_anchor(gtx_ctx, monkeypatch):
+    """The bench's configuration (3840x2160 frames, 1920x1920 input, rect = false, split-f16x3, two batch slots): the default
+    detector -- letterbox-padding rows computed once (GTX_PAD_SKIP), Detect's box branch at the candidates only (GTX_SPARSE_BOX) --
+    against one built with both switched off, over a moving clip: boxes, scores, classes and their order bit for bit, and the
+    layers the padding rows belong to as well."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.weights import calibrate_cls_bias, synthetic_yolov8
+
+    scene = make_scene(seed=0, h=H4, w=W4)
+    frames = np.stack([scene.render(3 * k, 150) for k in range(6)])
+    kw = dict(imgsz=1920, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True, half=False, rect=False, max_batch=2)
+    w = synthetic_yolov8(seed=0, nc=4, level_bias=(0.0, -1e4, -1e4), box_weight_scale=0.002, smooth_cls=True, box_decay=(0.2, 0.3, 0.2, 0.3))
+    monkeypatch.setenv("GTX_PAD_SKIP", "0")
+    monkeypatch.setenv("GTX_SPARSE_BOX", "0")
+    probe = Detector(w, (H4, W4), ctx=gtx_ctx, **kw)
+    probe.detect(frames[0])
+    w = calibrate_cls_bias(w, probe.raw_output(logits=True)[:, 4:], 0.25, 132)
+    probe.close()
+    plain = Detector(w, (H4, W4), ctx=gtx_ctx, **kw)
+    monkeypatch.setenv("GTX_PAD_SKIP", "1")
+    monkeypatch.setenv("GTX_SPARSE_BOX", "1")
+    fast = Detector(w, (H4, W4), ctx=gtx_ctx, **kw)
+    on, skipped, total = fast.pad_skip()
+    assert on and skipped > 0.15 * total and fast.sparse_box()[0] and not plain.pad_skip()[0] and not plain.sparse_box()[0]
+    dptr = gtx_ctx.dev_alloc(frames[:2].nbytes)
+    try:
+        n_boxes = 0
+        for k in (0, 2, 4, 1, 3):
+            gtx_ctx.dev_upload(dptr, np.ascontiguousarray(frames[k:k + 2]))
+            for x, y in zip(plain.detect_dev(dptr, 2), fast.detect_dev(dptr, 2)):
+                np.testing.assert_array_equal(y.xyxy, x.xyxy)
+                np.testing.assert_array_equal(y.conf, x.conf)
+                np.testing.assert_array_equal(y.cls, x.cls)
+                n_boxes += len(x)
+        assert n_boxes > 500
+        for name in ("model.2", "model.4", "model.6", "model.9", "model.15"):
+            for slot in (0, 1):
+                np.testing.assert_array_equal(fast.layer_output(name, slot), plain.layer_output(name, slot), err_msg=f"{name} slot {slot}")
+    finally:
+        gtx_ctx.dev_free(dptr)
+    assert fast.sparse_box() == (True, 0)
+    plain.close(); fast.close()
