@@ -1416,8 +1416,12 @@ void launch_obj_feats(int dtype, const FeatLevels& fl, int n, const NmsBuffers& 
   GTX_HIP(hipGetLastError());
 }
 
+// which == 0: everything (the single-workgroup kernel and the general rank / mask / resolve kernels, each of which leaves at
+// once when the other path has the image); 1: the single-workgroup kernel only; 2: the general kernels only. A caller that
+// knows the candidate counts (Detector: copied back with the results) launches 1 in the pass and 2 afterwards for a batch
+// that needs it (nms_small_covers): three launches less in every pass's dependent tail.
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
-                const Letterbox& lb, hipStream_t s) {
+                const Letterbox& lb, hipStream_t s, int which) {
   GTX_CHECK(nb.nms_cap <= kNmsWords * 64, "nms: capacity %d too large", nb.nms_cap);
   const int limit = std::min(max_nms, nb.nms_cap);
   const float cls_offset = agnostic ? 0.f : 7680.f;  // ultralytics max_wh
@@ -1425,9 +1429,12 @@ void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int m
   const double gain = lb.gain;
   const float padx = (float)std::nearbyint((lb.net_w - lb.src_w * gain) / 2 - 0.1);
   const float pady = (float)std::nearbyint((lb.net_h - lb.src_h * gain) / 2 - 0.1);
-  hipLaunchKernelGGL(nms_small_kernel, dim3(n), dim3(1024), 0, s, nb, iou_thr, cls_offset, (float)gain, padx, pady,
-                     (float)lb.src_w, (float)lb.src_h);
-  GTX_HIP(hipGetLastError());
+  if (which != 2) {
+    hipLaunchKernelGGL(nms_small_kernel, dim3(n), dim3(1024), 0, s, nb, iou_thr, cls_offset, (float)gain, padx, pady,
+                       (float)lb.src_w, (float)lb.src_h);
+    GTX_HIP(hipGetLastError());
+  }
+  if (which == 1) return;
   hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(nb.cap, 256), n), dim3(256), 0, s, nb, limit, cls_offset);
   GTX_HIP(hipGetLastError());
   hipLaunchKernelGGL(nms_mask_kernel, dim3(256, n), dim3(256), 0, s, nb, iou_thr, cls_offset);
@@ -1436,5 +1443,7 @@ void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int m
                      (float)lb.src_w, (float)lb.src_h);
   GTX_HIP(hipGetLastError());
 }
+
+bool nms_small_covers(int candidates, int max_det) { return candidates <= kSmallNms && max_det <= kSmallKeep; }
 
 }  // namespace gtx

@@ -120,12 +120,13 @@ struct SparseBoxLevel {
   const void* w1; const float* b1; float sc1;
   const void* w2; const float* b2; float sc2;
   int anchor_begin;
+  const float* wb; const float* bb; float stride;   // the level's final box 1x1 convolution ([64][64] transposed, bias) and its stride: HeadLevel
 };
 struct SparseBox {
   SparseBoxLevel lv[kMaxLevels];
   int n_levels;
   int cap;              // candidates per image the buffer holds (more: the caller runs the dense layers)
-  float* feat;          // [N][cap][64] fp32: the box features of candidate i, read by the decode when NmsBuffers::sparse_feat is set
+  float* feat;          // unused since the kernel decodes the boxes itself (kept: [N][cap][64] fp32)
   int* sat_flag;
 };
 void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s);
@@ -133,6 +134,8 @@ void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hi
 // (or class logits).
 void launch_head_raw(int dtype, const HeadParams& hp, int n, float* out, bool logits, hipStream_t s);
 void launch_nms(const NmsBuffers& nb, int n, float iou_thr, bool agnostic, int max_nms,
-                const Letterbox& lb, hipStream_t s);
+                const Letterbox& lb, hipStream_t s, int which = 0);
+// true when the single-workgroup kernel handles an image with that many candidates (the general kernels then have nothing to do)
+bool nms_small_covers(int candidates, int max_det);
 
 }  // namespace gtx

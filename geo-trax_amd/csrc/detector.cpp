@@ -481,6 +481,7 @@ void Detector::build_graph() {
         S.w1 = full.wpack; S.b1 = full.bias; S.sc1 = full.acc_scale;
         S.w2 = o2.grp.p[0].wpack; S.b2 = o2.grp.p[0].bias; S.sc2 = o2.grp.p[0].acc_scale;
         S.anchor_begin = head_.lv[l].anchor_begin;
+        S.wb = head_.lv[l].wb; S.bb = head_.lv[l].bb; S.stride = head_.lv[l].stride;
         GTX_CHECK(full.bias && o2.grp.p[0].bias && o2.grp.p[0].Cin == 64 && o2.grp.p[0].Cout == 64, "sparse box branch: unexpected Detect box layers");
         Op box1 = o1;                                // the box tile alone
         box1.grp.p[0].Cout = cb;
@@ -835,8 +836,8 @@ void Detector::finalize() {
     nms_.lvl_cap = kSparseCap;
     nms_.lvl_count = (int*)alloc(sizeof(int) * N * kMaxLevels);
     nms_.lvl_list = (int*)alloc(sizeof(int) * N * kMaxLevels * kSparseCap);
-    GTX_HIP(hipHostMalloc((void**)&h_count_, sizeof(int) * N));
   }
+  GTX_HIP(hipHostMalloc((void**)&h_count_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_n_, sizeof(int) * N));
   GTX_HIP(hipHostMalloc((void**)&h_out_rows_, sizeof(float) * 6 * N * cfg_.max_det));
   if (conv_dtype_ != DT_F32S) tensors_.clear();  // host copies are no longer needed (the split path keeps them for fall_back_to_exact)
@@ -944,14 +945,15 @@ void Detector::run_post(int nb, hipStream_t s) {
   if (sparse_on_) {                                // score gate -> the box branch at the candidates -> their boxes
     NmsBuffers nbuf = nms_;
     launch_head_gate(dtype_, head_, nb, nbuf, s);
-    launch_head_sparse_box(sparse_, nb, nbuf, s);
-    launch_head_boxes(dtype_, head_, nb, nbuf, s);
-    GTX_HIP(hipMemcpyAsync(h_count_, nms_.count, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+    launch_head_sparse_box(sparse_, nb, nbuf, s);    // the box branch at the candidates and their boxes
     dense_head_valid_ = false;
   } else {
     launch_head_candidates(dtype_, head_, nb, nms_, s);
   }
-  launch_nms(nms_, nb, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
+  // the candidate counts come back with the results: collect() runs what this pass leaves out for a batch that needs it (the
+  // general NMS kernels for > 4096 candidates in an image, the dense box layers for > kSparseCap)
+  GTX_HIP(hipMemcpyAsync(h_count_, nms_.count, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+  launch_nms(nms_, nb, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s, 1);
   GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
   GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * nb * cfg_.max_det, hipMemcpyDeviceToHost, s));
   if (sat_dev_) GTX_HIP(hipMemcpyAsync(h_sat_, sat_dev_, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1071,16 +1073,22 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
     }
     flight_traced_ = false;
   }
-  if (sparse_on_) {                                  // more candidates than the sparse buffer holds: the dense layers, then the tail again
-    bool over = false;
-    for (int b = 0; b < flight_nb_; ++b) over = over || h_count_[b] > kSparseCap;
-    if (over) {
+  {                                                  // what the pass left out for the common case
+    bool over = false, big = false;
+    for (int b = 0; b < flight_nb_; ++b) {
+      over = over || (sparse_on_ && h_count_[b] > kSparseCap);                 // more candidates than the sparse buffer holds
+      big = big || !nms_small_covers(std::min(h_count_[b], nms_.cap), nms_.max_det);   // ... than the single-workgroup NMS takes
+    }
+    if (over || big) {
       hipStream_t s = ctx_->stream;
-      run_dense_box(s);
       NmsBuffers dense = nms_;
-      dense.sparse_feat = nullptr;
-      launch_head_boxes(dtype_, head_, flight_nb_, dense, s);
-      launch_nms(dense, flight_nb_, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s);
+      if (over) {                                    // the dense box layers, then every candidate's box again
+        run_dense_box(s);
+        dense.sparse_feat = nullptr;
+        launch_head_boxes(dtype_, head_, flight_nb_, dense, s);
+        ++sparse_overflows_;
+      }
+      launch_nms(dense, flight_nb_, cfg_.iou, cfg_.agnostic_nms != 0, 30000, lb_, s, over ? 0 : 2);
       GTX_HIP(hipMemcpyAsync(h_out_n_, nms_.out_n, sizeof(int) * flight_nb_, hipMemcpyDeviceToHost, s));
       GTX_HIP(hipMemcpyAsync(h_out_rows_, nms_.out_rows, sizeof(float) * 6 * flight_nb_ * cfg_.max_det, hipMemcpyDeviceToHost, s));
       if (cfg_.obj_feats) {
@@ -1088,7 +1096,6 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
         GTX_HIP(hipMemcpyAsync(h_feats_, d_feats_, sizeof(float) * flight_nb_ * cfg_.max_det * feat_levels_.dim, hipMemcpyDeviceToHost, s));
       }
       GTX_HIP(hipStreamSynchronize(s));
-      ++sparse_overflows_;
     }
   }
   const int nb = flight_nb_;

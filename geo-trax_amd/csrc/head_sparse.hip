@@ -8,6 +8,8 @@
 // kernels it replaces (conv_k32_split.hip: same packed weight images and power-of-two scales, same v_mfma_f32_16x16x32_f16
 // sequence per output pixel -- chunk, kernel row, kernel column, small terms first -- same bias start, SiLU and hi / lo split,
 // zero padding at the image border for both layers), so a candidate's 64 box features are the dense path's bit for bit.
+// The wave then decodes its candidates' boxes (the final 1x1 convolution + DFL of head_boxes_kernel, same operations in the same
+// order), so the sparse path is one launch between the score gate and the NMS.
 // The dense convolutions stay available (Detector: GTX_SPARSE_BOX=0, the debug read-backs, more candidates than the buffer holds).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -198,15 +200,46 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
   }
 #undef GTXH_STEP2
 #undef GTXH_LOAD2
-  if (col < kCandPerWave && first + col < cnt) {   // plain fp32, what the decode reads (ConvProblem::out_plain of the dense layer)
-    int mine_ci = ci[0];
-#pragma unroll
-    for (int c = 1; c < kCandPerWave; ++c) mine_ci = col == c ? ci[c] : mine_ci;
-    float* o = sb.feat + ((size_t)n * sb.cap + mine_ci) * 64 + 4 * kg;
+  // the candidates' 64 box features (plain fp32: ConvProblem::out_plain of the dense layer) -> LDS, where the decode below reads
+  // them; the first-layer rows are no longer needed (a wave's LDS operations execute in order)
+  float* fl = reinterpret_cast<float*>(lds);       // [candidate][64]
+  if (col < kCandPerWave) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float2v v0 = silu2(float2v{acc2[q][0], acc2[q][1]} * L.sc2), v1 = silu2(float2v{acc2[q][2], acc2[q][3]} * L.sc2);
-      *reinterpret_cast<float4*>(o + 16 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
+      *reinterpret_cast<float4*>(fl + col * 64 + 16 * q + 4 * kg) = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+  }
+  // ---- box decode of the wave's candidates (head_boxes_kernel's arithmetic: the 64 x 64 final 1x1 convolution as one fmaf chain
+  // per output in feature order, DFL softmax expectation per side, dist2bbox, xywh -> xyxy) ----
+#pragma unroll 1
+  for (int c = 0; c < kCandPerWave; ++c) {
+    if (first + c >= cnt) break;                   // wave-uniform
+    float a = L.bb[lane];
+    const float* wr = L.wb + lane;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) a = fmaf(fl[c * 64 + k], wr[(size_t)k * 64], a);
+    const int anchor = __builtin_amdgcn_readfirstlane(nb.cand_anchor[(size_t)n * nb.cap + ci[c]]);
+    const int la = anchor - L.anchor_begin;
+    // softmax over the 16 lanes of a side
+    float m = a;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float e = expf(a - m);
+    float se = e, sw = e * (float)(lane & 15);
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+      se += __shfl_xor(se, o, 64);
+      sw += __shfl_xor(sw, o, 64);
+    }
+    const float d = sw / se;
+    const float d0 = __shfl(d, 0, 64), d1 = __shfl(d, 16, 64), d2 = __shfl(d, 32, 64), d3 = __shfl(d, 48, 64);
+    const float ax = (float)(la % L.W) + 0.5f, ay = (float)(la / L.W) + 0.5f;
+    const float bx1 = ax - d0, by1 = ay - d1, bx2 = ax + d2, by2 = ay + d3;
+    const float4 b = make_float4((bx1 + bx2) * 0.5f * L.stride, (by1 + by2) * 0.5f * L.stride, (bx2 - bx1) * L.stride, (by2 - by1) * L.stride);
+    if (lane == 0) {
+      const float hw = b.z / 2.f, hh = b.w / 2.f;   // xywh2xyxy
+      reinterpret_cast<float4*>(nb.cand_box)[(size_t)n * nb.cap + ci[c]] = make_float4(b.x - hw, b.y - hh, b.x + hw, b.y + hh);
     }
   }
   if (sb.sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(sb.sat_flag, 1);
