@@ -993,9 +993,8 @@ __global__ __launch_bounds__(256) void head_boxes_kernel(const HeadParams hp, co
     const HeadLevel& L = hp.lv[l];
     const int la = a - L.anchor_begin;
     const T* f = static_cast<const T*>(L.feat) + ((size_t)n * L.h * L.w + la) * L.cstride;
-    float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
+    const float f0 = lane < L.cb ? ldf(f + lane) : 0.f;
     const float f1 = lane + 64 < L.cb ? ldf(f + lane + 64) : 0.f;
-    if (nb.sparse_feat) f0 = i < nb.sparse_cap ? nb.sparse_feat[((size_t)n * nb.sparse_cap + i) * 64 + lane] : 0.f;   // cb == 64 (head_sparse.hip)
     float acc = L.bb[lane];
     const float* wr = s_wb + l * cbmax * 64 + lane;
     const int k0 = min(L.cb, 64);

@@ -82,9 +82,6 @@ struct NmsBuffers {
   int* out_n;           // [N]
   float* out_rows;      // [N][max_det][6] x1 y1 x2 y2 conf cls (frame pixels)
   int* out_anchor;      // [N][max_det] anchor index of every output row (may be null)
-  // box features of the candidates from the sparse box branch ([N][sparse_cap][cb] fp32; null: the decode reads HeadLevel::feat)
-  const float* sparse_feat;
-  int sparse_cap;
   // ... and the candidates filed by level for it (indices into the candidate arrays): lvl_count [N][kMaxLevels],
   // lvl_list [N][kMaxLevels][lvl_cap]; null: not kept
   int* lvl_count;
@@ -126,7 +123,6 @@ struct SparseBox {
   SparseBoxLevel lv[kMaxLevels];
   int n_levels;
   int cap;              // candidates per image the buffer holds (more: the caller runs the dense layers)
-  float* feat;          // unused since the kernel decodes the boxes itself (kept: [N][cap][64] fp32)
   int* sat_flag;
 };
 void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s);

@@ -829,10 +829,7 @@ void Detector::finalize() {
   }
   if (sparse_on_) {
     sparse_.cap = kSparseCap;
-    sparse_.feat = (float*)alloc(sizeof(float) * N * kSparseCap * 64);
     sparse_.sat_flag = sat_dev_;
-    nms_.sparse_feat = sparse_.feat;
-    nms_.sparse_cap = kSparseCap;
     nms_.lvl_cap = kSparseCap;
     nms_.lvl_count = (int*)alloc(sizeof(int) * N * kMaxLevels);
     nms_.lvl_list = (int*)alloc(sizeof(int) * N * kMaxLevels * kSparseCap);
@@ -943,9 +940,8 @@ void Detector::trace_report(std::vector<std::string>& names, std::vector<int>& l
 
 void Detector::run_post(int nb, hipStream_t s) {
   if (sparse_on_) {                                // score gate -> the box branch at the candidates -> their boxes
-    NmsBuffers nbuf = nms_;
-    launch_head_gate(dtype_, head_, nb, nbuf, s);
-    launch_head_sparse_box(sparse_, nb, nbuf, s);    // the box branch at the candidates and their boxes
+    launch_head_gate(dtype_, head_, nb, nms_, s);
+    launch_head_sparse_box(sparse_, nb, nms_, s);    // the box branch at the candidates and their boxes
     dense_head_valid_ = false;
   } else {
     launch_head_candidates(dtype_, head_, nb, nms_, s);
@@ -1084,7 +1080,6 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
       NmsBuffers dense = nms_;
       if (over) {                                    // the dense box layers, then every candidate's box again
         run_dense_box(s);
-        dense.sparse_feat = nullptr;
         launch_head_boxes(dtype_, head_, flight_nb_, dense, s);
         ++sparse_overflows_;
       }

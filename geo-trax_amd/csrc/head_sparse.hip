@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void head_sparse_box_kernel(const SparseBox sb
 }  // namespace
 
 void launch_head_sparse_box(const SparseBox& sb, int n, const NmsBuffers& nb, hipStream_t s) {
-  GTX_CHECK(sb.cap > 0 && sb.feat != nullptr && nb.lvl_count != nullptr && nb.lvl_list != nullptr && nb.lvl_cap == sb.cap, "sparse box branch: no buffers");
+  GTX_CHECK(sb.cap > 0 && nb.lvl_count != nullptr && nb.lvl_list != nullptr && nb.lvl_cap == sb.cap, "sparse box branch: no buffers");
   const int groups = (nb.lvl_cap + 4 * kCandPerWave - 1) / (4 * kCandPerWave);
   hipLaunchKernelGGL(head_sparse_box_kernel, dim3(sb.n_levels * groups, n), dim3(256), 4 * kWaveLds, s, sb, nb, groups);
   GTX_HIP(hipGetLastError());
