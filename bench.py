@@ -980,6 +980,8 @@ def main():
                 records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H, r.gmc, with_gmc=shard_gmc))
                 if live[0]:
                     gather_ready()
+        if engine.prof:                                          # GTX_ENGINE_PROF=1: where the host stages wait
+            print("engine host stages (s): " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(engine.prof.items())), file=sys.stderr)
         return n_rows
 
     # ---- N > 1: chunked gather to rank 0 + tracker replay on a second host thread

@@ -299,6 +299,7 @@ class ExtractEngine:
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer
         self._index, self._have_ref = 0, False
         self._last_H = None              # last valid current->reference transform, in frame order
+        self._prof = self.prof = None    # GTX_ENGINE_PROF=1: see run()
         self._gmc_sub = self._gmc_col = 0   # frames queued on the GMC stream / warps taken (one writer thread each)
 
     _IDLE = object()                 # drain() -> _stabilized(): no frame arrived for a few milliseconds
@@ -406,6 +407,9 @@ class ExtractEngine:
         stabilizer submit/collect + box warp (this thread, which yields). Per-frame results are the same as
         frame at a time; only the host work overlaps. GTX_ENGINE_THREADS=0 keeps everything on the calling thread."""
         self._paced = bool(getattr(batches, "paced", False)) if paced is None else bool(paced)
+        # GTX_ENGINE_PROF=1: seconds the host stages spend in their blocking calls, summed over the run (self.prof afterwards)
+        self._prof = collections.defaultdict(float) if os.environ.get("GTX_ENGINE_PROF") == "1" else None
+        self.prof = self._prof
         threaded = (self.tracker is not None or bool(self.stabs)) and os.environ.get("GTX_ENGINE_THREADS", "1") != "0"
         frames = self._tracked_frames_threaded(batches) if threaded else self._tracked_frames(batches)
         return self._stabilized(frames)
@@ -443,7 +447,10 @@ class ExtractEngine:
             fill()
             while inflight:
                 det, nb, prev = inflight.popleft()
+                t0 = time.perf_counter() if self._prof is not None else 0.0
                 dets = det.collect()
+                if self._prof is not None:
+                    self._prof["det_collect"] += time.perf_counter() - t0
                 grays = [det.gray_dptr(b) for b in range(nb)]
                 hosts = self._host_frames.pop(id(det), None)
                 det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
@@ -486,7 +493,10 @@ class ExtractEngine:
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
             warp = self._gmc_collect() if self.gmc is not None else None
             if self.tracker is not None:                        # also on frames without detections (frame counter, lost/removed ageing)
+                t0 = time.perf_counter() if self._prof is not None else 0.0
                 t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp, feats=d.feats)
+                if self._prof is not None:
+                    self._prof["tracker"] += time.perf_counter() - t0
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
             r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms, warp)
@@ -586,9 +596,14 @@ class ExtractEngine:
             else:
                 self._last_H = r.H.copy()
 
+        prof = self._prof
+
         def finish():
             st, r = pending.popleft()
+            t0 = time.perf_counter() if prof is not None else 0.0
             st.collect()
+            if prof is not None:
+                prof["stab_collect"] += time.perf_counter() - t0
             r.H = st.get_cur_trans_matrix(raw=True)
             r.stab_ms = st.last_ms()
             last_known(r)
@@ -621,7 +636,11 @@ class ExtractEngine:
                     yield finish()
                 st = self.stabs[r.index % len(self.stabs)]
                 if self.use_dev_gray:
+                    t0 = time.perf_counter() if prof is not None else 0.0
                     st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
+                    if prof is not None:
+                        prof["stab_submit"] += time.perf_counter() - t0
+                        prof["frames"] += 1
                     pending.append((st, r))
                 else:                                               # other downsample ratios: the stabilizer makes its own gray
                     st.stabilize(host, r.xywh)
