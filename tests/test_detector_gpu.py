@@ -509,3 +509,29 @@ def test_nothing_is_skipped_without_padding_rows(gtx_ctx, weights):
     rc = Detector(weights, (1080, 1920), imgsz=960, rect=True, ctx=gtx_ctx)        # rect: 544 x 960, 2 + 2 padding rows
     assert sq.pad_skip()[1] == 0 and rc.pad_skip()[1] == 0
     sq.close(); rc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,gain", [("n", 1.7), ("m", 1.7), ("l", 1.0)])
+def test_padding_rows_of_the_other_scales(gtx_ctx, monkeypatch, scale, gain):
+    """The same bit-for-bit check on the other YOLOv8 scales (other widths, one to three bottlenecks per C2f, 16-channel chunks where
+    the widths are multiples of 16 only), on an odd letterbox: 1080 x 1920 into 640 x 640 puts the frame in rows 140..499."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import synthetic_yolov8
+
+    w = synthetic_yolov8(seed=3, nc=4, scale=scale, cls_bias=-3.0, gain=gain)
+    hw = (1080, 1920)
+    kw = dict(imgsz=640, conf=0.25, iou=0.7, max_det=300, agnostic_nms=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_PAD_SKIP", "0")
+    full = Detector(w, hw, **kw)
+    monkeypatch.setenv("GTX_PAD_SKIP", "1")
+    skip = Detector(w, hw, **kw)
+    assert skip.pad_skip()[1] > 0
+    for s in (5, 6, 7):
+        f = _frame(s, hw)
+        a, b = full.detect(f), skip.detect(f)
+        np.testing.assert_array_equal(b.xyxy, a.xyxy)
+        np.testing.assert_array_equal(b.conf, a.conf)
+        for name in ("model.2", "model.4", "model.6", "model.8", "model.9", "model.22.feat0"):
+            np.testing.assert_array_equal(skip.layer_output(name), full.layer_output(name), err_msg=f"{scale} {name} frame {s}")
+    full.close(); skip.close()
