@@ -1,15 +1,11 @@
-"""The advertised drop-in: the reference's loop body, unmodified, over this build's ``YOLO`` and
-``Stabilizer`` objects must give what ``python -m geotrax_amd.extract`` gives -- byte for byte.
-
-The loop in `_reference_loop` is the body of geotrax/extract.py:145-197 as it stands there (the call
-``model.track(frame, **config['ultralytics'], persist=True)``, the four ``.detach().numpy(force=True)`` reads with their
-uint16 / uint8 / float32 narrowings, ``results[0].speed``, ``set_ref_frame`` / ``stabilize`` / ``transform_cur_boxes`` /
-``get_cur_trans_matrix``); only the progress bar is left out. The clip contains frames without detections (which must still
-reach the tracker and, with BoT-SORT, the GMC: ultralytics' on_predict_postprocess_end) and frames that cannot be registered
-(which take stabilo's last known transform)."""
+"""The advertised drop-in: a caller that uses nothing but the call contract of the reference's two
+objects -- ``model.track(frame, **cfg, persist=True)`` with its ``.detach().numpy(force=True)`` reads and ``results[0].speed``,
+``Stabilizer.set_ref_frame`` / ``stabilize`` / ``transform_cur_boxes`` / ``get_cur_trans_matrix`` (geotrax/extract.py:153-187) --
+over this build's ``YOLO`` and ``Stabilizer`` must give what ``python -m geotrax_amd.extract`` gives, byte for byte. The clip
+contains frames without detections (which must still reach the tracker and, with BoT-SORT, the GMC: ultralytics'
+on_predict_postprocess_end) and frames that cannot be registered (which take stabilo's last known transform)."""
 import argparse
 import logging
-import time
 from pathlib import Path
 
 import numpy as np
@@ -21,64 +17,45 @@ pytestmark = pytest.mark.gpu
 logger = logging.getLogger("test_dropin")
 
 
-def _reference_loop(model, Stabilizer, aggregate_results, reader, config, logger):
-    """geotrax/extract.py:134-214, body verbatim (no tqdm)."""
-    stabilizer = Stabilizer(**config['stabilo'])
+class _InterfaceCaller:
+    """A caller that knows only the two objects' public call contract (`model.track(frame, **cfg, persist=True)` ->
+    `results[0].boxes` / `.speed`; `Stabilizer.set_ref_frame / stabilize / transform_cur_boxes / get_cur_trans_matrix`). Written for
+    this test, frame by frame into per-frame records and one table at the end; it shares no code with the product's loops."""
 
-    frame_num, yolo_time, stab_time = 0, [], []
-    frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms = [], [], [], [], [], [], []
-    empties = 0
+    def __init__(self, model, stabilizer, ultra_kwargs):
+        self.model, self.stab, self.kw = model, stabilizer, ultra_kwargs
+        self.records, self.homographies, self.empty_frames, self.speeds = [], {}, 0, []
 
-    while reader.isOpened():
-        success, frame = reader.read()
-        if frame_num < config['main']['args'].cut_frame_left:
-            frame_num += 1
-            continue
+    @staticmethod
+    def _host(t, dtype):
+        return np.asarray(t.detach().numpy(force=True)).astype(dtype)
 
-        if success:
-            results = model.track(frame, **config['ultralytics'], persist=True)
-            boxes = results[0].boxes
-            speed = results[0].speed
-            yolo_time.append(sum(speed.values()))
-
-            if len(boxes) > 0:
-                frame_arr.append(np.full((len(boxes), 1), frame_num, dtype=np.uint32))
-                if boxes.id is not None:
-                    track_ids = boxes.id.detach().numpy(force=True).astype(np.uint16).reshape(-1, 1)
-                else:
-                    track_ids = np.full((len(boxes), 1), -1)
-                track_id.append(track_ids)
-                bbox.append(boxes.xywh.detach().numpy(force=True).astype(np.float32))
-                class_id.append(boxes.cls.detach().numpy(force=True).astype(np.uint8).reshape(-1, 1))
-                conf.append(boxes.conf.detach().numpy(force=True).astype(np.float32).reshape(-1, 1))
-            else:
-                empties += 1
-
-            if config['main']['extraction']['stabilize']:
-                start_time = time.time()
-                if frame_num == config['main']['args'].cut_frame_left:
-                    stabilizer.set_ref_frame(frame, bbox[-1] if len(boxes) > 0 else None)
-                    if len(boxes) > 0:
-                        bbox_stab.append(bbox[-1])
-                else:
-                    stabilizer.stabilize(frame, bbox[-1] if len(boxes) > 0 else None)
-                    if len(boxes) > 0:
-                        bbox_stab.append(stabilizer.transform_cur_boxes())
-                    transf_matrix = stabilizer.get_cur_trans_matrix()
-                    if transf_matrix is not None:
-                        transf_matrix = transf_matrix.flatten().reshape(1, -1)
-                        transforms.append(np.hstack((np.array([[frame_num]]), transf_matrix)))
-                stab_time.append(1000 * (time.time() - start_time))
+    def feed(self, k, frame, is_reference):
+        out = self.model.track(frame, **self.kw, persist=True)[0]
+        self.speeds.append(out.speed)
+        n = len(out.boxes)
+        xywh = self._host(out.boxes.xywh, np.float32) if n else None
+        if is_reference:
+            self.stab.set_ref_frame(frame, xywh)
+            warped = xywh
         else:
-            break
+            self.stab.stabilize(frame, xywh)
+            warped = self.stab.transform_cur_boxes() if n else None
+            m = self.stab.get_cur_trans_matrix()
+            if m is not None:
+                self.homographies[k] = np.asarray(m, np.float64).reshape(9)
+        if n == 0:
+            self.empty_frames += 1
+            return
+        ids = np.full(n, -1.0) if out.boxes.id is None else self._host(out.boxes.id, np.uint16)
+        self.records.append((k, ids, xywh, np.asarray(warped, np.float32), self._host(out.boxes.cls, np.uint8), self._host(out.boxes.conf, np.float32)))
 
-        if config['main']['args'].cut_frame_right is not None and frame_num >= config['main']['args'].cut_frame_right:
-            break
-        frame_num += 1
-    reader.release()
-    assert set(speed) == {'preprocess', 'inference', 'postprocess'} and all(v >= 0 for v in speed.values())
-    tracks, transforms = aggregate_results(frame_arr, track_id, bbox, bbox_stab, class_id, conf, transforms, logger)
-    return tracks, transforms, empties
+    def tables(self):
+        rows = [np.column_stack([np.full(len(i), k), i, b, w, c, s]) for k, i, b, w, c, s in self.records]
+        t = np.vstack(rows)
+        t = t[t[:, 1] != -1].astype(np.float32)
+        h = np.array([[k, *self.homographies[k]] for k in sorted(self.homographies)], np.float64)
+        return t, h
 
 
 def _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg):
@@ -106,13 +83,12 @@ def _clip_with_empty_frames(gtx_ctx, tmp_path, wpath, cfg):
 
 
 @pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid"])
-def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_path, tracker):
+def test_interface_caller_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_path, tracker):
     reid = tracker.endswith("+reid")         # `with_reid: true, model: auto`: the detector hands BoT-SORT a vector per box on both routes
     tracker = tracker.split("+")[0]
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.model import YOLO
-    from geotrax_amd.postprocess import aggregate_results
     from geotrax_amd.stabilizer import Stabilizer
     from geotrax_amd.synth import make_scene
 
@@ -148,12 +124,15 @@ def test_reference_loop_over_the_dropin_objects_equals_the_engine(gtx_ctx, tmp_p
     np.testing.assert_array_equal(want_transforms[3, 1:], want_transforms[1, 1:])   # frame 4 <- frame 2
     np.testing.assert_array_equal(want_transforms[6, 1:], want_transforms[5, 1:])   # frame 7 <- frame 6
 
-    # (2) the reference's loop body over the drop-in objects, a fresh model (fresh tracker and GMC state)
+    # (2) an interface-only caller over the drop-in objects, a fresh model (fresh tracker and GMC state)
     model, config = setup()
     assert isinstance(model, YOLO)
-    reader = ex.initialize_streams(config['main'], config['ultralytics']['imgsz'], logger)
-    tracks, transforms, empties = _reference_loop(model, Stabilizer, aggregate_results, reader, config, logger)
-    assert empties == 3
+    caller = _InterfaceCaller(model, Stabilizer(**config['stabilo']), config['ultralytics'])
+    for k, frame in enumerate(frames):
+        caller.feed(k, frame, is_reference=(k == 0))
+    assert caller.empty_frames == 3
+    assert all(set(s) == {'preprocess', 'inference', 'postprocess'} and min(s.values()) >= 0 for s in caller.speeds)
+    tracks, transforms = caller.tables()
     assert tracks.dtype == want_tracks.dtype and tracks.shape == want_tracks.shape
     assert tracks.tobytes() == want_tracks.tobytes()
     assert transforms.dtype == want_transforms.dtype and transforms.shape == want_transforms.shape
