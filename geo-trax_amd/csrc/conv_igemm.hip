@@ -325,7 +325,7 @@ void conv_igemm_kernel(const ConvGroup g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[i] = acc[j][4 * g4 + i];
-          if (P.act) v[i] = silu(v[i]);
+          if (P.act == 1) v[i] = silu(v[i]); else if (P.act == 2) v[i] = fmaxf(v[i], 0.f);
         }
         if (res && cl < cvalid) {
           float rv[4];
@@ -363,7 +363,7 @@ void conv_igemm_kernel(const ConvGroup g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[i] = acc[j][4 * g4 + i];
-          if (P.act) v[i] = silu(v[i]);
+          if (P.act == 1) v[i] = silu(v[i]); else if (P.act == 2) v[i] = fmaxf(v[i], 0.f);
         }
         if (cl >= cvalid) continue;               // channels past Cout (4 per lane: Cout is a multiple of 16)
         if (res) {

@@ -36,7 +36,7 @@ struct ConvProblem {
   int in_cstride, in_coff;
   int out_cstride, out_coff;
   int res_cstride, res_coff;
-  int act;              // 1 = SiLU, 0 = identity
+  int act;              // 0 = identity, 1 = SiLU, 2 = ReLU (RT-DETR's HGNetv2 blocks); applied before the residual is added
   int tiles_x, tiles_y; // output pixel tiles (TW=16, TH=8); tiles_y counts the tile rows the launch computes
   int ty_first, ty_count; // ty_count > 0: only tile rows [ty_first, ty_first + ty_count) are computed (the others keep what the
                         // buffer holds: Detector's letterbox-padding rows, whose values do not depend on the frame); 0 = all

@@ -85,6 +85,7 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // operations in the same order as the scalar forms (silu_f; hi = fp16(x), lo = fp16(x - hi)): the results are theirs bit for bit.
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v relu2(const float2v v) { return float2v{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }   // ConvProblem::act == 2 (RT-DETR's HGNetv2 blocks)
 __device__ __forceinline__ float2v silu2(const float2v v) {
   const float2v t = v * -1.44269504088896341f;                      // exp(-v) = exp2(-v log2 e): what __expf compiles to
   const float2v d = float2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
@@ -540,7 +541,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             v[q] = float2v{acc[0][j][4 * g4 + 2 * q], acc[0][j][4 * g4 + 2 * q + 1]} * P.acc_scale;
-            if (P.act) v[q] = silu2(v[q]);
+            if (P.act == 1) v[q] = silu2(v[q]); else if (P.act == 2) v[q] = relu2(v[q]);
           }
           uint2 hi, lo;
           split4(v, hi, lo, sat_y);
@@ -592,7 +593,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
   const float sc = post ? P.post_scale : P.acc_scale;
   const int cvalid = P.Cout - ct * BN;          // < BN in a last cout tile that is half empty (Cout = 16, 48, 80 ...)
   const bool plain = P.out_plain != 0;
-  const bool act = (post ? P.post_act : P.act) != 0;
+  const int act = post ? P.post_act : P.act;      // 0 none, 1 SiLU, 2 ReLU
   const void* const res_p = P.res;
   const int o_cstride = P.out_cstride, o_coff = P.out_coff;
   float* const o_base = static_cast<float*>(P.out);
@@ -617,7 +618,7 @@ __device__ __forceinline__ void conv_split_body(const ConvGroup& g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           v[q] = float2v{acc[m][j][4 * g4 + 2 * q], acc[m][j][4 * g4 + 2 * q + 1]} * sc;
-          if (act) v[q] = silu2(v[q]);
+          if (act == 1) v[q] = silu2(v[q]); else if (act == 2) v[q] = relu2(v[q]);
         }
         if (res_p) {                               // uniform; the swaps below need every lane
           uint4 rc = make_uint4(0, 0, 0, 0);       // lane l: the group's hi chunk, lane l + 32: its lo chunk

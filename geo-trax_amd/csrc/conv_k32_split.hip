@@ -60,6 +60,7 @@ struct K32Tile {
 static_assert(3 * K32Tile::LDS_BYTES <= 160 * 1024, "three workgroups per CU");
 
 // conv_igemm_split.hip's epilogue arithmetic (same operations in the same order)
+__device__ __forceinline__ float2v relu2(const float2v v) { return float2v{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }   // ConvProblem::act == 2 (RT-DETR's HGNetv2 blocks)
 __device__ __forceinline__ float2v silu2(const float2v v) {
   const float2v t = v * -1.44269504088896341f;
   const float2v d = float2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
@@ -285,7 +286,7 @@ void conv_k32_split_kernel(const ConvGroup g) {
   const float sc = P.acc_scale;
   const int cvalid = P.Cout - ct * BN;
   const bool plain = P.out_plain != 0;
-  const bool act = P.act != 0;
+  const int act = P.act;                          // 0 none, 1 SiLU, 2 ReLU
   const void* const res_p = P.res;
   float* const o_base = static_cast<float*>(P.out);
   bool sat = false;
@@ -306,7 +307,7 @@ void conv_k32_split_kernel(const ConvGroup g) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         v[q] = float2v{acc[a][m][2 * q], acc[a][m][2 * q + 1]} * sc;
-        if (act) v[q] = silu2(v[q]);
+        if (act == 1) v[q] = silu2(v[q]); else if (act == 2) v[q] = relu2(v[q]);
       }
       if (res_p) {                                 // uniform; the swaps need every lane
         uint4 rc = make_uint4(0, 0, 0, 0);         // even kg: the group's hi chunk, odd kg: its lo chunk

@@ -64,49 +64,76 @@ struct Op {
   double bytes = 0;      // algorithmic: inputs read once + outputs written once + weights
 };
 
-class Detector {
+// What the C ABI's gtx_detector_* entry points call: one implementation per detector family (gtx_det_config::arch), the way the
+// reference swaps YOLO for RTDETR on the model's yaml (geotrax/extract.py:222-225).
+class DetectorBase {
+ public:
+  virtual ~DetectorBase() = default;
+  virtual void set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape) = 0;
+  virtual void finalize() = 0;
+  virtual void input_size(int* h, int* w) const = 0;
+  virtual void detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) = 0;
+  virtual void submit_dev(const void* frames, int nb, int h, int w) = 0;
+  virtual void collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) = 0;
+  virtual void detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) = 0;
+  virtual const void* gray(int b, int* gh, int* gw) const = 0;
+  virtual void raw_output(int b, float* out, int* n_anchors, bool logits = false) = 0;
+  virtual void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c) = 0;
+  virtual void profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
+                       std::vector<double>& flops, std::vector<double>& bytes) = 0;
+  virtual void set_trace(int every_n) = 0;
+  virtual void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms, std::vector<double>& flops,
+                            std::vector<double>& bytes) = 0;
+  virtual void features(int b, float* out, int cap, int* n, int* dim) const = 0;
+  virtual bool saturated(bool clear) = 0;
+  virtual bool fell_back() const = 0;
+  virtual void pad_skip(int* on, int* skipped, int* total) const = 0;
+  virtual void sparse_box(int* on, int* overflows) const = 0;
+};
+
+class Detector : public DetectorBase {
  public:
   Detector(gtx_ctx* ctx, const gtx_det_config& cfg);
   ~Detector();
-  void set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape);
-  void finalize();
-  void input_size(int* h, int* w) const { *h = lb_.net_h; *w = lb_.net_w; }
+  void set_tensor(const std::string& name, const float* data, int ndim, const int64_t* shape) override;
+  void finalize() override;
+  void input_size(int* h, int* w) const override { *h = lb_.net_h; *w = lb_.net_w; }
 
   // frames: device pointer, nb frames [h][w][3] u8 back to back. Outputs sized [nb][max_det].
   void detect_dev(const void* frames, int nb, int h, int w, int* n_out, float* xyxy, float* conf,
-                  int* cls, float speed_ms[3]);
+                  int* cls, float speed_ms[3]) override;
   // asynchronous pair: submit enqueues the whole pass, collect waits for it and unpacks
-  void submit_dev(const void* frames, int nb, int h, int w);
-  void collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]);
+  void submit_dev(const void* frames, int nb, int h, int w) override;
+  void collect(int* n_out, float* xyxy, float* conf, int* cls, float speed_ms[3]) override;
   void detect_host(const uint8_t* frame, int h, int w, int* n_out, float* xyxy, float* conf,
-                   int* cls, float speed_ms[3]);
-  const void* gray(int b, int* gh, int* gw) const;
-  void raw_output(int b, float* out, int* n_anchors, bool logits = false);
-  void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c);
+                   int* cls, float speed_ms[3]) override;
+  const void* gray(int b, int* gh, int* gw) const override;
+  void raw_output(int b, float* out, int* n_anchors, bool logits = false) override;
+  void layer_output(int b, const std::string& layer, float* out, int* h, int* w, int* c) override;
   void profile(int nb, int iters, std::vector<std::string>& names, std::vector<int>& launches,
-               std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes);
+               std::vector<float>& ms, std::vector<double>& flops, std::vector<double>& bytes) override;
   // Live tracing: every `every_n`-th submitted pass gets a HIP event in front of every launch of the
   // forward graph (on the launch stream); collect() folds the elapsed times into per-op totals that
   // trace_report() returns per kernel family and clears. every_n = 0 switches tracing off.
-  void set_trace(int every_n);
+  void set_trace(int every_n) override;
   void trace_report(std::vector<std::string>& names, std::vector<int>& launches, std::vector<float>& ms,
-                    std::vector<double>& flops, std::vector<double>& bytes);
+                    std::vector<double>& flops, std::vector<double>& bytes) override;
   int max_det() const { return cfg_.max_det; }
   // gtx_det_config::obj_feats: appearance vectors of image b's boxes of the most recently collected batch, [n][dim] (n = its box count)
   int feat_dim() const { return exact_ ? exact_->feat_dim() : feat_levels_.dim; }
-  void features(int b, float* out, int cap, int* n, int* dim) const;
+  void features(int b, float* out, int cap, int* n, int* dim) const override;
   // split-f16x3 path: true when some activation of a collected pass (since the last call with clear) had to be clamped to
   // fp16's range on its way into the pair format. collect() then re-runs that batch through an exact-fp32 detector built
   // from the same tensors and every later pass goes there (`ultralytics.half: false` promises fp32's range,
   // default.yaml:245); GTX_SAT_FALLBACK=0 keeps the flag only.
-  bool saturated(bool clear);
-  bool fell_back() const { return exact_ != nullptr; }
-  void pad_skip(int* on, int* skipped, int* total) const {
+  bool saturated(bool clear) override;
+  bool fell_back() const override { return exact_ != nullptr; }
+  void pad_skip(int* on, int* skipped, int* total) const override {
     if (on) *on = (!exact_ && pad_skip_on_) ? 1 : 0;
     if (skipped) *skipped = pad_skip_rows_;
     if (total) *total = pad_skip_total_;
   }
-  void sparse_box(int* on, int* overflows) const {
+  void sparse_box(int* on, int* overflows) const override {
     if (on) *on = (!exact_ && sparse_on_) ? 1 : 0;
     if (overflows) *overflows = sparse_overflows_;
   }
@@ -207,5 +234,5 @@ class Detector {
 }  // namespace gtx
 
 struct gtx_detector {
-  std::unique_ptr<gtx::Detector> impl;
+  std::unique_ptr<gtx::DetectorBase> impl;
 };

@@ -13,6 +13,7 @@
 #include "conv_igemm.hpp"
 #include "det_kernels.hpp"
 #include "detector.hpp"
+#include "rtdetr.hpp"
 #include "geometry.hpp"
 #include "gmc.hpp"
 #include "match_l2.hpp"
@@ -541,7 +542,9 @@ int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** 
   return guarded([&] {
     need(ctx, "ctx"); need(cfg, "cfg"); need(out, "out");
     std::unique_ptr<gtx_detector> d(new gtx_detector);
-    d->impl.reset(new gtx::Detector(ctx, *cfg));
+    if (cfg->arch == 1) d->impl.reset(new gtx::RtDetr(ctx, *cfg));
+    else if (cfg->arch == 0) d->impl.reset(new gtx::Detector(ctx, *cfg));
+    else gtx::fail(-3, "gtx_det_config.arch %d: 0 (YOLOv8) or 1 (RT-DETR)", cfg->arch);
     *out = d.release();
   });
 }

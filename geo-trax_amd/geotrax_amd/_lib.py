@@ -32,7 +32,7 @@ class DetConfig(C.Structure):
         ("imgsz", C.c_int), ("conf", C.c_float), ("iou", C.c_float), ("max_det", C.c_int),
         ("agnostic_nms", C.c_int), ("half", C.c_int), ("rect", C.c_int), ("nc", C.c_int),
         ("n_classes", C.c_int), ("classes", C.c_int * 80), ("max_batch", C.c_int),
-        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int), ("obj_feats", C.c_int),
+        ("frame_h", C.c_int), ("frame_w", C.c_int), ("fp32_split", C.c_int), ("obj_feats", C.c_int), ("arch", C.c_int),
     ]
 
 
@@ -77,7 +77,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 8        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 9        # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),

@@ -57,10 +57,15 @@ class Detector:
         self.fp32_split = bool(fp32_split) and not half
         self.ctx = ctx or _lib.default_context()
         lib = self.ctx.lib
-        nc = int(tensors["model.22.cv3.0.2.weight"].shape[0])
+        from .weights import is_rtdetr
+
+        self.rtdetr = is_rtdetr(tensors)     # the graph the tensors describe picks the detector family (reference: the model's yaml, extract.py:222-225)
+        if self.rtdetr and (half or obj_feats):
+            raise NotImplementedError("RT-DETR: half=True and obj_feats (ReID `model: auto`) are not implemented")
+        nc = int(tensors["model.28.enc_score_head.weight" if self.rtdetr else "model.22.cv3.0.2.weight"].shape[0])
         cfg = DetConfig(imgsz=imgsz, conf=conf, iou=iou, max_det=max_det, agnostic_nms=int(agnostic_nms),
                         half=int(half), rect=int(rect), nc=nc, n_classes=0, max_batch=max_batch,
-                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split), obj_feats=int(bool(obj_feats)))
+                        frame_h=frame_hw[0], frame_w=frame_hw[1], fp32_split=int(self.fp32_split), obj_feats=int(bool(obj_feats)), arch=int(self.rtdetr))
         self.obj_feats = bool(obj_feats)
         if classes is not None:
             classes = list(classes)
@@ -87,6 +92,9 @@ class Detector:
         self._cls = np.zeros((max_batch, max_det), np.int32)
         self._speed = np.zeros(3, np.float32)
         self._sat_warned = False
+        if self.rtdetr:
+            meta = tensors.get("rtdetr.meta")
+            self.n_queries = int(meta[2]) if meta is not None else 300
 
     def close(self):
         if getattr(self, "handle", None):
@@ -196,11 +204,17 @@ class Detector:
         na = C.c_int()
         h, w = self.net_hw
         anchors = (h // 8) * (w // 8) + (h // 16) * (w // 16) + (h // 32) * (w // 32)
+        if self.rtdetr:                      # [queries, 4 + nc]: xywh normalised to the frame + class scores (or logits)
+            anchors = self.n_queries
         out = np.zeros((anchors, 4 + self.nc), np.float32)
         fn = self.ctx.lib.gtx_detector_raw_logits if logits else self.ctx.lib.gtx_detector_raw_output
         check(fn(self.handle, b, ptr(out), C.byref(na)))
         assert na.value == anchors
         return out
+
+    def layer_output_int(self, layer: str, b: int = 0) -> np.ndarray:
+        """An integer read-back (RT-DETR's selected anchor indices, layer 'model.28.topk')."""
+        return self.layer_output(layer, b).view(np.int32)
 
     def layer_output(self, layer: str, b: int = 0) -> np.ndarray:
         h, w, c = C.c_int(), C.c_int(), C.c_int()

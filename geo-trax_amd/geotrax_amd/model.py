@@ -119,11 +119,15 @@ class YOLO:
             side = p.with_suffix(".names.yaml")
             if side.is_file():
                 self.names = {int(k): str(v) for k, v in yaml.safe_load(side.read_text()).items()}
-        nc = int(self.tensors["model.22.cv3.0.2.weight"].shape[0])
+        from .weights import is_rtdetr
+
+        self.is_rtdetr = is_rtdetr(self.tensors)
+        nc = int(self.tensors["model.28.enc_score_head.weight" if self.is_rtdetr else "model.22.cv3.0.2.weight"].shape[0])
         if not self.names:
             self.names = {i: str(i) for i in range(nc)}
         self.model = self            # ultralytics exposes .model.yaml_file; keep attribute access harmless
-        self.yaml_file = "yolov8.yaml"
+        # the reference reads this attribute to swap YOLO for RTDETR (extract.py:223-225); here one class serves both graphs
+        self.yaml_file = "rtdetr-l.yaml" if self.is_rtdetr else "yolov8.yaml"
         self._det: Detector | None = None
         self._det_key = None
         self._tracker: Tracker | None = None
@@ -222,6 +226,8 @@ class YOLO:
         kwargs = dict(kwargs)
         kwargs["conf"] = kwargs.get("conf") or 0.1      # ultralytics Model.track default
         self._obj_feats = bool(getattr(self._tracker, "with_reid", False))   # `with_reid: true, model: auto`: the detector keeps a vector per box
+        if self._obj_feats and self.is_rtdetr:
+            raise NotImplementedError("with_reid: true, model: auto needs the YOLOv8 Detect layer's inputs; not implemented for RT-DETR")
         frame = np.ascontiguousarray(source, dtype=np.uint8)
         d = self._detector(frame.shape[:2], kwargs).detect(frame)
         res = Results(Boxes(d.xyxy, d.conf, d.cls, None), d.speed, frame.shape[:2], self.names)
@@ -251,3 +257,13 @@ class YOLO:
     @property
     def detector(self) -> Detector | None:
         return self._det
+
+
+class RTDETR(YOLO):
+    """ultralytics.RTDETR(model): what the reference constructs when the model's yaml names RT-DETR (extract.py:224-225). The
+    detector family is read off the tensors either way; this class only refuses a YOLOv8 graph."""
+
+    def __init__(self, model, task: str = "detect", ctx: _lib.Context | None = None):
+        super().__init__(model, task, ctx)
+        if not self.is_rtdetr:
+            raise ValueError("RTDETR(model): the tensors describe a YOLOv8 graph; use YOLO(model)")

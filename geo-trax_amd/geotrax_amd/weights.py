@@ -50,7 +50,10 @@ def load_weights(path: str | Path) -> dict[str, np.ndarray]:
 
     t = load_file(str(path))
     t = {k: np.asarray(v, dtype=np.float32) for k, v in t.items()}
-    return fold_bn(t)
+    t = fold_bn(t)
+    if is_rtdetr(t):
+        t = fold_input_proj(fuse_repconv(t))
+    return t
 
 
 def save_weights(tensors: dict[str, np.ndarray], path: str | Path) -> None:
@@ -166,4 +169,188 @@ def calibrate_cls_bias(tensors: dict[str, np.ndarray], raw_logits: np.ndarray, c
     for name in tensors:
         if ".cv3." in name and name.endswith(".2.bias"):
             out[name] = (tensors[name] + np.float32(delta)).astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------- RT-DETR (rtdetr-l topology)
+# The reference swaps YOLO for RTDETR when the model's yaml says so (geotrax/extract.py:222-225). Tensor names are ultralytics'
+# state_dict names of cfg/models/rt-detr/rtdetr-l.yaml; load_weights() brings a checkpoint to the fused form the library and the
+# oracle read: Conv+BN folded (fold_bn), RepConv's 3x3 + 1x1 pair fused into `.conv` (fuse_repconv), the decoder's
+# Sequential(Conv2d, BatchNorm2d) input projections folded into `.0.weight` / `.0.bias` (fold_input_proj).
+
+def is_rtdetr(tensors: dict) -> bool:
+    return any(k.startswith("model.28.decoder.layers.") for k in tensors)
+
+
+def fuse_repconv(t: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+    """RepConv.fuse_convs on folded tensors: `X.conv1.conv` (3x3) + `X.conv2.conv` (1x1, same Cin) -> `X.conv` (3x3, the 1x1 kernel
+    added at the centre tap; biases summed). LightConv's pair (1x1 then depthwise) has other shapes and is left alone."""
+    out = dict(t)
+    for k in list(t):
+        if not k.endswith(".conv1.conv.weight"):
+            continue
+        p = k[: -len(".conv1.conv.weight")]
+        w3, w1 = t[k], t.get(p + ".conv2.conv.weight")
+        if w1 is None or w3.shape[2] != 3 or w1.shape[2] != 1 or w1.shape[1] != w3.shape[1] or w3.shape[1] == 1:
+            continue
+        w = w3.astype(np.float64).copy()
+        w[:, :, 1, 1] += w1[:, :, 0, 0].astype(np.float64)
+        b = t.get(p + ".conv1.conv.bias", 0).astype(np.float64) + t.get(p + ".conv2.conv.bias", 0).astype(np.float64)
+        for s in (".conv1.conv.weight", ".conv1.conv.bias", ".conv2.conv.weight", ".conv2.conv.bias"):
+            out.pop(p + s, None)
+        out[p + ".conv.weight"], out[p + ".conv.bias"] = w.astype(np.float32), b.astype(np.float32)
+    return out
+
+
+def fold_input_proj(t: dict[str, np.ndarray], eps: float = BN_EPS) -> dict[str, np.ndarray]:
+    out = dict(t)
+    for k in list(t):
+        if ".input_proj." not in k or not k.endswith(".1.running_var"):
+            continue
+        p = k[: -len(".1.running_var")]
+        s = t[p + ".1.weight"].astype(np.float64) / np.sqrt(t[k].astype(np.float64) + eps)
+        out[p + ".0.weight"] = (t[p + ".0.weight"].astype(np.float64) * s[:, None, None, None]).astype(np.float32)
+        out[p + ".0.bias"] = (t[p + ".1.bias"].astype(np.float64) - t[p + ".1.running_mean"].astype(np.float64) * s).astype(np.float32)
+        for q in (".1.weight", ".1.bias", ".1.running_mean", ".1.running_var", ".1.num_batches_tracked"):
+            out.pop(p + q, None)
+    return out
+
+
+def rtdetr_layer_specs(nc: int = 80, width: float = 1.0, hd: int = 256, ndl: int = 6, nh: int = 8, npts: int = 4, d_ffn: int = 1024):
+    """(name, shape, kind) for every tensor of a fused RT-DETR-l; kind: 'relu' / 'silu' / 'lin' conv or linear weights (with a
+    bias of the leading dim), 'ln' LayerNorm pair. width scales the backbone / encoder channel counts (multiples of 16)."""
+    ch = lambda c: max(16, int(round(c * width / 16)) * 16)
+    specs = []
+
+    def conv(name, cin, cout, k, kind, groups=1):
+        specs.append((name, (cout, cin // groups, k, k), kind))
+
+    def lin(name, cin, cout):
+        specs.append((name, (cout, cin), "lin"))
+
+    def ln(name, c):
+        specs.append((name, (c,), "ln"))
+
+    cm = ch(32)
+    conv("model.0.stem1.conv", 3, cm, 3, "relu")
+    conv("model.0.stem2a.conv", cm, max(8, cm // 2), 2, "relu")
+    conv("model.0.stem2b.conv", max(8, cm // 2), cm, 2, "relu")
+    conv("model.0.stem3.conv", 2 * cm, cm, 3, "relu")
+    conv("model.0.stem4.conv", cm, ch(48), 1, "relu")
+
+    def hgblock(p, c1, cmid, c2, k, light, n=6):
+        for i in range(n):
+            cin = c1 if i == 0 else cmid
+            if light:
+                conv(f"{p}.m.{i}.conv1.conv", cin, cmid, 1, "lin")
+                conv(f"{p}.m.{i}.conv2.conv", cmid, cmid, k, "relu", groups=cmid)
+            else:
+                conv(f"{p}.m.{i}.conv", cin, cmid, k, "relu")
+        conv(p + ".sc.conv", c1 + n * cmid, c2 // 2, 1, "relu")
+        conv(p + ".ec.conv", c2 // 2, c2, 1, "relu")
+
+    c1, c2, c3, c4 = ch(128), ch(512), ch(1024), ch(2048)
+    hgblock("model.1", ch(48), ch(48), c1, 3, False)
+    conv("model.2.conv", c1, c1, 3, "lin", groups=c1)
+    hgblock("model.3", c1, ch(96), c2, 3, False)
+    conv("model.4.conv", c2, c2, 3, "lin", groups=c2)
+    hgblock("model.5", c2, ch(192), c3, 5, True)
+    hgblock("model.6", c3, ch(192), c3, 5, True)
+    hgblock("model.7", c3, ch(192), c3, 5, True)
+    conv("model.8.conv", c3, c3, 3, "lin", groups=c3)
+    hgblock("model.9", c3, ch(384), c4, 5, True)
+    e = hd
+    conv("model.10.conv", c4, e, 1, "lin")
+    lin("model.11.ma.in_proj", e, 3 * e)
+    lin("model.11.ma.out_proj", e, e)
+    lin("model.11.fc1", e, d_ffn)
+    lin("model.11.fc2", d_ffn, e)
+    ln("model.11.norm1", e)
+    ln("model.11.norm2", e)
+
+    def repc3(p, cin, c):
+        conv(p + ".cv1.conv", cin, c, 1, "silu")
+        conv(p + ".cv2.conv", cin, c, 1, "silu")
+        for i in range(3):
+            conv(f"{p}.m.{i}.conv", c, c, 3, "silu")
+
+    conv("model.12.conv", e, e, 1, "silu")
+    conv("model.14.conv", c3, e, 1, "lin")
+    repc3("model.16", 2 * e, e)
+    conv("model.17.conv", e, e, 1, "silu")
+    conv("model.19.conv", c2, e, 1, "lin")
+    repc3("model.21", 2 * e, e)
+    conv("model.22.conv", e, e, 3, "silu")
+    repc3("model.24", 2 * e, e)
+    conv("model.25.conv", e, e, 3, "silu")
+    repc3("model.27", 2 * e, e)
+    d = "model.28"
+    for i in range(3):
+        conv(f"{d}.input_proj.{i}.0", e, hd, 1, "lin")
+    for i in range(ndl):
+        lp = f"{d}.decoder.layers.{i}"
+        lin(lp + ".self_attn.in_proj", hd, 3 * hd)
+        lin(lp + ".self_attn.out_proj", hd, hd)
+        ln(lp + ".norm1", hd)
+        lin(lp + ".cross_attn.sampling_offsets", hd, nh * 3 * npts * 2)
+        lin(lp + ".cross_attn.attention_weights", hd, nh * 3 * npts)
+        lin(lp + ".cross_attn.value_proj", hd, hd)
+        lin(lp + ".cross_attn.output_proj", hd, hd)
+        ln(lp + ".norm2", hd)
+        lin(lp + ".linear1", hd, d_ffn)
+        lin(lp + ".linear2", d_ffn, hd)
+        ln(lp + ".norm3", hd)
+        lin(f"{d}.dec_score_head.{i}", hd, nc)
+        for j, (a, b) in enumerate(((hd, hd), (hd, hd), (hd, 4))):
+            lin(f"{d}.dec_bbox_head.{i}.layers.{j}", a, b)
+    lin(f"{d}.query_pos_head.layers.0", 4, 2 * hd)
+    lin(f"{d}.query_pos_head.layers.1", 2 * hd, hd)
+    lin(f"{d}.enc_output.0", hd, hd)
+    ln(f"{d}.enc_output.1", hd)
+    lin(f"{d}.enc_score_head", hd, nc)
+    for j, (a, b) in enumerate(((hd, hd), (hd, hd), (hd, 4))):
+        lin(f"{d}.enc_bbox_head.layers.{j}", a, b)
+    return specs
+
+
+def synthetic_rtdetr(seed: int = 0, nc: int = 80, width: float = 1.0, hd: int = 256, ndl: int = 6, nh: int = 8, npts: int = 4, nq: int = 300,
+                     d_ffn: int = 1024, score_bias: float = -1.5, box_scale: float = 0.3) -> dict[str, np.ndarray]:
+    """Seeded random fused weights of the RT-DETR-l architecture (no checkpoint is reachable here). Conv / linear weights
+    ~ N(0, g^2 / fan_in) with g = sqrt(2) in front of a ReLU, 1.7 in front of a SiLU, 1 otherwise; biases ~ N(0, 0.05^2);
+    LayerNorm weights 1 + N(0, 0.1^2). The box heads' last layers are damped (box_scale) so that refined boxes stay near their
+    anchors; the score heads' biases are shifted (score_bias) so that a minority of the queries clears conf = 0.25."""
+    rng = np.random.default_rng(seed)
+    t: dict[str, np.ndarray] = {}
+    for name, shape, kind in rtdetr_layer_specs(nc, width, hd, ndl, nh, npts, d_ffn):
+        if kind == "ln":
+            t[name + ".weight"] = (1 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+            t[name + ".bias"] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+            continue
+        fan_in = int(np.prod(shape[1:]))
+        g = {"relu": np.sqrt(2.0), "silu": 1.7, "lin": 1.0}[kind]
+        w = rng.standard_normal(shape) * (g / np.sqrt(fan_in))
+        b = rng.standard_normal(shape[0]) * 0.05
+        if name.endswith("bbox_head.layers.2"):
+            w *= box_scale
+        if "score_head" in name:
+            b += score_bias
+        if name.endswith("in_proj"):                      # nn.MultiheadAttention keeps in_proj_weight / in_proj_bias as parameters
+            t[name + "_weight"], t[name + "_bias"] = w.astype(np.float32), b.astype(np.float32)
+        else:
+            t[name + ".weight"], t[name + ".bias"] = w.astype(np.float32), b.astype(np.float32)
+    t["rtdetr.meta"] = np.asarray([nh, npts, nq, 8], np.float32)
+    return t
+
+
+def calibrate_rtdetr_scores(tensors: dict[str, np.ndarray], raw_logits: np.ndarray, conf: float, target: int) -> dict[str, np.ndarray]:
+    """A copy of `tensors` whose last decoder score head is shifted by one constant so that about `target` queries of the probed
+    frame clear `conf` (the classes keep their order). raw_logits: [queries, nc] class logits of one pass with the unshifted
+    weights (Detector.raw_output(logits=True)[:, 4:])."""
+    logit = np.sort(raw_logits.max(1).astype(np.float64))[::-1]
+    k = min(max(int(target), 1), len(logit) - 1)
+    delta = np.log(conf / (1 - conf)) - 0.5 * (logit[k - 1] + logit[k])
+    last = max(int(n.split(".")[3]) for n in tensors if n.startswith("model.28.dec_score_head.") and n.endswith(".bias"))
+    out = dict(tensors)
+    name = f"model.28.dec_score_head.{last}.bias"
+    out[name] = (tensors[name] + np.float32(delta)).astype(np.float32)
     return out

@@ -45,8 +45,9 @@ extern "C" {
  * 7: gtx_streams_overlap, gtx_device_mem_info and gtx_sift_stage_ms added; gtx_tracker_config.type 4 (fasttrack) with its parameters appended to the struct.
  * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
  *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added;
- *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box and gtx_detector_pad_skip added. */
-#define GTX_ABI_VERSION 8
+ *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box and gtx_detector_pad_skip added.
+ * 9: gtx_det_config.arch appended: 1 = RT-DETR (the reference swaps YOLO for RTDETR on the model's yaml, extract.py:222-225). */
+#define GTX_ABI_VERSION 9
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -234,6 +235,10 @@ typedef struct gtx_det_config {
                      * `with_reid: true, model: auto` (default.yaml:376-379; engine/predictor.py get_obj_feats): the Detect layer's
                      * three input maps, each level's channels averaged in consecutive groups down to the narrowest level's width
                      * (128 for YOLOv8s), read at the anchor the box came from */
+  int arch;         /* 0: YOLOv8 (Detect head + NMS). 1: RT-DETR (rtdetr-l topology: HGNetv2, AIFI + CCFM, deformable-attention
+                     * decoder, no NMS; ultralytics RTDETR, extract.py:222-225). The frame is then stretched to imgsz x imgsz
+                     * (RTDETRPredictor.pre_transform: scale_fill), iou / agnostic_nms / rect are not read, half and obj_feats must be 0;
+                     * gtx_detector_raw_output returns [queries][4 + nc] = xywh normalised to the frame + class scores */
 } gtx_det_config;
 
 int gtx_detector_create(gtx_ctx* ctx, const gtx_det_config* cfg, gtx_detector** out);

@@ -39,6 +39,22 @@ def _weights_file(tmp_path, gtx_ctx, probe_frame, half=False):
     return path, w
 
 
+def _rtdetr_weights_file(tmp_path, gtx_ctx, probe_frame):
+    """Seeded RT-DETR-l weights whose final score head is shifted so that ~40 of the 300 queries clear conf on the probe frame."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import calibrate_rtdetr_scores, save_weights, synthetic_rtdetr
+
+    w = synthetic_rtdetr(seed=3, nc=4)
+    det = Detector(w, (H, W), imgsz=IMGSZ, ctx=gtx_ctx)
+    det.detect(probe_frame)
+    w = calibrate_rtdetr_scores(w, det.raw_output(logits=True)[:, 4:], 0.25, 40)
+    det.close()
+    path = tmp_path / "rtdetr-l.safetensors"
+    save_weights(w, path)
+    path.with_suffix(".names.yaml").write_text("{0: car, 1: bus, 2: truck, 3: motorcycle}\n")
+    return path, w
+
+
 def _cfg_file(tmp_path, model_path, tracker="bytetrack", half=False, gmc_method=None, with_reid=False):
     import yaml
     from geotrax_amd.config_utils import DEFAULT_CFG
@@ -74,7 +90,15 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     from oracle.yolov8_ref import bgr2gray_half
 
     u = cfg["ultralytics"]
-    model = YoloV8Ref(weights, emulate_half=False)
+    from geotrax_amd.weights import is_rtdetr
+
+    rt = is_rtdetr(weights)                 # the RT-DETR graph (extract.py:222-225): oracle/rtdetr_ref.py in the detector's place
+    if rt:
+        from oracle import rtdetr_ref
+
+        model = rtdetr_ref.RtDetrRef(weights)
+    else:
+        model = YoloV8Ref(weights, emulate_half=False)
     active = cfg["tracker"]["active"]
     tp = cfg["tracker"][active]
     if active in ("ocsort", "deepocsort"):
@@ -101,8 +125,12 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
     rows, transforms = [], []
     for f, frame in enumerate(frames):
-        xyxy, conf, cls, *feats = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"],
-                                         return_feats=reid)
+        if rt:
+            xyxy, conf, cls = rtdetr_ref.detect(model, frame, u["imgsz"], u["conf"], u["classes"], u["max_det"])
+            feats = []
+        else:
+            xyxy, conf, cls, *feats = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"],
+                                             return_feats=reid)
         warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
         t = trk.update(xyxy, conf, cls, gmc=warp, **({"feats": feats[0]} if reid else {}))   # every frame, with or without detections (ultralytics track.py)
         if len(conf):
@@ -136,10 +164,11 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack", "tracktrack"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack", "tracktrack", "rtdetr"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     reid = tracker == "botsort+reid"        # BoT-SORT's appearance branch on detector-derived vectors (`with_reid: true, model: auto`)
-    tracker = tracker.split("+")[0]
+    rtdetr = tracker == "rtdetr"            # the RT-DETR detector (a weight file with that graph) in front of ByteTrack
+    tracker = "bytetrack" if rtdetr else tracker.split("+")[0]
     from geotrax_amd import extract as ex
     from geotrax_amd.config_utils import load_config_all
     from geotrax_amd.stabilizer import Stabilizer
@@ -149,13 +178,14 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     frames = np.stack([scene.render(t, 150) for t in range(0, NF * 12, 12)])
     src = tmp_path / "clip.npy"
     np.save(src, frames)
-    wpath, weights = _weights_file(tmp_path, gtx_ctx, frames[0])
+    wpath, weights = (_rtdetr_weights_file if rtdetr else _weights_file)(tmp_path, gtx_ctx, frames[0])
     cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="sparseOptFlow" if tracker == "deepocsort" else None, with_reid=reid)
     if tracker == "botsort":
         assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
                               class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
     model = ex.load_detector(args, logger)
+    assert ("rtdetr" in model.model.yaml_file) == rtdetr                     # what the reference reads to pick RTDETR (extract.py:223-225)
     config = load_config_all(args, logger, model_names=model.names)
     args.cut_frame_left, args.cut_frame_right = 0, None
     tracks, transforms = ex.track_with_model(model, config, logger)
