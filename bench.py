@@ -49,6 +49,9 @@ HBM_PEAK_GBS = 8000.0
 # fp16 MFMA FLOPs, so the roof for ALGORITHMIC FLOP/s is the dense fp16 peak / 3
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32s": 2500.0 / 3.0}
 DTYPE_NAME = {"f16": "f16", "f32": "f32", "f32s": "f32 (split-f16x3 MFMA)"}
+MODEL_LABEL = {"yolov8s": "YOLOv8s", "rtdetr-l": "RT-DETR-l (the reference's RTDETR branch, extract.py:222-225; frame stretched to imgsz x imgsz, no NMS)"}
+# 2 x MAC over the 63 convolutions of YOLOv8s per frame at the two network inputs of a 3840 x 2160 frame
+NOMINAL_GFLOP = {("yolov8s", 1920, 1920): 255.9, ("yolov8s", 1088, 1920): 145.0}
 TRACKER_LABEL = {"bytetrack": "ByteTrack", "botsort": "BoT-SORT (GPU GMC)", "ocsort": "OC-SORT", "deepocsort": "Deep OC-SORT motion half (GPU GMC)",
                  "fasttrack": "FastTracker", "tracktrack": "TrackTrack (GPU GMC; association thresholds of the other trackers: the seeded boxes sit just above conf 0.25)"}
 GMC_TRACKERS = ("botsort", "deepocsort", "tracktrack")   # trackers that take a camera-motion warp per frame (bench runs them with gmc_method: sparseOptFlow)
@@ -79,6 +82,8 @@ def parse():
     ap.add_argument("--cli-formats", default="y4m,npy", help="--workload cli: which containers to write and measure")
     ap.add_argument("--cli-dir", default=None, help="--workload cli: where the clip is written (default: a fresh directory under the system's temp dir)")
     ap.add_argument("--cli-compare-sync", type=int, default=1, help="--workload cli: also run with the synchronous reader (GTX_FEEDER=0), for the comparison")
+    ap.add_argument("--model", default="yolov8s", choices=["yolov8s", "rtdetr-l"],
+                    help="detector graph of the seeded weights: yolov8s (BASELINE's model) or rtdetr-l (the reference's RTDETR branch, extract.py:222-225; SURVEY N4)")
     ap.add_argument("--half", type=int, default=0, help="ultralytics.half: 0 = fp32 activations (the reference default, default.yaml:245), 1 = fp16 activations + fp16 MFMA")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary fp16 measurement (N = 1, --half 0 runs add a shorter --half 1 pass and report it under 'f16')")
     ap.add_argument("--fp32", default=None, choices=["exact", "split"],
@@ -201,6 +206,17 @@ def calibrated_detector(ctx, frame, args, target):
 
     kw = dict(imgsz=args.imgsz, conf=0.25, iou=0.7, max_det=1000, classes=[0, 1, 2, 3], agnostic_nms=True,
               half=bool(args.half), fp32_split=fp32_split(args), rect=bool(args.rect), max_batch=max(args.batch, 1), ctx=ctx)
+    if args.model == "rtdetr-l":            # seeded RT-DETR-l; the last score head shifted so that `target` of the 300 queries clear conf
+        from geotrax_amd.weights import calibrate_rtdetr_scores, synthetic_rtdetr
+
+        base = synthetic_rtdetr(seed=0, nc=4)
+        det = Detector(base, (H, W), **kw)
+        det.detect(frame)
+        weights = calibrate_rtdetr_scores(base, det.raw_output(logits=True)[:, 4:], 0.25, min(target, 280))
+        det.close()
+        det = Detector(weights, (H, W), **kw)
+        n_det = len(det.detect(frame))
+        return det, weights, n_det, n_det
     base = synthetic_yolov8(**SYNTH_KW)   # vehicle-sized boxes from the stride-8 head, candidates in clusters
     det = Detector(base, (H, W), **kw)
     det.detect(frame)
@@ -262,7 +278,7 @@ def live_traffic(kernel, args, B):
     kb = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"gtx_pmc_{counter.lower()}_")
-        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2",
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "bench.py"), "--model", args.model, "--steps", "6", "--warmup", "2",
                "--no-cpu-baseline", "--no-profile", "--no-f16-line", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams",
                str(args.det_streams), "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
                "--imgsz", str(args.imgsz), "--rect", str(args.rect)] + (["--fp32", args.fp32] if args.fp32 else [])
@@ -310,14 +326,20 @@ def cpu_baseline(weights, ref_frame, frame, args):
     from oracle.yolov8_ref import YoloV8Ref, detect
 
     cores = host_cores()
-    model = YoloV8Ref(weights, emulate_half=False)
+    rt = args.model == "rtdetr-l"
+    if rt:
+        from oracle import rtdetr_ref
+
+        model = rtdetr_ref.RtDetrRef(weights)
+    else:
+        model = YoloV8Ref(weights, emulate_half=False)
     stab_cfg = dict(downsample_ratio=0.5, max_features=2000, ref_multiplier=2.0, filter_ratio=0.9, ransac_threshold=2.0,
                     mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
 
     def detect_s(threads):
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        out = detect(model, frame, args.imgsz, bool(args.rect), 0.25, 0.7, [0, 1, 2, 3], True, 1000)
+        out = rtdetr_ref.detect(model, frame, args.imgsz, 0.25, [0, 1, 2, 3], 1000) if rt else detect(model, frame, args.imgsz, bool(args.rect), 0.25, 0.7, [0, 1, 2, 3], True, 1000)
         return time.perf_counter() - t0, out
 
     t_det, (xyxy, conf, cls) = detect_s(cores)
@@ -1103,9 +1125,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dt], "data": "synthetic" + (" (frames uploaded from host memory inside the timed region: PCIe-inclusive)" if getattr(args, "host_frames", False) else ""),
             "config": {
-                "workload": (f"full extract: YOLOv8s + {TRACKER_LABEL[args.tracker]} + homography stabilization on 3840x2160 frames, "
+                "workload": (f"full extract: {MODEL_LABEL[args.model]} + {TRACKER_LABEL[args.tracker]} + homography stabilization on 3840x2160 frames, "
                              f"{B} frame(s) per step (BASELINE {'configs[2]' if world == 1 else 'configs[4]: frames of one clip over the ranks'}; metric 'detect+stabilize+track')" if extract else
-                             f"YOLOv8s HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
+                             f"{MODEL_LABEL[args.model]} HIP inference only, 3840x2160 frames, batch={B} (BASELINE configs[1] is batch=1)"),
                 "imgsz": args.imgsz, "rect": bool(args.rect), "net_input": list(det.net_hw), "half": bool(args.half),
                 "arithmetic": {"f16": "fp16 activations and weights, fp16 MFMA, fp32 accumulate",
                                "f32": "fp32 activations, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
@@ -1119,9 +1141,11 @@ def main():
                                                     f"{ps[1]} of {ps[2]} tile rows per image and pass (results bit-identical to computing them every pass; the `every_row_every_pass` "
                                                     f"key is this line without it)") if ps[0] else "every row computed in every pass")(det.pad_skip())),
                 "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
-                "weights": "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)",
+                "weights": ("seeded synthetic RT-DETR-l (no checkpoint reachable; rtdetr-l.yaml topology, 32 M parameters): the last decoder score head shifted on one frame so that about the golden clip's box count of the 300 queries clears conf"
+                            if args.model == "rtdetr-l" else
+                            "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)"),
                 "detections_per_frame": n_det, "candidates_per_frame": n_cand, "tracks_last_step": int(n_tracks),
-                "nms_path": ("one workgroup per image (nms_small_kernel: <= 4096 candidates, the product's path for any frame of the golden clip's kind)"
+                "nms_path": "none (RT-DETR: the decoder's 300 queries, score threshold + class filter + descending order in rt_post_kernel)" if args.model == "rtdetr-l" else ("one workgroup per image (nms_small_kernel: <= 4096 candidates, the product's path for any frame of the golden clip's kind)"
                              if n_cand <= 4096 else "rank / mask / resolve kernels (> 4096 candidates)"),
                 "frames_per_step": B, "frames_per_rank_in_hbm": len(seq),
                 "pipeline": f"{n_det_streams} detector stream(s) take batches round-robin and stay in flight while tracker/stabilizers work through the collected batch; {n_stab} stabilizer streams (submit/collect C ABI)",
@@ -1169,8 +1193,10 @@ def main():
                                              "(durations include the time a launch shares the GPU with the other streams)"}
                 # the same family with every launch alone on its stream (gtx_detector_profile: HIP events around each launch of a few
                 # passes, nothing else running): what rocprofv3's per-kernel average for this command agrees with
+                prof_all = None
                 try:
-                    iso = {f["kernel"]: f for f in engine.dets[0].profile(B, 4)}.get(top["kernel"])
+                    prof_all = engine.dets[0].profile(B, 4)
+                    iso = {f["kernel"]: f for f in prof_all}.get(top["kernel"])
                 except Exception:
                     iso = None
                 if iso and iso["total_ms"] > 0:
@@ -1179,12 +1205,38 @@ def main():
                     out["roofline"]["alone"] = {"avg_launch_us": 1000.0 * iso["total_ms"] / iso["launches"], "achieved": a_gb if hbm_bound else a_tf,
                                                 "frac": (a_gb / HBM_PEAK_GBS) if hbm_bound else (a_tf / MFMA_PEAK_TFLOPS[dt]),
                                                 "note": "after the timed region, launches back to back on one stream with nothing else on the GPU"}
+                # what the pipeline executed, against what the graph nominally costs: the per-launch FLOPs the runtime
+                # reports are those of the rows a launch computes (letterbox-padding rows skipped) with the Detect box branch at the candidates only
+                try:
+                    pr = prof_all if prof_all is not None else engine.dets[0].profile(B, 2)
+                    it = 4 if prof_all is not None else 2
+                    ex_g = sum(f["flops"] for f in pr) / it / B / 1e9
+                    nominal = NOMINAL_GFLOP.get((args.model, det.net_hw[0], det.net_hw[1]), ex_g if args.model != "yolov8s" else None)
+                    fps = out["value"] / max(world, 1)
+                    R = out["roofline"]
+                    R["executed_gflop_per_frame"] = ex_g
+                    R["nominal_gflop_per_frame"] = nominal
+                    R["executed_over_nominal"] = (ex_g / nominal) if nominal else None
+                    R["pipeline_tflops_executed"] = ex_g * fps / 1e3
+                    R["pipeline_frac"] = ex_g * fps / 1e3 / MFMA_PEAK_TFLOPS[dt]
+                    R["pipeline_frac_nominal"] = (nominal * fps / 1e3 / MFMA_PEAK_TFLOPS[dt]) if nominal else None
+                    R["pipeline_note"] = "executed = sum of the launches' own FLOPs per frame (gtx_detector_profile) x frames/s per GPU; frac against the same MFMA roof as `peak`"
+                except Exception as e:
+                    out["roofline"]["pipeline_note"] = f"unavailable: {type(e).__name__}: {e}"
+                if args.model == "rtdetr-l":           # the two transformer kernels named on their own (in-situ timings of this run)
+                    for key, kname in (("attention", "rt_mha_kernel"), ("deformable_sampling", "rt_deform_kernel"), ("token_linear", "rt_linear_kernel")):
+                        d = merged.get(kname)
+                        if d and d["total_ms"] > 0:
+                            out["roofline"][key] = {"kernel": kname, "avg_launch_us": 1000.0 * d["total_ms"] / d["launches"], "launches_timed": d["launches"],
+                                                    "tflops": d["flops"] / (d["total_ms"] * 1e-3) / 1e12, "algo_gbs": d["bytes"] / (d["total_ms"] * 1e-3) / 1e9,
+                                                    "bound": {"attention": "vector fp32 (LDS-broadcast dot products)", "deformable_sampling": "latency (300 queries x 96 bilinear gathers per image)",
+                                                              "token_linear": "fp32 matrix pipe, v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s); launch latency at 300 rows"}[key]}
                 out["kernels"] = [{"kernel": d["kernel"], "launches_timed": d["launches"],
                                    "avg_launch_us": 1000.0 * d["total_ms"] / d["launches"],
                                    "tflops": (d["flops"] / (d["total_ms"] * 1e-3) / 1e12) if d["total_ms"] > 0 else 0.0,
                                    "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                                   for d in fam]
-        if world == 1 and dist is None and not args.half and not args.no_f16_line:
+        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and not args.no_f16_line:
             # secondary key: the same workload with ultralytics.half = true (a legitimate reference knob, not its default). Run as
             # a child process after this one has released the GPU: a second engine inside this process inherits its hardware-queue
             # mapping from the streams created (and not yet destroyed) above and measures ~25 % low.
@@ -1211,7 +1263,7 @@ def main():
             import subprocess
 
             nx = max(args.steps // 4, 10)
-            cmd = [sys.executable, str(ROOT / "bench.py"), "--fp32", "exact", "--steps", str(nx), "--warmup", str(min(args.warmup, 6)), "--no-cpu-baseline",
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--model", args.model, "--fp32", "exact", "--steps", str(nx), "--warmup", str(min(args.warmup, 6)), "--no-cpu-baseline",
                    "--no-profile", "--no-f16-line", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams", str(args.det_streams),
                    "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
                    "--imgsz", str(args.imgsz), "--rect", str(args.rect)]
@@ -1223,7 +1275,7 @@ def main():
                                             "after the primary measurement; secondary, not `value`"}
             except Exception as e:
                 out["f32_exact"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
+        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
                 and not args.candidates:
             # secondary key: the same pipeline under the post-processing load SURVEY 8d names (1-3 k anchors above conf per frame). The
             # seeded weights cannot cluster them the way a trained model does (their boxes sit on their anchors: neighbours overlap at
@@ -1244,7 +1296,7 @@ def main():
                                            "tracker and box warp at ~8 x the golden clip's box count; measured by a child process, secondary, not `value`"}
             except Exception as e:
                 out["nms_load"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
+        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
                 and os.environ.get("GTX_PAD_SKIP", "1") != "0":
             # secondary key: the same line with every row of every layer and every pixel of the Detect box branch computed in every pass
             import subprocess
@@ -1262,7 +1314,9 @@ def main():
                                                        "(tests/test_detector_gpu.py); measured by a child process, secondary, not `value`"}
             except Exception as e:
                 out["every_row_every_pass"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line:
+            if "roofline" in out:                                 # next to executed / nominal: the frame rate when every nominal FLOP is executed
+                out["roofline"]["value_every_row_every_pass"] = out["every_row_every_pass"].get("value")
+        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line:
             # secondary key: the N > 1 default workload (BoT-SORT + GPU GMC, BASELINE configs[4]) on this one GPU, so that a scaling
             # series started from this line has its like-for-like single-GPU base in it (the primary line here is configs[2], ByteTrack)
             import subprocess
@@ -1280,7 +1334,7 @@ def main():
                                           "measured by a child process of this run, secondary, not `value`"}
             except Exception as e:
                 out["botsort"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and dist is None and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
+        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and args.workload == "extract" and args.tracker == "bytetrack" and not args.no_f16_line \
                 and not args.host_frames:
             # secondary keys: what the same pipeline delivers when the frames do not start in HBM. `host_frames`: pageable host arrays,
             # uploaded inside the timed region (PCIe-inclusive); `from_file`: the product's own loop on a clip file on local disk
@@ -1312,7 +1366,7 @@ def main():
                                             "open file to the aggregated tables, read-ahead feeder; measured by a child process, secondary, not `value`"}
             except Exception as e:
                 out["from_file"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and dist is None and not extract and B == 1 and args.det_streams == 1 and not args.no_f16_line:
+        if world == 1 and dist is None and args.model == "yolov8s" and not extract and B == 1 and args.det_streams == 1 and not args.no_f16_line:
             # BASELINE configs[1] is "batch=1": one frame per pass. With ONE pass in flight a pass is ~46 short launches and the chip
             # idles between them (latency-bound: `value`); with two or three single-frame passes in flight on streams of their own
             # the same kernels fill each other's gaps. Secondary key, child processes.
