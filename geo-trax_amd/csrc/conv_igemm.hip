@@ -412,7 +412,11 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
     // frames/s; profiles/r05_winograd_probe.txt). GTX_WINO=1: every eligible layer, GTX_WINO=2: Cin >= 256 only, GTX_WINO=3: the second
     // form (16 x 16 pixels, one wave per SIMD: 1.04 x alone, its per-workgroup fixed cost is what is left).
     if (ks == 3 && stride == 1 && c.bn == 64 && c.kc == 16 && cout % 64 == 0) {
+#ifdef GTX_WITH_WINO
       const int mode = env_int("GTX_WINO", 0);
+#else
+      const int mode = 0;                     // the default libgtx.so carries only what runs: `make WINO=1` builds conv_wino_split.hip in
+#endif
       if (mode == 1 || (mode == 2 && cin >= 256)) c.variant = 3;
       if (mode == 3) { c.variant = 4; c.th = 16; }      // the 16 x 16-pixel form (one wave per SIMD)
       // 4: the second form only where it used less CU-time than the direct kernel alone: launches that fill the chip for several
@@ -451,6 +455,13 @@ inline uint16_t f32_to_f16_bits(float f) {
   return b;
 }
 }  // namespace
+
+#ifndef GTX_WITH_WINO
+// conv_wino_split.hip is not part of this build (closed with numbers: 1.00-1.04 x of the direct kernel alone, -0.8 % end to end,
+// profiles/r05_winograd_probe.txt); conv_pick_config never selects variants 3 / 4 here
+void conv_wino_launch(const ConvGroup&, const ConvConfig&, hipStream_t) { fail(-3, "the Winograd kernels are not in this build (make -C geo-trax_amd WINO=1)"); }
+std::vector<uint8_t> pack_conv_weights_wino(const float*, int, int, const ConvConfig&, float*) { fail(-3, "the Winograd kernels are not in this build (make -C geo-trax_amd WINO=1)"); }
+#endif
 
 std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   if (acc_scale) *acc_scale = 1.f;

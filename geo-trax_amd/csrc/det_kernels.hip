@@ -1277,7 +1277,10 @@ __global__ __launch_bounds__(1024) void nms_small_kernel(const NmsBuffers nb, fl
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
   const int cnt = min(nb.count[n], nb.cap);
-  if (cnt > kSmallNms || nb.max_det > kSmallKeep) return;   // general path handles it
+  if (cnt > kSmallNms || nb.max_det > kSmallKeep) {         // the general kernels handle it (Detector::collect runs them for such a batch)
+    if (tid == 0) nb.out_n[n] = 0;                          // until then the image has no rows: nothing of the previous pass is read as this one's
+    return;
+  }
   if (tid == 0) { nb.sorted_n[n] = 0; s_nkeep = 0; s_done = 0; }
   const size_t base = (size_t)n * nb.cap;
   int P = 64;

@@ -786,10 +786,22 @@ void Detector::prime_pad_skip() {
   set_batch(N);
   launch_preprocess(dtype_, (const uint8_t*)blank.p, N, lb_, img_.ptr, nullptr, gray_h_, gray_w_, s);
   for (const Op& op : ops_) run_op(op, N, s);
+  int sat = 0;
+  if (sat_dev_) GTX_HIP(hipMemcpyAsync(&sat, sat_dev_, sizeof(int), hipMemcpyDeviceToHost, s));
   GTX_HIP(hipStreamSynchronize(s));
-  if (sat_dev_) GTX_HIP(hipMemsetAsync(sat_dev_, 0, sizeof(int), s));
-  pad_skip_on_ = true;
   cur_nb_ = 0;
+  if (sat_dev_) GTX_HIP(hipMemsetAsync(sat_dev_, 0, sizeof(int), s));
+  if (sat) {
+    // A constant of the padding rows lies beyond fp16's range: it was clamped on its way into the pair format. With the rows
+    // left out of the later launches no pass would raise the flag for them again, so the skipping stays off for this detector:
+    // every pass computes (and checks) every row, and the first one falls back to the exact-fp32 kernels (collect()).
+    pad_skip_on_ = false;
+    pad_skip_rows_ = 0;
+    for (Op& op : ops_)
+      for (int i = 0; i < kMaxGroup; ++i) op.ty_first[i] = op.ty_count[i] = 0;
+    return;
+  }
+  pad_skip_on_ = true;
 }
 
 void Detector::finalize() {
@@ -1090,6 +1102,7 @@ void Detector::collect(int* n_out, float* xyxy, float* conf, int* cls, float spe
         launch_obj_feats(conv_dtype_, feat_levels_, flight_nb_, nms_, d_feats_, s);
         GTX_HIP(hipMemcpyAsync(h_feats_, d_feats_, sizeof(float) * flight_nb_ * cfg_.max_det * feat_levels_.dim, hipMemcpyDeviceToHost, s));
       }
+      GTX_HIP(hipEventRecord(ev_[3], s));            // the postprocess figure (ev_[2] -> ev_[3]) now includes the re-run
       GTX_HIP(hipStreamSynchronize(s));
     }
   }

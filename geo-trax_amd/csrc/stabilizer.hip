@@ -1025,13 +1025,14 @@ __global__ __launch_bounds__(512) void ransac_kernel(const float4* __restrict__ 
     unsigned long long k = s_key[0];
 #pragma unroll
     for (int i = 1; i < kHypPerWg; ++i) k = min(k, s_key[i]);
-    // Device-scope atomics execute in L2. The minimum is a RETURNING atomic and the wave waits for its return value before it
-    // draws the ticket: when the ticket add reaches L2, this workgroup's minimum has been applied there -- an ordering made by
-    // the wait, not by where the two words sit (an earlier version claimed a data dependency the compiler folded away). The
-    // last workgroup reads the result back with another L2 atomic, so no cache holds a stale copy on the way.
-    const unsigned long long before = __hip_atomic_fetch_min(&state[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" : : "v"(before) : "memory");
-    const unsigned long long ticket = __hip_atomic_fetch_add(&state[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The ordering is the memory model's: the minimum is published by the RELEASE half of the ticket's acq_rel read-modify-write
+    // (agent scope), and the workgroup that draws the last ticket ACQUIRES every earlier workgroup's release through the
+    // ticket word's modification order (a release sequence of RMWs), so its read of state[0] below sees every minimum.
+    // The s_waitcnt between the two is not part of that argument: cdna_hip_programming.md (section 6, Guideline 16, Pitfall 12)
+    // records that ROCm 7.2 can drop the wait a release implies, and prescribes keeping an explicit one in front of the ticket.
+    (void)__hip_atomic_fetch_min(&state[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ticket = __hip_atomic_fetch_add(&state[1], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = ticket == (unsigned long long)gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(512) void ransac_kernel(const float4* __restrict__ 
   // ---- the last workgroup: every minimum has been applied
   if (wv != 0) return;
   unsigned long long best_key = 0;
-  if (lane == 0) best_key = atomicMin(&state[0], kNoHyp);                  // an L2 atomic: a read that cannot be served from a stale cache line
+  if (lane == 0) best_key = __hip_atomic_fetch_min(&state[0], kNoHyp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // acquire read-back, in L2
   best_key = __shfl(best_key, 0, 64);
   const int b = best_key == kNoHyp ? -1 : (int)(best_key & 0xffffull);
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

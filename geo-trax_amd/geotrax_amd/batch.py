@@ -111,8 +111,23 @@ class WorkQueue:
     unequal videos even out by themselves; with the static deal a rank that drew the long ones finished last while the others
     idled."""
 
-    def __init__(self, files: list[Path], store, key: str = "gtx_batch_next"):
-        self.files, self.store, self.key = order_largest_first(files), store, key
+    def __init__(self, files: list[Path], store, key: str = "gtx_batch_next", rank: int = 0):
+        """The counter hands out INDICES, so every rank must index the same list: rank 0 publishes its ordered list through the
+        store and the others take that one instead of their own scan (a file still being copied, an output landing in the scanned
+        tree or an attribute cache would otherwise give ranks different orders -- videos done twice, others never -- silently).
+        A rank whose own scan disagrees says so."""
+        import json
+
+        mine = order_largest_first(files)
+        if rank == 0:
+            store.set(key + "_list", json.dumps([str(f) for f in mine]))
+        else:
+            agreed = [Path(p) for p in json.loads(bytes(store.get(key + "_list")).decode())]     # blocks until rank 0 has published
+            if agreed != mine:
+                logging.getLogger(__name__).warning(f"rank {rank}: this rank's scan found {len(mine)} videos in another order or number than rank 0's "
+                                                    f"{len(agreed)}; working from rank 0's list")
+            mine = agreed
+        self.files, self.store, self.key = mine, store, key
 
     def __iter__(self):
         while True:
@@ -206,7 +221,7 @@ def process_input(args, logger: logging.Logger, run=detect_track_stabilize, run_
                 store = None
         global _queue_calls                                       # one counter per call: every rank calls process_input the same number of times
         _queue_calls += 1
-        mine = WorkQueue(files, store, key=f"gtx_batch_next_{_queue_calls}") if store is not None else shard(files, rank, world)
+        mine = WorkQueue(files, store, key=f"gtx_batch_next_{_queue_calls}", rank=rank) if store is not None else shard(files, rank, world)
         logger.info(f"rank {rank}/{world}: {len(files)} videos, " + ("taken from the shared counter, largest first" if store is not None else f"{len(mine)} dealt to this rank"))
     taken = []
     for f in mine:

@@ -189,7 +189,7 @@ class StreamPlan:
                 cls._plans[device].verify()
             return cls._plans[device]
 
-    def overlap(self, a: _lib.Context, b: _lib.Context, spin_us: float = 150.0) -> tuple[float, float]:
+    def overlap(self, a: _lib.Context, b: _lib.Context, spin_us: float = 1000.0) -> tuple[float, float]:
         """(ms one idle wave spins on a's stream, ms the same on both streams at once): gtx_streams_overlap."""
         one, two = C.c_float(), C.c_float()
         _lib.check(_lib.load().gtx_streams_overlap(a.handle, b.handle, float(spin_us), C.byref(one), C.byref(two)))
@@ -200,7 +200,7 @@ class StreamPlan:
         and device: do the detector streams really run at the same time? If two of them share a hardware queue (a runtime that
         places streams differently), the later one is replaced by the first of up to eight fresh streams that does overlap with
         the first detector stream, and a warning says so -- 15-20 % of the frame rate depend on it (profiles/r04_stream_plan.txt).
-        GTX_ENGINE_VERIFY=0 skips the check (0.3 ms of spinning per pair)."""
+        GTX_ENGINE_VERIFY=0 skips the check (1 ms spins, best of three, ~10 ms per pair: well above a loaded host's launch and sync jitter)."""
         self.verified = None
         if os.environ.get("GTX_ENGINE_VERIFY", "1") == "0":
             return
@@ -213,6 +213,10 @@ class StreamPlan:
         self.verified = True
         for ent in dets[1:]:
             one, two = self.overlap(dets[0][1], ent[1])
+            log.debug(f"stream plan: device {self.device}: one spin {one:.2f} ms, two at once {two:.2f} ms")
+            if two < 1.5 * one:
+                continue
+            one, two = self.overlap(dets[0][1], ent[1])          # a loaded host can fake one verdict (launch / sync jitter): it has to repeat
             if two < 1.5 * one:
                 continue
             self.verified = False

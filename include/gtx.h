@@ -375,7 +375,8 @@ void gtx_tracker_destroy(gtx_tracker* trk);
 int gtx_tracker_reset(gtx_tracker* trk);
 /* One frame of detections (xyxy, conf, cls; n entries) -> active tracks. Outputs hold up to
  * cap rows: xyxy (Kalman posterior box), track id, score, class, index of the matched
- * detection. gmc_affine: optional 2x3 row-major camera-motion matrix (BoT-SORT GMC), NULL =
+ * detection (out_det_idx; -1 for a row without one: FastTracker, type 4, keeps an occluded track in the output on its
+ * prediction with its last score and class -- a caller that indexes the detections with it must test for -1). gmc_affine: optional 2x3 row-major camera-motion matrix (BoT-SORT GMC), NULL =
  * identity. Mirrors BYTETracker.update + the result rewrite in
  * ultralytics/trackers/track.py:on_predict_postprocess_end. */
 int gtx_tracker_update(gtx_tracker* trk, int n, const float* xyxy, const float* conf,

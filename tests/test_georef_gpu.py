@@ -97,3 +97,25 @@ def test_chain_edge_cases(gtx_ctx):
         transform_points([1.0], [1.0], HOM, ORTHO, "EPSG:4326", "EPSG:3857", ctx=gtx_ctx)
     with pytest.raises(ValueError):
         transform_points([1.0, 2.0], [1.0], HOM, ORTHO, ctx=gtx_ctx)
+
+
+def test_hip_chain_on_the_golden_georeference_rows(gtx_ctx):
+    """The HIP kernel itself (gtx_op_georef_points) on the reference-held rows: Ortho_X / Ortho_Y of the golden CSV ==
+    round(persp(H_geo, x_stab, y_stab), 1) for all 19 787 rows the CSV keeps (tests/test_geometry.py pins the HOST function on
+    the same rows; SURVEY 8c's fixture table: 100 % of the rows, exactly)."""
+    import gzip
+    from pathlib import Path
+
+    from geotrax_amd.georeference import transform_points
+
+    G = Path(__file__).parent / "golden"
+    with gzip.open(G / "U_video_cut.txt.gz", "rt") as f:
+        t = np.loadtxt(f, delimiter=",")
+    Hg = np.loadtxt(G / "U_video_cut_geo_transf.txt", delimiter=",").reshape(3, 3)
+    c = np.load(G / "U_video_cut_csv_cols.npz")
+    key = {(int(fr), int(i)): k for k, (fr, i) in enumerate(zip(t[:, 0], t[:, 1]))}
+    rows = np.array([key[(int(fr), int(i))] for fr, i in zip(c["frame"], c["vehicle_id"])])
+    got = transform_points(t[rows, 6], t[rows, 7], Hg, ORTHO, None, None, ctx=gtx_ctx)
+    assert len(got["ortho_x"]) == 19787
+    np.testing.assert_array_equal(np.round(got["ortho_x"], 1), c["ortho_x"])
+    np.testing.assert_array_equal(np.round(got["ortho_y"], 1), c["ortho_y"])
