@@ -1,5 +1,7 @@
 #include "geometry.hpp"
 
+#include <vector>
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -52,6 +54,70 @@ bool invert3x3(const double m[9], double inv[9]) {
   inv[0] = A * r; inv[1] = -(b * i - c * h) * r; inv[2] = (b * f - c * e) * r;
   inv[3] = B * r; inv[4] = (a * i - c * g) * r;  inv[5] = -(a * f - c * d) * r;
   inv[6] = C * r; inv[7] = -(a * h - b * g) * r; inv[8] = (a * e - b * d) * r;
+  return true;
+}
+
+namespace {
+inline unsigned hash_u32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+}  // namespace
+
+bool estimate_affine_partial(const float* p, const float* q, int n, unsigned seed, double A[6], int* n_inliers) {
+  constexpr int kHyp = 512;
+  constexpr double kThr2 = 3.0 * 3.0;
+  if (n_inliers) *n_inliers = 0;
+  if (n < 2) return false;
+  auto P = [&](int i, int k) { return (double)p[2 * i + k]; };
+  auto Q = [&](int i, int k) { return (double)q[2 * i + k]; };
+  int best = -1;
+  double M[6] = {1, 0, 0, 0, 1, 0};
+  for (unsigned hyp = 0; hyp < (unsigned)kHyp; ++hyp) {
+    const int i = (int)(hash_u32(seed ^ hash_u32(2u * hyp)) % (unsigned)n), j = (int)(hash_u32(seed ^ hash_u32(2u * hyp + 1u)) % (unsigned)n);
+    if (i == j) continue;
+    const double dpx = P(j, 0) - P(i, 0), dpy = P(j, 1) - P(i, 1), den = dpx * dpx + dpy * dpy;
+    if (den < 1e-12) continue;
+    const double dqx = Q(j, 0) - Q(i, 0), dqy = Q(j, 1) - Q(i, 1);
+    const double a = (dpx * dqx + dpy * dqy) / den, b = (dpx * dqy - dpy * dqx) / den;
+    const double tx = Q(i, 0) - (a * P(i, 0) - b * P(i, 1)), ty = Q(i, 1) - (b * P(i, 0) + a * P(i, 1));
+    int cnt = 0;
+    for (int k = 0; k < n; ++k) {
+      const double ex = a * P(k, 0) - b * P(k, 1) + tx - Q(k, 0), ey = b * P(k, 0) + a * P(k, 1) + ty - Q(k, 1);
+      cnt += (ex * ex + ey * ey < kThr2) ? 1 : 0;
+    }
+    if (cnt > best) { best = cnt; M[0] = a; M[1] = -b; M[2] = tx; M[3] = b; M[4] = a; M[5] = ty; }
+  }
+  if (best < 0) return false;
+  int inl_n = best;
+  for (int round = 0; round < 3; ++round) {
+    double mpx = 0, mpy = 0, mqx = 0, mqy = 0;
+    int cnt = 0;
+    std::vector<char> inl(n, 0);
+    for (int k = 0; k < n; ++k) {
+      const double ex = M[0] * P(k, 0) + M[1] * P(k, 1) + M[2] - Q(k, 0), ey = M[3] * P(k, 0) + M[4] * P(k, 1) + M[5] - Q(k, 1);
+      if (ex * ex + ey * ey < kThr2) { inl[k] = 1; ++cnt; mpx += P(k, 0); mpy += P(k, 1); mqx += Q(k, 0); mqy += Q(k, 1); }
+    }
+    inl_n = cnt;
+    if (cnt < 2) break;
+    mpx /= cnt; mpy /= cnt; mqx /= cnt; mqy /= cnt;
+    double den = 0, sa = 0, sb = 0;
+    for (int k = 0; k < n; ++k) {
+      if (!inl[k]) continue;
+      const double px = P(k, 0) - mpx, py = P(k, 1) - mpy, qx = Q(k, 0) - mqx, qy = Q(k, 1) - mqy;
+      den += px * px + py * py;
+      sa += px * qx + py * qy;
+      sb += px * qy - py * qx;
+    }
+    if (den <= 1e-12) break;
+    const double a = sa / den, b = sb / den;
+    M[0] = a; M[1] = -b; M[2] = mqx - (a * mpx - b * mpy);
+    M[3] = b; M[4] = a; M[5] = mqy - (b * mpx + a * mpy);
+  }
+  for (int k = 0; k < 6; ++k) A[k] = M[k];
+  if (n_inliers) *n_inliers = inl_n;
   return true;
 }
 

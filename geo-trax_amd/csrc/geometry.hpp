@@ -27,6 +27,12 @@ void warp_frame(gtx_ctx* ctx, const uint8_t* src_bgr, int h, int w, const double
 void yuv420_to_bgr_dev(gtx_ctx* ctx, const void* yuv, int h, int w, void* bgr);
 void warp_frame_dev(gtx_ctx* ctx, const void* src_bgr, int h, int w, const double H[9], void* dst_bgr);   // both in HBM, asynchronous
 
+// cv2.estimateAffinePartial2D(prev, cur, RANSAC) as ultralytics' GMC calls it for the feature-based methods (`gmc_method: orb` /
+// `sift`, default.yaml:374): a 4-parameter similarity p -> q from matched points. 512 two-point hypotheses (counter-hash sampling),
+// the one with the most points within 3 px wins (first on ties), three rounds of least squares on the inliers: the procedure of
+// gmc.hip's sparseOptFlow fit, on the host (a few hundred matches). p, q: [n][2] float32. Returns false when no model exists.
+bool estimate_affine_partial(const float* p, const float* q, int n, unsigned seed, double A[6], int* n_inliers);
+
 // 3x3 inverse (adjugate / det). Returns false if singular.
 bool invert3x3(const double m[9], double inv[9]);
 

@@ -679,8 +679,8 @@ int gtx_tracker_update_feats(gtx_tracker* trk, int n, const float* xyxy, const f
   return guarded([&] {
     need(trk, "trk"); need(n_out, "n_out");
     if (n > 0) { need(xyxy, "xyxy"); need(conf, "conf"); need(cls, "cls"); }
-    if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);   // no appearance branch there
-    else if (trk->tt) trk->tt->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx);
+    if (trk->oc) trk->oc->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx, feats, feat_dim);
+    else if (trk->tt) trk->tt->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx, feats, feat_dim);
     else trk->impl->update(n, xyxy, conf, cls, gmc_affine, cap, n_out, out_xyxy, out_id, out_score, out_cls, out_det_idx, feats, feat_dim);
   });
 }
@@ -821,6 +821,15 @@ int gtx_perspective_points(const double H[9], const double* x, const double* y, 
     need(H, "H");
     if (n > 0) { need(x, "x"); need(y, "y"); need(ox, "ox"); need(oy, "oy"); }
     gtx::perspective_points(H, x, y, n, ox, oy);
+  });
+}
+
+int gtx_op_estimate_affine_partial(const float* p_xy, const float* q_xy, int n, unsigned seed, double A[6], int* valid, int* n_inliers) {
+  return guarded([&] {
+    need(A, "A"); need(valid, "valid");
+    if (n > 0) { need(p_xy, "p_xy"); need(q_xy, "q_xy"); }
+    if (n < 0) gtx::fail(GTX_ERR_INVALID, "estimate_affine_partial: n = %d", n);
+    *valid = gtx::estimate_affine_partial(p_xy, q_xy, n, seed, A, n_inliers) ? 1 : 0;
   });
 }
 int gtx_op_georef_points(gtx_ctx* ctx, const gtx_georef_chain* chain, const double* x, const double* y, int n,

@@ -211,6 +211,14 @@ struct OcTrack {
   double vel[2] = {0, 0};                    // (dy, dx), unit length
   float score = 0.f;
   int cls = 0, idx = -1;
+  std::vector<double> emb;                   // Deep OC-SORT with_reid: unit-length appearance vector, dynamic-alpha EMA of the matched detections'
+  void update_emb(const std::vector<double>& e, double alpha) {
+    if (emb.empty()) { emb = e; return; }
+    double ss = 0.0;
+    for (size_t i = 0; i < e.size(); ++i) { emb[i] = alpha * emb[i] + (1.0 - alpha) * e[i]; ss += emb[i] * emb[i]; }
+    const double nrm = std::sqrt(ss);
+    for (double& v : emb) v /= nrm;
+  }
 
   bool seen() const { return last_obs.v[0] + last_obs.v[1] + last_obs.v[2] + last_obs.v[3] + last_obs.v[4] >= 0; }
   const Box5* obs_at(int a) const {
@@ -228,7 +236,7 @@ inline void direction(const double* b1, const double* b2, double out[2]) {
   out[0] = dy / n; out[1] = dx / n;
 }
 
-struct Det { Box5 b; int cls, idx; };
+struct Det { Box5 b; int cls, idx; std::vector<double> emb; double alpha = 0.0; };
 
 }  // namespace
 
@@ -237,6 +245,9 @@ struct OcSortTracker::Impl {
   double det_thresh, low, new_thr, iou_thr, inertia;
   int max_age, delta_t, min_hits;
   bool use_byte, cmc = false;
+  bool reid = false;                         // type 3 with gtx_tracker_config.with_reid
+  double prox = 0.5, app_thr = 0.9, alpha_fixed = 0.95;
+  static constexpr double kWEmb = 0.75, kAwBottom = 0.5;   // Deep OC-SORT's w_association_emb and aw_param (no config key: the authors' defaults)
   std::vector<OcTrack> trackers;
   int frame_count = 0, next_id = 0;
 
@@ -259,6 +270,9 @@ struct OcSortTracker::Impl {
     double z[4];
     to_z(d->b.v, z);
     t.kf.update(z);
+  }
+  void track_update_emb(OcTrack& t, const Det& d) const {
+    if (reid && !d.emb.empty()) t.update_emb(d.emb, d.alpha);
   }
 
   // camera-motion compensation of one track (type 3): g = [m00 m01 t0; m10 m11 t1], previous frame -> this frame
@@ -332,6 +346,44 @@ struct OcSortTracker::Impl {
           cost[(size_t)d * m + t] = -(iou[(size_t)d * m + t] + valid * ang * inertia * b[4]);
         }
       }
+      if (reid) {
+        // Deep OC-SORT's appearance term: cosine similarity of the unit vectors, kept only for pairs the config's two gates let
+        // through (IoU >= proximity_thresh -- the authors' own gate is IoU > 0 --, similarity >= appearance_thresh), weighted
+        // adaptively (compute_aw_max_metric: a row / column whose two best similarities are close counts for less)
+        std::vector<double> emb((size_t)n * m, 0.0), wgt((size_t)n * m, kWEmb);
+        for (int d = 0; d < n; ++d)
+          for (int t = 0; t < m; ++t) {
+            const std::vector<double>&u = dets[d].emb, &w = trackers[t].emb;
+            if (u.empty() || w.empty() || u.size() != w.size()) continue;
+            double dot = 0.0;
+            for (size_t k = 0; k < u.size(); ++k) dot += u[k] * w[k];
+            const double io = iou[(size_t)d * m + t];
+            if (io <= 0.0 || io < prox || dot < app_thr) continue;
+            emb[(size_t)d * m + t] = dot;
+          }
+        auto two_best = [](const std::vector<double>& v, size_t off, size_t step, int cnt, double& b0, double& b1) {
+          b0 = b1 = -1e300;
+          for (int i = 0; i < cnt; ++i) {
+            const double e = v[off + (size_t)i * step];
+            if (e > b0) { b1 = b0; b0 = e; } else if (e > b1) { b1 = e; }
+          }
+        };
+        if (m >= 2)
+          for (int d = 0; d < n; ++d) {
+            double b0, b1;
+            two_best(emb, (size_t)d * m, 1, m, b0, b1);
+            const double rw = b0 == 0.0 ? 0.0 : 1.0 - std::max(b1 / b0 - kAwBottom, 0.0) / (1.0 - kAwBottom);
+            for (int t = 0; t < m; ++t) wgt[(size_t)d * m + t] *= rw;
+          }
+        if (n >= 2)
+          for (int t = 0; t < m; ++t) {
+            double b0, b1;
+            two_best(emb, (size_t)t, (size_t)m, n, b0, b1);
+            const double cw = b0 == 0.0 ? 0.0 : 1.0 - std::max(b1 / b0 - kAwBottom, 0.0) / (1.0 - kAwBottom);
+            for (int d = 0; d < n; ++d) wgt[(size_t)d * m + t] *= cw;
+          }
+        for (size_t i = 0; i < cost.size(); ++i) cost[i] -= wgt[i] * emb[i];
+      }
       lap_full(cost, n, m, x);
     }
     std::vector<char> t_used(m, 0);
@@ -363,6 +415,10 @@ OcSortTracker::OcSortTracker(const gtx_tracker_config& cfg) : impl_(new Impl) {
   S.min_hits = cfg.min_hits > 0 ? cfg.min_hits : 3;
   S.use_byte = cfg.use_byte != 0;
   S.cmc = cfg.type == 3;
+  S.reid = cfg.type == 3 && cfg.with_reid != 0;
+  S.prox = cfg.proximity_thresh;
+  S.app_thr = cfg.appearance_thresh;
+  S.alpha_fixed = cfg.alpha_fixed_emb > 0.f ? cfg.alpha_fixed_emb : 0.95;
 }
 OcSortTracker::~OcSortTracker() = default;
 
@@ -373,13 +429,23 @@ void OcSortTracker::reset() {
 }
 
 void OcSortTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap,
-                           int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
+                           int* n_out, float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx, const float* feats, int feat_dim) {
   Impl& S = *impl_;
+  GTX_CHECK(!S.reid || n == 0 || (feats != nullptr && feat_dim > 0), "deepocsort: with_reid needs an appearance vector per detection (gtx_tracker_update_feats)");
   ++S.frame_count;
   std::vector<Det> dets, second;
   for (int i = 0; i < n; ++i) {
     const double c = (double)conf[i];
-    Det d{{{(double)xyxy[4 * i], (double)xyxy[4 * i + 1], (double)xyxy[4 * i + 2], (double)xyxy[4 * i + 3], c}}, cls[i], i};
+    Det d{{{(double)xyxy[4 * i], (double)xyxy[4 * i + 1], (double)xyxy[4 * i + 2], (double)xyxy[4 * i + 3], c}}, cls[i], i, {}, 0.0};
+    if (S.reid && c > S.det_thresh) {            // unit-length vector; dynamic appearance: a confident detection moves the track's vector more
+      d.emb.resize(feat_dim);
+      double ss = 0.0;
+      for (int k = 0; k < feat_dim; ++k) { d.emb[k] = (double)feats[(size_t)i * feat_dim + k]; ss += d.emb[k] * d.emb[k]; }
+      const double nrm = std::sqrt(ss);
+      for (double& v : d.emb) v /= nrm;
+      const double trust = (c - S.det_thresh) / (1.0 - S.det_thresh);
+      d.alpha = S.alpha_fixed + (1.0 - S.alpha_fixed) * (1.0 - trust);
+    }
     if (c > S.det_thresh) dets.push_back(d);
     else if (c > S.low && c < S.det_thresh) second.push_back(d);
   }
@@ -406,7 +472,7 @@ void OcSortTracker::update(int n, const float* xyxy, const float* conf, const in
   std::vector<std::pair<int, int>> matches;
   std::vector<int> u_d, u_t;
   S.associate(dets, trks, matches, u_d, u_t);
-  for (auto& m : matches) S.track_update(S.trackers[m.second], &dets[m.first]);
+  for (auto& m : matches) { S.track_update(S.trackers[m.second], &dets[m.first]); S.track_update_emb(S.trackers[m.second], dets[m.first]); }
 
   auto second_round = [&](const std::vector<Det>& cand, const std::vector<int>& cand_idx, bool against_last, std::vector<int>& used_c) {
     // IoU of the candidates with the leftover tracks (predicted boxes, or last observations for OCR), assignment on -IoU
@@ -428,6 +494,7 @@ void OcSortTracker::update(int n, const float* xyxy, const float* conf, const in
     for (int i = 0; i < a; ++i) {
       if (x[i] < 0 || io[(size_t)i * b + x[i]] < S.iou_thr) continue;
       S.track_update(S.trackers[u_t[x[i]]], &cand[cand_idx[i]]);
+      if (against_last) S.track_update_emb(S.trackers[u_t[x[i]]], cand[cand_idx[i]]);   // OCR updates the vector too, the BYTE pass does not
       done_t.push_back(u_t[x[i]]);
       used_c.push_back(cand_idx[i]);
     }
@@ -459,6 +526,7 @@ void OcSortTracker::update(int n, const float* xyxy, const float* conf, const in
     std::memcpy(t.kf.x, z, sizeof z);
     t.id = ++S.next_id;
     t.score = (float)dets[d].b.v[4]; t.cls = dets[d].cls; t.idx = dets[d].idx;
+    if (S.reid) t.emb = dets[d].emb;
     S.trackers.push_back(std::move(t));
   }
   // output, newest track first; tracks not updated for more than max_age frames leave

@@ -57,8 +57,9 @@ void register_images(gtx_ctx* ctx, const gtx_reg_config& cfg, const uint8_t* src
   auto t0 = clk::now();
   Sift& sift_dst = *sift_cache().get(ctx, dh, dw, nullptr);
   Sift& sift_src = *sift_cache().get(ctx, sh, sw, &sift_dst);
-  sift_dst.detect_and_compute(dst, dh, dw, cfg.max_features, true, cfg.rsift_eps);     // reference = destination
-  sift_src.detect_and_compute(src, sh, sw, cfg.max_features, true, cfg.rsift_eps);     // current = source (query)
+  const bool root = cfg.rsift_eps >= 0.f;        // rsift_eps < 0: plain SIFT descriptors (stabilo `detector_name: sift`, default.yaml:109)
+  sift_dst.detect_and_compute(dst, dh, dw, cfg.max_features, root, cfg.rsift_eps);     // reference = destination
+  sift_src.detect_and_compute(src, sh, sw, cfg.max_features, root, cfg.rsift_eps);     // current = source (query)
   GTX_HIP(hipStreamSynchronize(s));
   tm[0] = ms_since(t0);
   const int nq = sift_src.count(), nt = sift_dst.count();

@@ -205,6 +205,54 @@ __global__ __launch_bounds__(256) void rt_dwconv_kernel(RtMap in, RtMap out, int
   flag_sat(sat, s);
 }
 
+// Stride-1 form for channel counts that are multiples of 32 (HGBlock's LightConv 5x5 layers: 24 launches per pass): a workgroup
+// takes an 8 x 8 pixel tile x 32 channels, stages the (8 + K - 1)^2 input patch ONCE in LDS as fp32 (the per-thread form read and
+// converted every input pixel K^2 times: 25 small loads per thread made it latency-bound at 0.7 TB/s) and its K^2 x 32 weights,
+// then every thread runs the same K^2 fused multiply-adds in the same order: the results are the per-thread kernel's bit for bit.
+template <int FMT, int K>
+__global__ __launch_bounds__(256) void rt_dwconv_tile_kernel(RtMap in, RtMap out, const float* __restrict__ w, const float* __restrict__ bias, int act, int* sat) {
+  constexpr int T = 8, P = T + K - 1, R = K / 2;
+  __shared__ float s_in[P * P][32];
+  __shared__ float s_w[K * K][32];
+  const int tiles_x = (out.w + T - 1) / T;
+  const int tx0 = (blockIdx.x % tiles_x) * T, ty0 = (blockIdx.x / tiles_x) * T;
+  const int c0 = blockIdx.y * 32, n = blockIdx.z, C = in.c;
+  for (int i = threadIdx.x; i < P * P * 4; i += 256) {
+    const int g = i & 3, pp = i >> 2;
+    const int y = ty0 - R + pp / P, x = tx0 - R + pp % P;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < in.h && x >= 0 && x < in.w) load8<FMT>(in.ptr, (((size_t)n * in.h + y) * in.w + x) * in.cstride + in.coff + c0 + g * 8, v);
+    *reinterpret_cast<float4*>(&s_in[pp][g * 8]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&s_in[pp][g * 8 + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  for (int i = threadIdx.x; i < K * K * 32; i += 256) s_w[i >> 5][i & 31] = w[(size_t)(i >> 5) * C + c0 + (i & 31)];
+  __syncthreads();
+  const int g = threadIdx.x & 3, px = (threadIdx.x >> 2) & 7, py = threadIdx.x >> 5;
+  const int ox = tx0 + px, oy = ty0 + py;
+  if (ox >= out.w || oy >= out.h) return;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c0 + g * 8 + j] : 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float* v = &s_in[(py + ky) * P + px + kx][g * 8];
+      const float* ww = &s_w[ky * K + kx][g * 8];
+      const float4 v0 = *reinterpret_cast<const float4*>(v), v1 = *reinterpret_cast<const float4*>(v + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(ww), w1 = *reinterpret_cast<const float4*>(ww + 4);
+      acc[0] = fmaf(v0.x, w0.x, acc[0]); acc[1] = fmaf(v0.y, w0.y, acc[1]); acc[2] = fmaf(v0.z, w0.z, acc[2]); acc[3] = fmaf(v0.w, w0.w, acc[3]);
+      acc[4] = fmaf(v1.x, w1.x, acc[4]); acc[5] = fmaf(v1.y, w1.y, acc[5]); acc[6] = fmaf(v1.z, w1.z, acc[6]); acc[7] = fmaf(v1.w, w1.w, acc[7]);
+    }
+  if (act == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+  }
+  bool s = false;
+  store8<FMT>(out.ptr, (((size_t)n * out.h + oy) * out.w + ox) * out.cstride + out.coff + c0 + g * 8, acc, s);
+  flag_sat(sat, s);
+}
+
 // ============================================================================ nearest 2x upsampling (raw 8-channel groups)
 __global__ __launch_bounds__(256) void rt_upsample2x_kernel(RtMap in, RtMap out, int N, int gbytes) {
   const int groups = in.c / 8;
@@ -761,6 +809,13 @@ void launch_rt_dwconv(int fmt, const RtMap& in, const RtMap& out, int n, int k, 
   GTX_CHECK(in.c % 8 == 0 && in.c == out.c && (k == 3 || k == 5) && (stride == 1 || stride == 2), "rt_dwconv: unsupported %dx%d stride %d on %d channels", k, k, stride, in.c);
   GTX_CHECK(out.h == (in.h + 2 * (k / 2) - k) / stride + 1 && out.w == (in.w + 2 * (k / 2) - k) / stride + 1, "rt_dwconv: output size");
   const size_t total = (size_t)n * out.h * out.w * (in.c / 8);
+  static const bool tiled = [] { const char* e = getenv("GTX_RT_DW_TILE"); return !(e && e[0] == '0'); }();
+  if (stride == 1 && in.c % 32 == 0 && tiled) {
+    const dim3 grid(cdiv(out.w, 8) * cdiv(out.h, 8), in.c / 32, n);
+    if (k == 3) RT_FMT(fmt, hipLaunchKernelGGL((rt_dwconv_tile_kernel<F, 3>), grid, dim3(256), 0, s, in, out, w, bias, act, sat));
+    else RT_FMT(fmt, hipLaunchKernelGGL((rt_dwconv_tile_kernel<F, 5>), grid, dim3(256), 0, s, in, out, w, bias, act, sat));
+    return;
+  }
   if (k == 3) RT_FMT(fmt, hipLaunchKernelGGL((rt_dwconv_kernel<F, 3>), dim3(blocks_for(total)), dim3(256), 0, s, in, out, n, stride, w, bias, act, sat));
   else RT_FMT(fmt, hipLaunchKernelGGL((rt_dwconv_kernel<F, 5>), dim3(blocks_for(total)), dim3(256), 0, s, in, out, n, stride, w, bias, act, sat));
 }

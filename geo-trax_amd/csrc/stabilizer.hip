@@ -931,21 +931,28 @@ __device__ bool affine3(const double* px, const double* py, const double* qx, co
 // One hypothesis: 4 (projective) or 3 (affine) distinct matches drawn by a counter-based hash of (seed, hypothesis, draw),
 // exact minimal solve in normalised coordinates, de-normalised H. Straight-line f64 code without LDS: every lane of a wave
 // runs it on the same inputs and gets the same bits, which is how the scoring wave below obtains its hypothesis.
-__device__ __attribute__((noinline)) bool make_hypothesis(const float4* __restrict__ pts, int n, unsigned seed, int hyp, double cx, double cy, double sc, int affine, double H[9]) {
+__device__ __forceinline__ bool make_hypothesis(const float4* __restrict__ pts, int n, unsigned seed, int hyp, double cx, double cy, double sc, int affine, double H[9]) {
+  // inlined, and every small array indexed by unrolled constants: as a call with H behind a pointer and idx[] indexed by a
+  // run-time k the kernel kept 80 bytes of scratch per lane -- 9.2 MB of HBM writes per launch for a one-record result
+  // (profiles/r05_pmc_traffic.json)
   const int ns = affine ? 3 : 4;
   if (n < ns) return false;
   int idx[4] = {0, 0, 0, 0};
   unsigned ctr = 0;
-  for (int k = 0; k < ns; ++k) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= ns) break;
     for (;;) {
       const int cand = (int)(hash_u32(seed ^ hash_u32((unsigned)hyp * 977u + ctr)) % (unsigned)n);
       ++ctr;
       bool dup = false;
-      for (int j = 0; j < k; ++j) dup |= idx[j] == cand;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dup |= (j < k) && idx[j] == cand;
       if (!dup) { idx[k] = cand; break; }
     }
   }
   double px[4], py[4], qx[4], qy[4];
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float4 p = pts[idx[k]];
     px[k] = ((double)p.x - cx) * sc; py[k] = ((double)p.y - cy) * sc;

@@ -28,7 +28,7 @@ class OcSortTracker {
   ~OcSortTracker();
   void reset();
   void update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
-              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
+              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx, const float* feats = nullptr, int feat_dim = 0);
 
  private:
   struct Impl;
@@ -42,7 +42,7 @@ class TrackTrackTracker {
   ~TrackTrackTracker();
   void reset();
   void update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
-              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx);
+              float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx, const float* feats = nullptr, int feat_dim = 0);
 
  private:
   struct Impl;

@@ -33,6 +33,17 @@ struct TTrack {
   bool confirmed = false;
   bool was_lost = false;         // scratch: lost before this frame
   std::vector<Obs> obs;
+  // with_reid (`model: auto`): the detection's normalised appearance vector; a track's 0.9-EMA of them, re-normalised (BOTrack's rule)
+  std::vector<float> curr_feat, smooth_feat;
+  void update_features(const std::vector<float>& f) {
+    curr_feat = f;
+    if (smooth_feat.empty()) { smooth_feat = f; }
+    else for (size_t i = 0; i < f.size(); ++i) smooth_feat[i] = 0.9f * smooth_feat[i] + (1.f - 0.9f) * f[i];
+    float ss = 0.f;
+    for (float v : smooth_feat) ss += v * v;
+    const float nrm = std::sqrt(ss);
+    for (float& v : smooth_feat) v /= nrm;
+  }
   void xyxy(double o[4]) const {
     o[0] = mean[0] - mean[2] / 2; o[1] = mean[1] - mean[3] / 2; o[2] = mean[0] + mean[2] / 2; o[3] = mean[1] + mean[3] / 2;
   }
@@ -120,6 +131,7 @@ struct TrackTrackTracker::Impl {
     t.obs.push_back(o);
     if (t.obs.size() > 64) t.obs.erase(t.obs.begin(), t.obs.end() - 64);
     if ((int)t.obs.size() >= cfg.min_track_len) t.confirmed = true;
+    if (!d.curr_feat.empty()) t.update_features(d.curr_feat);
   }
 };
 
@@ -139,9 +151,11 @@ void TrackTrackTracker::reset() {
 }
 
 void TrackTrackTracker::update(int n, const float* xyxy, const float* conf, const int* cls, const double* gmc, int cap, int* n_out,
-                               float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx) {
+                               float* out_xyxy, int* out_id, float* out_score, int* out_cls, int* out_det_idx, const float* feats, int feat_dim) {
   Impl& S = *impl_;
   const gtx_tracker_config& A = S.cfg;
+  const bool reid = A.with_reid != 0;
+  GTX_CHECK(!reid || n == 0 || (feats != nullptr && feat_dim > 0), "tracktrack: with_reid needs an appearance vector per detection (gtx_tracker_update_feats)");
   S.frame_id += 1;
   std::vector<TTrack> dets;
   std::vector<char> low;
@@ -150,6 +164,14 @@ void TrackTrackTracker::update(int n, const float* xyxy, const float* conf, cons
     TTrack d;
     for (int k = 0; k < 4; ++k) d.det[k] = (double)xyxy[4 * i + k];
     d.score = conf[i]; d.cls = cls[i]; d.idx = i;
+    if (reid) {                                   // feat / ||feat|| in float32
+      d.curr_feat.assign(feats + (size_t)i * feat_dim, feats + (size_t)(i + 1) * feat_dim);
+      float ss = 0.f;
+      for (float v : d.curr_feat) ss += v * v;
+      const float nrm = std::sqrt(ss);
+      for (float& v : d.curr_feat) v /= nrm;
+      d.smooth_feat = d.curr_feat;
+    }
     dets.push_back(d);
     low.push_back(conf[i] < A.track_high_thresh ? 1 : 0);
   }
@@ -199,7 +221,14 @@ void TrackTrackTracker::update(int n, const float* xyxy, const float* conf, cons
       if (iou <= 0.0) continue;
       const double hi = (std::min(a[3], b[3]) - std::max(a[1], b[1])) / (std::max(a[3], b[3]) - std::min(a[1], b[1]));
       const double dist = 1.0 - iou * hi;
-      const double c = (double)A.iou_weight * dist + (double)A.reid_weight * dist +
+      double app = dist;                          // no appearance model: the HMIoU distance once more (default.yaml:456)
+      if (reid && !pool[i].smooth_feat.empty()) {  // cosine distance between the track's smoothed vector and the detection's, in [0, 1]
+        float dot = 0.f;
+        const std::vector<float>&u = pool[i].smooth_feat, &w = dets[j].curr_feat;
+        for (size_t k = 0; k < u.size(); ++k) dot += u[k] * w[k];
+        app = std::min(1.0, std::max(0.0, 1.0 - (double)dot));
+      }
+      const double c = (double)A.iou_weight * dist + (double)A.reid_weight * app +
                        (double)A.conf_weight * std::fabs((double)pool[i].score - (double)dets[j].score) + (double)A.angle_weight * S.angle(pool[i], b);
       C[(size_t)i * nd + j] = c + (low[j] ? (double)A.penalty_p : 0.0);
     }

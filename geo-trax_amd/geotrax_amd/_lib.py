@@ -48,7 +48,7 @@ class TrackerConfig(C.Structure):
         ("with_reid", C.c_int), ("proximity_thresh", C.c_float), ("appearance_thresh", C.c_float),
         ("lost_match_thr", C.c_float), ("iou_weight", C.c_float), ("reid_weight", C.c_float), ("conf_weight", C.c_float),
         ("angle_weight", C.c_float), ("penalty_p", C.c_float), ("penalty_q", C.c_float), ("reduce_step", C.c_float),
-        ("tai_thr", C.c_float), ("min_track_len", C.c_int),
+        ("tai_thr", C.c_float), ("min_track_len", C.c_int), ("alpha_fixed_emb", C.c_float),
     ]
 
 
@@ -163,6 +163,7 @@ _SIGNATURES = {
     "gtx_stabilizer_last_ms": (C.c_int, [_P, _P]),
     "gtx_warp_boxes": (C.c_int, [_P, _P, C.c_int, _P]),
     "gtx_perspective_points": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "gtx_op_estimate_affine_partial": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P, _P, _P]),
     "gtx_op_georef_points": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gtx_warp_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gtx_warp_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),

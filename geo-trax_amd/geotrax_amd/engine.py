@@ -258,7 +258,7 @@ class StreamPlan:
 
 class ExtractEngine:
     def __init__(self, weights: dict, frame_hw: tuple[int, int], det_kw: dict, tracker: Tracker | None, stab_kw: dict | None, *,
-                 device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool = False,
+                 device: int | None = None, batch: int = 2, det_streams: int = 2, stab_streams: int = 4, gmc: bool | str = False,
                  detectors: list[Detector] | None = None, feeder_stream: bool = False):
         """det_kw: Detector keywords (imgsz, conf, iou, max_det, classes, agnostic_nms, half, rect). tracker None: raw
         detections pass through (ids None; the frame-sharded bench tracks later on rank 0). stab_kw None: no
@@ -294,10 +294,10 @@ class ExtractEngine:
         while len(self.stabs) < n_stab:
             self.stabs.append(Stabilizer(self.frame_hw, ctx=take("s"), **stab_kw))
         self.feeder_ctx = take("f") if feeder_stream else None   # the context a read-ahead feeder's transfers run on
-        if gmc:
-            from .gmc import GMC
+        if gmc:                          # True / "sparseOptFlow": the GPU Lucas-Kanade GMC; "orb" / "sift": the feature-based ones (gmc.FeatureGMC)
+            from .gmc import make_gmc
 
-            self.gmc = GMC(self.frame_hw, ctx=take("g"))
+            self.gmc = make_gmc(self.frame_hw, method=gmc if isinstance(gmc, str) else "sparseOptFlow", ctx=take("g"))
         self.use_dev_gray = bool(self.stabs) and float(stab_kw.get("downsample_ratio", 0.5)) == 0.5
         self._stage = {}                 # per detector: device staging buffer for host frames
         self._host_frames = {}           # frames kept for the host-gray fallback of the stabilizer

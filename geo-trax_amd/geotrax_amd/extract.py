@@ -193,6 +193,8 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         raise NotImplementedError("the frame-sharded run carries boxes and warps between ranks, not appearance vectors: "
                                   "`with_reid: true` needs the single-process run (one GPU per video)")
     with_gmc = model._gmc_method is not None
+    if model._gmc_method in ('orb', 'sift'):
+        raise NotImplementedError(f"gmc_method '{model._gmc_method}': the frame-sharded run primes every rank's GMC with a frame in HBM, which only 'sparseOptFlow' takes; run unsharded")
     max_det = det_kw['max_det']
     state = {}
 
@@ -412,7 +414,7 @@ def track_with_model(model: YOLO, config: dict, logger: logging.Logger) -> tuple
         tracker = model._make_tracker(ul.get('tracker', {'tracker_type': 'botsort'}))
         engine = ExtractEngine(model.tensors, reader.frame_hw, det_kw, tracker, stab_kw, batch=int(eng_cfg.get('batch', 2)),
                                det_streams=int(eng_cfg.get('det_streams', 2)), stab_streams=int(eng_cfg.get('stab_streams', 4)),
-                               gmc=model._gmc_method is not None,
+                               gmc=model._gmc_method or False,          # the method's name: sparseOptFlow (GPU LK), orb / sift (gmc.FeatureGMC)
                                feeder_stream=os.environ.get("GTX_FEEDER", "1") != "0" and eng_cfg.get('read_ahead', True) is not False)
         model._det = engine.dets[0]                        # introspection (names, gray) keeps working on the model object
         t_engine = time.time()
@@ -531,6 +533,8 @@ def track_with_model_blocking(model: YOLO, config: dict, logger: logging.Logger)
 def pipelined(config: dict) -> bool:
     """`engine: {pipelined: false}` / GTX_ENGINE=blocking: the frame-at-a-time loop instead of the engine."""
     eng_cfg = config['main'].get('engine') or {}
+    if str((config.get('stabilo') or {}).get('detector_name', 'orb')) in ('sift', 'rsift') and config['main']['extraction'].get('stabilize', True):
+        return False                        # those detectors register host frames one at a time (stabilizer.py): the blocking loop
     return eng_cfg.get('pipelined', True) is not False and os.environ.get("GTX_ENGINE", "") != "blocking"
 
 

@@ -19,8 +19,10 @@ class GMC:
                  ctx: _lib.Context | None = None):
         if method in (None, "none", "None"):
             raise ValueError("GMC(method='none'): do not create the object, pass no warp to the tracker")
+        if method in ("orb", "sift"):
+            raise ValueError(f"GMC(method='{method}'): use gmc.make_gmc (FeatureGMC)")
         if method != "sparseOptFlow":
-            raise NotImplementedError(f"gmc_method='{method}': only 'sparseOptFlow' is implemented on the GPU path")
+            raise NotImplementedError(f"gmc_method='{method}': 'sparseOptFlow', 'orb' and 'sift' are implemented ('ecc' is not)")
         if downscale != 2:
             raise NotImplementedError("only downscale=2 (ultralytics' default) is implemented")
         self.ctx = ctx or _lib.default_context()
@@ -76,3 +78,180 @@ class GMC:
         xy, st = np.zeros((1024, 2), np.float32), np.zeros(1024, np.int32)
         check(self.ctx.lib.gtx_gmc_points(self.handle, which, 1024, C.byref(n), ptr(xy), ptr(st)))
         return xy[:n.value].copy(), st[:n.value].astype(bool)
+
+
+def estimate_affine_partial(p_xy: np.ndarray, q_xy: np.ndarray, seed: int = 0):
+    """cv2.estimateAffinePartial2D(p, q, RANSAC) stand-in (gtx_op_estimate_affine_partial, host C++): 2x3 float64 or None."""
+    p = np.ascontiguousarray(p_xy, np.float32).reshape(-1, 2)
+    q = np.ascontiguousarray(q_xy, np.float32).reshape(-1, 2)
+    A, valid, inl = np.zeros(6, np.float64), C.c_int(), C.c_int()
+    check(_lib.load().gtx_op_estimate_affine_partial(ptr(p) if len(p) else None, ptr(q) if len(q) else None, len(p), seed, ptr(A), C.byref(valid), C.byref(inl)))
+    return (A.reshape(2, 3), int(inl.value)) if valid.value else (None, 0)
+
+
+def filter_matches(prev_xy: np.ndarray, cur_xy: np.ndarray, frame_hw) -> np.ndarray:
+    """ultralytics GMC.apply_features' two spatial filters on ratio-tested matches: |displacement| < 0.25 x (width, height), then
+    displacement - mean < 2.5 x std per axis (one-sided, as upstream writes it). -> boolean mask of the kept matches."""
+    d = prev_xy.astype(np.float64) - cur_xy.astype(np.float64)
+    keep = (np.abs(d[:, 0]) < 0.25 * frame_hw[1]) & (np.abs(d[:, 1]) < 0.25 * frame_hw[0])
+    if keep.sum() == 0:
+        return keep
+    dk = d[keep]
+    inl = ((dk - dk.mean(0)) < 2.5 * dk.std(0)).all(1)
+    out = np.zeros(len(d), bool)
+    out[np.flatnonzero(keep)[inl]] = True
+    return out
+
+
+class FeatureGMC:
+    """ultralytics GMC(method='orb' | 'sift', downscale=2) (`gmc_method: orb` / `sift`, default.yaml:374,419,467): keypoints and
+    descriptors of the half-resolution gray image, brute-force 2-NN matching against the previous frame's with Lowe's ratio 0.9,
+    the two spatial filters of apply_features, then the RANSAC partial-affine fit. Built from what the path already has:
+
+    * orb: the stabilizer's detector / descriptor / Hamming matcher kernels (csrc/stabilizer.hip: FAST 20 on an 8-level pyramid,
+      Harris ranking, 256-bit rotated BRIEF; 1000 keypoints per frame), the previous frame set as its reference each step;
+    * sift: csrc/sift.hip's SIFT (plain, not RootSIFT) + the L2 2-NN kernel (csrc/match_l2.hip);
+    * the fit: gtx_op_estimate_affine_partial (the sparseOptFlow fit's procedure on the host).
+
+    Stated differences from the OpenCV calls upstream makes: the matcher's query is the CURRENT frame (stabilo's rule; upstream
+    queries with the previous one), no detection-box mask, SIFT with OpenCV's default thresholds (upstream: contrast 0.02, edge 20).
+    Synchronous: a frame's warp is computed when it is collected. Interface of GMC above."""
+
+    def __init__(self, frame_hw: tuple[int, int], method: str = "orb", downscale: int = 2, seed: int = 0, ctx: _lib.Context | None = None,
+                 max_features: int = 1000):
+        if method not in ("orb", "sift"):
+            raise NotImplementedError(f"gmc_method='{method}'")
+        if downscale != 2:
+            raise NotImplementedError("only downscale=2 (ultralytics' default) is implemented")
+        self.method, self.seed = method, seed
+        self.ctx = ctx or _lib.default_context()
+        self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
+        self.gh, self.gw = self.frame_hw[0] // 2, self.frame_hw[1] // 2
+        self.max_features = int(max_features)
+        self.stats = np.zeros(3, np.int32)              # keypoints of the previous frame, matches kept, inliers
+        self.valid = False
+        self._pending = []                               # gray images submitted and not yet collected (device pointers or host arrays)
+        self._prev = None
+        if method == "orb":
+            from .stabilizer import Stabilizer
+
+            self._st = Stabilizer(self.frame_hw, max_features=self.max_features, ref_multiplier=1.0, filter_ratio=0.9, mask_use=False,
+                                  downsample_ratio=0.5, seed=seed, ctx=self.ctx)
+            self._dev = None                             # device copies of (previous, current) gray for host-side submissions
+        else:
+            from .registration import Sift
+
+            self._sift = Sift((self.gh, self.gw), ctx=self.ctx)
+
+    def close(self):
+        if getattr(self, "_st", None) is not None:
+            self._st.close()
+            self._st = None
+        if getattr(self, "_sift", None) is not None:
+            self._sift.close()
+            self._sift = None
+        if getattr(self, "_dev", None):
+            for d in self._dev:
+                self.ctx.dev_free(d)
+            self._dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_params(self):
+        self._prev = None
+        self._pending.clear()
+
+    reset_sequence = reset_params
+
+    # ---- submission: half-resolution gray images, resident in HBM (the detector's) or on the host
+    def submit_gray_dev(self, gray_dptr: int, gh: int, gw: int) -> None:
+        if (gh, gw) != (self.gh, self.gw):
+            raise ValueError(f"gray image is {gw}x{gh}, the GMC was made for {self.gw}x{self.gh}")
+        self._pending.append(("dev", int(gray_dptr)))
+
+    def submit_gray(self, gray: np.ndarray) -> None:
+        g = np.ascontiguousarray(gray, np.uint8)
+        if g.shape != (self.gh, self.gw):
+            raise ValueError(f"gray image is {g.shape[1]}x{g.shape[0]}, the GMC was made for {self.gw}x{self.gh}")
+        self._pending.append(("host", g))
+
+    def submit_frame_dev(self, frame_dptr: int, h: int, w: int, restart: bool = False) -> None:
+        raise NotImplementedError("gmc_method orb / sift: a frame-sharded run primes its GMC with a BGR frame in HBM, which only 'sparseOptFlow' takes")
+
+    def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
+        """2x3 float64 warp previous -> current frame (identity for the first frame). raw_frame: BGR [h, w, 3] uint8."""
+        f = np.asarray(raw_frame, np.uint8).astype(np.int32)
+        g = (f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14          # cv2.cvtColor(BGR2GRAY), then the exact 2x reduction
+        g = ((g[0::2, 0::2] + g[0::2, 1::2] + g[1::2, 0::2] + g[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        self.submit_gray(g)
+        return self.collect()
+
+    # ---- one step
+    def _pairs_orb(self, kind, cur):
+        n = self.gh * self.gw
+        if kind == "host":                               # the stabilizer's gray entry points take device images
+            if self._dev is None:
+                self._dev = [self.ctx.dev_alloc(n), self.ctx.dev_alloc(n)]
+            self._dev.reverse()                          # [previous, current]
+            self.ctx.dev_upload(self._dev[1], cur)
+            cur_ptr = self._dev[1]
+        else:
+            cur_ptr = cur
+        prev_ptr, self._prev = self._prev, cur_ptr
+        if prev_ptr is None:
+            return None
+        self._st.set_ref_gray_dev(prev_ptr, self.gh, self.gw)
+        self._st.stabilize_gray_dev(cur_ptr, self.gh, self.gw)
+        qi, ti, _ = self._st.matches()
+        ref, cur_k = self._st.keypoints("ref")["xy"], self._st.keypoints("cur")["xy"]
+        self.stats[0] = len(ref)
+        return ref[ti], cur_k[qi]                        # previous-frame points, current-frame points (full-resolution pixels)
+
+    def _pairs_sift(self, kind, cur):
+        from .ops import match_2nn
+
+        if kind == "dev":
+            g = np.zeros((self.gh, self.gw), np.uint8)
+            self.ctx.dev_download(g, cur)
+        else:
+            g = cur
+        k = self._sift.detect_and_compute(np.repeat(g[:, :, None], 3, 2), max_features=self.max_features, root=False)
+        cur_f = (k["xy"].astype(np.float32) * 2.0, k["desc"])          # full-resolution pixels
+        prev_f, self._prev = self._prev, cur_f
+        if prev_f is None or len(prev_f[0]) < 2 or len(cur_f[0]) == 0:
+            return None
+        self.stats[0] = len(prev_f[0])
+        i1, i2, d1, d2 = match_2nn(cur_f[1], prev_f[1], ctx=self.ctx)
+        good = (i1 >= 0) & (i2 >= 0) & (d1 < np.float32(0.9) * d2)
+        return prev_f[0][i1[good]], cur_f[0][good]
+
+    def collect(self) -> np.ndarray:
+        if not self._pending:
+            raise RuntimeError("GMC.collect without a submitted frame")
+        kind, cur = self._pending.pop(0)
+        H = np.eye(2, 3)
+        self.valid = False
+        self.stats[:] = 0
+        pairs = self._pairs_orb(kind, cur) if self.method == "orb" else self._pairs_sift(kind, cur)
+        if pairs is None or len(pairs[0]) == 0:
+            return H
+        prev_xy, cur_xy = pairs
+        keep = filter_matches(prev_xy, cur_xy, self.frame_hw)
+        self.stats[1] = int(keep.sum())
+        if keep.sum() > 4:
+            M, inl = estimate_affine_partial(prev_xy[keep], cur_xy[keep], self.seed)
+            if M is not None:
+                H, self.valid = M, True
+                self.stats[2] = inl
+        return H
+
+
+def make_gmc(frame_hw, method: str = "sparseOptFlow", **kw):
+    """The GMC object of `gmc_method` (default.yaml:374): sparseOptFlow -> GMC, orb / sift -> FeatureGMC; ecc is not implemented."""
+    if method in ("orb", "sift"):
+        return FeatureGMC(frame_hw, method=method, **kw)
+    return GMC(frame_hw, method=method, **kw)

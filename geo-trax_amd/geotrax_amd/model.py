@@ -164,19 +164,17 @@ class YOLO:
             raise NotImplementedError(f"tracker_type '{ttype}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         if ttype in ("botsort", "deepocsort", "tracktrack"):  # the trackers that take a camera-motion warp per frame
             if params.get("with_reid"):
-                # botsort + `model: auto` (default.yaml:376-379): appearance vectors from the detector's own feature maps
+                # `model: auto` (default.yaml:379, :421, :470): appearance vectors from the detector's own feature maps
                 # (Detector(obj_feats=True) -> Tracker.update(feats=)); a separate ReID network's weights cannot be read here
-                if ttype != "botsort":
-                    raise NotImplementedError(f"{ttype}: the appearance (ReID) branch is not implemented")
                 if str(params.get("model", "auto")) != "auto":
-                    raise NotImplementedError(f"botsort with_reid: only `model: auto` (detector-derived features) is implemented, not '{params.get('model')}'")
+                    raise NotImplementedError(f"{ttype} with_reid: only `model: auto` (detector-derived features) is implemented, not '{params.get('model')}'")
             gm = params.get("gmc_method", "none")
             if gm in ("none", None):
                 self._gmc_method = None
-            elif gm == "sparseOptFlow":
-                self._gmc_method = gm                         # GPU corners + pyramidal LK + RANSAC similarity (gmc.py)
+            elif gm in ("sparseOptFlow", "orb", "sift"):
+                self._gmc_method = gm                         # sparseOptFlow: GPU corners + pyramidal LK + RANSAC similarity; orb / sift: gmc.FeatureGMC
             else:
-                raise NotImplementedError(f"{ttype} gmc_method '{gm}': only 'sparseOptFlow' and 'none' are implemented")
+                raise NotImplementedError(f"{ttype} gmc_method '{gm}': 'sparseOptFlow', 'orb', 'sift' and 'none' are implemented ('ecc' is not)")
         else:
             self._gmc_method = None
         self._gmc = None
@@ -184,7 +182,7 @@ class YOLO:
             self._tracktrack_warned = True
             logger.warning("tracker 'tracktrack': written from the description of its parameters in the config and the published method (height-modulated "
                            "IoU + confidence + corner-angle cost, iterative mutual-minimum assignment under a shrinking threshold, track-aware "
-                           "initialisation); no appearance model (reid_weight falls back to the HMIoU distance), penalty_q has nothing to act on; the "
+                           "initialisation); with_reid: true uses the detector's own vectors (`model: auto`; otherwise reid_weight falls back to the HMIoU distance), penalty_q has nothing to act on; the "
                            "pinned ultralytics' implementation may differ where that description leaves a choice open (oracle/tracktrack_ref.py lists "
                            "the choices). Score a reference run with tools/score_run.py to pin it.")
         if ttype == "fasttrack" and not getattr(self, "_fasttrack_warned", False):
@@ -205,7 +203,7 @@ class YOLO:
             "delta_t", "inertia", "use_byte", "min_hits", "reset_velocity_offset_occ", "reset_pos_offset_occ", "enlarge_bbox_occ",
             "dampen_motion_occ", "active_occ_to_lost_thresh", "occ_cover_thresh", "occ_reappear_window", "init_iou_suppress",
             "with_reid", "proximity_thresh", "appearance_thresh", "lost_match_thr", "iou_weight", "reid_weight", "conf_weight", "angle_weight",
-            "penalty_p", "penalty_q", "reduce_step", "tai_thr", "min_track_len")})
+            "penalty_p", "penalty_q", "reduce_step", "tai_thr", "min_track_len", "alpha_fixed_emb")})
 
     # ---- ultralytics-style entry points
     def predict(self, source: np.ndarray, **kwargs) -> list[Results]:
@@ -239,9 +237,9 @@ class YOLO:
         if self._gmc_method is not None:                    # BOTSORT.update: camera motion first, on this frame's gray image
             frame = np.asarray(source)
             if self._gmc is None or self._gmc.frame_hw != tuple(frame.shape[:2]):
-                from .gmc import GMC
+                from .gmc import make_gmc
 
-                self._gmc = GMC(frame.shape[:2], method=self._gmc_method, ctx=self.ctx)
+                self._gmc = make_gmc(frame.shape[:2], method=self._gmc_method, ctx=self.ctx)
             g = self._det.gray_dptr(0) if self._det is not None else (0, 0, 0)
             if g[0] and (g[1], g[2]) == (frame.shape[0] // 2, frame.shape[1] // 2):
                 self._gmc.submit_gray_dev(g[0], g[1], g[2])  # the half-resolution gray the detector left in HBM

@@ -28,8 +28,11 @@ class Stabilizer:
                  min_inliers_match_count_warning: int = 10, fast_threshold: int = 20, n_levels: int = 8,
                  scale_factor: float = 1.2, seed: int = 0, match_query_frame: str = "current",
                  ctx: _lib.Context | None = None, **unused):
-        if detector_name != "orb":
-            raise NotImplementedError(f"detector_name='{detector_name}': only 'orb' is implemented on the GPU path")
+        if detector_name not in ("orb", "sift", "rsift"):
+            raise NotImplementedError(f"detector_name='{detector_name}': 'orb', 'sift' and 'rsift' are implemented (not brisk / kaze / akaze)")
+        self._sift = detector_name if detector_name != "orb" else None
+        if self._sift and (filter_type != "ratio" or transformation_type != "projective" or clahe):
+            raise NotImplementedError(f"detector_name='{detector_name}' is built with filter_type 'ratio', transformation_type 'projective' and clahe off")
         if matcher_name != "bf":
             raise NotImplementedError(f"matcher_name='{matcher_name}': only 'bf' (exact brute force) is implemented")
         if filter_type not in ("ratio", "none"):
@@ -45,8 +48,12 @@ class Stabilizer:
         self.min_good, self.min_inl = min_good_match_count_warning, min_inliers_match_count_warning
         self.handle = None
         self.frame_hw = None
-        if frame_hw is not None:
+        self._ref_img = None
+        self._mask_warned = False
+        if frame_hw is not None and not self._sift:
             self._create(frame_hw)
+        elif frame_hw is not None:
+            self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
         self._H = None                   # what get_cur_trans_matrix() returns: this frame's transform, else the last known one
         self._H_raw = None               # this frame's own transform, None when the frame could not be registered
         self._H_last_known = None
@@ -78,8 +85,51 @@ class Stabilizer:
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 4)
         return b, len(b)
 
+    # ---- detector_name sift / rsift (default.yaml:109): the registration stage's kernels (csrc/sift.hip, match_l2.hip, the RANSAC of
+    # stabilizer.hip behind gtx_register_images) on the working-resolution frames; one blocking call per frame, host frames only
+    def _working(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        r = float(self._kw["downsample_ratio"])
+        if r == 1.0:
+            return f
+        if r != 0.5:
+            raise NotImplementedError("detector_name sift / rsift: downsample_ratio 1.0 or 0.5")
+        h, w = f.shape[0] // 2 * 2, f.shape[1] // 2 * 2
+        q = f[:h, :w].astype(np.uint16)
+        return ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8)      # cv2.resize(INTER_LINEAR) at exactly 1/2
+
+    def _sift_register(self, frame, boxes):
+        from .registration import register_once
+
+        if boxes is not None and len(boxes) and self._kw["mask_use"] and not self._mask_warned:
+            self._mask_warned = True
+            logger.warning(f"detector_name='{self._sift}': the vehicle mask (mask_use) is not applied on this path; keypoints on vehicles reach the matcher")
+        cur = self._working(frame)
+        n_cur = int(self._kw["max_features"])
+        Hh, stats, _ = register_once(cur, self._ref_img, max_features=max(n_cur, 4), filter_ratio=self._kw["filter_ratio"],
+                                     ransac_epipolar_threshold=self._kw["ransac_threshold"], ransac_max_iter=self._kw["ransac_max_iter"],
+                                     ransac_confidence=self._kw["ransac_confidence"], rsift_eps=1e-8 if self._sift == "rsift" else -1.0,
+                                     seed=self._kw["seed"], ctx=self.ctx)
+        self._stats[:] = (stats[1], stats[0], stats[2], stats[3])          # (reference, current, matches, inliers)
+        H = np.zeros(9, np.float64)
+        valid = C.c_int(0)
+        if Hh is not None:
+            r = float(self._kw["downsample_ratio"])
+            D = np.diag([r, r, 1.0])
+            Hf = np.linalg.inv(D) @ Hh @ D                                   # working-resolution pixels -> frame pixels on both sides
+            H[:] = (Hf / Hf[2, 2]).ravel()
+            valid = C.c_int(1)
+        b, _ = self._boxes(boxes)
+        self._finish(H, valid, b)
+
     # ---- stabilo interface
     def set_ref_frame(self, frame: np.ndarray, boxes: np.ndarray | None = None) -> None:
+        if self._sift:
+            self._ref_img = self._working(frame)
+            self.frame_hw = tuple(np.asarray(frame).shape[:2])
+            self._H = self._H_raw = self._H_last_known = None
+            self._cur_boxes = None
+            return
         f = np.ascontiguousarray(frame, dtype=np.uint8)
         if self.handle is None:
             self._create(f.shape[:2])
@@ -89,6 +139,8 @@ class Stabilizer:
         self._cur_boxes = None
 
     def set_ref_gray_dev(self, gray_dptr: int, gh: int, gw: int, boxes=None) -> None:
+        if self._sift:
+            raise NotImplementedError(f"detector_name='{self._sift}' takes host frames (set_ref_frame / stabilize): run with engine: {{pipelined: false}}")
         b, n = self._boxes(boxes)
         check(self.ctx.lib.gtx_stabilizer_set_ref_gray_dev(self.handle, C.c_void_p(gray_dptr), gh, gw, ptr(b), n))
         self._H = self._H_raw = self._H_last_known = None
@@ -108,6 +160,10 @@ class Stabilizer:
             logger.warning(f"Only {int(self._stats[3])} inliers found.")
 
     def stabilize(self, frame: np.ndarray, boxes: np.ndarray | None = None) -> None:
+        if self._sift:
+            if self._ref_img is None:
+                raise RuntimeError("stabilize() before set_ref_frame()")
+            return self._sift_register(frame, boxes)
         f = np.ascontiguousarray(frame, dtype=np.uint8)
         b, n = self._boxes(boxes)
         H, valid = np.zeros(9, np.float64), C.c_int()

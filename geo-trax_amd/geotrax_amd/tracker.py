@@ -30,7 +30,8 @@ class Tracker:
                  occ_cover_thresh: float = 0.7, occ_reappear_window: int = 40, init_iou_suppress: float = 0.7,
                  with_reid: bool = False, proximity_thresh: float = 0.5, appearance_thresh: float = 0.8,
                  lost_match_thr: float = 0.0, iou_weight: float = 0.5, reid_weight: float = 0.5, conf_weight: float = 0.1, angle_weight: float = 0.05,
-                 penalty_p: float = 0.2, penalty_q: float = 0.4, reduce_step: float = 0.05, tai_thr: float = 0.55, min_track_len: int = 3, **_ignored):
+                 penalty_p: float = 0.2, penalty_q: float = 0.4, reduce_step: float = 0.05, tai_thr: float = 0.55, min_track_len: int = 3,
+                 alpha_fixed_emb: float = 0.95, **_ignored):
         if tracker_type not in TRACKER_TYPES:
             raise NotImplementedError(f"tracker '{tracker_type}' is not implemented (available: {sorted(TRACKER_TYPES)})")
         self.lib = _lib.load()
@@ -42,11 +43,11 @@ class Tracker:
                             reset_pos_offset_occ=int(reset_pos_offset_occ), enlarge_bbox_occ=float(enlarge_bbox_occ),
                             dampen_motion_occ=float(dampen_motion_occ), active_occ_to_lost_thresh=int(active_occ_to_lost_thresh),
                             occ_cover_thresh=float(occ_cover_thresh), occ_reappear_window=int(occ_reappear_window),
-                            init_iou_suppress=float(init_iou_suppress), with_reid=int(bool(with_reid) and tracker_type == "botsort"),
+                            init_iou_suppress=float(init_iou_suppress), with_reid=int(bool(with_reid) and tracker_type in ("botsort", "deepocsort", "tracktrack")),
                             proximity_thresh=float(proximity_thresh), appearance_thresh=float(appearance_thresh),
                             lost_match_thr=float(lost_match_thr), iou_weight=float(iou_weight), reid_weight=float(reid_weight),
                             conf_weight=float(conf_weight), angle_weight=float(angle_weight), penalty_p=float(penalty_p), penalty_q=float(penalty_q),
-                            reduce_step=float(reduce_step), tai_thr=float(tai_thr), min_track_len=int(min_track_len))
+                            reduce_step=float(reduce_step), tai_thr=float(tai_thr), min_track_len=int(min_track_len), alpha_fixed_emb=float(alpha_fixed_emb))
         self.with_reid = bool(cfg.with_reid)
         h = C.c_void_p()
         check(self.lib.gtx_tracker_create(C.byref(cfg), C.byref(h)))

@@ -46,7 +46,9 @@ extern "C" {
  * 8: the appearance branch of BoT-SORT on detector-derived vectors (`with_reid: true, model: auto`): gtx_det_config.obj_feats,
  *    gtx_tracker_config.{with_reid, proximity_thresh, appearance_thresh} appended; gtx_detector_features, gtx_tracker_update_feats added;
  *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box and gtx_detector_pad_skip added.
- * 9: gtx_det_config.arch appended: 1 = RT-DETR (the reference swaps YOLO for RTDETR on the model's yaml, extract.py:222-225). */
+ * 9: gtx_det_config.arch appended: 1 = RT-DETR (the reference swaps YOLO for RTDETR on the model's yaml, extract.py:222-225);
+ *    gtx_tracker_config.alpha_fixed_emb appended, with_reid also read by types 3 (deepocsort) and 5 (tracktrack);
+ *    gtx_op_estimate_affine_partial added (GMC methods orb / sift). */
 #define GTX_ABI_VERSION 9
 
 typedef enum gtx_status {
@@ -330,8 +332,8 @@ int gtx_detector_profile(gtx_detector* det, int nb, int iters, int cap, char* na
  * (BYTETracker / BOTSORT.update; cfg tracker.* default.yaml:361-389). */
 
 typedef struct gtx_tracker_config {
-  int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404), 3 = deepocsort without the
-                              appearance branch: ocsort + camera-motion compensation by gmc_affine (default.yaml:406-427),
+  int type;                /* 0 = bytetrack, 1 = botsort, 2 = ocsort (default.yaml:391-404), 3 = deepocsort: ocsort + camera-motion
+                              compensation by gmc_affine + (with_reid) the appearance term (default.yaml:406-427),
                               4 = fasttrack (default.yaml:426-443): ByteTrack + the occlusion handling of the fields at the end,
                               5 = tracktrack (default.yaml:445-470): multi-cue cost + iterative assignment + track-aware initialisation */
   float track_high_thresh;
@@ -368,6 +370,11 @@ typedef struct gtx_tracker_config {
   float penalty_p, penalty_q, reduce_step;
   float tai_thr;
   int min_track_len;
+  /* Deep OC-SORT (type 3) with with_reid = 1 (default.yaml:420-425; `model: auto`: gtx_detector_features through
+   * gtx_tracker_update_feats): proximity_thresh / appearance_thresh gate the appearance term of the first association, and
+   * alpha_fixed_emb is the base factor of the track vectors' dynamic-alpha EMA (0 = 0.95). TrackTrack (type 5) with with_reid = 1
+   * replaces the second HMIoU term of its cost by the cosine distance (reid_weight, default.yaml:456). */
+  float alpha_fixed_emb;
 } gtx_tracker_config;
 
 int gtx_tracker_create(const gtx_tracker_config* cfg, gtx_tracker** out);
@@ -516,7 +523,7 @@ typedef struct gtx_reg_config {
   float ransac_threshold;   /* reprojection threshold in destination pixels (3.0) */
   int ransac_max_iter;      /* hypotheses (10000; clamped to [256, 16384]) */
   float ransac_confidence;  /* accepted for interface parity; the hypothesis count is fixed */
-  float rsift_eps;          /* RootSIFT L1-normalisation epsilon (1e-8) */
+  float rsift_eps;          /* RootSIFT L1-normalisation epsilon (1e-8); negative: plain SIFT descriptors (stabilo `detector_name: sift`) */
   int seed;
 } gtx_reg_config;
 /* src/dst: BGR u8 [h][w][3] host images. H (row-major 3x3 f64) maps src pixels to dst pixels;
@@ -550,6 +557,11 @@ int gtx_warp_boxes(const double H[9], const float* xywh_in, int n, float* xywh_o
 /* cv2.perspectiveTransform on N points (georeference.py:599-605), f64. */
 int gtx_perspective_points(const double H[9], const double* x, const double* y, int n,
                            double* ox, double* oy);
+
+/* cv2.estimateAffinePartial2D(prev, cur, RANSAC) as ultralytics' GMC calls it for `gmc_method: orb` / `sift` (default.yaml:374):
+ * the 4-parameter similarity p -> q of n matched points ([n][2] float32 each), A row-major 2x3 f64; *valid = 0 when no model
+ * exists (fewer than two distinct points). Host code (a few hundred matches); no device needed. */
+int gtx_op_estimate_affine_partial(const float* p_xy, const float* q_xy, int n, unsigned seed, double A[6], int* valid, int* n_inliers);
 
 /* The georeference stage's per-row transform chain in one HIP pass (replaces
  * geotrax/georeference.py:173-177 = apply_homography :599-605 -> ortho2geo :608-615 -> geo2local :618-628, where the

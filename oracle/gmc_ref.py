@@ -250,3 +250,73 @@ class GmcRef:
                     H[:, 2] *= 2.0
         self.prev_pyr, self.prev_pts = pyr, pts
         return H
+
+
+# --------------------------------------------------------------------------- feature-based methods (gmc_method: orb / sift)
+def filter_matches(prev_xy, cur_xy, frame_hw):
+    """ultralytics GMC.apply_features after the ratio test: |displacement| < 0.25 x (width, height) per axis, then
+    (displacement - mean) < 2.5 x std per axis -- one-sided, as upstream writes it."""
+    d = np.asarray(prev_xy, np.float64) - np.asarray(cur_xy, np.float64)
+    keep = (np.abs(d[:, 0]) < 0.25 * frame_hw[1]) & (np.abs(d[:, 1]) < 0.25 * frame_hw[0])
+    idx = np.flatnonzero(keep)
+    if len(idx) == 0:
+        return keep
+    dk = d[idx]
+    inl = ((dk - dk.mean(0)) < 2.5 * dk.std(0)).all(1)
+    out = np.zeros(len(d), bool)
+    out[idx[inl]] = True
+    return out
+
+
+class GmcFeatureRef:
+    """GMC(method='orb' | 'sift', downscale=2).apply(frame) -> 2x3 float64 (default.yaml:374 `gmc_method: orb` / `sift`), restated
+    with this repository's own restatements of the detectors: oracle/stabilo_ref.py's ORB (FAST 20, 8 levels, Harris ranking,
+    rotated BRIEF; 1000 keypoints) with its Hamming 2-NN matcher, or oracle/sift_ref.py's SIFT (plain descriptors) with an exact
+    L2 2-NN; Lowe's ratio 0.9, the two spatial filters of apply_features, estimate_affine_partial above. CHOICES (also in the
+    product, geotrax_amd/gmc.py FeatureGMC): the matcher's query is the current frame, no detection-box mask, SIFT with OpenCV's
+    default thresholds. PARITY UNPINNED against ultralytics / OpenCV."""
+
+    def __init__(self, frame_hw, method="orb", seed=0, max_features=1000):
+        self.hw, self.method, self.seed, self.max_features = tuple(frame_hw), method, seed, max_features
+        self.prev = None
+        self.last = {}
+
+    def _features(self, gray_half):
+        if self.method == "orb":
+            from . import stabilo_ref as S
+
+            cfg = dict(downsample_ratio=0.5, max_features=self.max_features, ref_multiplier=1.0, filter_ratio=0.9, ransac_threshold=2.0,
+                       mask_use=False, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=self.seed)
+            if not hasattr(self, "_pattern"):
+                self._pattern = S.brief_pattern()
+            f = S.extract(gray_half, None, cfg, self.max_features, self._pattern)
+            return f["xy"], f["desc"]
+        from . import sift_ref
+
+        k = sift_ref.detect_and_compute(np.repeat(gray_half[:, :, None], 3, 2), max_features=self.max_features, root=False)
+        return k["xy"].astype(np.float32) * np.float32(2.0), k["desc"]
+
+    def apply(self, gray_half: np.ndarray) -> np.ndarray:
+        H = np.eye(2, 3)
+        xy, desc = self._features(gray_half)
+        prev, self.prev = self.prev, (xy, desc)
+        if prev is None or len(prev[0]) < 2 or len(xy) == 0:
+            return H
+        if self.method == "orb":
+            from . import stabilo_ref as S
+
+            qi, ti, _ = S.match(desc, prev[1], 0.9)
+        else:
+            d = ((desc[:, None, :].astype(np.float32) - prev[1][None, :, :].astype(np.float32)) ** 2).sum(-1)
+            order = np.argsort(d, 1, kind="stable")[:, :2]
+            d1, d2 = np.sqrt(d[np.arange(len(d)), order[:, 0]]), np.sqrt(d[np.arange(len(d)), order[:, 1]])
+            good = d1 < np.float32(0.9) * d2
+            qi, ti = np.flatnonzero(good), order[good, 0]
+        p, q = prev[0][ti], xy[qi]
+        keep = filter_matches(p, q, self.hw)
+        self.last = dict(prev=p, cur=q, keep=keep)
+        if keep.sum() > 4:
+            M = estimate_affine_partial(p[keep], q[keep], self.seed)
+            if M is not None:
+                H = M
+        return H

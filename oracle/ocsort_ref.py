@@ -36,6 +36,16 @@ corner by corner. Two deliberate differences from that code, both stated in DESI
 (there the last observation and its entry in the age table are one array and are moved twice), and the observation ORU
 starts its virtual trajectory from is moved too (there it stays in the old frame's coordinates).
 
+`OCSortRef(cmc=True, with_reid=True)` adds Deep OC-SORT's appearance branch on vectors handed in per detection (`model: auto`:
+the detector's own, default.yaml:421), as the authors' public code runs it: unit-length vectors; the first association's
+cost gains -(w * similarity) with similarity = <detection vector, track vector> and w = 0.75 adaptively reduced per row and
+per column by how close the two best similarities are (compute_aw_max_metric, bottom 0.5; neither has a config key: the
+authors' defaults); a matched track's vector moves by a dynamic-alpha EMA, alpha = alpha_fixed_emb + (1 - alpha_fixed_emb) *
+(1 - (score - det_thresh) / (1 - det_thresh)), in the first association and in OCR (not in the BYTE pass); the
+unambiguous-IoU shortcut skips the term as it does there. CHOICE for the config's two gates, which the authors' code does not
+have (default.yaml:422-423): a pair keeps its similarity only when IoU >= proximity_thresh (theirs: IoU > 0) and
+similarity >= appearance_thresh. PARITY UNPINNED against the ultralytics port.
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 from __future__ import annotations
@@ -183,6 +193,14 @@ class _Trk:
         self.velocity = None
         self.delta_t = delta_t
         self.score, self.cls, self.idx = score, cls, idx
+        self.emb = None
+
+    def update_emb(self, emb, alpha):
+        if self.emb is None:
+            self.emb = emb
+            return
+        self.emb = alpha * self.emb + (1.0 - alpha) * emb
+        self.emb = self.emb / np.sqrt(np.sum(self.emb * self.emb))
 
     def update(self, det):
         """det: [x1,y1,x2,y2,score,cls,idx] or None"""
@@ -241,7 +259,10 @@ class _Trk:
 
 class OCSortRef:
     def __init__(self, track_high_thresh=0.25, track_low_thresh=0.1, new_track_thresh=0.25, track_buffer=30, match_thresh=0.8,
-                 delta_t=3, inertia=0.2, use_byte=False, min_hits=3, cmc=False, **_ignored):
+                 delta_t=3, inertia=0.2, use_byte=False, min_hits=3, cmc=False, with_reid=False, proximity_thresh=0.5, appearance_thresh=0.9,
+                 alpha_fixed_emb=0.95, **_ignored):
+        self.reid = bool(with_reid) and bool(cmc)
+        self.prox, self.app_thr, self.alpha_fixed = float(proximity_thresh), float(appearance_thresh), float(alpha_fixed_emb)
         self.det_thresh, self.low, self.new_thr = track_high_thresh, track_low_thresh, new_track_thresh
         self.max_age, self.iou_thr = int(track_buffer), 1.0 - match_thresh
         self.delta_t, self.inertia, self.use_byte, self.min_hits = int(delta_t), float(inertia), bool(use_byte), int(min_hits)
@@ -250,7 +271,22 @@ class OCSortRef:
         self.frame_count = 0
         self._count = 0
 
-    def _associate(self, dets, trks, velocities, prev_obs):
+    @staticmethod
+    def _aw(emb, w=0.75, bottom=0.5):
+        """Deep OC-SORT compute_aw_max_metric: w reduced per row / column by the ratio of the second best to the best similarity."""
+        wm = np.full_like(emb, w)
+        for axis, n_other in ((1, emb.shape[1]), (0, emb.shape[0])):
+            if n_other < 2:
+                continue
+            s = -np.sort(-emb, axis=axis)
+            b0 = np.take(s, 0, axis=axis)
+            b1 = np.take(s, 1, axis=axis)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                f = np.where(b0 == 0, 0.0, 1.0 - np.maximum(b1 / np.where(b0 == 0, 1.0, b0) - bottom, 0.0) / (1.0 - bottom))
+            wm = wm * (f[:, None] if axis == 1 else f[None, :])
+        return wm * emb
+
+    def _associate(self, dets, trks, velocities, prev_obs, det_emb=None):
         n, m = len(dets), len(trks)
         if m == 0:
             return [], list(range(n)), []
@@ -270,7 +306,13 @@ class OCSortRef:
         if a.sum(1).max() == 1 and a.sum(0).max() == 1:
             pairs = list(zip(*[v.tolist() for v in np.where(a)]))
         else:
-            pairs = _lap(-(iou + angle_cost))
+            emb_cost = 0.0
+            if self.reid and det_emb is not None:
+                trk_emb = np.stack([t.emb for t in self.trackers])
+                sim = det_emb @ trk_emb.T                                              # [det, trk]
+                sim = np.where((iou <= 0) | (iou < self.prox) | (sim < self.app_thr), 0.0, sim)
+                emb_cost = self._aw(sim)
+            pairs = _lap(-(iou + angle_cost + emb_cost))
         md, mt = {p[0] for p in pairs}, {p[1] for p in pairs}
         u_d = [d for d in range(n) if d not in md]
         u_t = [t for t in range(m) if t not in mt]
@@ -283,7 +325,7 @@ class OCSortRef:
                 matches.append((d, t))
         return matches, u_d, u_t
 
-    def update(self, xyxy, conf, cls, gmc=None):
+    def update(self, xyxy, conf, cls, gmc=None, feats=None):
         """One frame. Returns rows [x1,y1,x2,y2,id,score,cls,idx] (float32), newest track first."""
         self.frame_count += 1
         xyxy = np.asarray(xyxy, dtype=np.float64).reshape(-1, 4)
@@ -307,9 +349,18 @@ class OCSortRef:
         last_boxes = np.array([trk.last_observation for trk in self.trackers]).reshape(-1, 5)
         prev_obs = np.array([trk.k_previous(self.delta_t) for trk in self.trackers]).reshape(-1, 5)
 
-        matches, u_d, u_t = self._associate(dets, trks, velocities, prev_obs)
+        det_emb = alpha = None
+        if self.reid:
+            f = np.asarray(feats, dtype=np.float32)
+            f = (f.reshape(len(conf), -1)[dets[:, 6].astype(int)] if len(conf) else np.zeros((0, 1), np.float32)).astype(np.float64)
+            det_emb = f / np.sqrt(np.sum(f * f, axis=1, keepdims=True)) if len(f) else f
+            trust = (dets[:, 4] - self.det_thresh) / (1.0 - self.det_thresh)
+            alpha = self.alpha_fixed + (1.0 - self.alpha_fixed) * (1.0 - trust)
+        matches, u_d, u_t = self._associate(dets, trks, velocities, prev_obs, det_emb)
         for d, t in matches:
             self.trackers[t].update(dets[d])
+            if self.reid:
+                self.trackers[t].update_emb(det_emb[d], alpha[d])
         if self.use_byte and len(second) and len(u_t):
             iou_left = _iou(second, trks[u_t])
             if iou_left.max() > self.iou_thr:
@@ -328,6 +379,8 @@ class OCSortRef:
                     if iou_left[a, b] < self.iou_thr:
                         continue
                     self.trackers[u_t[b]].update(dets[u_d[a]])
+                    if self.reid:
+                        self.trackers[u_t[b]].update_emb(det_emb[u_d[a]], alpha[u_d[a]])
                     dd.append(u_d[a])
                     dt.append(u_t[b])
                 u_d = [d for d in u_d if d not in dd]
@@ -340,6 +393,8 @@ class OCSortRef:
             self._count += 1
             self.trackers.append(_Trk(dets[d, :5], float(dets[d, 4]), int(dets[d, 5]), int(dets[d, 6]), self._count, self.delta_t))
             self.trackers[-1].last_observation = np.array([-1.0, -1.0, -1.0, -1.0, -1.0])
+            if self.reid:
+                self.trackers[-1].emb = det_emb[d]
         out = []
         i = len(self.trackers)
         for trk in reversed(self.trackers):

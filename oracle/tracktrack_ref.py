@@ -18,6 +18,9 @@ CHOICES
     below track_high_thresh carry penalty_p. A pair whose boxes do not overlap is infeasible.
   * cost = iou_weight * (1 - HMIoU) + reid_weight * (1 - HMIoU) [no appearance model: "HMIoU fallback"] + conf_weight * |track
     score - detection score| + angle_weight * corner-angle distance. HMIoU = IoU * (overlap of the vertical extents / their union).
+  * with_reid (`model: auto`: one vector per detection from the detector): the reid_weight term is the cosine distance
+    clip(1 - <track vector, detection vector>, 0, 1) between unit vectors in float32; a track keeps BOTrack's vectors (the matched
+    detection's normalised vector and a 0.9-EMA of them, re-normalised), updated on every match.
   * Corner-angle distance: for each of the four corners, the angle between the track's own motion (last observation minus the
     observation delta_t = 3 frames before it, OC-SORT's rule for picking it) and the step from that earlier observation to the
     detection, divided by pi, averaged; 0 for a track with fewer than two observations or for a corner that did not move.
@@ -50,6 +53,15 @@ class _Trk:
         self.frame_id = self.start_frame = 0
         self.confirmed = False
         self.obs = []                      # (frame, xyxy float64) of every matched detection
+        self.curr_feat = self.smooth_feat = None
+
+    def update_features(self, f):
+        self.curr_feat = f
+        if self.smooth_feat is None:
+            self.smooth_feat = f
+        else:
+            self.smooth_feat = np.float32(0.9) * self.smooth_feat + (np.float32(1) - np.float32(0.9)) * f
+        self.smooth_feat = self.smooth_feat / np.sqrt(np.sum(self.smooth_feat * self.smooth_feat, dtype=np.float32))
 
     def xyxy(self):
         cx, cy, w, h = self.mean[:4]
@@ -76,7 +88,8 @@ def _corners(b):
 class TrackTrackRef:
     def __init__(self, track_high_thresh=0.6, track_low_thresh=0.25, new_track_thresh=0.7, track_buffer=30, match_thresh=0.7,
                  lost_match_thr=0.0, iou_weight=0.5, reid_weight=0.5, conf_weight=0.1, angle_weight=0.05, penalty_p=0.2,
-                 penalty_q=0.4, reduce_step=0.05, tai_thr=0.55, min_track_len=3, frame_rate=30, delta_t=3, **_ignored):
+                 penalty_q=0.4, reduce_step=0.05, tai_thr=0.55, min_track_len=3, frame_rate=30, delta_t=3, with_reid=False, **_ignored):
+        self.reid = bool(with_reid)
         self.hi, self.lo, self.new_thr = track_high_thresh, track_low_thresh, new_track_thresh
         self.match_thresh, self.lost_thr = match_thresh, lost_match_thr
         self.w = (iou_weight, reid_weight, conf_weight, angle_weight)
@@ -125,7 +138,13 @@ class TrackTrackRef:
                     continue
                 hi = (min(a[3], b[3]) - max(a[1], b[1])) / (max(a[3], b[3]) - min(a[1], b[1]))
                 dist = 1.0 - iou * hi
-                c = self.w[0] * dist + self.w[1] * dist + self.w[2] * abs(t.score - d.score) + self.w[3] * self._angle(t, b)
+                app = dist
+                if self.reid and t.smooth_feat is not None:
+                    dot = np.float32(0)
+                    for k in range(len(d.curr_feat)):           # the C++ loop's float32 accumulation order
+                        dot = np.float32(dot + t.smooth_feat[k] * d.curr_feat[k])
+                    app = min(1.0, max(0.0, 1.0 - float(dot)))
+                c = self.w[0] * dist + self.w[1] * app + self.w[2] * abs(t.score - d.score) + self.w[3] * self._angle(t, b)
                 C[i, j] = c + (self.penalty_p if low[j] else 0.0)
         return C
 
@@ -155,13 +174,22 @@ class TrackTrackRef:
             t.obs = t.obs[-64:]
         if len(t.obs) >= self.min_len:
             t.confirmed = True
+        if d.curr_feat is not None:
+            t.update_features(d.curr_feat)
 
-    def update(self, xyxy, conf, cls, gmc=None):
+    def update(self, xyxy, conf, cls, gmc=None, feats=None):
         """One frame. Returns rows [x1,y1,x2,y2,id,score,cls,idx] of the reported tracks (float32)."""
         self.frame_id += 1
         xyxy = np.asarray(xyxy, dtype=np.float32).reshape(-1, 4)
         conf = np.asarray(conf, dtype=np.float32)
         dets = [_Trk(xyxy[i], conf[i], cls[i], i) for i in range(len(conf)) if conf[i] > np.float32(self.lo)]
+        if self.reid:
+            for d in dets:
+                f = np.asarray(feats[d.idx], dtype=np.float32)
+                ss = np.float32(0)
+                for v in f:
+                    ss = np.float32(ss + v * v)
+                d.curr_feat = d.smooth_feat = f / np.sqrt(ss)
         low = [d.score < float(np.float32(self.hi)) for d in dets]
         pool = list(self.tracked) + list(self.lost)
         was_lost = {id(t) for t in self.lost}

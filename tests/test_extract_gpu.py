@@ -105,7 +105,8 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
         from oracle.ocsort_ref import OCSortRef
 
         trk = OCSortRef(cmc=(active == "deepocsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh", "track_buffer",
-                                                                            "match_thresh", "delta_t", "inertia", "use_byte")})
+                                                                            "match_thresh", "delta_t", "inertia", "use_byte")},
+                        **({k: tp[k] for k in ("with_reid", "proximity_thresh", "appearance_thresh", "alpha_fixed_emb")} if active == "deepocsort" else {}))
     elif active == "fasttrack":
         from oracle.fasttrack_ref import FastTrackRef
 
@@ -113,12 +114,12 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     elif active == "tracktrack":
         from oracle.tracktrack_ref import TrackTrackRef
 
-        trk = TrackTrackRef(**{k: v for k, v in tp.items() if k not in ("tracker_type", "gmc_method", "with_reid", "model")})
+        trk = TrackTrackRef(**{k: v for k, v in tp.items() if k not in ("tracker_type", "gmc_method", "model")})
     else:
         trk = ByteTrackRef(botsort=(active == "botsort"), **{k: tp[k] for k in ("track_high_thresh", "track_low_thresh", "new_track_thresh",
                                                                                  "track_buffer", "match_thresh", "fuse_score")},
                            **({k: tp[k] for k in ("with_reid", "proximity_thresh", "appearance_thresh")} if active == "botsort" else {}))
-    reid = active == "botsort" and bool(tp.get("with_reid"))
+    reid = active in ("botsort", "deepocsort", "tracktrack") and bool(tp.get("with_reid"))
     gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort", "tracktrack") and tp.get("gmc_method") == "sparseOptFlow" else None
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
@@ -164,9 +165,9 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "fasttrack", "tracktrack", "rtdetr"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "deepocsort+reid", "fasttrack", "tracktrack", "tracktrack+reid", "rtdetr"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
-    reid = tracker == "botsort+reid"        # BoT-SORT's appearance branch on detector-derived vectors (`with_reid: true, model: auto`)
+    reid = tracker.endswith("+reid")        # the appearance branch on detector-derived vectors (`with_reid: true, model: auto`): BoT-SORT, Deep OC-SORT, TrackTrack
     rtdetr = tracker == "rtdetr"            # the RT-DETR detector (a weight file with that graph) in front of ByteTrack
     tracker = "bytetrack" if rtdetr else tracker.split("+")[0]
     from geotrax_amd import extract as ex

@@ -79,3 +79,27 @@ def test_warp_boxes_projective_and_empty():
         exp = [(p[0].min() + p[0].max()) / 2, (p[1].min() + p[1].max()) / 2, np.ptp(p[0]), np.ptp(p[1])]
         np.testing.assert_allclose(g, exp, rtol=1e-6)
     assert geo.warp_boxes(H, np.zeros((0, 4), np.float32)).shape == (0, 4)
+
+
+def test_estimate_affine_partial_equals_the_oracle_and_recovers_a_similarity():
+    """gtx_op_estimate_affine_partial (host C++; the fit of `gmc_method: orb` / `sift`) == oracle/gmc_ref.estimate_affine_partial on
+    seeded matches with 30 % outliers, and both recover the similarity the inliers were made with."""
+    from geotrax_amd.gmc import estimate_affine_partial
+    from oracle import gmc_ref
+
+    rng = np.random.default_rng(7)
+    for n in (5, 60, 800):
+        p = rng.uniform(0, 1000, (n, 2)).astype(np.float32)
+        a, s = 0.01, 1.002
+        M = np.array([[s * np.cos(a), -s * np.sin(a), 12.5], [s * np.sin(a), s * np.cos(a), -7.25]])
+        q = (p.astype(np.float64) @ M[:, :2].T + M[:, 2] + 0.3 * rng.standard_normal((n, 2))).astype(np.float32)
+        bad = rng.random(n) < 0.3
+        q[bad] += rng.uniform(-200, 200, (int(bad.sum()), 2)).astype(np.float32)
+        got, inl = estimate_affine_partial(p, q, seed=3)
+        want = gmc_ref.estimate_affine_partial(p, q, seed=3)
+        assert got is not None and want is not None
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+        if n >= 60:
+            assert np.abs(got - M).max() < 0.2 and inl > 0.6 * n
+    got, inl = estimate_affine_partial(np.zeros((1, 2), np.float32), np.zeros((1, 2), np.float32))
+    assert got is None and inl == 0

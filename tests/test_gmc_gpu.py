@@ -74,6 +74,62 @@ def test_state_rules(gtx_ctx, frames):
     g.reset_params()
     np.testing.assert_array_equal(g.apply(fr[1]), np.eye(2, 3))      # first frame again
     with pytest.raises(NotImplementedError):
-        GMC(HW, method="orb", ctx=gtx_ctx)
+        GMC(HW, method="ecc", ctx=gtx_ctx)                            # orb / sift: gmc.make_gmc -> FeatureGMC (below)
     with pytest.raises(GtxError):
         g.apply(np.zeros((100, 100, 3), np.uint8))                    # wrong frame size
+
+
+@pytest.mark.parametrize("method", ["orb", "sift"])
+def test_feature_gmc_matches_the_oracle_and_the_camera(gtx_ctx, frames, method):
+    """`gmc_method: orb` / `sift` (default.yaml:374): the stabilizer's ORB kernels / csrc/sift.hip + the L2 matcher, ratio 0.9,
+    apply_features' spatial filters and the partial-affine RANSAC -- against oracle/gmc_ref.py GmcFeatureRef (same matches, same
+    filtered pairs, the same warp) and against the synthetic camera."""
+    from geotrax_amd.gmc import make_gmc
+    from oracle.gmc_ref import GmcFeatureRef
+    from oracle.yolov8_ref import bgr2gray_half
+
+    sc, fr = frames
+    hw = HW if method == "orb" else (HW[0] // 2 * 2, HW[1] // 2 * 2)
+    g, o = make_gmc(hw, method=method, ctx=gtx_ctx), GmcFeatureRef(hw, method=method)
+    A0 = g.apply(fr[0])
+    np.testing.assert_array_equal(A0, np.eye(2, 3))
+    assert not g.valid
+    o.apply(bgr2gray_half(fr[0]))
+    for k in (1, 2):
+        A = g.apply(fr[k])
+        Ao = o.apply(bgr2gray_half(fr[k]))
+        assert g.valid and g.stats[1] > 30 and g.stats[2] > 0.5 * g.stats[1]
+        if method == "orb":                                              # integer stages: the same pairs survive the filters
+            assert g.stats[1] == int(o.last["keep"].sum())
+            np.testing.assert_allclose(A, Ao, rtol=0, atol=1e-9)
+        else:                                                            # float32 pyramids: a keypoint or two may differ
+            assert abs(int(g.stats[1]) - int(o.last["keep"].sum())) <= max(3, int(0.05 * g.stats[1]))
+            P = np.array([[0, 0, 1], [hw[1], 0, 1], [0, hw[0], 1], [hw[1], hw[0], 1.0]]).T
+            assert np.abs(A @ P - Ao @ P).max() < 0.25
+    G = sc.camera(100) @ np.linalg.inv(sc.camera(50))                    # frame 50 -> frame 100 pixels
+    ys, xs = np.meshgrid(np.linspace(0, HW[0] - 1, 5), np.linspace(0, HW[1] - 1, 7), indexing="ij")
+    P = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    q = G @ P
+    assert np.abs(A @ P - q[:2] / q[2]).max() < 0.8                      # px; a similarity fitted to a tiny homography from integer keypoints of the half-resolution pyramid
+    g.close()
+
+
+def test_feature_gmc_through_the_model_object(gtx_ctx):
+    """BoT-SORT with `gmc_method: orb`: model.track hands the detector's gray image in HBM to the feature GMC; `ecc` is refused by name."""
+    from geotrax_amd.model import YOLO
+    from geotrax_amd.synth import make_scene
+    from geotrax_amd.weights import synthetic_yolov8
+
+    sc = make_scene(seed=3, h=HW[0], w=HW[1])
+    m = YOLO(synthetic_yolov8(seed=1, nc=4), ctx=gtx_ctx)
+    kw = dict(imgsz=384, conf=0.25, iou=0.7, max_det=300, classes=None, agnostic_nms=True, half=False, rect=True,
+              tracker=dict(tracker_type="botsort", gmc_method="orb", track_high_thresh=0.25, track_low_thresh=0.1, new_track_thresh=0.25, track_buffer=30,
+                           match_thresh=0.8, fuse_score=True))
+    warps = []
+    for t in (0, 20, 40):
+        m.track(sc.render(t), persist=True, **kw)
+        warps.append(m._gmc.valid)
+    assert warps == [False, True, True] and type(m._gmc).__name__ == "FeatureGMC"
+    m.detector.close()
+    with pytest.raises(NotImplementedError):
+        YOLO(synthetic_yolov8(seed=1, nc=4), ctx=gtx_ctx)._make_tracker(dict(tracker_type="botsort", gmc_method="ecc"))

@@ -100,8 +100,9 @@ def test_config_selects_ocsort(tmp_path):
     assert isinstance(m._make_tracker({"tracker_type": "fasttrack", "occ_cover_thresh": 0.6}), Tracker)
     t = m._make_tracker({"tracker_type": "tracktrack", "gmc_method": "sparseOptFlow", "tai_thr": 0.5})   # round 5: tests/test_tracktrack.py
     assert isinstance(t, Tracker) and m._gmc_method == "sparseOptFlow"
+    assert m._make_tracker({"tracker_type": "tracktrack", "with_reid": True}).with_reid        # round 6: `model: auto` (tests/test_tracktrack.py)
     with pytest.raises(NotImplementedError):
-        m._make_tracker({"tracker_type": "tracktrack", "with_reid": True})
+        m._make_tracker({"tracker_type": "tracktrack", "with_reid": True, "model": "osnet_x0_25.pt"})   # a separate ReID network is not built
 
 
 @pytest.mark.parametrize("kind", ["bytetrack", "botsort", "ocsort"])
@@ -208,7 +209,36 @@ def test_camera_motion_compensation_keeps_the_identities_a_panning_camera_breaks
     assert len(plain) > len(still) + 5
 
 
-def test_config_selects_deepocsort_and_refuses_the_appearance_branch():
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cpp_deepocsort_with_reid_equals_oracle(seed):
+    """Deep OC-SORT's appearance branch (`with_reid: true, model: auto`, default.yaml:420-425; csrc/ocsort.cpp) against
+    oracle/ocsort_ref.py: adaptive-weighted similarity term in the first association, dynamic-alpha EMA of the track vectors, also
+    seen through a panning camera with the warps handed in; the term does change associations on this stream."""
+    from geotrax_amd.tracker import Tracker
+    from oracle.ocsort_ref import OCSortRef
+    from test_tracker import _stream_with_feats
+
+    kw = dict(with_reid=True, proximity_thresh=0.3, appearance_thresh=0.6, alpha_fixed_emb=0.9, track_high_thresh=0.3, new_track_thresh=0.3)
+    ref, trk, plain = OCSortRef(cmc=True, **kw), Tracker("deepocsort", **kw), OCSortRef(cmc=True, **{**kw, "with_reid": False})
+    assert trk.with_reid
+    warps, total = _camera_path(seed + 20, 90, step=6.0)
+    rows, differs = 0, False
+    for t, (xyxy, conf, cls, feats) in enumerate(_stream_with_feats(seed, n_obj=70, jitter=5.0, p_miss=0.15, n_frames=90)):
+        xyxy = _moved(xyxy, total[t])
+        want = ref.update(xyxy, conf, cls, warps[t], feats=feats)
+        p = plain.update(xyxy, conf, cls, warps[t])
+        got_xyxy, got_id, got_score, got_cls, got_idx = trk.update(xyxy, conf, cls, warps[t], feats=feats)
+        assert len(want) == len(got_id), f"frame {t}"
+        if len(want):
+            np.testing.assert_array_equal(want[:, 4].astype(np.int32), got_id, err_msg=f"frame {t}")
+            np.testing.assert_array_equal(want[:, 7].astype(np.int32), got_idx)
+            np.testing.assert_allclose(got_xyxy, want[:, :4], rtol=0, atol=2e-3)
+        differs |= len(p) != len(want) or not np.array_equal(p[:, [4, 7]], want[:, [4, 7]])
+        rows += len(want)
+    assert rows > 1000 and differs
+
+
+def test_config_selects_deepocsort_and_its_appearance_branch():
     from geotrax_amd.model import YOLO
 
     m = YOLO.__new__(YOLO)
@@ -218,8 +248,9 @@ def test_config_selects_deepocsort_and_refuses_the_appearance_branch():
     assert m._gmc_method == "sparseOptFlow" and trk.update(np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int32))[1].size == 0
     m._make_tracker({"tracker_type": "deepocsort", "gmc_method": "none"})
     assert m._gmc_method is None
+    assert m._make_tracker({"tracker_type": "deepocsort", "with_reid": True, "model": "auto", "appearance_thresh": 0.9}).with_reid
     with pytest.raises(NotImplementedError):
-        m._make_tracker({"tracker_type": "deepocsort", "with_reid": True})
+        m._make_tracker({"tracker_type": "deepocsort", "with_reid": True, "model": "osnet_x0_25.pt"})
 
 
 def test_ocsort_choice_is_announced_and_min_hits_is_a_config_key(caplog):

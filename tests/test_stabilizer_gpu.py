@@ -218,8 +218,30 @@ def test_affine_model_and_unfiltered_matches_equal_the_oracle(gtx_ctx, seq, opts
         assert _grid_err(H, np.linalg.inv(sc.camera(40)), HW) < 1.0
 
 
+@pytest.mark.parametrize("name", ["rsift", "sift"])
+def test_sift_detectors_recover_the_ground_truth_homography(gtx_ctx, seq, name):
+    """stabilo `detector_name: rsift` / `sift` (default.yaml:109): the registration stage's SIFT + L2 matcher + RANSAC on the
+    half-resolution frames, one blocking call per frame. Known camera to 1 px on the 9 x 16 grid, stabilo's counters filled,
+    the last-known-transform rule kept, box warp as with ORB."""
+    sc, fr = seq
+    st = _make(gtx_ctx, detector_name=name, max_features=3000, filter_ratio=0.75)
+    st.set_ref_frame(fr[0], sc.boxes(0))
+    for t in (40, 149):
+        st.stabilize(fr[t], sc.boxes(t))
+        H = st.get_cur_trans_matrix()
+        assert H is not None and st.registered
+        assert _grid_err(H, np.linalg.inv(sc.camera(t)), HW) < 1.0
+        n_ref, n_cur = st.get_cur_num_keypoints()
+        assert n_ref > 200 and n_cur > 200 and st.get_cur_num_matches() > 50 and st.get_cur_inliers_count() > 30
+    st.stabilize(np.full_like(fr[0], 90), None)                       # nothing to register: the last known transform is reported
+    assert not st.registered and np.array_equal(st.get_cur_trans_matrix(), H)
+    with pytest.raises(NotImplementedError):
+        st.set_ref_gray_dev(0, HW[0] // 2, HW[1] // 2)                 # host frames only on this path
+
+
 def test_unsupported_stabilizer_choices_raise(gtx_ctx):
-    for kw in (dict(detector_name="sift"), dict(matcher_name="flann"), dict(filter_type="distance")):
+    for kw in (dict(detector_name="brisk"), dict(detector_name="akaze"), dict(matcher_name="flann"), dict(filter_type="distance"),
+               dict(detector_name="sift", transformation_type="affine")):
         with pytest.raises(NotImplementedError):
             _make(gtx_ctx, **kw)
     with pytest.raises(ValueError):

@@ -189,4 +189,4 @@ def test_with_reid_needs_a_vector_per_detection():
     xyxy = np.array([[10, 10, 50, 40]], np.float32)
     with pytest.raises(ValueError):
         trk.update(xyxy, np.array([0.9], np.float32), np.array([0], np.int32))
-    assert Tracker("bytetrack", with_reid=True).with_reid is False      # only BoT-SORT has the branch
+    assert Tracker("bytetrack", with_reid=True).with_reid is False      # BoT-SORT, Deep OC-SORT and TrackTrack have the branch

@@ -36,6 +36,31 @@ def test_tracktrack_matches_oracle(seed, with_gmc):
     assert _run(kw, _stream(seed, n_obj=60, jitter=3.0, p_miss=0.12), gmc_seed=seed + 7 if with_gmc else None) > 800
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_tracktrack_with_reid_matches_oracle(seed):
+    """`with_reid: true, model: auto` (default.yaml:469-470): the reid_weight term is the cosine distance between the track's smoothed
+    vector and the detection's; C++ == oracle, and the term changes associations on this stream."""
+    from geotrax_amd.tracker import Tracker
+    from oracle.tracktrack_ref import TrackTrackRef
+    from test_tracker import _stream_with_feats
+
+    kw = dict(track_high_thresh=0.6, track_low_thresh=0.25, new_track_thresh=0.7, match_thresh=0.7, min_track_len=3, with_reid=True)
+    trk, ref, plain = Tracker("tracktrack", **kw), TrackTrackRef(**kw), TrackTrackRef(**{**kw, "with_reid": False})
+    assert trk.with_reid
+    rows, differs = 0, False
+    for t, (xyxy, conf, cls, feats) in enumerate(_stream_with_feats(seed, n_obj=60, jitter=4.0, p_miss=0.15)):
+        b, i, s, c, d = trk.update(xyxy, conf, cls, None, feats=feats)
+        r = ref.update(xyxy, conf, cls, None, feats=feats)
+        p = plain.update(xyxy, conf, cls, None)
+        assert len(i) == len(r), f"frame {t}"
+        np.testing.assert_array_equal(i, r[:, 4].astype(np.int32), err_msg=f"frame {t} ids")
+        np.testing.assert_array_equal(d, r[:, 7].astype(np.int32), err_msg=f"frame {t} detection index")
+        np.testing.assert_allclose(b, r[:, :4], rtol=0, atol=2e-3)
+        differs |= len(p) != len(r) or not np.array_equal(p[:, [4, 7]], r[:, [4, 7]])
+        rows += len(i)
+    assert rows > 800 and differs
+
+
 def test_tracktrack_lost_rebinding_and_other_knobs_match_oracle():
     kw = dict(track_high_thresh=0.5, track_low_thresh=0.2, new_track_thresh=0.55, match_thresh=0.8, lost_match_thr=0.9, reduce_step=0.1,
               penalty_p=0.1, tai_thr=0.4, min_track_len=2, angle_weight=0.2, conf_weight=0.2, track_buffer=10)

@@ -10,7 +10,13 @@ import sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final/stats"
 f = sorted(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True))[-1]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in csv.DictReader(open(f)))
-starts = [e[0] for e in ev if "conv_igemm" in e[2] or "conv_front" in e[2]]
+def is_conv(n):
+    """Every convolution family of the detector: conv_igemm[_split], conv_k32_split (the dominant one since round 5 -- the round-5
+    digest's filter missed it and reported 62 % where this prints ~90 %), conv_front_split, conv_wino*, the stems."""
+    return "conv_" in n or "stem" in n
+
+
+starts = [e[0] for e in ev if is_conv(e[2])]
 W, best, j = 100e6, (0, None), 0
 for i, s in enumerate(starts):
     while starts[j] < s - W:
@@ -36,7 +42,8 @@ def levels(pred, cap):
 
 print(f"# {f}: densest {(b - a) / 1e6:.0f} ms window ({best[0]} convolution launches)")
 print("kernels in flight (share of time):          ", levels(lambda n: True, 6))
-print("convolution / stem kernels in flight:       ", levels(lambda n: "conv_igemm" in n or "conv_front" in n or "stem" in n, 4))
+print("convolution / stem kernels in flight:       ", levels(is_conv, 4))
+print("stabilizer / GMC kernels in flight:         ", levels(lambda n: any(k in n for k in ("pyr_", "fast_detect", "harris", "select_kernel", "describe", "match_kernel", "ransac", "gmc", "lk_")), 4))
 for q in sorted({e[3] for e in ev}):
     iv = [(max(s, a), min(e, b)) for s, e, n, qq in ev if qq == q and e > a and s < b]
     print(f"hardware queue {q}: busy {sum(e - s for s, e in iv) / (b - a):.3f} of the window, {len(iv)} launches")
