@@ -181,7 +181,7 @@ def test_identical_frame_gives_identity_and_state_errors(gtx_ctx, seq):
     st.stabilize(flat, None)
     assert st.get_cur_trans_matrix() is None
     with pytest.raises(NotImplementedError):
-        Stabilizer(HW, detector_name="sift")
+        Stabilizer(HW, detector_name="brisk")                         # orb, sift and rsift are built (round 6)
 
 
 @pytest.mark.parametrize("opts", [dict(transformation_type="affine"), dict(filter_type="none"),
