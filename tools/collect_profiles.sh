@@ -12,6 +12,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq2 -- python3 $R/tools/op_profile.py 2 f32s 3 > $O/sq2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_iso -- python3 $R/tools/op_profile.py 2 f32s 5 > $O/op_profile_under_rocprof.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_stab -- python3 $R/tools/stab_profile.py 60 > $O/stab_profile.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_rtdetr -- python3 $R/bench.py --model rtdetr-l --steps 40 --warmup 6 --no-cpu-baseline --no-f16-line --no-live-traffic > $O/bench_rtdetr_under_rocprof.json 2> $O/stats_rtdetr.log
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.log
 python bench.py --tracker botsort --no-cpu-baseline --no-f16-line > $O/bench_botsort.json 2>/dev/null
@@ -28,6 +29,10 @@ python bench.py --workload register --ortho 15000 --steps 3 > $O/bench_register_
 python bench.py --workload georef > $O/bench_georef.json 2>/dev/null
 python bench.py --workload warp > $O/bench_warp.json 2>/dev/null
 python bench.py --workload extract+georef > $O/bench_extract_georef.json 2>/dev/null
+python bench.py --model rtdetr-l --steps 100 < /dev/null > $O/bench_rtdetr.json 2>/dev/null                  # the reference's RTDETR branch
+python bench.py --model rtdetr-l --workload detect --no-cpu-baseline --steps 100 < /dev/null > $O/bench_rtdetr_detect.json 2>/dev/null
+python bench.py --det-streams 1 --no-cpu-baseline --no-f16-line --steps 200 < /dev/null > $O/bench_one_det_stream.json 2>/dev/null   # the front launch in situ with one detector stream
+timeout 300 python tools/rt_probe.py 1920 1 1 < /dev/null > $O/rtdetr_op_profile.txt 2>&1
 for p in f32s f16 f32; do python tools/op_profile.py 2 $p 10 > $O/op_profile_${p}_b2.txt 2>/dev/null; done
 python tools/conv_sweep.py 1920 2 all f32s f16 > $O/conv_layer_sweep_b2.txt 2>/dev/null
 GTX_TIME_ZEROS=1 python tools/conv_sweep.py 1920 2 all f32s > $O/conv_layer_sweep_b2_zeros.txt 2>/dev/null
