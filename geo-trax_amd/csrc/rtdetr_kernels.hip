@@ -94,6 +94,14 @@ __device__ __forceinline__ float wave_max(float v) {
 template <int FMT>
 __global__ __launch_bounds__(256) void rt_stem1_kernel(const uchar4* __restrict__ img, int N, int H, int W, const float* __restrict__ w27,
                                                        const float* __restrict__ bias, RtMap out, int* sat) {
+  // ultralytics' `im.float() / 255` has 256 possible results: one correctly rounded division per table entry instead of 27 x 3 per thread
+  __shared__ float s_lut[256];
+  {
+    float f = (float)threadIdx.x / 255.f;
+    if constexpr (FMT == DT_F16) f = (float)(_Float16)f;
+    s_lut[threadIdx.x] = f;
+  }
+  __syncthreads();
   const int groups = out.c / 8, c0 = out.c;
   const size_t total = (size_t)N * out.h * out.w * groups;
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -114,8 +122,7 @@ __global__ __launch_bounds__(256) void rt_stem1_kernel(const uchar4* __restrict_
       const int ix = ox * 2 - 1 + kx;
       if (ix < 0 || ix >= W) continue;
       const uchar4 u = base[(size_t)iy * W + ix];
-      float px[3] = {(float)u.x / 255.f, (float)u.y / 255.f, (float)u.z / 255.f};   // ultralytics: im.float() / 255
-      if constexpr (FMT == DT_F16) { px[0] = (float)(_Float16)px[0]; px[1] = (float)(_Float16)px[1]; px[2] = (float)(_Float16)px[2]; }
+      const float px[3] = {s_lut[u.x], s_lut[u.y], s_lut[u.z]};
       const float* wt = w27 + (size_t)(ky * 3 + kx) * 3 * c0 + g * 8;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci)
