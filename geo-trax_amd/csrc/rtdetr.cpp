@@ -164,7 +164,8 @@ void RtDetr::dwconv(const std::string& name, const View& x, const View& out, int
   Op op;
   op.kind = Op::DWCONV;
   op.name = name;
-  op.family = k == 3 ? "rt_dwconv_kernel<3>" : "rt_dwconv_kernel<5>";
+  const bool tiled = stride == 1 && C % 32 == 0;               // launch_rt_dwconv's rule (GTX_RT_DW_TILE=0 aside)
+  op.family = std::string(tiled ? "rt_dwconv_tile_kernel<" : "rt_dwconv_kernel<") + (k == 3 ? "3>" : "5>");
   op.a = x.map(); op.b = out.map();
   op.w = upload(wt);
   op.bias = has(name + ".bias") ? upload(tensor(name + ".bias").data) : nullptr;
@@ -318,7 +319,7 @@ void RtDetr::build_graph() {
   const HostTensor& w1 = tensor("model.0.stem1.conv.weight");
   GTX_CHECK(w1.shape.size() == 4 && w1.shape[1] == 3 && w1.shape[2] == 3, "model.0.stem1 must be a 3x3 conv on 3 channels");
   const int cm0 = (int)w1.shape[0];
-  GTX_CHECK(cm0 % 8 == 0, "model.0.stem1: %d output channels (a multiple of 8 is needed)", cm0);
+  GTX_CHECK(cm0 % 16 == 0, "model.0.stem1: %d output channels (a multiple of 16 is needed)", cm0);
   View s1 = new_view(S / 2, S / 2, cm0);
   {
     std::vector<float> w27((size_t)27 * cm0);
@@ -426,7 +427,7 @@ void RtDetr::build_graph() {
       Op m;
       m.kind = Op::MHA;
       m.name = A + ".ma";
-      m.family = "rt_mha_kernel";
+      m.family = E / enc_heads_ == 32 ? "rt_mha32_kernel" : "rt_mha_kernel";
       m.p0 = qkv; m.ld0 = 3 * E; m.p1 = attn; m.ld1 = E;
       m.T = T5; m.C = E; m.heads = enc_heads_;
       m.flops = 4.0 * T5 * (double)T5 * E;
@@ -597,7 +598,7 @@ void RtDetr::build_graph() {
       Op m;
       m.kind = Op::MHA;
       m.name = lp + ".self_attn";
-      m.family = "rt_mha_kernel";
+      m.family = hd_ / nh_ == 32 ? "rt_mha32_kernel" : "rt_mha_kernel";
       m.p0 = qkv; m.ld0 = 3 * hd_; m.p1 = attn; m.ld1 = hd_;
       m.T = nq_; m.C = hd_; m.heads = nh_;
       m.flops = 4.0 * nq_ * (double)nq_ * hd_;

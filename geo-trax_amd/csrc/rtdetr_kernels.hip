@@ -102,38 +102,43 @@ __global__ __launch_bounds__(256) void rt_stem1_kernel(const uchar4* __restrict_
     s_lut[threadIdx.x] = f;
   }
   __syncthreads();
-  const int groups = out.c / 8, c0 = out.c;
-  const size_t total = (size_t)N * out.h * out.w * groups;
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int g = (int)(t % groups);
-  const size_t pix = t / groups;
+  // One thread per output pixel, every channel: the weight addresses are then the same for the whole wave (scalar loads, the
+  // multiplier straight from a scalar register). With a channel group per thread they were 81 x 8 vector loads per thread and the
+  // kernel ran at 1 TB/s of stores; the nine image words and their table look-ups are now made once per pixel, too.
+  const int c0 = out.c;
+  const size_t total = (size_t)N * out.h * out.w;
+  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
   const int ox = (int)(pix % out.w), oy = (int)((pix / out.w) % out.h), n = (int)(pix / ((size_t)out.w * out.h));
-  float acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
   const uchar4* base = img + (size_t)n * H * W;
+  float px[27];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * 2 - 1 + ky;
-    if (iy < 0 || iy >= H) continue;
+  for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * 2 - 1 + kx;
-      if (ix < 0 || ix >= W) continue;
-      const uchar4 u = base[(size_t)iy * W + ix];
-      const float px[3] = {s_lut[u.x], s_lut[u.y], s_lut[u.z]};
-      const float* wt = w27 + (size_t)(ky * 3 + kx) * 3 * c0 + g * 8;
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(px[ci], wt[ci * c0 + j], acc[j]);
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const uchar4 u = in ? base[(size_t)iy * W + ix] : make_uchar4(0, 0, 0, 0);
+      px[(ky * 3 + kx) * 3 + 0] = in ? s_lut[u.x] : 0.f;      // zero padding is zero AFTER the division (0 / 255 = 0 anyway)
+      px[(ky * 3 + kx) * 3 + 1] = in ? s_lut[u.y] : 0.f;
+      px[(ky * 3 + kx) * 3 + 2] = in ? s_lut[u.z] : 0.f;
     }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
   bool s = false;
-  store8<FMT>(out.ptr, pix * out.cstride + out.coff + g * 8, acc, s);
+  for (int h16 = 0; h16 < c0 / 16; ++h16) {
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[h16 * 16 + j];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float* wt = w27 + (size_t)k * c0 + h16 * 16;       // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(px[k], wt[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    store8<FMT>(out.ptr, pix * out.cstride + out.coff + h16 * 16, acc, s);
+    store8<FMT>(out.ptr, pix * out.cstride + out.coff + h16 * 16 + 8, acc + 8, s);
+  }
   flag_sat(sat, s);
 }
 
@@ -539,6 +544,97 @@ __global__ __launch_bounds__(256) void rt_mha_kernel(const float* __restrict__ q
   }
 }
 
+// Head dimension 32 (RT-DETR's 256 / 8) on the fp32 matrix pipe. A wave owns 16 queries and walks the keys 16 at a time:
+//   S^T[key][query]  = sum_dim K[key][dim] Q[query][dim]         8 x v_mfma_f32_16x16x4_f32 (A = K rows from LDS, B = the wave's Q fragment)
+//   O^T[dim][query] += sum_key V[key][dim] P^T[key][query]       8 x (two 16-dim tiles x four key groups)
+// S^T comes out with the query on the lane's column and four keys (4 kk + r) in its registers -- exactly the B operand of the second
+// product when MFMA r sums the key set {4 kk + r}: the probabilities never move between lanes (the order inside a sum is free), only the
+// running maximum and denominator of a query are reduced over its four lanes (two shuffles each). The four waves of a workgroup share
+// the K / V tiles (64 keys per stage) through LDS.
+__global__ __launch_bounds__(256) void rt_mha32_kernel(const float* __restrict__ qkv, int ld, int T, int C, float* __restrict__ out, int ldo) {
+  constexpr int D = 32, KS = 64, PITCH = 36;
+  __shared__ float s_k[KS * PITCH];
+  __shared__ float s_v[KS * PITCH];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane & 15, kk = lane >> 4;
+  const int head = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const float* base = qkv + (size_t)n * T * ld + head * D;
+  const float scale = 1.f / sqrtf((float)D);
+  float qf[8];                                     // B operand of the first product: Q[query lc][4 i + kk], scaled
+  {
+    const int qi = q0 + lc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] = qi < T ? base[(size_t)qi * ld + 4 * i + kk] * scale : 0.f;
+  }
+  floatx4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};   // O^T[dim 4 kk + r (+16)][query lc]
+  float m = -FLT_MAX, l = 0.f;
+  // stage s + 1's K / V rows are loaded into registers while stage s is multiplied (two float4 of each per thread): without it
+  // every stage began with an exposed global round trip (57 of them for AIFI's 3 600 keys)
+  constexpr int NLD = KS * (D / 4) / 256;          // 2
+  float4 pk[NLD], pv[NLD];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = threadIdx.x + 256 * j, kr = i / (D / 4), d4 = (i % (D / 4)) * 4;
+      pk[j] = pv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + kr < T) {
+        const float* row = base + (size_t)(k0 + kr) * ld + d4;
+        pk[j] = *reinterpret_cast<const float4*>(row + C);
+        pv[j] = *reinterpret_cast<const float4*>(row + 2 * C);
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < T; k0 += KS) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = threadIdx.x + 256 * j, kr = i / (D / 4), d4 = (i % (D / 4)) * 4;
+      *reinterpret_cast<float4*>(&s_k[kr * PITCH + d4]) = pk[j];
+      *reinterpret_cast<float4*>(&s_v[kr * PITCH + d4]) = pv[j];
+    }
+    if (k0 + KS < T) fetch(k0 + KS);
+    __syncthreads();
+    const int nk = min(KS, T - k0);
+    for (int t0 = 0; t0 < nk; t0 += 16) {
+      floatx4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_k[(t0 + lc) * PITCH + 4 * i + kk], qf[i], sc, 0, 0, 0);
+      float mx = -FLT_MAX;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (t0 + 4 * kk + r >= nk) sc[r] = -FLT_MAX;          // keys past the end
+        mx = fmaxf(mx, sc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m, mx), resc = __expf(m - mn);
+      float p[4], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = sc[r] > -FLT_MAX ? __expf(sc[r] - mn) : 0.f; ps += p[r]; }
+      ps += __shfl_xor(ps, 16);
+      ps += __shfl_xor(ps, 32);
+      l = l * resc + ps;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o0[r] *= resc; o1[r] *= resc; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vr = &s_v[(t0 + 4 * kk + r) * PITCH];
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[lc], p[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[16 + lc], p[r], o1, 0, 0, 0);
+      }
+    }
+  }
+  const int qi = q0 + lc;
+  if (qi < T) {
+    const float inv = 1.f / l;
+    float* o = out + ((size_t)n * T + qi) * ldo + head * D + 4 * kk;
+    *reinterpret_cast<float4*>(o) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+    *reinterpret_cast<float4*>(o + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+  }
+}
+
 // ============================================================================ query selection (top-k anchors per image)
 __device__ __forceinline__ unsigned sortable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -801,8 +897,8 @@ inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256
 
 // ---------------------------------------------------------------------------- launchers
 void launch_rt_stem1(int fmt, const void* img, int n, int H, int W, const float* w27, const float* bias, const RtMap& out, int* sat, hipStream_t s) {
-  GTX_CHECK(out.c % 8 == 0 && out.h * 2 == H && out.w * 2 == W, "rt_stem1: bad shapes");
-  const size_t total = (size_t)n * out.h * out.w * (out.c / 8);
+  GTX_CHECK(out.c % 16 == 0 && out.h * 2 == H && out.w * 2 == W, "rt_stem1: bad shapes");
+  const size_t total = (size_t)n * out.h * out.w;
   RT_FMT(fmt, hipLaunchKernelGGL(rt_stem1_kernel<F>, dim3(blocks_for(total)), dim3(256), 0, s, (const uchar4*)img, n, H, W, w27, bias, out, sat));
 }
 
@@ -870,7 +966,9 @@ void launch_rt_mha(const float* qkv, int ld, int n, int T, int C, int heads, flo
   const int d = C / heads;
   GTX_CHECK(C % heads == 0 && ld % 4 == 0 && ldo % 4 == 0, "rt_mha: C=%d heads=%d", C, heads);
   const dim3 grid(cdiv(T, 64), heads, n), block(256);
-  if (d == 32) hipLaunchKernelGGL(rt_mha_kernel<32>, grid, block, 0, s, qkv, ld, T, C, out, ldo);
+  static const bool mfma = [] { const char* e = getenv("GTX_RT_MHA_MFMA"); return !(e && e[0] == '0'); }();
+  if (d == 32 && mfma) hipLaunchKernelGGL(rt_mha32_kernel, grid, block, 0, s, qkv, ld, T, C, out, ldo);
+  else if (d == 32) hipLaunchKernelGGL(rt_mha_kernel<32>, grid, block, 0, s, qkv, ld, T, C, out, ldo);
   else if (d == 16) hipLaunchKernelGGL(rt_mha_kernel<16>, grid, block, 0, s, qkv, ld, T, C, out, ldo);
   else if (d == 8) hipLaunchKernelGGL(rt_mha_kernel<8>, grid, block, 0, s, qkv, ld, T, C, out, ldo);
   else fail(-3, "rt_mha: head dimension %d is not built (8, 16, 32)", d);
