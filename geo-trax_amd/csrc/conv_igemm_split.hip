@@ -689,11 +689,14 @@ void launch_front_t(const ConvGroup& g, hipStream_t stream) {
   constexpr int lds = split_lds_bytes<3, 2, WN, 2, 1, NCH>();
   static_assert(FrontTile::TILES % 4 == 0 && 2 * lds <= 160 * 1024, "front stage: 9 patch tiles per wave, two workgroups per CU");
   auto kern = conv_front_split_kernel<WN, NCH>;
+  // GTX_FRONT_LDS_PAD=bytes: measurement hook (round 6): requests that much LDS on top of what the kernel uses, to price what its
+  // 74 KB footprint costs beside the other detector stream's workgroups (profiles/r06_front_lds.txt)
+  static const int pad = [] { const char* e = getenv("GTX_FRONT_LDS_PAD"); return e ? std::max(0, std::min(atoi(e), 160 * 1024 - lds)) : 0; }();
   static std::once_flag once;
   std::call_once(once, [&] {
-    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds + pad));
   });
-  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), lds + pad, stream, g);
   GTX_HIP(hipGetLastError());
 }
 

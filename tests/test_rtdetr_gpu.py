@@ -175,3 +175,33 @@ def test_rtdetr_through_the_model_object(gtx_ctx, weights, tmp_path):
     save_weights(synthetic_yolov8(seed=0, nc=4), q)
     with pytest.raises(ValueError):
         RTDETR(str(q), ctx=gtx_ctx)
+
+
+def test_rtdetr_saturating_checkpoint_falls_back_to_the_exact_kernels(gtx_ctx, weights, caplog):
+    """A checkpoint whose stem output leaves fp16's range (weights x 3e4: activations ~1e5) cannot be carried in the pair format: the
+    pass that clamps is re-run on the exact-fp32 kernels inside collect() and the detector stays there (Detector's rule, rtdetr.cpp
+    fall_back_to_exact) -- the same boxes, scores and queries as a detector built with fp32_split=False, bit for bit."""
+    import logging
+
+    from geotrax_amd.detector import Detector
+
+    w = dict(weights)
+    w["model.0.stem1.conv.weight"] = (weights["model.0.stem1.conv.weight"] * np.float32(3e4)).astype(np.float32)
+    frame = _frame(0)
+    kw = dict(imgsz=320, conf=0.25, max_det=300, ctx=gtx_ctx)
+    exact = Detector(w, FRAME_HW, fp32_split=False, **kw)
+    want = exact.detect(frame)
+    assert np.abs(exact.layer_output("model.0.stem1.conv")).max() > 65504.0          # the case is what it claims to be
+    det = Detector(w, FRAME_HW, fp32_split=True, **kw)
+    assert not det.fell_back()
+    with caplog.at_level(logging.WARNING, logger="geotrax_amd.detector"):
+        got = det.detect(frame)
+    assert det.saturated() and det.fell_back() and "exact-fp32" in caplog.text
+    assert len(got) == len(want)
+    np.testing.assert_array_equal(got.xyxy, want.xyxy)
+    np.testing.assert_array_equal(got.conf, want.conf)
+    np.testing.assert_array_equal(det.raw_output(), exact.raw_output())
+    again = det.detect(_frame(1))                                                    # ... and stays there
+    np.testing.assert_array_equal(again.conf, exact.detect(_frame(1)).conf)
+    det.close()
+    exact.close()
