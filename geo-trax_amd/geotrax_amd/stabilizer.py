@@ -31,6 +31,10 @@ class Stabilizer:
         if detector_name not in ("orb", "sift", "rsift"):
             raise NotImplementedError(f"detector_name='{detector_name}': 'orb', 'sift' and 'rsift' are implemented (not brisk / kaze / akaze)")
         self._sift = detector_name if detector_name != "orb" else None
+        if self._sift and not unused.get("sift_enable_precise_upscale", False):
+            logger.warning(f"detector_name='{detector_name}': this build's SIFT doubles the base image with OpenCV's precise (half-pixel aligned) "
+                           "upscaling; `sift_enable_precise_upscale: false` (default.yaml:112) is not implemented -- keypoints sit ~0.25 px from where "
+                           "stabilo's default would put them, on both frames alike")
         if self._sift and (filter_type != "ratio" or transformation_type != "projective" or clahe):
             raise NotImplementedError(f"detector_name='{detector_name}' is built with filter_type 'ratio', transformation_type 'projective' and clahe off")
         if matcher_name != "bf":
