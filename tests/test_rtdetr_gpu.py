@@ -205,3 +205,21 @@ def test_rtdetr_saturating_checkpoint_falls_back_to_the_exact_kernels(gtx_ctx, w
     np.testing.assert_array_equal(again.conf, exact.detect(_frame(1)).conf)
     det.close()
     exact.close()
+
+
+def test_rtdetr_other_head_sizes_match_the_oracle(gtx_ctx):
+    """What the tensors and `rtdetr.meta` say instead of the defaults: 80 classes (COCO's head), 100 queries, three decoder layers,
+    max_det below the number of queries that clear conf -- probed layers, queries, boxes, scores and the truncated output."""
+    from geotrax_amd.detector import Detector
+    from geotrax_amd.weights import synthetic_rtdetr
+    from oracle.rtdetr_ref import RtDetrRef, postprocess, stretch
+
+    w = synthetic_rtdetr(seed=11, nc=80, nq=100, ndl=3, score_bias=-0.5)
+    frame = _frame(3)
+    det = Detector(w, FRAME_HW, imgsz=384, conf=0.05, max_det=20, ctx=gtx_ctx)
+    assert det.n_queries == 100 and det.nc == 80
+    ref = RtDetrRef(w)
+    assert (ref.nq, ref.ndl, ref.nc) == (100, 3, 80)
+    got, pred, _ = _check_against_oracle(det, ref, frame, 384, 0.05, None, layers=["model.9", "model.11", "model.27"])
+    assert len(got) == 20 and len(postprocess(pred, frame.shape[:2], 0.05, None, 300)[1]) > 20      # max_det cut the list
+    det.close()
