@@ -1237,7 +1237,7 @@ def main():
                                    "tflops": (d["flops"] / (d["total_ms"] * 1e-3) / 1e12) if d["total_ms"] > 0 else 0.0,
                                    "algo_gbs": (d["bytes"] / (d["total_ms"] * 1e-3) / 1e9) if d["total_ms"] > 0 else 0.0}
                                   for d in fam]
-        if world == 1 and dist is None and args.model == "yolov8s" and not args.half and not args.no_f16_line:
+        if world == 1 and dist is None and not args.half and not args.no_f16_line:
             # secondary key: the same workload with ultralytics.half = true (a legitimate reference knob, not its default). Run as
             # a child process after this one has released the GPU: a second engine inside this process inherits its hardware-queue
             # mapping from the streams created (and not yet destroyed) above and measures ~25 % low.
@@ -1246,7 +1246,7 @@ def main():
             engine.close()
             ctx.synchronize()
             n16 = max(args.steps // 2, 10)
-            cmd = [sys.executable, str(ROOT / "bench.py"), "--half", "1", "--steps", str(n16), "--warmup", str(min(args.warmup, 10)), "--no-cpu-baseline",
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--model", args.model, "--half", "1", "--steps", str(n16), "--warmup", str(min(args.warmup, 10)), "--no-cpu-baseline",
                    "--no-profile", "--workload", args.workload, "--tracker", args.tracker, "--batch", str(B), "--det-streams", str(args.det_streams),
                    "--stab-streams", str(args.stab_streams), "--frames", str(args.frames), "--detections", str(args.detections),
                    "--imgsz", str(args.imgsz), "--rect", str(args.rect)]

@@ -19,10 +19,10 @@ RtDetr::RtDetr(gtx_ctx* ctx, const gtx_det_config& cfg) : ctx_(ctx), cfg_(cfg) {
   GTX_CHECK(cfg.imgsz > 0 && cfg.imgsz % 32 == 0, "imgsz must be a positive multiple of 32 (got %d)", cfg.imgsz);
   GTX_CHECK(cfg.max_det > 0 && cfg.nc > 0 && cfg.nc <= 128, "max_det must be positive and nc in [1, 128] (got %d, %d)", cfg.max_det, cfg.nc);
   GTX_CHECK(cfg.frame_h > 0 && cfg.frame_w > 0, "frame size must be given");
-  GTX_CHECK(!cfg.half, "RT-DETR: half = true (fp16 activations) is not implemented; run with ultralytics.half: false");
   GTX_CHECK(!cfg.obj_feats, "RT-DETR: appearance vectors (obj_feats) are not implemented");
   if (cfg_.max_batch < 1) cfg_.max_batch = 1;
-  fmt_ = cfg.fp32_split ? DT_F32S : DT_F32;
+  // half: fp16 maps and weights on the fp16 MFMA convolutions (fp32 accumulate); the token side (AIFI, the decoder's queries) stays fp32
+  fmt_ = cfg.half ? DT_F16 : (cfg.fp32_split ? DT_F32S : DT_F32);
   // RTDETRPredictor.pre_transform: LetterBox(imgsz, auto=False, scale_fill=True) -- the frame is stretched to the square, no padding
   lb_ = Letterbox{};
   lb_.src_h = cfg.frame_h; lb_.src_w = cfg.frame_w;
@@ -92,7 +92,8 @@ RtDetr::View RtDetr::conv_raw(const std::string& name, const std::vector<float>&
   const int ho = (x.h + 2 * pad - ks) / stride + 1, wo = (x.w + 2 * pad - ks) / stride + 1;
   View out = out_slice ? *out_slice : new_view(ho, wo, cout, plain_out);
   GTX_CHECK(out.h == ho && out.w == wo && out.c == cout, "%s: output view mismatch", name.c_str());
-  GTX_CHECK(!x.plain || fmt_ == DT_F32, "%s: a plain fp32 tensor cannot feed a split convolution", name.c_str());
+  if (fmt_ == DT_F16) out.plain = false;                       // fp16 maps everywhere, the score maps included (rt_topk reads them as such)
+  GTX_CHECK(!x.plain || fmt_ == DT_F32, "%s: a plain fp32 tensor cannot feed this convolution", name.c_str());
   if (fmt_ == DT_F32S)
     GTX_CHECK(x.cstride % 8 == 0 && x.coff % 8 == 0 && out.cstride % 8 == 0 && out.coff % 8 == 0 && (!residual || (residual->cstride % 8 == 0 && residual->coff % 8 == 0)),
               "%s: channel strides / offsets of the split-f16x3 path must be multiples of 8", name.c_str());
@@ -695,7 +696,7 @@ void RtDetr::run_op(const Op& op, int nb, hipStream_t s) {
     case Op::LAYERNORM: launch_rt_layernorm(op.r_in, op.r_out, op.rows * nb, op.C, op.w, op.bias, sat_dev_, s); break;
     case Op::MHA: launch_rt_mha(op.p0, op.ld0, nb, op.T, op.C, op.heads, op.p1, op.ld1, s); break;
     case Op::MASK: launch_rt_mask_invalid(fmt_, op.a, nb, op.level, s); break;
-    case Op::TOPK: launch_rt_topk(op.lv, nc_, nb, nq_, (unsigned*)op.p1, (int*)op.p2, s); break;
+    case Op::TOPK: launch_rt_topk(fmt_ == DT_F16 ? DT_F16 : DT_F32, op.lv, nc_, nb, nq_, (unsigned*)op.p1, (int*)op.p2, s); break;
     case Op::GATHER: launch_rt_gather(fmt_, op.lv, hd_, nb, nq_, (const int*)op.p0, op.p1, op.p2, s); break;
     case Op::REFER: launch_rt_refer(op.p0, op.ld0, op.p1, op.p2, nb * nq_, op.mode, s); break;
     case Op::DEFORM: launch_rt_deform(fmt_, op.lv, hd_, nh_, npts_, op.p0, op.p2, nb, nq_, op.p1, s); break;
@@ -908,13 +909,15 @@ void RtDetr::layer_output(int b, const std::string& layer, float* out, int* h, i
   if (!out) return;
   GTX_CHECK(b >= 0 && b < cfg_.max_batch, "bad batch slot");
   const size_t px = (size_t)v.h * v.w;
-  std::vector<uint8_t> host(px * v.cstride * 4);
-  GTX_HIP(hipMemcpy(host.data(), (const uint8_t*)v.ptr + (size_t)b * px * v.cstride * 4, host.size(), hipMemcpyDeviceToHost));
+  const size_t es = (fmt_ == DT_F16 && !v.plain) ? 2 : 4;
+  std::vector<uint8_t> host(px * v.cstride * es);
+  GTX_HIP(hipMemcpy(host.data(), (const uint8_t*)v.ptr + (size_t)b * px * v.cstride * es, host.size(), hipMemcpyDeviceToHost));
   for (size_t p = 0; p < px; ++p)
     for (int k = 0; k < v.c; ++k) {
       const size_t src = p * v.cstride + v.coff + k;
       float f;
       if (fmt_ == DT_F32S && !v.plain) f = pair_element(host.data(), src);
+      else if (es == 2) { _Float16 hv; memcpy(&hv, host.data() + src * 2, 2); f = (float)hv; }
       else memcpy(&f, host.data() + src * 4, 4);
       out[p * v.c + k] = f;
     }

@@ -650,6 +650,7 @@ __device__ __forceinline__ void level_of(const RtLevels& L, int a, int& lv, int&
 // One workgroup of 1024 threads per image: keys = max class score per anchor; an 8-bit MSB-first radix select finds the nq-th
 // largest key; the strictly larger ones and the first (lowest anchor index) of the equal ones are collected; a bitonic sort
 // orders them (key descending, index ascending).
+template <int FMT>
 __global__ __launch_bounds__(1024) void rt_topk_kernel(RtLevels sc, int nc, int S, int nq, unsigned* __restrict__ keys_all, int* __restrict__ out_idx) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long items[1024];
@@ -660,9 +661,9 @@ __global__ __launch_bounds__(1024) void rt_topk_kernel(RtLevels sc, int nc, int 
   for (int a = tid; a < S; a += 1024) {
     int lv, y, x;
     level_of(sc, a, lv, y, x);
-    const float* row = static_cast<const float*>(sc.ptr[lv]) + (((size_t)n * sc.h[lv] + y) * sc.w[lv] + x) * sc.cstride[lv] + sc.coff[lv];
-    float mx = row[0];
-    for (int c = 1; c < nc; ++c) mx = fmaxf(mx, row[c]);
+    const size_t e = (((size_t)n * sc.h[lv] + y) * sc.w[lv] + x) * sc.cstride[lv] + sc.coff[lv];
+    float mx = load1<FMT>(sc.ptr[lv], e);
+    for (int c = 1; c < nc; ++c) mx = fmaxf(mx, load1<FMT>(sc.ptr[lv], e + c));
     keys[a] = sortable(mx);
   }
   if (tid == 0) { s_prefix = 0; s_need = (unsigned)nq; }
@@ -975,11 +976,12 @@ void launch_rt_mha(const float* qkv, int ld, int n, int T, int C, int heads, flo
   GTX_HIP(hipGetLastError());
 }
 
-void launch_rt_topk(const RtLevels& scores, int nc, int n, int nq, unsigned* keys_scratch, int* out_idx, hipStream_t s) {
+void launch_rt_topk(int fmt, const RtLevels& scores, int nc, int n, int nq, unsigned* keys_scratch, int* out_idx, hipStream_t s) {
   int S = 0;
   for (int l = 0; l < scores.n_levels; ++l) S += scores.h[l] * scores.w[l];
   GTX_CHECK(nq >= 1 && nq <= 1024 && S >= nq, "rt_topk: %d queries of %d anchors", nq, S);
-  hipLaunchKernelGGL(rt_topk_kernel, dim3(n), dim3(1024), 0, s, scores, nc, S, nq, keys_scratch, out_idx);
+  if (fmt == DT_F16) hipLaunchKernelGGL(rt_topk_kernel<DT_F16>, dim3(n), dim3(1024), 0, s, scores, nc, S, nq, keys_scratch, out_idx);
+  else hipLaunchKernelGGL(rt_topk_kernel<DT_F32>, dim3(n), dim3(1024), 0, s, scores, nc, S, nq, keys_scratch, out_idx);   // plain fp32 maps (both fp32-grade paths)
   GTX_HIP(hipGetLastError());
 }
 

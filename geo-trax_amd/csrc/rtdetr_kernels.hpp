@@ -52,13 +52,14 @@ void launch_rt_layernorm(const RtRows& in, const RtRows& out, long rows, int C, 
 void launch_rt_mha(const float* qkv, int ld, int n, int T, int C, int heads, float* out, int ldo, hipStream_t s);
 
 // query selection: per image, the nq anchors with the largest max-over-classes score, descending (ties: lower anchor index
-// first). scores: per level plain fp32 maps [N][h][w][cs] with the classes in channels [0, nc).
+// first). scores: per level maps [N][h][w][cs] with the classes in channels [0, nc): plain fp32 (fmt DT_F32, both fp32-grade
+// paths) or fp16 (fmt DT_F16, `half: true`).
 struct RtLevels {
   const void* ptr[3];
   int h[3], w[3], cstride[3], coff[3];
   int n_levels;
 };
-void launch_rt_topk(const RtLevels& scores, int nc, int n, int nq, unsigned* keys_scratch, int* out_idx, hipStream_t s);
+void launch_rt_topk(int fmt, const RtLevels& scores, int nc, int n, int nq, unsigned* keys_scratch, int* out_idx, hipStream_t s);
 // embed[n][q][:] = enc(level, y, x)[:] of the selected anchors (map format -> plain), anchor logits [N * nq][4]
 void launch_rt_gather(int fmt, const RtLevels& enc, int C, int n, int nq, const int* idx, float* embed, float* anchors, hipStream_t s);
 // reference boxes: mode 0: refer = sigmoid(delta + anchors); mode 1: refer = sigmoid(delta + inverse_sigmoid(refer)).

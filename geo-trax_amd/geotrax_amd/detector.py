@@ -60,8 +60,8 @@ class Detector:
         from .weights import is_rtdetr
 
         self.rtdetr = is_rtdetr(tensors)     # the graph the tensors describe picks the detector family (reference: the model's yaml, extract.py:222-225)
-        if self.rtdetr and (half or obj_feats):
-            raise NotImplementedError("RT-DETR: half=True and obj_feats (ReID `model: auto`) are not implemented")
+        if self.rtdetr and obj_feats:
+            raise NotImplementedError("RT-DETR: obj_feats (ReID `model: auto`) is not implemented")
         nc = int(tensors["model.28.enc_score_head.weight" if self.rtdetr else "model.22.cv3.0.2.weight"].shape[0])
         cfg = DetConfig(imgsz=imgsz, conf=conf, iou=iou, max_det=max_det, agnostic_nms=int(agnostic_nms),
                         half=int(half), rect=int(rect), nc=nc, n_classes=0, max_batch=max_batch,

@@ -239,7 +239,8 @@ typedef struct gtx_det_config {
                      * (128 for YOLOv8s), read at the anchor the box came from */
   int arch;         /* 0: YOLOv8 (Detect head + NMS). 1: RT-DETR (rtdetr-l topology: HGNetv2, AIFI + CCFM, deformable-attention
                      * decoder, no NMS; ultralytics RTDETR, extract.py:222-225). The frame is then stretched to imgsz x imgsz
-                     * (RTDETRPredictor.pre_transform: scale_fill), iou / agnostic_nms / rect are not read, half and obj_feats must be 0;
+                     * (RTDETRPredictor.pre_transform: scale_fill), iou / agnostic_nms / rect are not read, obj_feats must be 0; half = 1: fp16 maps and
+                     * weights on the fp16 MFMA convolutions, the token side (AIFI, the decoder's queries) stays fp32;
                      * gtx_detector_raw_output returns [queries][4 + nc] = xywh normalised to the frame + class scores */
 } gtx_det_config;
 

@@ -223,3 +223,30 @@ def test_rtdetr_other_head_sizes_match_the_oracle(gtx_ctx):
     got, pred, _ = _check_against_oracle(det, ref, frame, 384, 0.05, None, layers=["model.9", "model.11", "model.27"])
     assert len(got) == 20 and len(postprocess(pred, frame.shape[:2], 0.05, None, 300)[1]) > 20      # max_det cut the list
     det.close()
+
+
+def test_rtdetr_half_precision_maps(gtx_ctx, weights):
+    """`ultralytics.half: true` (default.yaml:245) for RT-DETR: fp16 maps and weights on the fp16 MFMA convolutions (fp32 accumulate),
+    the token side stays fp32 -- so this path is MORE exact than a half() model upstream, and it is held against the fp32 oracle at
+    fp16's accumulated rounding (3e-2 of the layer maximum; YOLOv8's half bar). The decoder's input changes with it, so queries are
+    compared as a set: most selected anchors are the fp32 run's."""
+    from geotrax_amd.detector import Detector
+    from oracle.rtdetr_ref import RtDetrRef, stretch
+
+    frame = _frame(0)
+    det = Detector(weights, FRAME_HW, imgsz=640, conf=0.3, max_det=300, half=True, ctx=gtx_ctx)
+    assert det.rtdetr and not det.fp32_split
+    got = det.detect(frame)
+    ref = RtDetrRef(weights)
+    pred = ref.forward(stretch(frame, 640))[0].numpy()
+    for name in ["model.0", "model.1", "model.3", "model.7", "model.9", "model.11", "model.16", "model.21", "model.27"]:
+        a = det.layer_output(name)
+        r = ref.acts[name][0].permute(1, 2, 0).numpy()
+        assert a.shape == r.shape and _rel(a, r) <= 3e-2, (name, _rel(a, r))
+    idx = set(det.layer_output_int("model.28.topk").ravel().tolist())
+    assert len(idx & set(ref.topk[0].numpy().tolist())) >= 240           # of 300
+    raw = det.raw_output()
+    assert raw.shape == pred.shape and np.isfinite(raw).all() and (raw[:, :4] >= 0).all() and (raw[:, :4] <= 1).all()
+    n_ref = int((pred[:, 4:].max(1) > 0.3).sum())
+    assert abs(len(got) - n_ref) <= max(5, n_ref // 4)
+    det.close()
