@@ -37,8 +37,13 @@ class Stabilizer:
                            "stabilo's default would put them, on both frames alike")
         if self._sift and (filter_type != "ratio" or transformation_type != "projective" or clahe):
             raise NotImplementedError(f"detector_name='{detector_name}' is built with filter_type 'ratio', transformation_type 'projective' and clahe off")
-        if matcher_name != "bf":
-            raise NotImplementedError(f"matcher_name='{matcher_name}': only 'bf' (exact brute force) is implemented")
+        if matcher_name == "flann":
+            # FLANN returns APPROXIMATE nearest neighbours (LSH for binary descriptors, kd-trees for SIFT); the GPU matcher is exact
+            # and faster than either here, so the option runs on it: the matches are the ones FLANN approximates, not FLANN's own
+            logger.warning("matcher_name='flann': matched with the exact brute-force kernel (what FLANN approximates); a stabilo run with FLANN "
+                           "may keep slightly different matches")
+        elif matcher_name != "bf":
+            raise NotImplementedError(f"matcher_name='{matcher_name}': 'bf' (exact brute force) and 'flann' (served by the same exact kernel) are implemented")
         if filter_type not in ("ratio", "none"):
             raise NotImplementedError(f"filter_type='{filter_type}': only 'ratio' and 'none' are implemented")
         if transformation_type not in ("projective", "affine"):

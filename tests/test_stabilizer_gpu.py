@@ -240,7 +240,8 @@ def test_sift_detectors_recover_the_ground_truth_homography(gtx_ctx, seq, name):
 
 
 def test_unsupported_stabilizer_choices_raise(gtx_ctx):
-    for kw in (dict(detector_name="brisk"), dict(detector_name="akaze"), dict(matcher_name="flann"), dict(filter_type="distance"),
+    _make(gtx_ctx, matcher_name="flann").close()                      # served by the exact matcher, with a warning
+    for kw in (dict(detector_name="brisk"), dict(detector_name="akaze"), dict(matcher_name="annoy"), dict(filter_type="distance"),
                dict(detector_name="sift", transformation_type="affine")):
         with pytest.raises(NotImplementedError):
             _make(gtx_ctx, **kw)
