@@ -67,6 +67,56 @@ long run_tracker(int type, unsigned seed) {
   }
   return rows;
 }
+
+// Round 6: the trackers with an appearance branch (Deep OC-SORT, TrackTrack; BoT-SORT's is in run_tracker's type 1 when feats are
+// handed in) on the same streams with one seeded vector per detection, a camera warp, and the partial-affine fit of the feature GMC.
+template <class Tracker>
+long run_reid_tracker(int type, unsigned seed) {
+  gtx_tracker_config cfg{};
+  cfg.type = type; cfg.track_high_thresh = 0.3f; cfg.track_low_thresh = 0.1f; cfg.new_track_thresh = 0.3f; cfg.track_buffer = 30;
+  cfg.match_thresh = 0.8f; cfg.fuse_score = 1; cfg.frame_rate = 30; cfg.delta_t = 3; cfg.inertia = 0.2f; cfg.min_hits = 3;
+  cfg.with_reid = 1; cfg.proximity_thresh = 0.3f; cfg.appearance_thresh = 0.5f; cfg.alpha_fixed_emb = 0.9f;
+  cfg.iou_weight = 0.5f; cfg.reid_weight = 0.5f; cfg.conf_weight = 0.1f; cfg.angle_weight = 0.05f; cfg.penalty_p = 0.2f; cfg.penalty_q = 0.4f;
+  cfg.reduce_step = 0.05f; cfg.tai_thr = 0.55f; cfg.min_track_len = 3; cfg.lost_match_thr = 0.9f;
+  Tracker trk(cfg);
+  const int cap = 512, dim = 24;
+  std::vector<float> ob(cap * 4), os(cap);
+  std::vector<int> oi(cap), oc(cap), od(cap);
+  std::mt19937 rng(seed * 7 + 1);
+  std::normal_distribution<float> N(0.f, 1.f);
+  long rows = 0;
+  for (const Frame& f : stream(seed, 80, 300, 1920.f, 1080.f)) {
+    const int n_det = (int)f.conf.size();
+    std::vector<float> feats((size_t)n_det * dim);
+    for (int i = 0; i < n_det; ++i)
+      for (int k = 0; k < dim; ++k) feats[(size_t)i * dim + k] = (float)((f.cls[i] + 1) * ((k % 5) - 2)) + 0.4f * N(rng);
+    const double warp[6] = {1.0, 2e-4, 0.5, -2e-4, 1.0, -0.3};
+    int n = 0;
+    trk.update(n_det, f.xyxy.data(), f.conf.data(), f.cls.data(), warp, cap, &n, ob.data(), oi.data(), os.data(), oc.data(), od.data(),
+               n_det ? feats.data() : nullptr, dim);
+    rows += n;
+  }
+  return rows;
+}
+
+bool run_affine_fit(unsigned seed) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> U(0.f, 1000.f);
+  for (int n : {0, 1, 2, 5, 400}) {
+    std::vector<float> p((size_t)2 * n), q((size_t)2 * n);
+    for (int i = 0; i < n; ++i) {
+      p[2 * i] = U(rng); p[2 * i + 1] = U(rng);
+      q[2 * i] = 1.001f * p[2 * i] - 0.002f * p[2 * i + 1] + 3.f + (i % 4 == 0 ? U(rng) * 0.3f : 0.f);     // a quarter of the pairs are outliers
+      q[2 * i + 1] = 0.002f * p[2 * i] + 1.001f * p[2 * i + 1] - 2.f;
+    }
+    double A[6];
+    int inl = 0;
+    const bool ok = gtx::estimate_affine_partial(p.data(), q.data(), n, seed, A, &inl);
+    if (n >= 5 && (!ok || std::fabs(A[0] - 1.001) > 0.01 || inl < n / 2)) return false;
+    if (n < 2 && ok) return false;
+  }
+  return true;
+}
 }  // namespace
 
 // The result-file writers (table_writer.cpp): several chunks per call so that their own threads hand the file to each other in
@@ -108,11 +158,16 @@ int main(int argc, char** argv) {
   if (threads) {
     std::vector<long> r(6);
     std::vector<std::thread> th;
-    for (int i = 0; i < 6; ++i) th.emplace_back([&r, i] { r[i] = run_tracker(i & 1, 100 + i); });
+    for (int i = 0; i < 6; ++i)
+      th.emplace_back([&r, i] {
+        r[i] = i < 4 ? run_tracker(i & 1, 100 + i) : (i == 4 ? run_reid_tracker<gtx::OcSortTracker>(3, 104) : run_reid_tracker<gtx::TrackTrackTracker>(5, 105));
+      });
     for (auto& t : th) t.join();
     for (long v : r) rows += v;
   } else {
     rows = run_tracker(0, 1) + run_tracker(1, 2);
+    rows += run_reid_tracker<gtx::OcSortTracker>(3, 3) + run_reid_tracker<gtx::TrackTrackTracker>(5, 4);
+    if (!run_affine_fit(5)) { std::fprintf(stderr, "partial-affine fit wrong\n"); return 4; }
     // geometry helpers on edge inputs: zero boxes, a point on the line at infinity, a degenerate matrix
     const double H[9] = {1.01, 0.002, 3.0, -0.001, 0.99, -6.0, 1e-7, -1e-7, 1.0};
     std::vector<float> in = {100, 200, 50, 20, 3800, 2100, 90, 40}, outb(8);
