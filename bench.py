@@ -996,12 +996,20 @@ def main():
         import itertools
 
         src = itertools.islice(host_batches, n_steps) if host_feed is not None else (batch_item(k0 + k) for k in range(n_steps))
+        stamps = [] if os.environ.get("GTX_BENCH_STAMPS") == "1" else None   # experiment: when each frame's result leaves the engine
+        t_run = time.perf_counter()
         for r in engine.run(src):
             n_rows = len(r.xyxy)
+            if stamps is not None:
+                stamps.append(time.perf_counter() - t_run)
             if sharded and extract:
                 records.append(pack_frame_record(max_det, r.xyxy, r.conf, r.cls, r.H, r.gmc, with_gmc=shard_gmc))
                 if live[0]:
                     gather_ready()
+        if stamps:
+            print("result stamps (ms since run()): " + " ".join(f"{1e3 * t:.2f}" for t in stamps) + f" | generator done {1e3 * (time.perf_counter() - t_run):.2f}", file=sys.stderr)
+        if engine.prof and stamps is not None:
+            print("stage marks (ms): " + " ".join(f"{w}{i}@{1e3 * t:.2f}" for w, i, t in sorted(engine.marks, key=lambda m: m[2])), file=sys.stderr)
         if engine.prof:                                          # GTX_ENGINE_PROF=1: where the host stages wait
             print("engine host stages (s): " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(engine.prof.items())), file=sys.stderr)
         return n_rows

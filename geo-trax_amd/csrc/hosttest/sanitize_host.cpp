@@ -19,6 +19,7 @@
 #include "../../../include/gtx.h"
 #include "../geometry.hpp"
 #include "../tracker.hpp"
+#include "../vec_acos.hpp"
 
 namespace {
 struct Frame { std::vector<float> xyxy, conf; std::vector<int> cls; };
@@ -99,6 +100,25 @@ long run_reid_tracker(int type, unsigned seed) {
   return rows;
 }
 
+// vec_acos.hpp against libm over the whole argument range, the range borders and the neighbourhoods of +-1 (where acos is
+// steepest): at most 2 ulp of pi apart, 0 and pi exactly at the ends.
+bool run_acos_check(unsigned seed) {
+  std::mt19937_64 g(seed);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  const int n = 1 << 18;
+  std::vector<double> x(n), y(n);
+  for (int i = 0; i < n; ++i) x[i] = U(g);
+  const double edge[] = {1.0, -1.0, 0.0, -0.0, 0.5, -0.5, 0.49999999999999994, -0.49999999999999994, 1.0 - 1e-16, -1.0 + 1e-16, 1e-300, -1e-300};
+  int k = 0;
+  for (double e : edge) x[k++] = e;
+  for (int i = 0; i < 4000; ++i) { x[k++] = std::cos(i * 1e-9); x[k++] = -std::cos(i * 1e-9); }
+  gtx::acos_block(x.data(), y.data(), n);
+  if (y[0] != 0.0 || y[1] != M_PI) return false;
+  for (int i = 0; i < n; ++i)
+    if (!(std::fabs(y[i] - std::acos(x[i])) <= 9e-16)) { std::fprintf(stderr, "acos_block(%.17g) = %.17g, libm %.17g\n", x[i], y[i], std::acos(x[i])); return false; }
+  return true;
+}
+
 bool run_affine_fit(unsigned seed) {
   std::mt19937 rng(seed);
   std::uniform_real_distribution<float> U(0.f, 1000.f);
@@ -168,6 +188,7 @@ int main(int argc, char** argv) {
     rows = run_tracker(0, 1) + run_tracker(1, 2);
     rows += run_reid_tracker<gtx::OcSortTracker>(3, 3) + run_reid_tracker<gtx::TrackTrackTracker>(5, 4);
     if (!run_affine_fit(5)) { std::fprintf(stderr, "partial-affine fit wrong\n"); return 4; }
+    if (!run_acos_check(6)) { std::fprintf(stderr, "vector acos differs from libm\n"); return 5; }
     // geometry helpers on edge inputs: zero boxes, a point on the line at infinity, a degenerate matrix
     const double H[9] = {1.01, 0.002, 3.0, -0.001, 0.99, -6.0, 1e-7, -1e-7, 1.0};
     std::vector<float> in = {100, 200, 50, 20, 3800, 2100, 90, 40}, outb(8);

@@ -414,6 +414,8 @@ class ExtractEngine:
         # GTX_ENGINE_PROF=1: seconds the host stages spend in their blocking calls, summed over the run (self.prof afterwards)
         self._prof = collections.defaultdict(float) if os.environ.get("GTX_ENGINE_PROF") == "1" else None
         self.prof = self._prof
+        self.marks = [] if self._prof is not None else None     # (what, frame or pass, seconds since run()) of every stage boundary
+        self._t_run = time.perf_counter()
         threaded = (self.tracker is not None or bool(self.stabs)) and os.environ.get("GTX_ENGINE_THREADS", "1") != "0"
         frames = self._tracked_frames_threaded(batches) if threaded else self._tracked_frames(batches)
         return self._stabilized(frames)
@@ -455,6 +457,7 @@ class ExtractEngine:
                 dets = det.collect()
                 if self._prof is not None:
                     self._prof["det_collect"] += time.perf_counter() - t0
+                    self.marks.append(("det", k - len(inflight) - 1, time.perf_counter() - self._t_run))
                 grays = [det.gray_dptr(b) for b in range(nb)]
                 hosts = self._host_frames.pop(id(det), None)
                 det_ms = float(sum(dets[0].speed.values())) / nb if dets else 0.0
@@ -489,9 +492,9 @@ class ExtractEngine:
 
     # ---- stage 2: camera-motion compensation + tracker, strictly in clip order
     def _track_batch(self, det, dets, grays, hosts, det_ms, n_skip=0):
+        # a generator: a frame goes on to the stabilizer stage while the tracker works on the next one of its batch
         for _ in range(n_skip):                                 # warp of the frame that only primed the GMC (identity)
             self._gmc_collect()
-        out = []
         for b, (d, g) in enumerate(zip(dets, grays)):
             ids = None
             xyxy, conf, cls = d.xyxy, d.conf, d.cls
@@ -501,12 +504,12 @@ class ExtractEngine:
                 t_xyxy, t_ids, t_score, t_cls, _ = self.tracker.update(d.xyxy, d.conf, d.cls, gmc=warp, feats=d.feats)
                 if self._prof is not None:
                     self._prof["tracker"] += time.perf_counter() - t0
+                    self.marks.append(("trk", self._index, time.perf_counter() - self._t_run))
                 if len(t_ids):
                     xyxy, conf, cls, ids = t_xyxy, t_score, t_cls, t_ids
             r = FrameResult(self._index, xyxy, conf, cls, ids, xyxy_to_xywh(xyxy), None, None, len(d), det_ms, warp)
             self._index += 1
-            out.append((r, det, g, hosts[b] if hosts is not None else None))
-        return out
+            yield r, det, g, hosts[b] if hosts is not None else None
 
     def _gmc_collect(self):
         warp = self.gmc.collect()
@@ -608,6 +611,7 @@ class ExtractEngine:
             st.collect()
             if prof is not None:
                 prof["stab_collect"] += time.perf_counter() - t0
+                self.marks.append(("stab", r.index, time.perf_counter() - self._t_run))
             r.H = st.get_cur_trans_matrix(raw=True)
             r.stab_ms = st.last_ms()
             last_known(r)
@@ -644,6 +648,7 @@ class ExtractEngine:
                     st.submit_gray_dev(g[0], g[1], g[2], r.xywh)
                     if prof is not None:
                         prof["stab_submit"] += time.perf_counter() - t0
+                        self.marks.append(("sub", r.index, time.perf_counter() - self._t_run))
                         prof["frames"] += 1
                     pending.append((st, r))
                 else:                                               # other downsample ratios: the stabilizer makes its own gray
