@@ -428,6 +428,10 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
       c.variant = 5;
       c.kc = 32;
     }
+    // 1x1 with whole 64-cout tiles and 32-channel chunks: the pointwise v_mfma_f32_16x16x32_f16 form (conv_k32p_split.hip); same weight
+    // image as variant 2, so a caller that needs what only the 32x32x16 kernel has (a second upsampled source, a fused stage) sets
+    // the variant back to 2. GTX_K32P=0: off
+    if (ks == 1 && c.variant == 2 && c.kc == 32 && c.bn == 64 && cout % 64 == 0 && env_int("GTX_K32P", 1) != 0) c.variant = 6;
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -465,7 +469,7 @@ std::vector<uint8_t> pack_conv_weights_wino(const float*, int, int, const ConvCo
 
 std::vector<uint8_t> pack_conv_weights(const float* w, int cout, int cin, const ConvConfig& cfg, float* acc_scale) {
   if (acc_scale) *acc_scale = 1.f;
-  if (cfg.variant >= 2 && cfg.variant <= 5) {
+  if (cfg.variant >= 2 && cfg.variant <= 6) {
     float sc = 1.f;
     std::vector<uint8_t> r = (cfg.variant == 3 || cfg.variant == 4) ? pack_conv_weights_wino(w, cout, cin, cfg, &sc) : pack_conv_weights_split(w, cout, cin, cfg, &sc);
     if (acc_scale) *acc_scale = sc;
@@ -590,6 +594,7 @@ void conv_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream) 
   }
   if (cfg.variant == 3 || cfg.variant == 4) return conv_wino_launch(g, cfg, stream);
   if (cfg.variant == 5) return conv_k32_launch(g, cfg, stream);
+  if (cfg.variant == 6) return conv_k32p_launch(g, cfg, stream);
   if (cfg.variant == 2) return conv_split_launch(g, cfg, stream);
   if (cfg.dtype == DT_F16) launch_dt<_Float16>(g, cfg, stream);
   else launch_dt<float>(g, cfg, stream);
@@ -600,6 +605,7 @@ const char* conv_kernel_name(const ConvConfig& c) {
   if (c.variant == 3) return "conv_wino_split_kernel";
   if (c.variant == 4) return "conv_wino2_split_kernel";
   if (c.variant == 5) return "conv_k32_split_kernel";
+  if (c.variant == 6) return "conv_k32p_split_kernel";
   if (c.variant == 2) {
     snprintf(buf, sizeof buf, "conv_igemm_split_kernel<%d, %d, %d, %d, %d>", c.ks, c.stride, c.bn / 32, c.kc / 8, c.th / 8);
     return buf;

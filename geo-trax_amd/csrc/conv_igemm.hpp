@@ -94,7 +94,7 @@ struct ConvConfig {
   int stride;  // 1 or 2
   int bn;      // cout tile: 32, 64 or 128
   int kc;      // cin elements staged per K chunk
-  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S), 3 / 4 = its Winograd forms (conv_wino_split.hip), 5 = its 16x16x32 form for 3x3 stride 1 (conv_k32_split.hip)
+  int variant; // 0 = register-staged kernel (conv_igemm.hip: fp16, exact fp32), 2 = split-f16x3 (conv_igemm_split.hip, DT_F32S), 3 / 4 = its Winograd forms (conv_wino_split.hip), 5 = its 16x16x32 form for 3x3 stride 1 (conv_k32_split.hip), 6 = its 16x16x32 form for plain 1x1 layers (conv_k32p_split.hip)
   int th, tw;  // output pixel tile (rows x cols)
 };
 
@@ -127,6 +127,9 @@ std::vector<uint8_t> pack_conv_weights_wino(const float* w_ohwi, int cout, int c
 
 // conv_k32_split.hip: the 3x3 stride-1 split-f16x3 convolution on v_mfma_f32_16x16x32_f16 (ConvConfig::variant 5; weights: pack_conv_weights_split, kc = 32)
 void conv_k32_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
+
+// conv_k32p_split.hip: the 1x1 split-f16x3 convolution on v_mfma_f32_16x16x32_f16 (ConvConfig::variant 6; the weight image of variant 2 with kc = 32)
+void conv_k32p_launch(const ConvGroup& g, const ConvConfig& cfg, hipStream_t stream);
 
 // Kernel symbol name as rocprof shows it (for the roofline bookkeeping).
 const char* conv_kernel_name(const ConvConfig& cfg);

@@ -206,6 +206,7 @@ View Detector::conv(const std::string& name, const View& x, int stride, bool act
   p.out_plain = out.plain ? 1 : 0;
   p.sat_flag = conv_dtype_ == DT_F32S ? sat_dev_ : nullptr;
   if (up_src) {
+    if (op.cfg.variant == 6) op.cfg.variant = 2;     // the second source is read by the 32x32x16 kernel only (same weight image)
     GTX_CHECK(ks == 1 && stride == 1 && op.cfg.variant == 2 && up_src->h * 2 == x.h && up_src->w * 2 == x.w && up_src->c < cin,
               "%s: upsampled source does not fit", name.c_str());
     p.in2 = up_src->ptr; p.in2_cstride = up_src->cstride; p.in2_coff = up_src->coff; p.c_split = up_src->c;
@@ -536,7 +537,7 @@ void Detector::fuse_front() {
     if (a.kind != Op::CONV || b.kind != Op::CONV || a.grp.count != 1 || b.grp.count != 1) return;
     const ConvProblem &pa = a.grp.p[0], &pb = b.grp.p[0];
     const bool ok = a.cfg.variant == 2 && a.cfg.ks == 3 && a.cfg.stride == 2 && pa.Cout == a.cfg.bn && !pa.res &&
-                    b.cfg.variant == 2 && b.cfg.ks == 1 && b.cfg.kc == 32 && b.cfg.bn == pb.Cout && pb.Cin == pa.Cout && pb.Cout == pa.Cout &&
+                    (b.cfg.variant == 2 || b.cfg.variant == 6) && b.cfg.ks == 1 && b.cfg.kc == 32 && b.cfg.bn == pb.Cout && pb.Cin == pa.Cout && pb.Cout == pa.Cout &&
                     pb.in == pa.out && pb.in_cstride == pa.out_cstride && pb.in_coff == pa.out_coff && !pb.res && !pb.in2;
     if (!ok) return;
     unfused_ = {a, b};

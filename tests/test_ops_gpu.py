@@ -154,6 +154,44 @@ def test_conv2d_k32_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
     assert np.abs(k32 - y).max() / scale < 2e-6 and np.abs(k32 - direct).max() / scale < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 16, 64, 64, False), (2, 20, 30, 96, 64, True), (1, 60, 60, 32, 128, False), (2, 37, 53, 160, 192, True),
+                                   (1, 16, 32, 704, 256, False), (1, 9, 17, 96, 80, True)])
+def test_conv2d_k32_pointwise_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
+    """The v_mfma_f32_16x16x32_f16 form of the split-f16x3 1x1 convolution (csrc/conv_k32p_split.hip, GTX_K32P=1): two 32-channel
+    chunks per stage -- an odd chunk count (96, 160 channels), a single chunk (32) and RT-DETR's deep concatenations (704) --,
+    partial tiles, several cout tiles, residual and SiLU: the direct kernel's bar against a float64 convolution of the values
+    the pair format holds, and within 2e-6 of the 32x32x16 kernel."""
+    import torch
+    from geotrax_amd import ops
+
+    n, h, w, cin, cout, use_res = shape
+    rng = np.random.default_rng(13)
+    x = (rng.standard_normal((n, h, w, cin)) * np.exp(rng.uniform(-3, 3, (n, h, w, cin)))).astype(np.float32)
+    wt = (rng.standard_normal((cout, 1, 1, cin)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+
+    def pairs(a):
+        hi = a.astype(np.float16).astype(np.float32)
+        return hi.astype(np.float64) + (a - hi).astype(np.float16).astype(np.float64)
+
+    y = torch.nn.functional.conv2d(torch.from_numpy(pairs(x)).permute(0, 3, 1, 2), torch.from_numpy(wt.astype(np.float64)).permute(0, 3, 1, 2),
+                                   torch.from_numpy(b.astype(np.float64)))
+    y = torch.nn.functional.silu(y).permute(0, 2, 3, 1).numpy()
+    if res is not None:
+        y = y + pairs(res)
+    monkeypatch.setenv("GTX_K32P", "0")
+    direct = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
+    monkeypatch.setenv("GTX_K32P", "1")
+    k32 = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
+    scale = np.abs(y).max()
+    if cout % 64 == 0:
+        assert not np.array_equal(k32, direct)        # the other kernel did run (cout % 64 != 0: 32-cout tiles, not eligible)
+    else:
+        np.testing.assert_array_equal(k32, direct)
+    assert np.abs(k32 - y).max() / scale < 2e-6 and np.abs(k32 - direct).max() / scale < 2e-6
+
+
 def test_conv2d_split_slices_residual_and_exact_integers(gtx_ctx):
     from geotrax_amd import ops
     from oracle.yolov8_ref import conv2d_nhwc
