@@ -428,10 +428,14 @@ ConvConfig conv_pick_config(int dtype, int ks, int stride, int cin, int cout, in
       c.variant = 5;
       c.kc = 32;
     }
-    // 1x1 with whole 64-cout tiles and 32-channel chunks: the pointwise v_mfma_f32_16x16x32_f16 form (conv_k32p_split.hip); same weight
+    // 1x1 with whole 64-cout tiles and 32-channel chunks: the pointwise v_mfma_f32_16x16x32_f16 forms (conv_k32p_split.hip) are built
+    // by `make K32P=1`, bit-comparison-tested and OFF: 0.97 x / 0.81 x of the 32x32x16 kernel on RT-DETR's 1x1 layers
+    // (profiles/r06_k32p_probe.txt). GTX_K32P=1: pixels staged in LDS, 2: pixels straight into the operand registers. Same weight
     // image as variant 2, so a caller that needs what only the 32x32x16 kernel has (a second upsampled source, a fused stage) sets
-    // the variant back to 2. GTX_K32P=0: off
-    if (ks == 1 && c.variant == 2 && c.kc == 32 && c.bn == 64 && cout % 64 == 0 && env_int("GTX_K32P", 1) != 0) c.variant = 6;
+    // the variant back to 2.
+#ifdef GTX_WITH_K32P
+    if (ks == 1 && c.variant == 2 && c.kc == 32 && c.bn == 64 && cout % 64 == 0 && env_int("GTX_K32P", 0) != 0) c.variant = 6;
+#endif
     return c;
   }
   const int epc = dtype == DT_F16 ? 8 : 4;
@@ -459,6 +463,11 @@ inline uint16_t f32_to_f16_bits(float f) {
   return b;
 }
 }  // namespace
+
+#ifndef GTX_WITH_K32P
+// conv_k32p_split.hip is not part of this build (closed with numbers, profiles/r06_k32p_probe.txt); conv_pick_config never selects variant 6 here
+void conv_k32p_launch(const ConvGroup&, const ConvConfig&, hipStream_t) { fail(-3, "the pointwise 16x16x32 kernels are not in this build (make -C geo-trax_amd K32P=1)"); }
+#endif
 
 #ifndef GTX_WITH_WINO
 // conv_wino_split.hip is not part of this build (closed with numbers: 1.00-1.04 x of the direct kernel alone, -0.8 % end to end,

@@ -1,4 +1,5 @@
-// 1x1 (pointwise) split-f16x3 convolution on v_mfma_f32_16x16x32_f16 ("K32 pointwise form", ConvConfig::variant 6). gfx950 only.
+// 1x1 (pointwise) split-f16x3 convolution on v_mfma_f32_16x16x32_f16 ("K32 pointwise forms", ConvConfig::variant 6). gfx950 only.
+// EXPERIMENT, closed with numbers: built by `make K32P=1` only, selected with GTX_K32P=1 / 2, never by default.
 //
 // The arithmetic contract, the packed weight image (pack_conv_weights_split, 32-channel chunks, one tap) and the output tile
 // (8 x 16 pixels x 64 couts per 4-wave workgroup, wave w owning tile rows 2w and 2w + 1) are conv_k32_split.hip's; what differs
@@ -6,12 +7,18 @@
 // 256 B of activations (32 KB: every pixel's 256-byte run of the pair format is one coalesced read) beside 2 x 64 couts x 128 B
 // of weights (16 KB) -- 48 KB per workgroup, three per CU -- and 48 MFMAs per wave between two barrier pairs. Fragments are read
 // as in the 3x3 kernel: the weights' (A) one 16-cout block ahead, the second chunk's pixels (B) while the first chunk multiplies.
-// RT-DETR's HGNetv2 is mostly such layers (57 launches of a pass, K up to 3328: 35 % of its time on the 32x32x16 kernel at
-// 198 TFLOP/s); YOLOv8's C2f / SPPF 1x1 layers take it too. Not for launches with a second (upsampled) source or a fused
-// stage: conv_pick_config leaves those on the 32x32x16 kernel (conv_igemm_split.hip), which reads the same weight image.
+// The question it answers: RT-DETR's HGNetv2 is mostly such layers (57 launches of a pass, K up to 3328: 35 % of its time on the
+// 32x32x16 kernel at 200 TFLOP/s, where the 3x3 layers reach 350 on the 16x16x32 instruction) -- is it the instruction shape?
+// It is not (MI355X, 3840x2160 -> 1920^2, batch 2; profiles/r06_k32p_probe.txt): 4.04 ms for the 57 launches with the pixels
+// staged (201 TFLOP/s), 4.86 ms with the pixels loaded straight into the operand registers (two half-used 128-byte lines per
+// lane and instruction), 3.92 ms on the 32x32x16 kernel. A 1x1 layer stages 9 x the bytes per MFMA of a 3x3 layer (no taps to
+// reuse the patch over): per 32-channel chunk a workgroup moves 24 KB through the CU's load path and 72 KB through LDS for 384
+// MFMA cycles per SIMD, whichever instruction issues them. Not for launches with a second (upsampled) source or a fused stage:
+// those stay on the 32x32x16 kernel (conv_igemm_split.hip), which reads the same weight image.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "conv_igemm.hpp"
@@ -41,6 +48,7 @@ struct K32PTile {
   static constexpr int EPI_PITCH = BN * 4 + 16;
   static constexpr int EPI_BYTES = 4 * 32 * EPI_PITCH;
   static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int LDS_DIRECT_BYTES = W_BYTES > EPI_BYTES ? W_BYTES : EPI_BYTES;     // direct form: only the weights are staged
   static __host__ __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 };
 static_assert(3 * K32PTile::LDS_BYTES <= 160 * 1024, "three workgroups per CU");
@@ -62,13 +70,17 @@ __device__ __forceinline__ void split2(const float2v v, unsigned& hi, unsigned& 
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// DIRECT: the pixels' fragments never pass through LDS. A wave's pixels are its own (rows 2w, 2w + 1 of the tile), and lane (col, kg)'s
+// operand of chunk ch is exactly the 32-byte unit 4 ch + kg of pixel (row, col) in the pair format: the four (row, chunk) units a
+// lane needs per stage are prefetched straight into the registers the MFMAs read; only the weights (shared by the four waves) are staged.
+template <bool DIRECT>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 256), amdgpu_waves_per_eu(3)))
 void conv_k32p_split_kernel(const ConvGroup g) {
   using Tile = K32PTile;
   constexpr int RB = Tile::RB, BN = Tile::BN, CPR = Tile::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_patch = smem;
-  char* lds_w = smem + Tile::PATCH_BYTES;
+  char* lds_w = DIRECT ? smem : smem + Tile::PATCH_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,23 +113,30 @@ void conv_k32p_split_kernel(const ConvGroup g) {
   const int nchunks = P.Cin / Tile::KC;
   const int nstages = (nchunks + 1) >> 1;
 
-  // unit qid = tid + 256 s: pixel qid / 8 of the tile, unit qid % 8 of the stage's 64 channels (chunk (qid % 8) / 4)
+  const int col = lane & 15, kg = lane >> 4;
+  const int p0 = (2 * wave) * 16 + col;           // tile pixel of (row 2 wave, column col)
+
+  // staged form: unit qid = tid + 256 s is pixel qid / 8 of the tile, unit qid % 8 of the stage's 64 channels (chunk (qid % 8) / 4).
+  // direct form: slot s = 2 chunk + m is unit 4 chunk + kg of this lane's pixel (row 2 wave + m, column col)
   int goff[Tile::PATCH_SLOTS];                    // element offset of the unit, -1 = zero fill (pixel outside the map)
   int loff[Tile::PATCH_SLOTS];                    // LDS byte offset of the unit's hi chunk; its lo chunk: ^ 64
 #pragma unroll
   for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {
-    const int qid = tid + 256 * s;
-    const int p = qid >> 3, c = qid & 7;
-    const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-    const bool inb = oy < P.H && ox < P.W;
-    goff[s] = inb ? ((n * P.H + oy) * P.W + ox) * P.in_cstride + P.in_coff + c * 8 : -1;
-    loff[s] = (c >> 2) * Tile::PATCH_CHUNK_BYTES + p * RB + (((c & 3) ^ Tile::swz(p)) << 4);
+    if (DIRECT) {
+      const int oy = oy0 + 2 * wave + (s & 1), ox = ox0 + col;
+      goff[s] = (oy < P.H && ox < P.W) ? ((n * P.H + oy) * P.W + ox) * P.in_cstride + P.in_coff + (4 * (s >> 1) + kg) * 8 : -1;
+      loff[s] = 0;
+    } else {
+      const int qid = tid + 256 * s;
+      const int p = qid >> 3, c = qid & 7;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      const bool inb = oy < P.H && ox < P.W;
+      goff[s] = inb ? ((n * P.H + oy) * P.W + ox) * P.in_cstride + P.in_coff + c * 8 : -1;
+      loff[s] = (c >> 2) * Tile::PATCH_CHUNK_BYTES + p * RB + (((c & 3) ^ Tile::swz(p)) << 4);
+    }
   }
   // packed image: [cout tile][chunk][n][8 swizzled 16-byte pieces]: a stage's two chunks are 1024 contiguous uint4
   const uint4* __restrict__ wsrc = reinterpret_cast<const uint4*>(P.wpack) + (size_t)ct * nchunks * Tile::W_CHUNK_U4 + tid;
-
-  const int col = lane & 15, kg = lane >> 4;
-  const int p0 = (2 * wave) * 16 + col;           // tile pixel of (row 2 wave, column col)
 
   uint4 pre_a[Tile::PATCH_SLOTS], pre_b[Tile::PATCH_SLOTS];
   uint4 pw0, pw1, pw2, pw3;
@@ -129,7 +148,7 @@ void conv_k32p_split_kernel(const ConvGroup g) {
     const bool two__ = 2 * (STAGE) + 1 < nchunks;                                            \
     _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
       uint4 va__ = make_uint4(0, 0, 0, 0), vb__ = make_uint4(0, 0, 0, 0);                    \
-      if (goff[s] >= 0 && (two__ || ((tid + 256 * s) & 4) == 0)) {                           \
+      if (goff[s] >= 0 && (two__ || (DIRECT ? s < 2 : ((tid + 256 * s) & 4) == 0))) {        \
         const uint4* src__ = reinterpret_cast<const uint4*>(in + goff[s] + c0__);            \
         va__ = src__[0];                                                                     \
         vb__ = src__[1];                                                                     \
@@ -143,9 +162,11 @@ void conv_k32p_split_kernel(const ConvGroup g) {
   }
 #define GTXP_COMMIT()                                                                        \
   {                                                                                          \
-    _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                          \
-      *reinterpret_cast<uint4*>(lds_patch + loff[s]) = pre_a[s];                             \
-      *reinterpret_cast<uint4*>(lds_patch + (loff[s] ^ (CPR << 4))) = pre_b[s];              \
+    if (!DIRECT) {                                                                           \
+      _Pragma("unroll") for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {                        \
+        *reinterpret_cast<uint4*>(lds_patch + loff[s]) = pre_a[s];                           \
+        *reinterpret_cast<uint4*>(lds_patch + (loff[s] ^ (CPR << 4))) = pre_b[s];            \
+      }                                                                                      \
     }                                                                                        \
     uint4* d__ = reinterpret_cast<uint4*>(lds_w) + tid;                                      \
     d__[0] = pw0; d__[256] = pw1; d__[512] = pw2; d__[768] = pw3;                            \
@@ -191,7 +212,7 @@ void conv_k32p_split_kernel(const ConvGroup g) {
       constexpr int ch__ = (U) / 4, a__ = (U) % 4;                                             \
       __builtin_amdgcn_sched_barrier(0);                                                       \
       if ((U) + 1 < 8) GTXP_LOAD_A(((U) + 1) / 4, ((U) + 1) % 4, ((U) + 1) & 1)                \
-      if (ch__ == 0) GTXP_LOAD_B(1, a__)                                                       \
+      if (!DIRECT && ch__ == 0) GTXP_LOAD_B(1, a__)                                            \
       acc[a__][0] = GTXP_MFMA(al[(U) & 1], bh[ch__][0], acc[a__][0]);                          \
       acc[a__][1] = GTXP_MFMA(al[(U) & 1], bh[ch__][1], acc[a__][1]);                          \
       acc[a__][0] = GTXP_MFMA(ah[(U) & 1], bl[ch__][0], acc[a__][0]);                          \
@@ -210,8 +231,15 @@ void conv_k32p_split_kernel(const ConvGroup g) {
     __syncthreads();                               // the previous stage's fragment reads are done
     GTXP_COMMIT()
     __syncthreads();
+    if (DIRECT) {                                  // this stage's pixels are the registers the previous stage prefetched
+#pragma unroll
+      for (int s = 0; s < Tile::PATCH_SLOTS; ++s) {
+        bh[s >> 1][s & 1] = __builtin_bit_cast(half8, pre_a[s]);
+        bl[s >> 1][s & 1] = __builtin_bit_cast(half8, pre_b[s]);
+      }
+    }
     if (stage + 1 < nstages) GTXP_PREFETCH(stage + 1)
-    GTXP_LOAD_B(0, 0) GTXP_LOAD_B(0, 1) GTXP_LOAD_B(0, 2) GTXP_LOAD_B(0, 3)
+    if (!DIRECT) { GTXP_LOAD_B(0, 0) GTXP_LOAD_B(0, 1) GTXP_LOAD_B(0, 2) GTXP_LOAD_B(0, 3) }
     GTXP_LOAD_A(0, 0, 0)
     GTXP_UNIT(0) GTXP_UNIT(1) GTXP_UNIT(2) GTXP_UNIT(3)
     // an absent second chunk is zeros on both sides: its products add nothing (exact), the loop stays uniform
@@ -294,12 +322,15 @@ void conv_k32p_launch(const ConvGroup& g, const ConvConfig& c, hipStream_t strea
   for (int i = 0; i < g.count; ++i)
     GTX_CHECK(g.p[i].Cin % K32PTile::KC == 0 && g.p[i].post_w == nullptr && g.p[i].front_img == nullptr && g.p[i].c_split == 0,
               "conv (K32 pointwise form): Cin %d must be a multiple of 32 and the launch a plain 1x1 layer", g.p[i].Cin);
-  auto kern = conv_k32p_split_kernel;
+  const char* e = getenv("GTX_K32P");               // 1: the form that stages the pixels in LDS too (A/B; read per launch so that one process can compare)
+  const bool direct = !(e && e[0] == '1');
   static std::once_flag once;
   std::call_once(once, [&] {
-    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, K32PTile::LDS_BYTES));
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_k32p_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, K32PTile::LDS_BYTES));
+    GTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_k32p_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, K32PTile::LDS_DIRECT_BYTES));
   });
-  hipLaunchKernelGGL(kern, dim3(g.grid_blocks), dim3(256), K32PTile::LDS_BYTES, stream, g);
+  if (direct) hipLaunchKernelGGL(conv_k32p_split_kernel<true>, dim3(g.grid_blocks), dim3(256), K32PTile::LDS_DIRECT_BYTES, stream, g);
+  else hipLaunchKernelGGL(conv_k32p_split_kernel<false>, dim3(g.grid_blocks), dim3(256), K32PTile::LDS_BYTES, stream, g);
   GTX_HIP(hipGetLastError());
 }
 

@@ -157,7 +157,8 @@ def test_conv2d_k32_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
 @pytest.mark.parametrize("shape", [(1, 8, 16, 64, 64, False), (2, 20, 30, 96, 64, True), (1, 60, 60, 32, 128, False), (2, 37, 53, 160, 192, True),
                                    (1, 16, 32, 704, 256, False), (1, 9, 17, 96, 80, True)])
 def test_conv2d_k32_pointwise_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, shape):
-    """The v_mfma_f32_16x16x32_f16 form of the split-f16x3 1x1 convolution (csrc/conv_k32p_split.hip, GTX_K32P=1): two 32-channel
+    """The v_mfma_f32_16x16x32_f16 forms of the split-f16x3 1x1 convolution (csrc/conv_k32p_split.hip; `make K32P=1`, GTX_K32P=1 / 2;
+    green on a K32P=1 library on MI355X, skipped on the default one): two 32-channel
     chunks per stage -- an odd chunk count (96, 160 channels), a single chunk (32) and RT-DETR's deep concatenations (704) --,
     partial tiles, several cout tiles, residual and SiLU: the direct kernel's bar against a float64 convolution of the values
     the pair format holds, and within 2e-6 of the 32x32x16 kernel."""
@@ -182,14 +183,19 @@ def test_conv2d_k32_pointwise_split_meets_the_fp32_bar(gtx_ctx, monkeypatch, sha
         y = y + pairs(res)
     monkeypatch.setenv("GTX_K32P", "0")
     direct = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
-    monkeypatch.setenv("GTX_K32P", "1")
-    k32 = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
     scale = np.abs(y).max()
-    if cout % 64 == 0:
-        assert not np.array_equal(k32, direct)        # the other kernel did run (cout % 64 != 0: 32-cout tiles, not eligible)
-    else:
-        np.testing.assert_array_equal(k32, direct)
-    assert np.abs(k32 - y).max() / scale < 2e-6 and np.abs(k32 - direct).max() / scale < 2e-6
+    forms = []
+    for form in ("1", "2"):                           # 1: pixels staged in LDS, 2: pixels straight into the MFMA operand registers
+        monkeypatch.setenv("GTX_K32P", form)
+        k32 = ops.conv2d(x, wt, b, act=True, residual=res, split=True, ctx=gtx_ctx)
+        if cout % 64 == 0:
+            if np.array_equal(k32, direct):           # the default libgtx.so does not carry these kernels (closed with numbers, round 6)
+                pytest.skip("libgtx.so was built without conv_k32p_split.hip (make -C geo-trax_amd clean && make -C geo-trax_amd K32P=1)")
+        else:
+            np.testing.assert_array_equal(k32, direct)
+        assert np.abs(k32 - y).max() / scale < 2e-6 and np.abs(k32 - direct).max() / scale < 2e-6
+        forms.append(k32)
+    np.testing.assert_array_equal(forms[0], forms[1])  # same MFMAs in the same order
 
 
 def test_conv2d_split_slices_residual_and_exact_integers(gtx_ctx):
