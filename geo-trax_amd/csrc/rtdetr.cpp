@@ -252,7 +252,7 @@ float* RtDetr::linear(const std::string& name, const std::vector<float>& w, cons
   op.name = name;
   op.family = "rt_linear_kernel";
   RtLinear& L = op.lin;
-  L.x = x; L.ldx = ldx; L.x2 = x2; L.ldx2 = ldx;
+  L.x = x; L.ldx = ldx; L.x2 = x2; L.ldx2 = ldx; L.x2_cols = np;
   L.w = upload(wp); L.bias = upload(bp);
   L.res = res; L.ldr = ldr;
   L.y = y; L.ldy = ldy;
@@ -592,8 +592,13 @@ void RtDetr::build_graph() {
     const HostTensor &ipw = tensor(lp + ".self_attn.in_proj_weight"), &ipb = tensor(lp + ".self_attn.in_proj_bias");
     GTX_CHECK((int)ipw.shape[0] == 3 * hd_ && (int)ipw.shape[1] == hd_, "%s.self_attn.in_proj shape", lp.c_str());
     float* qkv = new_tokens(nq_, 3 * hd_, "");
-    linear(lp + ".self_attn.in_proj.qk", rows_of(ipw, 0, 2 * hd_), part_of(ipb.data, 0, 2 * hd_), 2 * hd_, hd_, out, hd_, qpos, nq_, 0, nullptr, 0, qkv, 3 * hd_, "");
-    linear(lp + ".self_attn.in_proj.v", rows_of(ipw, 2 * hd_, 3 * hd_), part_of(ipb.data, 2 * hd_, 3 * hd_), hd_, hd_, out, hd_, nullptr, nq_, 0, nullptr, 0, qkv + 2 * hd_, 3 * hd_, "");
+    if ((2 * hd_) % 64 == 0) {                       // q, k from query + query_pos and v from the query alone, one launch
+      linear(lp + ".self_attn.in_proj", ipw.data, ipb.data, 3 * hd_, hd_, out, hd_, qpos, nq_, 0, nullptr, 0, qkv, 3 * hd_, "");
+      ops_.back().lin.x2_cols = 2 * hd_;
+    } else {
+      linear(lp + ".self_attn.in_proj.qk", rows_of(ipw, 0, 2 * hd_), part_of(ipb.data, 0, 2 * hd_), 2 * hd_, hd_, out, hd_, qpos, nq_, 0, nullptr, 0, qkv, 3 * hd_, "");
+      linear(lp + ".self_attn.in_proj.v", rows_of(ipw, 2 * hd_, 3 * hd_), part_of(ipb.data, 2 * hd_, 3 * hd_), hd_, hd_, out, hd_, nullptr, nq_, 0, nullptr, 0, qkv + 2 * hd_, 3 * hd_, "");
+    }
     float* attn = new_tokens(nq_, hd_, "");
     {
       Op m;

@@ -333,74 +333,84 @@ __global__ __launch_bounds__(256) void rt_mask_invalid_kernel(RtMap m, int N, in
 // a lane holds X[row = l & 15][k0 + 4 (l >> 4) .. + 3] and, per column block, W[col = l & 15][the same four k]: MFMA j of the
 // four sums the k set {4 kk + j}, the same in both operands (the order inside a dot product is free). W is read in its own
 // row-major layout (16 bytes per lane, 64 contiguous bytes per column); the X tile goes through LDS once per workgroup.
-constexpr int kLinKC = 128;                       // K values of X staged per step
-constexpr int kLinPitch = kLinKC + 4;             // floats per staged row: rows 4 banks apart
+constexpr int kLinKC = 128;                       // K values per step of a wave's weight fragments
+constexpr int kLinSpan = 512;                     // K values of the X tile staged at a time (one staging round per 512: K <= 512 has one)
+constexpr int kLinPitch = kLinSpan + 4;           // floats per staged row: rows 4 banks apart
+// A workgroup = 16 rows x 64 columns, one 16-column block per wave (600 query rows are 38 row blocks: 64-column workgroups put 152
+// of them on the chip for a 256-wide layer where 128-column ones put 76). The X tile of a span is staged once; inside it a wave
+// streams its weight fragments one 128-value step ahead of the MFMAs that use them, so a step costs its 32 MFMAs (two
+// accumulators: even and odd k groups, summed at the end) and not an L2 round trip -- the FFN's K = 1024 layer was 8 exposed
+// round trips long.
 __global__ __launch_bounds__(256) void rt_linear_kernel(const RtLinear p) {
   __shared__ float xs[16 * kLinPitch];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 128 + wave * 32;
+  const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 64 + wave * 16;
   const int lr = lane & 15, kk = lane >> 4;
-  const bool cb0 = col0 < p.Nout, cb1 = col0 + 16 < p.Nout;      // Nout % 16 == 0: whole column blocks
+  const bool cb = col0 < p.Nout;                                  // Nout % 16 == 0: whole column blocks
+  const float* x2 = (p.x2 && (int)blockIdx.y * 64 < p.x2_cols) ? p.x2 : nullptr;   // the second addend feeds the first x2_cols columns only (x2_cols % 64 == 0)
   floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* w0 = p.w + (size_t)(col0 + lr) * p.K + 4 * kk;
-  const float* w1 = w0 + (size_t)16 * p.K;
-  for (int k0 = 0; k0 < p.K; k0 += kLinKC) {
-    const int kc = min(kLinKC, p.K - k0);                         // a multiple of 16
-    // the chunk's weight fragments first: their L2 round trip runs under the X tile's staging (one exposed latency per chunk
-    // instead of one per 16 values of K)
-    float4 b0[kLinKC / 16], b1[kLinKC / 16];
-#pragma unroll
-    for (int i = 0; i < kLinKC / 16; ++i) {
-      b0[i] = b1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cb0 && 16 * i < kc) b0[i] = *reinterpret_cast<const float4*>(w0 + k0 + 16 * i);
-      if (cb1 && 16 * i < kc) b1[i] = *reinterpret_cast<const float4*>(w1 + k0 + 16 * i);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 16 * (kLinKC / 4); i += 256) {
-      const int r = i / (kLinKC / 4), c4 = (i % (kLinKC / 4)) * 4;
+  float4 bcur[kLinKC / 16], bnext[kLinKC / 16];
+#define RT_LIN_LOAD_W(DST, KABS)                                                             \
+  {                                                                                          \
+    const int kc__ = min(kLinKC, p.K - (KABS));                                              \
+    _Pragma("unroll") for (int i = 0; i < kLinKC / 16; ++i) {                                \
+      DST[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+      if (cb && 16 * i < kc__) DST[i] = *reinterpret_cast<const float4*>(w0 + (KABS) + 16 * i); \
+    }                                                                                        \
+  }
+  for (int kb = 0; kb < p.K; kb += kLinSpan) {
+    const int ks = min(kLinSpan, p.K - kb);                       // a multiple of 16
+    RT_LIN_LOAD_W(bcur, kb)                                       // the span's first fragments: their L2 round trip runs under the staging
+    __syncthreads();                                              // the previous span's reads are done
+    for (int i = threadIdx.x; i < 16 * (kLinSpan / 4); i += 256) {
+      const int r = i / (kLinSpan / 4), c4 = (i % (kLinSpan / 4)) * 4;
+      if (c4 >= ks) continue;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < p.M && c4 < kc) {
-        v = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + r) * p.ldx + k0 + c4);
-        if (p.x2) {
-          const float4 u = *reinterpret_cast<const float4*>(p.x2 + (size_t)(row0 + r) * p.ldx2 + k0 + c4);
+      if (row0 + r < p.M) {
+        v = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + r) * p.ldx + kb + c4);
+        if (x2) {
+          const float4 u = *reinterpret_cast<const float4*>(x2 + (size_t)(row0 + r) * p.ldx2 + kb + c4);
           v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
       }
       *reinterpret_cast<float4*>(&xs[r * kLinPitch + c4]) = v;
     }
     __syncthreads();
-    if (cb0) {
+    for (int k0 = 0; k0 < ks; k0 += kLinKC) {
+      const int kc = min(kLinKC, ks - k0);
+      if (k0 + kLinKC < ks) RT_LIN_LOAD_W(bnext, kb + k0 + kLinKC)
+      if (cb) {
 #pragma unroll
-      for (int i = 0; i < kLinKC / 16; ++i) {
-        if (16 * i >= kc) break;
-        const float4 a = *reinterpret_cast<const float4*>(&xs[lr * kLinPitch + 16 * i + 4 * kk]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[i].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[i].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[i].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[i].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[i].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[i].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[i].w, acc1, 0, 0, 0);
+        for (int i = 0; i < kLinKC / 16; ++i) {
+          if (16 * i >= kc) break;
+          const float4 a = *reinterpret_cast<const float4*>(&xs[lr * kLinPitch + k0 + 16 * i + 4 * kk]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bcur[i].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bcur[i].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bcur[i].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bcur[i].w, acc1, 0, 0, 0);
+        }
+      }
+      if (k0 + kLinKC < ks) {
+#pragma unroll
+        for (int i = 0; i < kLinKC / 16; ++i) bcur[i] = bnext[i];
       }
     }
   }
+#undef RT_LIN_LOAD_W
   // C: lane l holds rows 4 (l >> 4) + i of column l & 15
+  if (!cb) return;
+  const int col = col0 + lr;
+  const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    if (!(blk ? cb1 : cb0)) continue;
-    const int col = col0 + 16 * blk + lr;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = row0 + 4 * kk + i;
-      if (row >= p.M) continue;
-      float v = (blk ? acc1[i] : acc0[i]) + bv;
-      if (p.act == 2) v = fmaxf(v, 0.f);
-      else if (p.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU(): exact erf form
-      if (p.res) v += p.res[(size_t)row * p.ldr + col];
-      p.y[(size_t)row * p.ldy + col] = v;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + 4 * kk + i;
+    if (row >= p.M) continue;
+    float v = (acc0[i] + acc1[i]) + bv;
+    if (p.act == 2) v = fmaxf(v, 0.f);
+    else if (p.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU(): exact erf form
+    if (p.res) v += p.res[(size_t)row * p.ldr + col];
+    p.y[(size_t)row * p.ldy + col] = v;
   }
 }
 
@@ -945,7 +955,8 @@ void launch_rt_mask_invalid(int fmt, const RtMap& m, int n, int level, hipStream
 
 void launch_rt_linear(const RtLinear& p, hipStream_t s) {
   GTX_CHECK(p.K % 16 == 0 && p.Nout % 16 == 0 && p.M > 0 && p.ldx % 4 == 0 && (!p.x2 || p.ldx2 % 4 == 0), "rt_linear: K=%d Nout=%d M=%d", p.K, p.Nout, p.M);
-  hipLaunchKernelGGL(rt_linear_kernel, dim3(cdiv(p.M, 16), cdiv(p.Nout, 128)), dim3(256), 0, s, p);
+  GTX_CHECK(!p.x2 || p.x2_cols % 64 == 0 || p.x2_cols >= p.Nout, "rt_linear: the second addend feeds %d columns (a multiple of 64, or all %d)", p.x2_cols, p.Nout);
+  hipLaunchKernelGGL(rt_linear_kernel, dim3(cdiv(p.M, 16), cdiv(p.Nout, 64)), dim3(256), 0, s, p);
   GTX_HIP(hipGetLastError());
 }
 

@@ -33,10 +33,11 @@ void launch_rt_tokens_in(int fmt, const RtMap& in, int n, const float* pos, floa
 // zero the rows of anchors outside (eps, 1 - eps) (RTDETRDecoder._generate_anchors' valid_mask) of a level's map
 void launch_rt_mask_invalid(int fmt, const RtMap& m, int n, int level, hipStream_t s);
 
-// Y[M][ldy] (+coly) = act(X[M][K] (+ X2) . W[Nout][K]^T + bias) (+ R); K % 16 == 0, Nout % 16 == 0. act: 0 none, 2 ReLU, 3 GELU (erf)
+// Y[M][ldy] (+coly) = act(X[M][K] (+ X2 for the first x2_cols columns) . W[Nout][K]^T + bias) (+ R); K % 16 == 0, Nout % 16 == 0. act: 0 none, 2 ReLU, 3 GELU (erf)
 struct RtLinear {
   const float* x; int ldx;
-  const float* x2; int ldx2;      // optional second addend of the input rows (query + query_pos)
+  const float* x2; int ldx2;      // optional second addend of the input rows (query + query_pos) ...
+  int x2_cols;                    // ... for the output columns [0, x2_cols) only: q and k of an in_proj take query + pos, v the query alone
   const float* w; const float* bias;
   const float* res; int ldr;      // optional residual added after the activation
   float* y; int ldy;
