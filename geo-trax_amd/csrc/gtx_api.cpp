@@ -15,6 +15,7 @@
 #include "detector.hpp"
 #include "rtdetr.hpp"
 #include "geometry.hpp"
+#include "ecc.hpp"
 #include "gmc.hpp"
 #include "match_l2.hpp"
 #include "register.hpp"
@@ -409,6 +410,42 @@ int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]) {
 }
 int gtx_gmc_points(gtx_gmc* g, int which, int cap, int* n, float* xy, int* status) {
   return guarded([&] { need(g, "gmc"); need(n, "n"); g->impl->debug_points(which, cap, n, xy, status); });
+}
+
+struct gtx_ecc {
+  gtx_ctx* ctx;
+  std::unique_ptr<gtx::Ecc> impl;
+};
+
+int gtx_ecc_create(gtx_ctx* ctx, int frame_h, int frame_w, int max_iters, double eps, gtx_ecc** out) {
+  return guarded([&] {
+    need(ctx, "ctx"); need(out, "out");
+    GTX_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<gtx_ecc> e(new gtx_ecc);
+    e->ctx = ctx;
+    e->impl.reset(new gtx::Ecc(ctx->device, ctx->stream, frame_h, frame_w, max_iters, eps));
+    *out = e.release();
+  });
+}
+void gtx_ecc_destroy(gtx_ecc* e) { delete e; }
+int gtx_ecc_reset(gtx_ecc* e) {
+  return guarded([&] { need(e, "ecc"); e->impl->reset(); });
+}
+int gtx_ecc_submit(gtx_ecc* e, const uint8_t* frame_bgr, int h, int w) {
+  return guarded([&] { need(e, "ecc"); need(frame_bgr, "frame"); e->impl->submit_frame(frame_bgr, h, w); });
+}
+int gtx_ecc_submit_dev(gtx_ecc* e, gtx_ctx* producer, const void* frame_bgr_dptr, int h, int w) {
+  return guarded([&] {
+    need(e, "ecc"); need(frame_bgr_dptr, "frame");
+    if (producer && producer->device != e->ctx->device) gtx::fail(-1, "gtx_ecc_submit_dev: the producer's context is on another device");
+    e->impl->submit_frame_dev(frame_bgr_dptr, h, w, producer ? producer->stream : e->ctx->stream);
+  });
+}
+int gtx_ecc_collect(gtx_ecc* e, double A[6], int info[2], double* rho) {
+  return guarded([&] { need(e, "ecc"); need(A, "A"); e->impl->collect(A, info, rho); });
+}
+int gtx_ecc_image(gtx_ecc* e, int which, float* out) {
+  return guarded([&] { need(e, "ecc"); need(out, "out"); e->impl->debug_image(which, out); });
 }
 
 struct gtx_sift {

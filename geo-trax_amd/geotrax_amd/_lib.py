@@ -77,7 +77,7 @@ class StabConfig(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against
 # include/gtx.h.
-ABI_VERSION = 9        # GTX_ABI_VERSION of include/gtx.h
+ABI_VERSION = 10       # GTX_ABI_VERSION of include/gtx.h
 _P = C.c_void_p
 _SIGNATURES = {
     "gtx_abi_version": (C.c_int, []),
@@ -112,6 +112,13 @@ _SIGNATURES = {
     "gtx_gmc_submit_frame_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "gtx_gmc_collect": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
     "gtx_gmc_points": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P]),
+    "gtx_ecc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(_P)]),
+    "gtx_ecc_destroy": (None, [_P]),
+    "gtx_ecc_reset": (C.c_int, [_P]),
+    "gtx_ecc_submit": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gtx_ecc_submit_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "gtx_ecc_collect": (C.c_int, [_P, _P, _P, C.POINTER(C.c_double)]),
+    "gtx_ecc_image": (C.c_int, [_P, C.c_int, _P]),
     "gtx_register_images": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P, _P]),
     "gtx_sift_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "gtx_sift_destroy": (None, [_P]),

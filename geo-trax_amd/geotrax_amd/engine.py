@@ -294,7 +294,7 @@ class ExtractEngine:
         while len(self.stabs) < n_stab:
             self.stabs.append(Stabilizer(self.frame_hw, ctx=take("s"), **stab_kw))
         self.feeder_ctx = take("f") if feeder_stream else None   # the context a read-ahead feeder's transfers run on
-        if gmc:                          # True / "sparseOptFlow": the GPU Lucas-Kanade GMC; "orb" / "sift": the feature-based ones (gmc.FeatureGMC)
+        if gmc:                          # True / "sparseOptFlow": the GPU Lucas-Kanade GMC; "orb" / "sift": the feature-based ones (gmc.FeatureGMC); "ecc": gmc.EccGMC
             from .gmc import make_gmc
 
             self.gmc = make_gmc(self.frame_hw, method=gmc if isinstance(gmc, str) else "sparseOptFlow", ctx=take("g"))
@@ -361,6 +361,7 @@ class ExtractEngine:
     def _submit(self, det: Detector, batch) -> int:
         if isinstance(batch, (int, np.integer)):                # device pointer to B contiguous frames
             det.submit_dev(int(batch), self.B)
+            self._gmc_frames(det, int(batch), self.B)
             return self.B
         from .feeder import DeviceBatch
         from .frames import Yuv420Frame
@@ -372,6 +373,7 @@ class ExtractEngine:
                 raise ValueError("device batches need the stabilizer to work on the detector's gray image (downsample_ratio 0.5)")
             batch.wait_on(det.ctx)
             det.submit_dev(batch.ptr, batch.n)
+            self._gmc_frames(det, batch.ptr, batch.n)
             return batch.n
 
         frames = [f if isinstance(f, Yuv420Frame) else np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
@@ -394,9 +396,21 @@ class ExtractEngine:
             else:
                 det.ctx.dev_upload(self._stage[key] + i * nbytes, f)
         det.submit_dev(self._stage[key], len(frames))
+        self._gmc_frames(det, self._stage[key], len(frames))
         if self.stabs and not self.use_dev_gray:
             self._host_frames[key] = [f.bgr() if isinstance(f, Yuv420Frame) else f for f in frames]
         return len(frames)
+
+    def _gmc_frames(self, det: Detector, ptr: int, n: int) -> None:
+        """A GMC that works on the BGR frames (gmc_method ecc) gets every frame of a batch here, when the batch goes to its
+        detector: the frame's image is prepared on the detector's stream, behind whatever brought the frame into HBM and ahead
+        of whatever reuses its buffer. Submission order = clip order (batches go to the detectors in clip order)."""
+        if self.gmc is None or not getattr(self.gmc, "wants_frames", False):
+            return
+        nbytes = self.frame_hw[0] * self.frame_hw[1] * 3
+        for i in range(n):
+            self.gmc.submit_frame_dev(ptr + i * nbytes, self.frame_hw[0], self.frame_hw[1], producer=det.ctx)
+            self._gmc_sub += 1
 
     def run(self, batches, paced: bool | None = None):
         """paced: the source is a live stream (see PacedSource); None = what the source declares (`batches.paced`, default False).
@@ -465,7 +479,10 @@ class ExtractEngine:
                 if not late:
                     fill()                                      # keep the detectors busy while the host works on the batch
                 n_skip = 0
-                if self.gmc is not None:                        # the batch queues on the GMC stream now, results in order
+                if self.gmc is not None and getattr(self.gmc, "wants_frames", False):
+                    if prev is not None:
+                        raise NotImplementedError("gmc_method ecc registers every frame against the first frame of the clip: not available to a frame-sharded run")
+                elif self.gmc is not None:                      # the batch queues on the GMC stream now, results in order
                     restart = prev is not None                  # a shard rank's batch: it does not continue the previous one
                     if restart and prev is not False:           # the frame that precedes the batch in the clip, from HBM
                         self.gmc.submit_frame_dev(int(prev), self.frame_hw[0], self.frame_hw[1], restart=True)
@@ -529,6 +546,8 @@ class ExtractEngine:
         in_flight = (n_batches + 1) * self.B + n_frames + len(self.stabs) + 1
         assert in_flight <= 14 * len(self.dets) * self.B, "engine queues outlive the detector's gray ring"
         assert self.gmc is None or (n_batches + 2) * self.B <= 63, "engine queues outrun the GMC's 64-deep result ring"
+        assert self.gmc is None or not getattr(self.gmc, "wants_frames", False) or (len(self.dets) + n_batches + 1) * self.B <= 31, \
+            "engine queues outrun the ECC GMC's 32-deep frame ring"
         q_det = queue.Queue(maxsize=n_batches)                  # detected batches
         q_trk = queue.Queue(maxsize=n_frames)                   # tracked frames
         stop = threading.Event()

@@ -193,8 +193,9 @@ def track_with_model_sharded(model: YOLO, config: dict, logger: logging.Logger) 
         raise NotImplementedError("the frame-sharded run carries boxes and warps between ranks, not appearance vectors: "
                                   "`with_reid: true` needs the single-process run (one GPU per video)")
     with_gmc = model._gmc_method is not None
-    if model._gmc_method in ('orb', 'sift'):
-        raise NotImplementedError(f"gmc_method '{model._gmc_method}': the frame-sharded run primes every rank's GMC with a frame in HBM, which only 'sparseOptFlow' takes; run unsharded")
+    if model._gmc_method in ('orb', 'sift', 'ecc'):
+        raise NotImplementedError(f"gmc_method '{model._gmc_method}': the frame-sharded run primes every rank's GMC with the frame before its batch, which only 'sparseOptFlow' takes "
+                                  "('ecc' registers every frame against the first frame of the clip); run unsharded")
     max_det = det_kw['max_det']
     state = {}
 

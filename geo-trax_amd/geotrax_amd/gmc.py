@@ -22,7 +22,7 @@ class GMC:
         if method in ("orb", "sift"):
             raise ValueError(f"GMC(method='{method}'): use gmc.make_gmc (FeatureGMC)")
         if method != "sparseOptFlow":
-            raise NotImplementedError(f"gmc_method='{method}': 'sparseOptFlow', 'orb' and 'sift' are implemented ('ecc' is not)")
+            raise ValueError(f"GMC(method='{method}'): use gmc.make_gmc ('sparseOptFlow', 'orb', 'sift' and 'ecc' are implemented)")
         if downscale != 2:
             raise NotImplementedError("only downscale=2 (ultralytics' default) is implemented")
         self.ctx = ctx or _lib.default_context()
@@ -250,8 +250,87 @@ class FeatureGMC:
         return H
 
 
+class EccGMC:
+    """ultralytics GMC(method='ecc', downscale=2) (`gmc_method: ecc`, default.yaml:374,419,467): cv2.findTransformECC with the
+    Euclidean motion model, 5000 iterations / 1e-6, on cvtColor -> GaussianBlur(3x3, 1.5) -> resize(1/2) of the frame
+    (csrc/ecc.hip over gtx_ecc_*; oracle/ecc_ref.py states the procedure and the OpenCV source it follows). Two properties of the
+    upstream method are kept because the reference computes them: every frame is registered against the FIRST frame since
+    reset_params() -- upstream never replaces its `prevFrame` for this method --, and the translation stays in half-resolution
+    pixels. `last` holds {iters, status, rho} of the frame collected last (status 1 / 2: the two conditions under which
+    cv2.findTransformECC raises; upstream catches it and keeps the matrix as the failed call left it, as collect() does).
+
+    The method needs the BGR frame, not the detector's gray image (the blur comes before the reduction): `wants_frames` tells
+    the engine to hand it every frame of a batch when the batch is submitted to a detector, on that detector's stream."""
+
+    wants_frames = True
+
+    def __init__(self, frame_hw: tuple[int, int], method: str = "ecc", downscale: int = 2, seed: int = 0, ctx: _lib.Context | None = None,
+                 max_iters: int = 5000, eps: float = 1e-6):
+        if method != "ecc":
+            raise ValueError(f"EccGMC(method='{method}')")
+        if downscale != 2:
+            raise NotImplementedError("only downscale=2 (ultralytics' default) is implemented")
+        self.ctx = ctx or _lib.default_context()
+        self.frame_hw = (int(frame_hw[0]), int(frame_hw[1]))
+        h = C.c_void_p()
+        check(self.ctx.lib.gtx_ecc_create(self.ctx.handle, self.frame_hw[0], self.frame_hw[1], int(max_iters), float(eps), C.byref(h)))
+        self.handle = h
+        self.method = "ecc"
+        self.valid = False
+        self.stats = np.zeros(3, np.int32)               # {iterations, status, 0}: the slot the other methods fill with point counts
+        self.last = {}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.gtx_ecc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_params(self):
+        check(self.ctx.lib.gtx_ecc_reset(self.handle))
+
+    reset_sequence = reset_params
+
+    def submit_frame_dev(self, frame_dptr: int, h: int, w: int, restart: bool = False, producer: _lib.Context | None = None) -> None:
+        if restart:
+            raise NotImplementedError("gmc_method ecc registers against the first frame of the sequence: a frame-sharded run cannot prime it with another frame")
+        check(self.ctx.lib.gtx_ecc_submit_dev(self.handle, producer.handle if producer is not None else None, C.c_void_p(int(frame_dptr)), int(h), int(w)))
+
+    def submit_gray_dev(self, gray_dptr: int, gh: int, gw: int) -> None:
+        raise NotImplementedError("gmc_method ecc blurs the full-resolution gray image before reducing it: it takes BGR frames (submit_frame_dev / apply)")
+
+    def submit_frame(self, frame: np.ndarray) -> None:
+        f = np.ascontiguousarray(frame, np.uint8)
+        check(self.ctx.lib.gtx_ecc_submit(self.handle, ptr(f), f.shape[0], f.shape[1]))
+
+    def collect(self) -> np.ndarray:
+        A, info, rho = np.zeros(6, np.float64), np.zeros(2, np.int32), C.c_double()
+        check(self.ctx.lib.gtx_ecc_collect(self.handle, ptr(A), ptr(info), C.byref(rho)))
+        self.last = dict(iters=int(info[0]), status=int(info[1]), rho=float(rho.value))
+        self.stats[:2] = info
+        self.valid = info[0] > 0 and info[1] == 0
+        return A.reshape(2, 3)
+
+    def apply(self, raw_frame: np.ndarray, detections=None) -> np.ndarray:
+        """2x3 float64 warp first frame -> this frame in half-resolution pixels (identity for the first frame)."""
+        self.submit_frame(raw_frame)
+        return self.collect()
+
+    def image(self, which: int = 0) -> np.ndarray:
+        out = np.zeros((self.frame_hw[0] // 2, self.frame_hw[1] // 2), np.float32)
+        check(self.ctx.lib.gtx_ecc_image(self.handle, int(which), ptr(out)))
+        return out
+
+
 def make_gmc(frame_hw, method: str = "sparseOptFlow", **kw):
-    """The GMC object of `gmc_method` (default.yaml:374): sparseOptFlow -> GMC, orb / sift -> FeatureGMC; ecc is not implemented."""
+    """The GMC object of `gmc_method` (default.yaml:374): sparseOptFlow -> GMC, orb / sift -> FeatureGMC, ecc -> EccGMC."""
     if method in ("orb", "sift"):
         return FeatureGMC(frame_hw, method=method, **kw)
+    if method == "ecc":
+        return EccGMC(frame_hw, method=method, **kw)
     return GMC(frame_hw, method=method, **kw)

@@ -171,10 +171,10 @@ class YOLO:
             gm = params.get("gmc_method", "none")
             if gm in ("none", None):
                 self._gmc_method = None
-            elif gm in ("sparseOptFlow", "orb", "sift"):
-                self._gmc_method = gm                         # sparseOptFlow: GPU corners + pyramidal LK + RANSAC similarity; orb / sift: gmc.FeatureGMC
+            elif gm in ("sparseOptFlow", "orb", "sift", "ecc"):
+                self._gmc_method = gm                         # sparseOptFlow: GPU corners + pyramidal LK + RANSAC similarity; orb / sift: gmc.FeatureGMC; ecc: gmc.EccGMC
             else:
-                raise NotImplementedError(f"{ttype} gmc_method '{gm}': 'sparseOptFlow', 'orb', 'sift' and 'none' are implemented ('ecc' is not)")
+                raise NotImplementedError(f"{ttype} gmc_method '{gm}': the reference's choices are 'sparseOptFlow', 'orb', 'sift', 'ecc' and 'none'")
         else:
             self._gmc_method = None
         self._gmc = None
@@ -241,7 +241,9 @@ class YOLO:
 
                 self._gmc = make_gmc(frame.shape[:2], method=self._gmc_method, ctx=self.ctx)
             g = self._det.gray_dptr(0) if self._det is not None else (0, 0, 0)
-            if g[0] and (g[1], g[2]) == (frame.shape[0] // 2, frame.shape[1] // 2):
+            if getattr(self._gmc, "wants_frames", False):   # ecc: the blur comes before the reduction, it works on the frame itself
+                warp = self._gmc.apply(frame)
+            elif g[0] and (g[1], g[2]) == (frame.shape[0] // 2, frame.shape[1] // 2):
                 self._gmc.submit_gray_dev(g[0], g[1], g[2])  # the half-resolution gray the detector left in HBM
                 warp = self._gmc.collect()
             else:

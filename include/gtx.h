@@ -48,8 +48,9 @@ extern "C" {
  *    gtx_tracker_config.type 5 (tracktrack) with its parameters appended; gtx_detector_sparse_box and gtx_detector_pad_skip added.
  * 9: gtx_det_config.arch appended: 1 = RT-DETR (the reference swaps YOLO for RTDETR on the model's yaml, extract.py:222-225);
  *    gtx_tracker_config.alpha_fixed_emb appended, with_reid also read by types 3 (deepocsort) and 5 (tracktrack);
- *    gtx_op_estimate_affine_partial added (GMC methods orb / sift). */
-#define GTX_ABI_VERSION 9
+ *    gtx_op_estimate_affine_partial added (GMC methods orb / sift).
+ * 10: gtx_ecc_* added (GMC method ecc). */
+#define GTX_ABI_VERSION 10
 
 typedef enum gtx_status {
   GTX_OK = 0,
@@ -277,7 +278,7 @@ int gtx_detector_submit_dev(gtx_detector* det, const void* frames_dptr, int nb, 
 int gtx_detector_collect(gtx_detector* det, int* n_out, float* xyxy, float* conf, int* cls,
                          float speed_ms[3]);
 /* Device pointer of the half-resolution gray image the preprocess pass wrote for batch slot b of
- * the most recently *collected* batch (the images live in a 16-deep ring: an image stays valid until
+ * the most recently *collected* batch (the images live in a 32-deep ring: an image stays valid until
  * fourteen more batches have been submitted after the one that follows it), or NULL. The stabilizer consumes it so the frame is read from HBM once. */
 const void* gtx_detector_gray(gtx_detector* det, int b, int* gray_h, int* gray_w);
 /* Raw head output of the last forward for parity tests: [anchors][4+nc] fp32 (xywh in network
@@ -511,6 +512,25 @@ int gtx_gmc_collect(gtx_gmc* g, double A[6], int* valid, int stats[3]);
 /* Parity hook: which 0 = corners of the last frame, 1 = corners of the frame before, 2 = where LK put
  * those in the last frame (+ status). xy in half-resolution pixels. */
 int gtx_gmc_points(gtx_gmc* g, int which, int cap, int* n, float* xy, int* status);
+
+/* ------------------------------------------------------------------ camera-motion compensation, method 'ecc'
+ * `gmc_method: ecc` (geotrax/cfg/default.yaml:374,419,467): ultralytics' GMC.apply_ecc, i.e. cv2.findTransformECC(first frame,
+ * current frame, MOTION_EUCLIDEAN, (EPS | COUNT, max_iters = 5000, eps = 1e-6), None, 1) on cvtColor(BGR2GRAY) -> GaussianBlur(3x3, 1.5)
+ * -> resize(1/2). As upstream, every frame is registered against the FIRST frame since the last reset, and A -- row-major 2x3,
+ * float32 values -- is in half-resolution pixels (upstream does not scale the translation back for this method). Identity for
+ * the first frame. info = {iterations run, status: 0 finished, 1 NaN correlation, 2 the correlation was about to be minimised
+ * (both raise cv2.error upstream, which the caller there catches and keeps the matrix as the failed call left it: so does A)}.
+ * _submit_dev prepares the frame's image at once on `producer`'s stream (the context whose stream wrote the frame, e.g. the
+ * detector's; NULL = the object's own) into a 32-deep ring; _collect returns the frames in submission order. */
+typedef struct gtx_ecc gtx_ecc;
+int gtx_ecc_create(gtx_ctx* ctx, int frame_h, int frame_w, int max_iters, double eps, gtx_ecc** out);
+void gtx_ecc_destroy(gtx_ecc* e);
+int gtx_ecc_reset(gtx_ecc* e);
+int gtx_ecc_submit(gtx_ecc* e, const uint8_t* frame_bgr, int h, int w);
+int gtx_ecc_submit_dev(gtx_ecc* e, gtx_ctx* producer, const void* frame_bgr_dptr, int h, int w);
+int gtx_ecc_collect(gtx_ecc* e, double A[6], int info[2], double* rho);
+/* Parity hook: which 0 = the prepared image of the frame collected last, 1 = the template; out [h / 2][w / 2] float32 */
+int gtx_ecc_image(gtx_ecc* e, int which, float* out);
 
 /* ------------------------------------------------------------------ registration (once per video)
  * Replaces estimate_homography() of geotrax/utils/registration.py:21-95 -- stabilo.Stabilizer with

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/gtx.h but not exported by libgtx.so"
     assert declared == set(_lib._SIGNATURES), declared ^ set(_lib._SIGNATURES)
-    assert lib.gtx_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.gtx_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_errors_are_codes_with_messages_not_exceptions():

@@ -73,8 +73,8 @@ def test_state_rules(gtx_ctx, frames):
     assert not g.valid
     g.reset_params()
     np.testing.assert_array_equal(g.apply(fr[1]), np.eye(2, 3))      # first frame again
-    with pytest.raises(NotImplementedError):
-        GMC(HW, method="ecc", ctx=gtx_ctx)                            # orb / sift: gmc.make_gmc -> FeatureGMC (below)
+    with pytest.raises(ValueError):
+        GMC(HW, method="ecc", ctx=gtx_ctx)                            # orb / sift / ecc: gmc.make_gmc -> FeatureGMC / EccGMC (below, tests/test_ecc_gpu.py)
     with pytest.raises(GtxError):
         g.apply(np.zeros((100, 100, 3), np.uint8))                    # wrong frame size
 
@@ -115,7 +115,7 @@ def test_feature_gmc_matches_the_oracle_and_the_camera(gtx_ctx, frames, method):
 
 
 def test_feature_gmc_through_the_model_object(gtx_ctx):
-    """BoT-SORT with `gmc_method: orb`: model.track hands the detector's gray image in HBM to the feature GMC; `ecc` is refused by name."""
+    """BoT-SORT with `gmc_method: orb`: model.track hands the detector's gray image in HBM to the feature GMC; a method outside the reference's list is refused by name."""
     from geotrax_amd.model import YOLO
     from geotrax_amd.synth import make_scene
     from geotrax_amd.weights import synthetic_yolov8
@@ -132,4 +132,4 @@ def test_feature_gmc_through_the_model_object(gtx_ctx):
     assert warps == [False, True, True] and type(m._gmc).__name__ == "FeatureGMC"
     m.detector.close()
     with pytest.raises(NotImplementedError):
-        YOLO(synthetic_yolov8(seed=1, nc=4), ctx=gtx_ctx)._make_tracker(dict(tracker_type="botsort", gmc_method="ecc"))
+        YOLO(synthetic_yolov8(seed=1, nc=4), ctx=gtx_ctx)._make_tracker(dict(tracker_type="botsort", gmc_method="akaze"))
