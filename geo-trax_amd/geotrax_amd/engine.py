@@ -360,8 +360,8 @@ class ExtractEngine:
     # ---- feeding
     def _submit(self, det: Detector, batch) -> int:
         if isinstance(batch, (int, np.integer)):                # device pointer to B contiguous frames
-            det.submit_dev(int(batch), self.B)
             self._gmc_frames(det, int(batch), self.B)
+            det.submit_dev(int(batch), self.B)
             return self.B
         from .feeder import DeviceBatch
         from .frames import Yuv420Frame
@@ -372,8 +372,8 @@ class ExtractEngine:
             if self.stabs and not self.use_dev_gray:
                 raise ValueError("device batches need the stabilizer to work on the detector's gray image (downsample_ratio 0.5)")
             batch.wait_on(det.ctx)
-            det.submit_dev(batch.ptr, batch.n)
             self._gmc_frames(det, batch.ptr, batch.n)
+            det.submit_dev(batch.ptr, batch.n)
             return batch.n
 
         frames = [f if isinstance(f, Yuv420Frame) else np.ascontiguousarray(f, dtype=np.uint8) for f in batch]
@@ -395,16 +395,17 @@ class ExtractEngine:
                                                              C.c_void_p(self._stage[key] + i * nbytes)))
             else:
                 det.ctx.dev_upload(self._stage[key] + i * nbytes, f)
-        det.submit_dev(self._stage[key], len(frames))
         self._gmc_frames(det, self._stage[key], len(frames))
+        det.submit_dev(self._stage[key], len(frames))
         if self.stabs and not self.use_dev_gray:
             self._host_frames[key] = [f.bgr() if isinstance(f, Yuv420Frame) else f for f in frames]
         return len(frames)
 
     def _gmc_frames(self, det: Detector, ptr: int, n: int) -> None:
         """A GMC that works on the BGR frames (gmc_method ecc) gets every frame of a batch here, when the batch goes to its
-        detector: the frame's image is prepared on the detector's stream, behind whatever brought the frame into HBM and ahead
-        of whatever reuses its buffer. Submission order = clip order (batches go to the detectors in clip order)."""
+        detector: the frame's image is prepared on the detector's stream, behind whatever brought the frame into HBM and AHEAD of
+        the detector pass -- collect() of that pass therefore also covers it, and the next batch may overwrite the frame buffer.
+        Submission order = clip order (batches go to the detectors in clip order)."""
         if self.gmc is None or not getattr(self.gmc, "wants_frames", False):
             return
         nbytes = self.frame_hw[0] * self.frame_hw[1] * 3
