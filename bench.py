@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--imgsz", type=int, default=1920)
     ap.add_argument("--tracker", default=None, choices=["bytetrack", "botsort", "ocsort", "deepocsort", "fasttrack", "tracktrack"],
                     help="default: bytetrack at N = 1 (BASELINE configs[2]), botsort at N > 1 (configs[4]; the reference's own default, default.yaml:362)")
+    ap.add_argument("--gmc-method", default="sparseOptFlow", choices=["sparseOptFlow", "orb", "sift", "ecc"],
+                    help="camera-motion compensation of the trackers that take a warp (botsort, deepocsort, tracktrack): the reference's default "
+                         "(default.yaml:374) or one of its other choices (N = 1 only: the frame-sharded run takes sparseOptFlow)")
     ap.add_argument("--batch", type=int, default=2, help="frames per detector pass (= per step)")
     ap.add_argument("--det-streams", type=int, default=2, help="detector instances (own HIP stream and activation buffers each) taking batches round-robin")
     ap.add_argument("--stab-streams", type=int, default=4, help="stabilizer instances (own HIP stream each) working on consecutive frames")
@@ -972,9 +975,12 @@ def main():
     if os.environ.get("GTX_BENCH_NO_STAB") == "1":               # experiment: the extract loop without its stabilizer stage (tracker only)
         stab_kw = None
     shard_gmc = sharded and extract and args.tracker in GMC_TRACKERS
+    if shard_gmc and args.gmc_method != "sparseOptFlow":
+        raise SystemExit(f"bench: --gmc-method {args.gmc_method} runs unsharded only (a shard rank primes its GMC with the frame before its batch, which sparseOptFlow takes)")
     engine = ExtractEngine(weights, (H, W), det_kw, None if (sharded or not extract) else tracker, stab_kw, device=local, batch=B,
                            det_streams=args.det_streams, stab_streams=args.stab_streams,
-                           gmc=extract and args.tracker in GMC_TRACKERS, detectors=[det], feeder_stream=bool(args.host_frames and world == 1))
+                           gmc=(args.gmc_method if extract and args.tracker in GMC_TRACKERS else False), detectors=[det],
+                           feeder_stream=bool(args.host_frames and world == 1))
     n_det_streams, n_stab, gmc = len(engine.dets), len(engine.stabs), engine.gmc
     host_feed = None
     if args.host_frames and world == 1:
@@ -1148,7 +1154,7 @@ def main():
                                                     f"of them are constants of the checkpoint, computed once when the detector is created and left out of the launches afterwards: "
                                                     f"{ps[1]} of {ps[2]} tile rows per image and pass (results bit-identical to computing them every pass; the `every_row_every_pass` "
                                                     f"key is this line without it)") if ps[0] else "every row computed in every pass")(det.pad_skip())),
-                "tracker": args.tracker + (" + sparseOptFlow GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
+                "tracker": args.tracker + (f" + {args.gmc_method} GMC on the GPU" + (" (per shard rank, primed with the frame before each batch)" if shard_gmc else "") if gmc is not None else ""), "stabilo": "orb 2000/4000 features, ratio 0.9, ransac 2 px, downsample 0.5, mask on",
                 "weights": ("seeded synthetic RT-DETR-l (no checkpoint reachable; rtdetr-l.yaml topology, 32 M parameters): the last decoder score head shifted on one frame so that about the golden clip's box count of the 300 queries clears conf"
                             if args.model == "rtdetr-l" else
                             "seeded synthetic YOLOv8s (no checkpoint reachable): class bias calibrated on one frame to the golden clip's box count, only the stride-8 head fires so boxes are vehicle-sized (~100 px in 4K)"),
