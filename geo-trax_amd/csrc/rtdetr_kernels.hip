@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void rt_dwconv_kernel(RtMap in, RtMap out, int
 // takes an 8 x 8 pixel tile x 32 channels, stages the (8 + K - 1)^2 input patch ONCE in LDS as fp32 (the per-thread form read and
 // converted every input pixel K^2 times: 25 small loads per thread made it latency-bound at 0.7 TB/s) and its K^2 x 32 weights,
 // then every thread runs the same K^2 fused multiply-adds in the same order: the results are the per-thread kernel's bit for bit.
+// (A 16 x 16-pixel tile with four pixels of a row per thread -- 26 LDS reads per 160 multiply-adds instead of 80, 1.56 x instead of 2.25 x
+// halo -- was measured at the end of round 6: 0.609 against 0.59-0.60 ms for the 24 launches. Not LDS reads; the staging's round trip per workgroup.)
 template <int FMT, int K>
 __global__ __launch_bounds__(256) void rt_dwconv_tile_kernel(RtMap in, RtMap out, const float* __restrict__ w, const float* __restrict__ bias, int act, int* sat) {
   constexpr int T = 8, P = T + K - 1, R = K / 2;
@@ -660,22 +662,27 @@ __device__ __forceinline__ void level_of(const RtLevels& L, int a, int& lv, int&
 // One workgroup of 1024 threads per image: keys = max class score per anchor; an 8-bit MSB-first radix select finds the nq-th
 // largest key; the strictly larger ones and the first (lowest anchor index) of the equal ones are collected; a bitonic sort
 // orders them (key descending, index ascending).
+// the keys first, one anchor per thread over the whole chip (75 600 anchors per image at 1920^2: one workgroup walking them, 74 dependent
+// round trips per thread, was half of the selection's time: 0.27 -> 0.13 ms)
 template <int FMT>
-__global__ __launch_bounds__(1024) void rt_topk_kernel(RtLevels sc, int nc, int S, int nq, unsigned* __restrict__ keys_all, int* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void rt_topk_keys_kernel(RtLevels sc, int nc, int S, unsigned* __restrict__ keys_all) {
+  const int a = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (a >= S) return;
+  int lv, y, x;
+  level_of(sc, a, lv, y, x);
+  const size_t e = (((size_t)n * sc.h[lv] + y) * sc.w[lv] + x) * sc.cstride[lv] + sc.coff[lv];
+  float mx = load1<FMT>(sc.ptr[lv], e);
+  for (int c = 1; c < nc; ++c) mx = fmaxf(mx, load1<FMT>(sc.ptr[lv], e + c));
+  keys_all[(size_t)n * S + a] = sortable(mx);
+}
+
+__global__ __launch_bounds__(1024) void rt_topk_kernel(int S, int nq, const unsigned* __restrict__ keys_all, int* __restrict__ out_idx) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long items[1024];
   __shared__ unsigned s_prefix, s_need, s_count, s_eq_base;
   __shared__ unsigned wave_cnt[16];
   const int n = blockIdx.x, tid = threadIdx.x;
-  unsigned* keys = keys_all + (size_t)n * S;
-  for (int a = tid; a < S; a += 1024) {
-    int lv, y, x;
-    level_of(sc, a, lv, y, x);
-    const size_t e = (((size_t)n * sc.h[lv] + y) * sc.w[lv] + x) * sc.cstride[lv] + sc.coff[lv];
-    float mx = load1<FMT>(sc.ptr[lv], e);
-    for (int c = 1; c < nc; ++c) mx = fmaxf(mx, load1<FMT>(sc.ptr[lv], e + c));
-    keys[a] = sortable(mx);
-  }
+  const unsigned* keys = keys_all + (size_t)n * S;
   if (tid == 0) { s_prefix = 0; s_need = (unsigned)nq; }
   __syncthreads();
   unsigned mask = 0;
@@ -991,8 +998,9 @@ void launch_rt_topk(int fmt, const RtLevels& scores, int nc, int n, int nq, unsi
   int S = 0;
   for (int l = 0; l < scores.n_levels; ++l) S += scores.h[l] * scores.w[l];
   GTX_CHECK(nq >= 1 && nq <= 1024 && S >= nq, "rt_topk: %d queries of %d anchors", nq, S);
-  if (fmt == DT_F16) hipLaunchKernelGGL(rt_topk_kernel<DT_F16>, dim3(n), dim3(1024), 0, s, scores, nc, S, nq, keys_scratch, out_idx);
-  else hipLaunchKernelGGL(rt_topk_kernel<DT_F32>, dim3(n), dim3(1024), 0, s, scores, nc, S, nq, keys_scratch, out_idx);   // plain fp32 maps (both fp32-grade paths)
+  if (fmt == DT_F16) hipLaunchKernelGGL(rt_topk_keys_kernel<DT_F16>, dim3(cdiv(S, 256), n), dim3(256), 0, s, scores, nc, S, keys_scratch);
+  else hipLaunchKernelGGL(rt_topk_keys_kernel<DT_F32>, dim3(cdiv(S, 256), n), dim3(256), 0, s, scores, nc, S, keys_scratch);   // plain fp32 maps (both fp32-grade paths)
+  hipLaunchKernelGGL(rt_topk_kernel, dim3(n), dim3(1024), 0, s, S, nq, (const unsigned*)keys_scratch, out_idx);
   GTX_HIP(hipGetLastError());
 }
 
