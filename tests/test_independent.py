@@ -125,6 +125,27 @@ def test_oracle_gmc_agrees_with_skimage_similarity(inp, fx, mi):
     assert np.abs(_proj(A, P) - _proj(G, P)).max() < 0.25
 
 
+def _ecc_full(A, P):
+    """An ECC warp (half-resolution pixels, first frame -> frame) applied to full-resolution points: the 2 x 2 reduction puts
+    half-resolution pixel i at full-resolution coordinate 2 i + 0.5."""
+    h = np.vstack([(P[:2] - 0.5) / 2.0, np.ones(P.shape[1])])
+    return 2.0 * (np.asarray(A, np.float64) @ h) + 0.5
+
+
+def test_oracle_ecc_agrees_with_skimage_similarity(inp, fx):
+    """EccRef (cv2.findTransformECC restated: dense, iterative, Euclidean) vs ORB + ransac(SimilarityTransform) (sparse, feature
+    based) for frames 0 -> 1 of the synthetic clip, and both vs the clip's camera: two unrelated estimators of one motion."""
+    from oracle.ecc_ref import EccRef
+
+    e = EccRef(max_iters=300)
+    e.apply(inp["f0"])
+    A = e.apply(inp["f1"])
+    assert e.last["status"] == 0 and e.last["rho"] > 0.9
+    P = _grid(HW)
+    assert np.abs(_ecc_full(A, P) - _proj(fx["orb_S_1"][:2], P)).max() < 0.3
+    assert np.abs(_ecc_full(A, P) - _proj(inp["scene"].camera(1), P)).max() < 0.3
+
+
 def test_oracle_warp_agrees_with_skimage_warp(inp, fx, mi):
     """oracle.warp_ref (OpenCV's 1/32-pixel coordinate quantisation) vs transform.warp(order=1) (exact float coordinates): the
     quantisation moves a value by at most |gradient| / 64, i.e. <= 1 grey level except on the sharpest edges of the crop (2)."""
@@ -230,6 +251,18 @@ def test_gpu_gmc_agrees_with_skimage_similarity(gtx_ctx, inp, fx):
     A = g.apply(inp["f1"])
     P = _grid(HW)
     assert g.valid and np.abs(_proj(A, P) - _proj(fx["orb_S_1"][:2], P)).max() < 0.25
+
+
+@pytest.mark.gpu
+def test_gpu_ecc_agrees_with_skimage_similarity(gtx_ctx, inp, fx):
+    from geotrax_amd.gmc import make_gmc
+
+    g = make_gmc(HW, method="ecc", ctx=gtx_ctx, max_iters=300)
+    g.apply(inp["f0"])
+    A = g.apply(inp["f1"])
+    P = _grid(HW)
+    assert g.valid and np.abs(_ecc_full(A, P) - _proj(fx["orb_S_1"][:2], P)).max() < 0.3
+    g.close()
 
 
 @pytest.mark.gpu
