@@ -267,7 +267,7 @@ struct Ecc::Impl {
   hipEvent_t done_ev;
   std::mutex mu;
   long submitted = 0, collected = 0;
-  bool have_template = false;
+  bool have_template = false, replace_template = false;
   int last_slot = -1;
 
   float* slot(long i) const { return ring.as<float>() + (size_t)(i % kRing) * h2 * w2; }
@@ -302,6 +302,8 @@ void Ecc::reset() {
   S.have_template = false;
   S.last_slot = -1;
 }
+
+void Ecc::set_replace_template(bool on) { impl_->replace_template = on; }
 
 int Ecc::pending() const {
   Impl& S = *impl_;
@@ -382,6 +384,10 @@ void Ecc::collect(double A[6], int info[2], double* rho) {
     for (int k = 0; k < 6; ++k) A[k] = (double)S.h_state->map[k];
     if (info) { info[0] = S.h_state->iter; info[1] = S.h_state->status; }
     if (rho) *rho = S.h_state->rho;
+    if (S.replace_template) {
+      GTX_HIP(hipMemcpyAsync(S.tmpl.p, img, px * 4, hipMemcpyDeviceToDevice, S.stream));
+      GTX_HIP(hipStreamSynchronize(S.stream));     // the slot may be reused by a later submission
+    }
   }
   std::lock_guard<std::mutex> lk(S.mu);
   S.last_slot = (int)(i % kRing);

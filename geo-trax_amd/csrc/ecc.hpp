@@ -14,6 +14,9 @@ class Ecc {
   Ecc(int device, hipStream_t stream, int frame_h, int frame_w, int max_iters, double eps);
   ~Ecc();
   void reset();                                               // forget the template (nothing may be in flight)
+  // false (default): the template stays the first frame of the sequence, as upstream's apply_ecc leaves `prevFrame`; true: every
+  // collected frame becomes the template of the next one (frame-to-frame warps: what the method's name promises)
+  void set_replace_template(bool on);
   // Queue a BGR u8 frame that lives in HBM: its blurred half-resolution image is made NOW, on `producer` (the stream that
   // wrote the frame, e.g. a detector's: the frame buffer may be reused by later work on that stream), into the next slot of a
   // 32-deep ring. collect() returns the frames in submission order. One thread may submit while another collects.

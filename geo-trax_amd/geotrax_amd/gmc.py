@@ -258,6 +258,8 @@ class EccGMC:
     reset_params() -- upstream never replaces its `prevFrame` for this method --, and the translation stays in half-resolution
     pixels. `last` holds {iters, status, rho} of the frame collected last (status 1 / 2: the two conditions under which
     cv2.findTransformECC raises; upstream catches it and keeps the matrix as the failed call left it, as collect() does).
+    `replace_template=True` is NOT upstream's behaviour: every collected frame becomes the template of the next one (frame-to-frame
+    warps, what a tracker's "previous -> current" compensation expects); off unless a caller asks for it.
 
     The method needs the BGR frame, not the detector's gray image (the blur comes before the reduction): `wants_frames` tells
     the engine to hand it every frame of a batch when the batch is submitted to a detector, on that detector's stream."""
@@ -265,7 +267,7 @@ class EccGMC:
     wants_frames = True
 
     def __init__(self, frame_hw: tuple[int, int], method: str = "ecc", downscale: int = 2, seed: int = 0, ctx: _lib.Context | None = None,
-                 max_iters: int = 5000, eps: float = 1e-6):
+                 max_iters: int = 5000, eps: float = 1e-6, replace_template: bool = False):
         if method != "ecc":
             raise ValueError(f"EccGMC(method='{method}')")
         if downscale != 2:
@@ -275,6 +277,8 @@ class EccGMC:
         h = C.c_void_p()
         check(self.ctx.lib.gtx_ecc_create(self.ctx.handle, self.frame_hw[0], self.frame_hw[1], int(max_iters), float(eps), C.byref(h)))
         self.handle = h
+        if replace_template:                             # NOT upstream's behaviour: frame-to-frame warps (each collected frame becomes the next template)
+            check(self.ctx.lib.gtx_ecc_replace_template(h, 1))
         self.method = "ecc"
         self.valid = False
         self.stats = np.zeros(3, np.int32)               # {iterations, status, 0}: the slot the other methods fill with point counts

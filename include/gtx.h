@@ -526,6 +526,8 @@ typedef struct gtx_ecc gtx_ecc;
 int gtx_ecc_create(gtx_ctx* ctx, int frame_h, int frame_w, int max_iters, double eps, gtx_ecc** out);
 void gtx_ecc_destroy(gtx_ecc* e);
 int gtx_ecc_reset(gtx_ecc* e);
+/* replace != 0: every collected frame becomes the template of the next one (frame-to-frame warps). Default 0 = upstream's behaviour. */
+int gtx_ecc_replace_template(gtx_ecc* e, int replace);
 int gtx_ecc_submit(gtx_ecc* e, const uint8_t* frame_bgr, int h, int w);
 int gtx_ecc_submit_dev(gtx_ecc* e, gtx_ctx* producer, const void* frame_bgr_dptr, int h, int w);
 int gtx_ecc_collect(gtx_ecc* e, double A[6], int info[2], double* rho);

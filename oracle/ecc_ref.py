@@ -224,9 +224,10 @@ def find_transform_ecc(template_u8: np.ndarray, image_u8: np.ndarray, M: np.ndar
 class EccRef:
     """GMC(method='ecc', downscale=2).apply(frame_bgr) -> 2x3 float64 (see the module text for the two upstream properties kept)."""
 
-    def __init__(self, max_iters: int = MAX_ITERS, eps: float = EPS):
+    def __init__(self, max_iters: int = MAX_ITERS, eps: float = EPS, replace_template: bool = False):
         self.template = None
         self.max_iters, self.eps = max_iters, eps
+        self.replace_template = replace_template         # True: NOT upstream -- every frame becomes the template of the next one
         self.last = {}
 
     def apply(self, frame_bgr: np.ndarray) -> np.ndarray:
@@ -237,4 +238,6 @@ class EccRef:
             return H.astype(np.float64)
         rho, iters, status = find_transform_ecc(self.template, g, H, self.max_iters, self.eps)
         self.last = dict(rho=rho, iters=iters, status=status)
+        if self.replace_template:
+            self.template = g
         return H.astype(np.float64)

@@ -102,6 +102,12 @@ def test_error_conditions_and_sequence_rules(gtx_ctx):
     want = [g.apply(f) for f in fr]
     for x, y in zip(got, want):
         np.testing.assert_array_equal(x, y)
+    # the switch upstream does not have: frame-to-frame templates
+    g2, o2 = EccGMC(hw, ctx=gtx_ctx, max_iters=100, replace_template=True), EccRef(max_iters=100, replace_template=True)
+    for f in fr:
+        np.testing.assert_allclose(g2.apply(f), o2.apply(f), rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(g2.image(1), g2.image(0))              # the last frame is the template now
+    g2.close()
     g1 = EccGMC(hw, ctx=gtx_ctx, max_iters=3)
     g1.apply(fr[0])
     g1.apply(fr[3])
