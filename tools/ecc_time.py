@@ -1,5 +1,5 @@
 """Time per iteration of the ECC motion compensation (gmc.EccGMC) on a frame pair of the synthetic clip, at two frame sizes and two
-iteration caps: python tools/exp_ecc_time.py (one GPU). DESIGN.md section 3, round 6, quotes it."""
+iteration caps: python tools/ecc_time.py (one GPU). DESIGN.md section 3, round 6, quotes it."""
 import sys, time, numpy as np
 sys.path.insert(0, 'geo-trax_amd')
 from geotrax_amd import _lib
