@@ -27,6 +27,7 @@ constexpr int kBlocks = 512, kThreads = 256, kRing = 32, kItersPerCheck = 6, kSu
 struct EccState {
   float map[6];
   int iter, status, done, max_iters;
+  int exact, pad_;                // 1: source positions in floating point (OpenCV >= 4.11), 0: warpAffine's fixed point (through 4.10)
   double eps, rho, last_rho;
   double n;                       // pixels under the mask
   double img_norm, tmp_norm;
@@ -82,29 +83,38 @@ __global__ __launch_bounds__(256) void ecc_gradient_kernel(const float* __restri
   gy[(size_t)y * w + x] = (-0.5f * ym + 0.f * c) + 0.5f * yp;
 }
 
-// warpAffine(INTER_LINEAR | WARP_INVERSE_MAP) source position of template pixel (x, y): integer pixel + 1/32 fractions, and the
-// INTER_NEAREST pixel the mask uses. m: the map as float64.
-struct Src { int sx, sy, fx, fy, nx, ny; };
-__device__ __forceinline__ Src source_of(const double* m, int x, int y) {
+// warpAffine(INTER_LINEAR | WARP_INVERSE_MAP) source position of template pixel (x, y), in the two forms OpenCV has had
+// (oracle/ecc_ref.py): exact -- the position m0 x + m1 y + m2 in floating point, floor + fraction, p00 + a (p01 - p00) ... --
+// or fixed point: integer pixel + 1/32 fractions, table weights. And the INTER_NEAREST pixel the mask uses (fixed point in both).
+// m: the map as float64.
+struct Src { int sx, sy, nx, ny; float ax, ay; };
+__device__ __forceinline__ Src source_of(const double* m, int x, int y, bool exact) {
   const long long ad = __double2ll_rn(m[0] * (double)x * 1024.0), bd = __double2ll_rn(m[3] * (double)x * 1024.0);
   const long long X0 = __double2ll_rn((m[1] * (double)y + m[2]) * 1024.0), Y0 = __double2ll_rn((m[4] * (double)y + m[5]) * 1024.0);
-  const long long xl = (X0 + 16 + ad) >> 5, yl = (Y0 + 16 + bd) >> 5;
   Src s;
-  s.sx = (int)(xl >> 5); s.sy = (int)(yl >> 5); s.fx = (int)(xl & 31); s.fy = (int)(yl & 31);
   s.nx = (int)((X0 + 512 + ad) >> 10); s.ny = (int)((Y0 + 512 + bd) >> 10);
+  if (exact) {
+    const double fx = (m[0] * (double)x + m[1] * (double)y) + m[2], fy = (m[3] * (double)x + m[4] * (double)y) + m[5];
+    const double ix = floor(fx), iy = floor(fy);
+    s.sx = (int)ix; s.sy = (int)iy; s.ax = (float)(fx - ix); s.ay = (float)(fy - iy);
+  } else {
+    const long long xl = (X0 + 16 + ad) >> 5, yl = (Y0 + 16 + bd) >> 5;
+    s.sx = (int)(xl >> 5); s.sy = (int)(yl >> 5);
+    s.ax = (float)(int)(xl & 31) * (1.f / 32.f); s.ay = (float)(int)(yl & 31) * (1.f / 32.f);
+  }
   return s;
-}
-struct Weights { float w00, w01, w10, w11; };
-__device__ __forceinline__ Weights weights_of(const Src& s) {
-  const float ax = (float)s.fx * (1.f / 32.f), ay = (float)s.fy * (1.f / 32.f);
-  return Weights{(1.f - ay) * (1.f - ax), (1.f - ay) * ax, ay * (1.f - ax), ay * ax};
 }
 __device__ __forceinline__ float fetch0(const float* __restrict__ a, int h, int w, int y, int x) {
   return (y >= 0 && y < h && x >= 0 && x < w) ? a[(size_t)y * w + x] : 0.f;
 }
-__device__ __forceinline__ float sample(const float* __restrict__ a, int h, int w, const Src& s, const Weights& k) {
-  return ((fetch0(a, h, w, s.sy, s.sx) * k.w00 + fetch0(a, h, w, s.sy, s.sx + 1) * k.w01) + fetch0(a, h, w, s.sy + 1, s.sx) * k.w10) +
-         fetch0(a, h, w, s.sy + 1, s.sx + 1) * k.w11;
+__device__ __forceinline__ float sample(const float* __restrict__ a, int h, int w, const Src& s, bool exact) {
+  const float p00 = fetch0(a, h, w, s.sy, s.sx), p01 = fetch0(a, h, w, s.sy, s.sx + 1), p10 = fetch0(a, h, w, s.sy + 1, s.sx), p11 = fetch0(a, h, w, s.sy + 1, s.sx + 1);
+  if (exact) {
+    const float v0 = p00 + s.ax * (p01 - p00), v1 = p10 + s.ax * (p11 - p10);
+    return v0 + s.ay * (v1 - v0);
+  }
+  const float w00 = (1.f - s.ay) * (1.f - s.ax), w01 = (1.f - s.ay) * s.ax, w10 = s.ay * (1.f - s.ax), w11 = s.ay * s.ax;
+  return ((p00 * w00 + p01 * w01) + p10 * w10) + p11 * w11;
 }
 
 template <int N>
@@ -132,12 +142,13 @@ __global__ __launch_bounds__(kThreads) void ecc_stats_kernel(const EccState* __r
 #pragma unroll
   for (int i = 0; i < 6; ++i) m[i] = (double)st->map[i];
   double v[5] = {0, 0, 0, 0, 0};
+  const bool exact = st->exact != 0;
   const int total = h * w;
   for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += kBlocks * kThreads) {
     const int y = idx / w, x = idx - y * w;
-    const Src s = source_of(m, x, y);
+    const Src s = source_of(m, x, y, exact);
     if (!(s.ny >= 0 && s.ny < h && s.nx >= 0 && s.nx < w)) continue;
-    const double a = (double)sample(img, h, w, s, weights_of(s)), t = (double)tmpl[idx];
+    const double a = (double)sample(img, h, w, s, exact), t = (double)tmpl[idx];
     v[0] += 1.0; v[1] += a; v[2] += a * a; v[3] += t; v[4] += t * t;
   }
   block_sums<5>(v, partial + (size_t)blockIdx.x * kSums);
@@ -185,17 +196,17 @@ __global__ __launch_bounds__(kThreads) void ecc_accum_kernel(const EccState* __r
 #pragma unroll
   for (int i = 0; i < 6; ++i) m[i] = (double)st->map[i];
   const float h0 = st->map[0], h1 = st->map[3], img_mean = st->img_mean, tmp_mean = st->tmp_mean;
+  const bool exact = st->exact != 0;
   double v[kSums];
 #pragma unroll
   for (int i = 0; i < kSums; ++i) v[i] = 0.0;
   const int total = h * w;
   for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += kBlocks * kThreads) {
     const int y = idx / w, x = idx - y * w;
-    const Src s = source_of(m, x, y);
-    const Weights k = weights_of(s);
+    const Src s = source_of(m, x, y, exact);
     const bool mask = s.ny >= 0 && s.ny < h && s.nx >= 0 && s.nx < w;
-    float iw = sample(img, h, w, s, k);
-    const float gxw = sample(gx, h, w, s, k), gyw = sample(gy, h, w, s, k);
+    float iw = sample(img, h, w, s, exact);
+    const float gxw = sample(gx, h, w, s, exact), gyw = sample(gy, h, w, s, exact);
     float tz = 0.f;
     if (mask) { iw = iw - img_mean; tz = tmpl[idx] - tmp_mean; }
     const float X = (float)x, Y = (float)y;
@@ -267,7 +278,7 @@ struct Ecc::Impl {
   hipEvent_t done_ev;
   std::mutex mu;
   long submitted = 0, collected = 0;
-  bool have_template = false, replace_template = false;
+  bool have_template = false, replace_template = false, exact = true;
   int last_slot = -1;
 
   float* slot(long i) const { return ring.as<float>() + (size_t)(i % kRing) * h2 * w2; }
@@ -304,6 +315,7 @@ void Ecc::reset() {
 }
 
 void Ecc::set_replace_template(bool on) { impl_->replace_template = on; }
+void Ecc::set_exact_positions(bool on) { impl_->exact = on; }
 
 int Ecc::pending() const {
   Impl& S = *impl_;
@@ -363,7 +375,7 @@ void Ecc::collect(double A[6], int info[2], double* rho) {
     hipLaunchKernelGGL(ecc_gradient_kernel, dim3(cdiv(S.w2, 64), cdiv(S.h2, 4)), dim3(256), 0, S.stream, img, S.h2, S.w2, S.gx.as<float>(), S.gy.as<float>());
     EccState init{};
     init.map[0] = init.map[4] = 1.f;
-    init.max_iters = S.max_iters; init.eps = S.eps; init.rho = -1.0; init.last_rho = -S.eps;
+    init.max_iters = S.max_iters; init.eps = S.eps; init.rho = -1.0; init.last_rho = -S.eps; init.exact = S.exact ? 1 : 0;
     *S.h_state = init;
     GTX_HIP(hipMemcpyAsync(S.state.p, S.h_state, sizeof(EccState), hipMemcpyHostToDevice, S.stream));
     EccState* st = S.state.as<EccState>();

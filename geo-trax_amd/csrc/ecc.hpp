@@ -17,6 +17,9 @@ class Ecc {
   // false (default): the template stays the first frame of the sequence, as upstream's apply_ecc leaves `prevFrame`; true: every
   // collected frame becomes the template of the next one (frame-to-frame warps: what the method's name promises)
   void set_replace_template(bool on);
+  // true (default): warpAffine's bilinear path as OpenCV >= 4.11 computes it (source positions in floating point); false: as through
+  // 4.10 (fixed point, 1/32 pixel) -- under which many fits dither in the coefficient's sixth decimal and run to the iteration cap
+  void set_exact_positions(bool on);
   // Queue a BGR u8 frame that lives in HBM: its blurred half-resolution image is made NOW, on `producer` (the stream that
   // wrote the frame, e.g. a detector's: the frame buffer may be reused by later work on that stream), into the next slot of a
   // 32-deep ring. collect() returns the frames in submission order. One thread may submit while another collects.

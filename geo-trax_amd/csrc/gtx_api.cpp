@@ -434,6 +434,9 @@ int gtx_ecc_reset(gtx_ecc* e) {
 int gtx_ecc_replace_template(gtx_ecc* e, int replace) {
   return guarded([&] { need(e, "ecc"); e->impl->set_replace_template(replace != 0); });
 }
+int gtx_ecc_exact_positions(gtx_ecc* e, int exact) {
+  return guarded([&] { need(e, "ecc"); e->impl->set_exact_positions(exact != 0); });
+}
 int gtx_ecc_submit(gtx_ecc* e, const uint8_t* frame_bgr, int h, int w) {
   return guarded([&] { need(e, "ecc"); need(frame_bgr, "frame"); e->impl->submit_frame(frame_bgr, h, w); });
 }

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "gtx_ecc_destroy": (None, [_P]),
     "gtx_ecc_reset": (C.c_int, [_P]),
     "gtx_ecc_replace_template": (C.c_int, [_P, C.c_int]),
+    "gtx_ecc_exact_positions": (C.c_int, [_P, C.c_int]),
     "gtx_ecc_submit": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "gtx_ecc_submit_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "gtx_ecc_collect": (C.c_int, [_P, _P, _P, C.POINTER(C.c_double)]),

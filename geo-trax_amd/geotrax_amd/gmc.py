@@ -258,6 +258,9 @@ class EccGMC:
     reset_params() -- upstream never replaces its `prevFrame` for this method --, and the translation stays in half-resolution
     pixels. `last` holds {iters, status, rho} of the frame collected last (status 1 / 2: the two conditions under which
     cv2.findTransformECC raises; upstream catches it and keeps the matrix as the failed call left it, as collect() does).
+    `warp`: which of OpenCV's two warpAffine forms takes the bilinear samples -- 'exact' (default; OpenCV >= 4.11, floating-point source
+    positions: fits end after 5-30 iterations) or 'fixed' (through 4.10: positions rounded to 1/32 pixel, under which the coefficient
+    can dither in its sixth decimal for good and the fit runs to the 5000-iteration cap).
     `replace_template=True` is NOT upstream's behaviour: every collected frame becomes the template of the next one (frame-to-frame
     warps, what a tracker's "previous -> current" compensation expects); off unless a caller asks for it.
 
@@ -267,7 +270,7 @@ class EccGMC:
     wants_frames = True
 
     def __init__(self, frame_hw: tuple[int, int], method: str = "ecc", downscale: int = 2, seed: int = 0, ctx: _lib.Context | None = None,
-                 max_iters: int = 5000, eps: float = 1e-6, replace_template: bool = False):
+                 max_iters: int = 5000, eps: float = 1e-6, replace_template: bool = False, warp: str = "exact"):
         if method != "ecc":
             raise ValueError(f"EccGMC(method='{method}')")
         if downscale != 2:
@@ -277,6 +280,10 @@ class EccGMC:
         h = C.c_void_p()
         check(self.ctx.lib.gtx_ecc_create(self.ctx.handle, self.frame_hw[0], self.frame_hw[1], int(max_iters), float(eps), C.byref(h)))
         self.handle = h
+        if warp not in ("exact", "fixed"):
+            raise ValueError(f"EccGMC(warp='{warp}'): 'exact' (OpenCV >= 4.11's warpAffine) or 'fixed' (through 4.10)")
+        if warp == "fixed":
+            check(self.ctx.lib.gtx_ecc_exact_positions(h, 0))
         if replace_template:                             # NOT upstream's behaviour: frame-to-frame warps (each collected frame becomes the next template)
             check(self.ctx.lib.gtx_ecc_replace_template(h, 1))
         self.method = "ecc"

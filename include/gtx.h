@@ -528,6 +528,9 @@ void gtx_ecc_destroy(gtx_ecc* e);
 int gtx_ecc_reset(gtx_ecc* e);
 /* replace != 0: every collected frame becomes the template of the next one (frame-to-frame warps). Default 0 = upstream's behaviour. */
 int gtx_ecc_replace_template(gtx_ecc* e, int replace);
+/* exact != 0 (default): warpAffine's bilinear samples as OpenCV >= 4.11 takes them (source position in floating point); 0: as through
+ * 4.10 (fixed point, rounded to 1/32 pixel; many fits then never meet eps and run to max_iters -- oracle/ecc_ref.py). */
+int gtx_ecc_exact_positions(gtx_ecc* e, int exact);
 int gtx_ecc_submit(gtx_ecc* e, const uint8_t* frame_bgr, int h, int w);
 int gtx_ecc_submit_dev(gtx_ecc* e, gtx_ctx* producer, const void* frame_bgr_dptr, int h, int w);
 int gtx_ecc_collect(gtx_ecc* e, double A[6], int info[2], double* rho);

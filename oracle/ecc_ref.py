@@ -17,7 +17,7 @@ correlation, or the correlation about to be minimised) upstream logs a warning a
 left it (the array is updated in place): so does this.
 
 ultralytics and OpenCV are absent from /root/reference (pyproject pins ultralytics>=8.4.80; OpenCV comes with it, version
-open), so this follows OpenCV's published source as it stood through the 4.x series -- video/src/ecc.cpp (Evangelidis &
+open), so this follows OpenCV's published source -- video/src/ecc.cpp (Evangelidis &
 Psarakis, PAMI 2008: forward additive ECC) and imgproc's warpAffine -- operation by operation and is **PARITY UNPINNED**
 against OpenCV itself (held against an estimator nobody here wrote: scikit-image's ORB + ransac(SimilarityTransform) on a
 consecutive frame pair and the clip's own camera, <= 0.3 px apart on a 9 x 16 grid, tests/test_independent.py):
@@ -26,12 +26,15 @@ consecutive frame pair and the clip's own camera, <= 0.3 px apart on a 9 x 16 gr
     BORDER_REFLECT_101, rounded once at the end ((v + 2^15) >> 16);
   * resize to exactly half: INTER_LINEAR becomes the 2 x 2 area mean, (a + b + c + d + 2) >> 2;
   * ECC: float32 images, gradients by filter2D with (-0.5, 0, 0.5) (BORDER_REFLECT_101), warpAffine(INTER_LINEAR |
-    WARP_INVERSE_MAP, constant border 0) with its fixed-point source coordinates (10 fractional bits per term, rounded to
-    1/32 pixel) and float32 bilinear weights, the validity mask by warpAffine(INTER_NEAREST) of ones, mean / std / dot
+    WARP_INVERSE_MAP, constant border 0) in one of the two forms below, the validity mask by warpAffine(INTER_NEAREST) of ones, mean / std / dot
     products accumulated in float64, the 3 x 3 Hessian and the projections stored as float32, its inverse by cofactors in
     float64, the Euclidean update theta += dp0, t += (dp1, dp2).
-(OpenCV 4.11 replaced warpAffine's linear path by one with exact float coordinates; a reference run on such a build differs
-from this restatement by the 1/32-pixel quantisation of every sample -- below 1e-3 px in the fitted translation on the test clips.)
+Two forms of warpAffine's bilinear path exist upstream and both are restated (`warp=`): "exact" -- OpenCV >= 4.11, whose new
+kernels take the source position m0 x + m1 y + m2 as it is and interpolate p00 + a (p01 - p00) ..., the build an installation
+of the pinned ultralytics resolves to today -- and "fixed" -- OpenCV through 4.10: the position in fixed point, rounded to
+1/32 pixel, table weights. The difference matters for more than the last digits: under "fixed" the samples stop changing
+smoothly near the optimum, the coefficient dithers in its sixth decimal and many fits never meet the 1e-6 criterion (they run
+to the 5000-iteration cap); under "exact" the same fits end after 5-30 iterations. The mask (INTER_NEAREST) is fixed point in both.
 """
 from __future__ import annotations
 
@@ -130,6 +133,25 @@ def warp_linear(img: np.ndarray, lin) -> np.ndarray:
     return ((_fetch(img, sy, sx) * w00 + _fetch(img, sy, sx + 1) * w01) + _fetch(img, sy + 1, sx) * w10) + _fetch(img, sy + 1, sx + 1) * w11
 
 
+def warp_coords_exact(M: np.ndarray, hs: int, ws: int):
+    """OpenCV >= 4.11: source position in floating point, floor + fraction (float32 fraction)."""
+    m = M.astype(np.float64)
+    x = np.arange(ws, dtype=np.float64)[None, :]
+    y = np.arange(hs, dtype=np.float64)[:, None]
+    sx = (m[0, 0] * x + m[0, 1] * y) + m[0, 2]
+    sy = (m[1, 0] * x + m[1, 1] * y) + m[1, 2]
+    ix, iy = np.floor(sx), np.floor(sy)
+    return ix.astype(np.int64), iy.astype(np.int64), (sx - ix).astype(np.float32), (sy - iy).astype(np.float32)
+
+
+def warp_linear_exact(img: np.ndarray, ex) -> np.ndarray:
+    sx, sy, ax, ay = ex
+    p00, p01, p10, p11 = _fetch(img, sy, sx), _fetch(img, sy, sx + 1), _fetch(img, sy + 1, sx), _fetch(img, sy + 1, sx + 1)
+    v0 = p00 + ax * (p01 - p00)
+    v1 = p10 + ax * (p11 - p10)
+    return (v0 + ay * (v1 - v0)).astype(np.float32)
+
+
 def _masked_mean_std(a, mask, n):
     s = a[mask].astype(np.float64)
     mean = s.sum() / n
@@ -158,7 +180,7 @@ def _inv3(hm: np.ndarray):
     return t.astype(np.float32)
 
 
-def find_transform_ecc(template_u8: np.ndarray, image_u8: np.ndarray, M: np.ndarray, max_iters: int = MAX_ITERS, eps: float = EPS):
+def find_transform_ecc(template_u8: np.ndarray, image_u8: np.ndarray, M: np.ndarray, max_iters: int = MAX_ITERS, eps: float = EPS, warp: str = "exact"):
     """cv2.findTransformECC(template, image, M, MOTION_EUCLIDEAN, (EPS | COUNT, max_iters, eps), None, 1). M (2x3 float32) is
     updated in place. Returns (rho, iterations run, status): status 0 = finished, 1 = NaN correlation, 2 = the correlation
     would be minimised (both are cv2.error upstream)."""
@@ -174,8 +196,11 @@ def find_transform_ecc(template_u8: np.ndarray, image_u8: np.ndarray, M: np.ndar
     while it < max_iters and abs(rho - last_rho) >= eps:
         it += 1
         lin, (nx, ny) = warp_coords(M, hs, ws)
-        iw = warp_linear(img, lin)
-        gxw, gyw = warp_linear(gx, lin), warp_linear(gy, lin)
+        if warp == "exact":
+            ex = warp_coords_exact(M, hs, ws)
+            iw, gxw, gyw = warp_linear_exact(img, ex), warp_linear_exact(gx, ex), warp_linear_exact(gy, ex)
+        else:
+            iw, gxw, gyw = warp_linear(img, lin), warp_linear(gx, lin), warp_linear(gy, lin)
         mask = _fetch(ones, ny, nx) > 0
         n = int(mask.sum())
         img_mean, img_std = _masked_mean_std(iw, mask, n) if n else (0.0, 0.0)
@@ -224,7 +249,9 @@ def find_transform_ecc(template_u8: np.ndarray, image_u8: np.ndarray, M: np.ndar
 class EccRef:
     """GMC(method='ecc', downscale=2).apply(frame_bgr) -> 2x3 float64 (see the module text for the two upstream properties kept)."""
 
-    def __init__(self, max_iters: int = MAX_ITERS, eps: float = EPS, replace_template: bool = False):
+    def __init__(self, max_iters: int = MAX_ITERS, eps: float = EPS, replace_template: bool = False, warp: str = "exact"):
+        assert warp in ("exact", "fixed")
+        self.warp = warp
         self.template = None
         self.max_iters, self.eps = max_iters, eps
         self.replace_template = replace_template         # True: NOT upstream -- every frame becomes the template of the next one
@@ -236,7 +263,7 @@ class EccRef:
         if self.template is None:
             self.template = g
             return H.astype(np.float64)
-        rho, iters, status = find_transform_ecc(self.template, g, H, self.max_iters, self.eps)
+        rho, iters, status = find_transform_ecc(self.template, g, H, self.max_iters, self.eps, self.warp)
         self.last = dict(rho=rho, iters=iters, status=status)
         if self.replace_template:
             self.template = g

@@ -68,15 +68,19 @@ def test_warp_coordinates_follow_warpaffine_fixed_point():
     assert w[0, 0] == pytest.approx(0.75 * 0.5 * (2 + 3)) and w[0, 4] == 0.0                     # row -1 and column 6 are the constant border
 
 
+@pytest.mark.parametrize("warp", ["exact", "fixed"])
 @pytest.mark.parametrize("motion", [(3.0, -1.5, 0.0), (-4.25, 2.0, 0.004), (0.0, 0.0, -0.01), (7.5, 5.0, 0.002)])
-def test_fit_recovers_a_known_euclidean_motion(motion):
+def test_fit_recovers_a_known_euclidean_motion(motion, warp):
+    """Both forms of warpAffine's bilinear path. The texture here is piecewise linear (box-filtered blocks): the Gauss-Newton step
+    keeps hopping over its kinks by a few thousandths of a pixel, so the 1e-6 criterion may never be met -- the cap of 100 ends the
+    fit, well inside the accuracy asked for (on the rendered scenes of tests/test_ecc_gpu.py the exact form ends after 8-10 iterations)."""
     tx, ty, th = motion
     h, w = 216, 384
     big = _texture(h + 40, w + 40, seed=3)
-    ref = ecc_ref.EccRef()
+    ref = ecc_ref.EccRef(max_iters=100, warp=warp)
     np.testing.assert_array_equal(ref.apply(_view(big, h, w, 0, 0, 0)), np.eye(2, 3))
     H = ref.apply(_view(big, h, w, tx, ty, th))
-    assert ref.last["status"] == 0 and 2 <= ref.last["iters"] < 200 and ref.last["rho"] > 0.95
+    assert ref.last["status"] == 0 and 2 <= ref.last["iters"] <= 100 and ref.last["rho"] > 0.95
     # frame(x) = first(R x + t) in full-resolution pixels; the warp maps first-frame (template) pixels to frame pixels: x -> R^-1 (x - t),
     # in half-resolution units (pixel centres: x_half = (x_full - 0.5) / 2)
     c, s = np.cos(th), np.sin(th)
@@ -89,6 +93,28 @@ def test_fit_recovers_a_known_euclidean_motion(motion):
     np.testing.assert_array_equal(again, H)
 
 
+def test_exact_positions_end_fits_that_fixed_point_positions_keep_dithering():
+    """A rendered scene pair: with OpenCV >= 4.11's floating-point source positions the coefficient settles and the 1e-6 criterion
+    ends the fit; with the 1/32-pixel positions of older builds the samples change in steps, the coefficient dithers in its sixth
+    decimal and the fit runs to its cap. The two warps agree to a hundredth of a pixel."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "geo-trax_amd"))
+    from geotrax_amd.synth import make_scene
+
+    sc = make_scene(seed=3, h=270, w=480)
+    f0, f1 = sc.render(0), sc.render(30)
+    out = {}
+    for warp in ("exact", "fixed"):
+        e = ecc_ref.EccRef(max_iters=150, warp=warp)
+        e.apply(f0)
+        out[warp] = (e.apply(f1), dict(e.last))
+    assert out["exact"][1]["iters"] < 40 and out["exact"][1]["status"] == 0
+    assert out["fixed"][1]["iters"] >= out["exact"][1]["iters"]
+    assert np.abs(out["exact"][0] - out["fixed"][0]).max() < 0.02
+
+
 def test_error_conditions_keep_the_matrix_as_the_failed_call_left_it():
     flat = np.full((64, 96, 3), 100, np.uint8)                           # zero variance: the correlation coefficient is 0 / 0
     ref = ecc_ref.EccRef()
@@ -97,7 +123,7 @@ def test_error_conditions_keep_the_matrix_as_the_failed_call_left_it():
     assert ref.last["status"] == 1 and ref.last["iters"] == 1
     rng = np.random.default_rng(5)
     a = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
-    ref = ecc_ref.EccRef(max_iters=50)
+    ref = ecc_ref.EccRef(max_iters=50, warp="fixed")
     ref.apply(a)
     H = ref.apply(255 - a)                                               # anti-correlated: lambda's denominator is not positive
     assert ref.last["status"] == 2 and np.isfinite(H).all()

@@ -137,7 +137,7 @@ def test_oracle_ecc_agrees_with_skimage_similarity(inp, fx):
     based) for frames 0 -> 1 of the synthetic clip, and both vs the clip's camera: two unrelated estimators of one motion."""
     from oracle.ecc_ref import EccRef
 
-    e = EccRef(max_iters=300)
+    e = EccRef()                                                       # the defaults: 5000 / 1e-6, floating-point source positions
     e.apply(inp["f0"])
     A = e.apply(inp["f1"])
     assert e.last["status"] == 0 and e.last["rho"] > 0.9
@@ -257,7 +257,7 @@ def test_gpu_gmc_agrees_with_skimage_similarity(gtx_ctx, inp, fx):
 def test_gpu_ecc_agrees_with_skimage_similarity(gtx_ctx, inp, fx):
     from geotrax_amd.gmc import make_gmc
 
-    g = make_gmc(HW, method="ecc", ctx=gtx_ctx, max_iters=300)
+    g = make_gmc(HW, method="ecc", ctx=gtx_ctx)
     g.apply(inp["f0"])
     A = g.apply(inp["f1"])
     P = _grid(HW)
