@@ -121,6 +121,11 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
                            **({k: tp[k] for k in ("with_reid", "proximity_thresh", "appearance_thresh")} if active == "botsort" else {}))
     reid = active in ("botsort", "deepocsort", "tracktrack") and bool(tp.get("with_reid"))
     gmc = GmcRef(seed=0) if active in ("botsort", "deepocsort", "tracktrack") and tp.get("gmc_method") == "sparseOptFlow" else None
+    ecc = None
+    if active in ("botsort", "deepocsort", "tracktrack") and tp.get("gmc_method") == "ecc":
+        from oracle.ecc_ref import EccRef
+
+        ecc = EccRef()                                       # takes the BGR frame: the blur comes before the reduction
     scfg = dict(downsample_ratio=0.5, max_features=STAB["max_features"], ref_multiplier=2.0, filter_ratio=0.9,
                 ransac_threshold=2.0, mask_use=True, mask_margin_ratio=0.15, fast_threshold=20, n_levels=8, scale_factor=1.2, seed=0)
     stab = StabilizerRef(scfg, (H, W), pattern, n_hyp=2048)
@@ -132,7 +137,7 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
         else:
             xyxy, conf, cls, *feats = detect(model, frame, u["imgsz"], u["rect"], u["conf"], u["iou"], u["classes"], u["agnostic_nms"], u["max_det"],
                                              return_feats=reid)
-        warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else None     # BOTSORT.update: camera motion first
+        warp = gmc.apply(bgr2gray_half(frame)) if gmc is not None else (ecc.apply(frame) if ecc is not None else None)     # BOTSORT.update: camera motion first
         t = trk.update(xyxy, conf, cls, gmc=warp, **({"feats": feats[0]} if reid else {}))   # every frame, with or without detections (ultralytics track.py)
         if len(conf):
             if len(t):
@@ -165,9 +170,10 @@ def _oracle_chain(frames, weights, cfg, pattern=None):
     return t[t[:, 1] != -1], np.asarray(transforms)
 
 
-@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "ocsort", "deepocsort", "deepocsort+reid", "fasttrack", "tracktrack", "tracktrack+reid", "rtdetr"])
+@pytest.mark.parametrize("tracker", ["bytetrack", "botsort", "botsort+reid", "botsort+ecc", "ocsort", "deepocsort", "deepocsort+reid", "fasttrack", "tracktrack", "tracktrack+reid", "rtdetr"])
 def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     reid = tracker.endswith("+reid")        # the appearance branch on detector-derived vectors (`with_reid: true, model: auto`): BoT-SORT, Deep OC-SORT, TrackTrack
+    ecc = tracker.endswith("+ecc")          # `gmc_method: ecc` instead of BoT-SORT's default sparseOptFlow
     rtdetr = tracker == "rtdetr"            # the RT-DETR detector (a weight file with that graph) in front of ByteTrack
     tracker = "bytetrack" if rtdetr else tracker.split("+")[0]
     from geotrax_amd import extract as ex
@@ -180,8 +186,8 @@ def test_extract_path_matches_oracle_chain(gtx_ctx, tmp_path, tracker):
     src = tmp_path / "clip.npy"
     np.save(src, frames)
     wpath, weights = (_rtdetr_weights_file if rtdetr else _weights_file)(tmp_path, gtx_ctx, frames[0])
-    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="sparseOptFlow" if tracker == "deepocsort" else None, with_reid=reid)
-    if tracker == "botsort":
+    cfg_path, cfg = _cfg_file(tmp_path, wpath, tracker=tracker, gmc_method="ecc" if ecc else ("sparseOptFlow" if tracker == "deepocsort" else None), with_reid=reid)
+    if tracker == "botsort" and not ecc:
         assert cfg["tracker"]["botsort"]["gmc_method"] == "sparseOptFlow"     # the reference default (default.yaml:374)
     args = argparse.Namespace(source=str(src), cfg=cfg_path, output_folder=None, log_path=None, verbose=False, model=None,
                               class_names=None, conf=None, classes=None, cut_frame_left=None, cut_frame_right=None, interpolate=None)
