@@ -823,6 +823,9 @@ int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr,
     st->impl->stabilize_gray_dev(gray_dptr, gh, gw, boxes_xywh, n, H, valid, stats);
   });
 }
+int gtx_stabilizer_promote_cur(gtx_stabilizer* st) {
+  return guarded([&] { need(st, "st"); st->impl->promote_cur_to_ref(); });
+}
 int gtx_stabilizer_submit_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw, const float* boxes_xywh, int n) {
   return guarded([&] { need(st, "st"); need(gray_dptr, "gray"); st->impl->submit_gray_dev(gray_dptr, gh, gw, boxes_xywh, n); });
 }

@@ -1638,6 +1638,16 @@ void Stabilizer::submit_gray_dev(const void* gray, int gh, int gw, const float* 
   S.submit_match();
 }
 
+// The features of the frame stabilized last become the reference (their buffers are swapped): a caller that registers every
+// frame against the one before it (gmc.FeatureGMC) does not extract each frame's features twice. Both plans must be the same.
+void Stabilizer::promote_cur_to_ref() {
+  Impl& S = *impl_;
+  if (!S.have_ref) fail(GTX_ERR_STATE, "promote_cur_to_ref before a frame was stabilized");
+  GTX_CHECK(!S.pending, "stabilizer: a frame is in flight");
+  GTX_CHECK(S.slots_ref == S.slots_cur, "stabilizer: the reference holds %d keypoint slots, a frame %d (ref_multiplier must be 1)", S.slots_ref, S.slots_cur);
+  std::swap(S.ref, S.cur);
+}
+
 float Stabilizer::last_ms() const { return impl_->last_ms; }
 
 void Stabilizer::collect(double H[9], int* valid, int stats[4]) {

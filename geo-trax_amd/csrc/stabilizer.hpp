@@ -23,6 +23,7 @@ class Stabilizer {
   void submit_gray_dev(const void* gray, int gh, int gw, const float* boxes_xywh, int n);
   void collect(double H[9], int* valid, int stats[4]);
   void keypoints(int which, int cap, int* n, float* xy, int* level, int* angle_bin, uint8_t* desc);
+  void promote_cur_to_ref();      // the last stabilized frame's features become the reference (ref_multiplier 1 only)
   void matches(int cap, int* n, int* cur_idx, int* ref_idx, int* dist);
   // rotated sampling pattern table [256 bins][256 tests][ax, ay, bx, by] int8 (data, for the oracle)
   void pattern(int8_t* out) const;

@@ -166,6 +166,7 @@ _SIGNATURES = {
     "gtx_stabilizer_stabilize_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.POINTER(C.c_int), _P]),
     "gtx_stabilizer_submit_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "gtx_stabilizer_collect": (C.c_int, [_P, _P, C.POINTER(C.c_int), _P]),
+    "gtx_stabilizer_promote_cur": (C.c_int, [_P]),
     "gtx_stabilizer_keypoints": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P]),
     "gtx_stabilizer_matches": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P, _P, _P]),
     "gtx_stabilizer_pattern": (C.c_int, [_P, _P]),

@@ -203,11 +203,12 @@ class FeatureGMC:
             cur_ptr = cur
         prev_ptr, self._prev = self._prev, cur_ptr
         if prev_ptr is None:
+            self._st.set_ref_gray_dev(cur_ptr, self.gh, self.gw)     # the sequence's first frame: its features wait as the reference
             return None
-        self._st.set_ref_gray_dev(prev_ptr, self.gh, self.gw)
-        self._st.stabilize_gray_dev(cur_ptr, self.gh, self.gw)
+        self._st.stabilize_gray_dev(cur_ptr, self.gh, self.gw)      # features of this frame + matches against the previous frame's
         qi, ti, _ = self._st.matches()
         ref, cur_k = self._st.keypoints("ref")["xy"], self._st.keypoints("cur")["xy"]
+        self._st.promote_cur()                                      # ... which now become the reference of the next frame (no second extraction)
         self.stats[0] = len(ref)
         return ref[ti], cur_k[qi]                        # previous-frame points, current-frame points (full-resolution pixels)
 

@@ -234,6 +234,10 @@ class Stabilizer:
         return int(self._stats[3])
 
     # ---- introspection for the parity tests
+    def promote_cur(self) -> None:
+        """The frame stabilized last becomes the reference (its features are kept, nothing is extracted again); ref_multiplier 1 only."""
+        check(self.ctx.lib.gtx_stabilizer_promote_cur(self.handle))
+
     def keypoints(self, which: str = "cur"):
         cap = 1 << 16
         n = C.c_int()

@@ -468,6 +468,9 @@ int gtx_stabilizer_stabilize_gray_dev(gtx_stabilizer* st, const void* gray_dptr,
 int gtx_stabilizer_submit_gray_dev(gtx_stabilizer* st, const void* gray_dptr, int gh, int gw,
                                    const float* boxes_xywh, int n);
 int gtx_stabilizer_collect(gtx_stabilizer* st, double H[9], int* valid, int stats[4]);
+/* The features of the frame stabilized last become the reference (buffers swapped; needs ref_multiplier = 1): frame-to-frame
+ * registration (gmc_method orb) without extracting every frame's features twice. */
+int gtx_stabilizer_promote_cur(gtx_stabilizer* st);
 /* GPU time (ms) of the last collected asynchronous pass: what the reference logs as "Average stabilization
  * time" (geotrax/extract.py:175,188,206) is the wall time of the blocking stabilo calls; here the pass runs on
  * its own stream beside the detector, so its stream-ordered duration is reported instead. */
